@@ -1,0 +1,114 @@
+"""Registry of parity cases (TEST INFRASTRUCTURE).
+
+One entry = (config overrides, batch size, proposals/frame, seeds). Inputs and
+weights are regenerated from the seeds by `vognet-pytorch_amd/synth.py`
+(numpy PCG64, platform independent); the fixture files under `tests/golden/`
+hold the REFERENCE outputs for them plus SHA-256 of the generated inputs and
+weights, so drift of the generator is detected.
+
+`full/*` are the five BASELINE.json configs at their real sizes;
+`small/*` cover every model x conc-type combination and the ablation knobs at
+shrunken dims (d_obj = 32 -> uneven heads 11/11/10, d_mul = 48).
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import os
+import sys
+from typing import Dict
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+_ec = importlib.import_module("vognet-pytorch_amd.extended_config")
+_synth = importlib.import_module("vognet-pytorch_amd.synth")
+
+SMALL_DIMS = {
+    "mdl.prop_feat_dim": 64, "mdl.seg_feat_dim": 48, "mdl.input_encoding_size": 16,
+    "mdl.rnn.rnn_size": 32, "mdl.vsrl.prop_encode_size": 16,
+    "mdl.vsrl.seg_encode_size": 16, "mdl.vsrl.lang_encode_size": 16,
+}
+REL = {"mdl.obj_tx.use_rel": True, "mdl.mul_tx.use_rel": True}
+
+
+def _case(over, B, nppf0=5, vocab=5000, ragged=False, wseed=1, dseed=3,
+          perturb_ln=False, ncmp=4):
+    return dict(over=over, B=B, nppf0=nppf0, vocab=vocab, ragged=ragged,
+                wseed=wseed, dseed=dseed, perturb_ln=perturb_ln, ncmp=ncmp)
+
+
+CASES: Dict[str, dict] = {}
+# ---- BASELINE.json configs, full size
+CASES["full/cfg1_igrnd_spat_gt5_bs2"] = _case(
+    {"mdl.name": "igrnd", "ds.conc_type": "spat"}, B=2)
+CASES["full/cfg2_vog_spat_gt5_bs4"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL}, B=4)
+CASES["full/cfg3_vog_temp_gt5_bs8"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "temp", **REL}, B=8)
+CASES["full/cfg4_vog_spat_p100_bs4"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", "ds.exp_setting": "p100", **REL},
+    B=4, nppf0=100)
+CASES["full/cfg5_vog_svsq_gt5_bs16"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "svsq", **REL}, B=16)
+CASES["full/vog_sep_gt5_bs4_ragged"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "sep", **REL}, B=4, ragged=True, dseed=11)
+CASES["full/cfg2_ragged"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL}, B=4, ragged=True, dseed=12)
+# ---- every model x conc combination, shrunken dims, ragged sentences
+for _m in ("igrnd", "vgrnd", "vog"):
+    for _c in ("spat", "temp", "sep", "svsq"):
+        CASES[f"small/{_m}_{_c}"] = _case(
+            {"mdl.name": _m, "ds.conc_type": _c, **REL, **SMALL_DIMS},
+            B=2, vocab=50, ragged=True, perturb_ln=True)
+CASES["small/vog_spat_norel"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **SMALL_DIMS},
+    B=2, vocab=50, ragged=True, perturb_ln=True)
+CASES["small/vog_spat_3layers"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, **SMALL_DIMS,
+     "mdl.obj_tx.n_layers": 3, "mdl.mul_tx.n_layers": 3},
+    B=2, vocab=50, ragged=True, perturb_ln=True)
+CASES["small/vog_temp_objonefrm"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "temp", **REL, **SMALL_DIMS,
+     "mdl.obj_tx.one_frm": True}, B=2, vocab=50, ragged=True, perturb_ln=True)
+CASES["small/vog_spat_noobj"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, **SMALL_DIMS,
+     "mdl.obj_tx.to_use": False}, B=2, vocab=50, ragged=True, perturb_ln=True)
+CASES["small/vog_sep_cmpmsk"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "sep", **REL, **SMALL_DIMS},
+    B=3, vocab=50, ragged=True, perturb_ln=True, dseed=21)
+CASES["small/vog_spat_p7"] = _case(       # nppf0 = 7 -> N = 140 / 28: not tile multiples
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, **SMALL_DIMS},
+    B=2, nppf0=7, vocab=50, ragged=True, perturb_ln=True)
+
+
+def build(name: str):
+    """-> (cfg, state_dict(np), batch(np), case)."""
+    c = CASES[name]
+    cfg = _ec.get_default_cfg()
+    _ec.update_from_dict(cfg, dict(c["over"]))
+    sd = _synth.init_state_dict(cfg, c["vocab"], seed=c["wseed"],
+                                perturb_ln=c["perturb_ln"])
+    msk = None
+    if name.endswith("cmpmsk"):
+        msk = np.array([[1, 1, 1, 1], [1, 1, 0, 0], [1, 0, 1, 1]], np.int64)
+    batch = _synth.make_batch(
+        cfg.ds.conc_type, c["B"], c["nppf0"], ncmp=c["ncmp"], vocab_size=c["vocab"],
+        prop_dim=cfg.mdl.prop_feat_dim, seg_dim=cfg.mdl.seg_feat_dim,
+        seed=c["dseed"], ragged=c["ragged"], num_cmp_msk=msk)
+    return cfg, sd, batch, c
+
+
+def digest(d: Dict[str, np.ndarray]) -> str:
+    h = hashlib.sha256()
+    for k in sorted(d):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(d[k]).tobytes())
+    return h.hexdigest()
+
+
+def golden_path(name: str) -> str:
+    return os.path.join(_ROOT, "tests", "golden", name.replace("/", "__") + ".npz")

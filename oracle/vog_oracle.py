@@ -1,0 +1,426 @@
+"""CPU oracle for the VOGNet forward path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A from-scratch restatement (torch-CPU fp32 tensor ops, no nn.Module, no
+nn.LSTM) of the reference algorithm on the hot path, written from the
+semantics in SURVEY.md section 8(a) / Appendix B. Each function cites the reference
+file:line it restates. Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import this module; the product path
+(`vognet-pytorch_amd/`) never does.
+
+Parity status: PINNED. The reference ships no tests or golden vectors
+(SURVEY.md section 4), so the oracle is pinned against the reference itself imported in
+the build container (`oracle/ref_import.py`, `oracle/make_golden.py`) — outputs
+committed as fixtures under `tests/golden/` and re-checked on every CPU test
+run (`tests/test_oracle_golden.py`); when `/root/reference` is present
+`tests/test_oracle_vs_reference.py` additionally compares live.
+
+`quant` hooks: `forward(..., quant=fn)` rounds the operands of the matrix
+contractions in the named scopes through `fn` (e.g. fp32->bf16->fp32). They
+exist only to size the tolerance budget of the 16-bit MFMA path in tests.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Optional
+
+import torch
+
+F32 = torch.float32
+
+
+# --------------------------------------------------------------------------- #
+# configuration of one model instance (what the reference reads from cfg/comm)
+# --------------------------------------------------------------------------- #
+@dataclass
+class OracleCfg:
+    mdl_name: str = "vog"            # igrnd | vgrnd | vog     (mdl_selector.py:26-69)
+    conc_type: str = "spat"          # sep | svsq | temp | spat
+    vocab_size: int = 5000
+    nppf0: int = 5                   # comm.num_prop_per_frm
+    nfrm0: int = 10                  # cfg.ds.num_sampled_frm
+    vid_w: float = 720.0
+    vid_h: float = 405.0
+    rnn_layers: int = 2
+    obj_layers: int = 1
+    obj_heads: int = 3
+    obj_use_rel: bool = True
+    obj_one_frm: bool = False
+    obj_to_use: bool = True
+    mul_layers: int = 1
+    mul_heads: int = 3
+    mul_use_rel: bool = True
+
+    @staticmethod
+    def from_cfg(cfg, vocab_size: int, nppf0: int) -> "OracleCfg":
+        m = cfg.mdl
+        return OracleCfg(
+            mdl_name=m.name, conc_type=cfg.ds.conc_type, vocab_size=vocab_size,
+            nppf0=nppf0, nfrm0=cfg.ds.num_sampled_frm,
+            vid_w=float(cfg.ds.resized_width), vid_h=float(cfg.ds.resized_height),
+            rnn_layers=m.rnn.num_layers,
+            obj_layers=m.obj_tx.n_layers, obj_heads=m.obj_tx.n_heads,
+            obj_use_rel=m.obj_tx.use_rel, obj_one_frm=m.obj_tx.one_frm,
+            obj_to_use=m.obj_tx.to_use,
+            mul_layers=m.mul_tx.n_layers, mul_heads=m.mul_tx.n_heads,
+            mul_use_rel=m.mul_tx.use_rel)
+
+
+def _q(quant, scope, *xs):
+    """Apply the test-only operand rounding hook."""
+    if quant is None:
+        return xs if len(xs) > 1 else xs[0]
+    ys = tuple(quant(scope, x) for x in xs)
+    return ys if len(ys) > 1 else ys[0]
+
+
+# --------------------------------------------------------------------------- #
+# language side
+# --------------------------------------------------------------------------- #
+def srl_arg_seq_to_sent_seq(words_ind, word_mask, vocab_size):
+    """Token re-index (reference mdl_vog.py:67-95).
+    tok[b,t] = words[b, m[b,t]] if m[b,t] >= 0 else V. Does NOT mutate inputs."""
+    B, nv, nsrl, sl = words_ind.shape
+    words = words_ind.reshape(B * nv, nsrl * sl)
+    m = word_mask.reshape(B * nv, -1)
+    pad = m < 0
+    tok = torch.gather(words, 1, m.clamp(min=0))
+    tok = torch.where(pad, torch.full_like(tok, vocab_size), tok)
+    return tok
+
+
+def _lstm_dir(xg, w_hh, lens, reverse, quant):
+    """One direction of one layer with packed-sequence semantics
+    (reference utils/mdl_srl_utils.py:134-148 via nn.LSTM + pack/pad; gate
+    order i,f,g,o). xg = x W_ih^T + b_ih + b_hh, [Bn,T,4R]."""
+    Bn, T, G = xg.shape
+    R = G // 4
+    h = torch.zeros(Bn, R, dtype=F32)
+    c = torch.zeros(Bn, R, dtype=F32)
+    out = torch.zeros(Bn, T, R, dtype=F32)
+    ar = torch.arange(Bn)
+    w_hh_t = _q(quant, "lstm", w_hh).t()
+    for s in range(T):
+        active = s < lens                                   # [Bn]
+        pos = (lens - 1 - s).clamp(min=0) if reverse else torch.full_like(lens, s)
+        g = xg[ar, pos] + _q(quant, "lstm", h) @ w_hh_t
+        i, f, gg, o = g.split(R, dim=1)
+        c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h_new = torch.sigmoid(o) * torch.tanh(c_new)
+        a = active.unsqueeze(1)
+        c = torch.where(a, c_new, c)
+        h = torch.where(a, h_new, h)
+        idx = torch.nonzero(active).squeeze(1)
+        out[idx, pos[idx]] = h_new[idx]
+    return out, h
+
+
+def lstm_encoder(tokens, lens, sd, num_layers, quant=None):
+    """Embedding + packed multi-layer BiLSTM (reference
+    utils/mdl_srl_utils.py:114-169).
+    Returns (x [Bn,T,2R] zero past each length, final_hidden_last [Bn,2R] =
+    [h_fwd(last valid) || h_bwd(step 0)] of the top layer)."""
+    emb = sd["lstm_encoder.embed_tokens.weight"]
+    x = emb[tokens]                                          # [Bn,T,E]
+    hf = hb = None
+    for l in range(num_layers):
+        outs = []
+        for sfx, rev in (("", False), ("_reverse", True)):
+            p = "lstm_encoder.lstm."
+            w_ih = sd[f"{p}weight_ih_l{l}{sfx}"]
+            w_hh = sd[f"{p}weight_hh_l{l}{sfx}"]
+            b = sd[f"{p}bias_ih_l{l}{sfx}"] + sd[f"{p}bias_hh_l{l}{sfx}"]
+            xq, wq = _q(quant, "lstm", x, w_ih)
+            xg = xq @ wq.t() + b
+            o, h = _lstm_dir(xg, w_hh, lens, rev, quant)
+            outs.append(o)
+            if rev:
+                hb = h
+            else:
+                hf = h
+        x = torch.cat(outs, dim=2)
+    return x, torch.cat([hf, hb], dim=1)
+
+
+def linear(x, sd, name, relu=False, quant=None, scope="enc"):
+    w = sd[name + ".weight"]
+    xq, wq = _q(quant, scope, x, w)
+    y = xq @ wq.t()
+    if (name + ".bias") in sd:
+        y = y + sd[name + ".bias"]
+    return torch.relu(y) if relu else y
+
+
+def lang_encode(tokens, lens, sd, num_layers, quant=None):
+    """reference mdl_vog.py:250-283: truncate to T = max len, LSTM, then
+    lstm_out_feat_proj on every step and on final_hidden[-1]."""
+    T = int(lens.max().item())
+    x, fin = lstm_encoder(tokens[:, :T].contiguous(), lens, sd, num_layers, quant)
+    full = linear(x, sd, "lstm_out_feat_proj.0", relu=True, quant=quant)
+    hid = linear(fin, sd, "lstm_out_feat_proj.0", relu=True, quant=quant)
+    return full, hid
+
+
+def retrieve_srl_args(full, capture, inds_msk, sd, quant=None):
+    """reference mdl_vog.py:97-140."""
+    B, nv, nsrl, _ = capture.shape
+    cap = capture.reshape(B * nv, nsrl, 2)
+    D = full.shape[-1]
+    st = torch.gather(full, 1, cap[..., 0].unsqueeze(-1).expand(-1, -1, D))
+    en = torch.gather(full, 1, cap[..., 1].unsqueeze(-1).expand(-1, -1, D))
+    enc = torch.cat([st, en], dim=2).reshape(B, nv, nsrl, 2 * D)
+    out = linear(enc, sd, "srl_arg_words_out_enc.0", relu=True, quant=quant)
+    return out * inds_msk.unsqueeze(-1).to(F32)
+
+
+# --------------------------------------------------------------------------- #
+# transformer
+# --------------------------------------------------------------------------- #
+def chunk_sizes(d, n):
+    """torch.chunk split sizes (transformer_code.py:66-67,182-183): ceil(d/n)
+    each, last one shorter -> 512/3 = 171,171,170."""
+    c = -(-d // n)
+    out = []
+    r = d
+    while r > 0:
+        out.append(min(c, r))
+        r -= c
+    assert len(out) == n
+    return out
+
+
+def normalise_boxes(props5, vid_w, vid_h, nfrm_div):
+    """reference mdl_vog.py:456-463 (on a clone)."""
+    p = props5.clone()
+    p[..., 0] /= vid_w
+    p[..., 1] /= vid_h
+    p[..., 2] /= vid_w
+    p[..., 3] /= vid_h
+    p[..., 4] /= nfrm_div
+    return p
+
+
+def box_bias_head(boxes, w, b):
+    """bias[s,p,q] = relu(w . (box[s,p]-box[s,q]) + b) for ONE head
+    (compute_pe mdl_vog.py:471-480 + do_cross 'subtract' mdl_srl_utils.py:30-69
+    + Linear(5,H)+ReLU mdl_vog.py:446-451). boxes [S,n,5] -> [S,n,n]."""
+    d = boxes.unsqueeze(2) - boxes.unsqueeze(1)              # [S,n,n,5]
+    return torch.relu(d @ w + b)
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
+                  quant=None, scope="tx"):
+    """One (Rel)EncoderLayer (transformer_code.py:84-95,189-203,136-186,
+    21-31,73-81). x [S,N,d]; boxes [S,n,5] normalised, N = nsrl*n, token index
+    = arg*n + p; the bias on (n x n) is tiled over the nsrl x nsrl arg blocks
+    (mdl_vog.py:482-488). scale = sqrt(d_model)."""
+    S, N, d = x.shape
+    p = f"{prefix}.selfattn.layer."
+    xq = _q(quant, scope, x)
+    q = xq @ _q(quant, scope, sd[p + "wq.weight"]).t()
+    k = xq @ _q(quant, scope, sd[p + "wk.weight"]).t()
+    v = xq @ _q(quant, scope, sd[p + "wv.weight"]).t()
+    scale = math.sqrt(d)
+    heads = []
+    off = 0
+    for h, dh in enumerate(chunk_sizes(d, n_heads)):
+        qh, kh, vh = (t[..., off:off + dh] for t in (q, k, v))
+        off += dh
+        qh, kh = _q(quant, scope, qh, kh)
+        logits = qh @ kh.transpose(1, 2)
+        if use_rel:
+            bh = box_bias_head(boxes, sd[pe_name + ".weight"][h],
+                               sd[pe_name + ".bias"][h])
+            if nsrl > 1:
+                bh = bh.repeat(1, nsrl, nsrl)
+            logits = logits + bh
+        attn = torch.softmax(logits / scale, dim=-1)
+        attn, vh = _q(quant, scope, attn, vh)
+        heads.append(attn @ vh)
+    a = _q(quant, scope, torch.cat(heads, dim=-1)) @ _q(quant, scope, sd[p + "wo.weight"]).t()
+    x1 = layer_norm(x + a, sd[f"{prefix}.selfattn.layernorm.weight"],
+                    sd[f"{prefix}.selfattn.layernorm.bias"])
+    f = f"{prefix}.feedforward.layer."
+    hdn = torch.relu(_q(quant, scope, x1) @ _q(quant, scope, sd[f + "linear1.weight"]).t()
+                     + sd[f + "linear1.bias"])
+    y = _q(quant, scope, hdn) @ _q(quant, scope, sd[f + "linear2.weight"]).t() + sd[f + "linear2.bias"]
+    return layer_norm(x1 + y, sd[f"{prefix}.feedforward.layernorm.weight"],
+                      sd[f"{prefix}.feedforward.layernorm.bias"])
+
+
+def transformer(x, boxes, nsrl, sd, name, pe_name, n_layers, n_heads, use_rel,
+                quant=None):
+    """(Rel)Transformer: stack, return last layer output
+    (transformer_code.py:227-241,244-279)."""
+    for l in range(n_layers):
+        x = encoder_layer(x, boxes, nsrl, sd, f"{name}.encoder.layers.{l}",
+                          pe_name, n_heads, use_rel, quant)
+    return x
+
+
+# --------------------------------------------------------------------------- #
+# whole forward
+# --------------------------------------------------------------------------- #
+def _geometry(oc: OracleCfg, ncmp: int):
+    """(nc_v, nfrm, nppf) of the model 'video' per conc type
+    (mdl_conc_single.py:24-37,131-143; mdl_conc_sep.py:14-26)."""
+    if oc.conc_type == "temp":
+        return 1, ncmp * oc.nfrm0, oc.nppf0
+    if oc.conc_type == "spat":
+        return 1, oc.nfrm0, ncmp * oc.nppf0
+    return ncmp, oc.nfrm0, oc.nppf0
+
+
+def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Tensor],
+            quant: Optional[Callable] = None, keep_stages: bool = False):
+    """Conc{TEMP,SPAT,SEP}.forward (mdl_conc_single.py:68-127,
+    mdl_conc_sep.py:131-217) for ImgGrnd / VidGrnd / VOGNet."""
+    st = {}
+    words = inp["srl_arg_words_ind"]
+    B, nv, nsrl, _ = words.shape
+    ncmp = inp["new_srl_idxs"].shape[1]
+    sep = oc.conc_type in ("sep", "svsq")
+    nc_v, nfrm, nppf = _geometry(oc, ncmp)
+
+    # ---- language (a14-a16)
+    tok = srl_arg_seq_to_sent_seq(words, inp["srl_arg_word_mask"], oc.vocab_size)
+    lens = inp["srl_arg_word_mask_len"].reshape(B * nv)
+    full, hid = lang_encode(tok, lens, sd, oc.rnn_layers, quant)
+    lang = retrieve_srl_args(full, inp["srl_arg_words_capture"],
+                             inp["srl_arg_inds_msk"], sd, quant)   # [B,nv,5,L]
+    st.update(tokens=tok, lstm_full_output=full, final_hidden=hid, lang=lang)
+
+    # ---- visual encoders (a13, a12)
+    prop = linear(inp["pad_region_feature"].to(F32), sd, "prop_encoder.0", True, quant)
+    seg = linear(inp["seg_feature_for_frms"].to(F32), sd, "seg_encoder.0", True, quant)
+    if not sep:
+        prop = prop.unsqueeze(1)                                  # [B,1,NP,256]
+        seg = seg.unsqueeze(1)                                    # [B,1,F,256]
+    NP = prop.shape[2]
+    Fv = seg.shape[2]
+    assert NP == Fv * oc.nppf0 and NP == nfrm * nppf
+    seg_b = seg.unsqueeze(3).expand(B, nc_v, Fv, oc.nppf0, seg.shape[-1]).reshape(
+        B, nc_v, NP, -1)
+    ps = torch.cat([prop, seg_b], dim=-1)                         # [B,nc_v,NP,512]
+    st.update(prop_seg=ps)
+    props = inp["pad_proposals"].to(F32)
+    props5 = (props if sep else props.unsqueeze(1))[..., :5]      # [B,nc_v,NP,5]
+
+    # ---- object transformer (a7, a8)
+    if oc.mdl_name in ("vgrnd", "vog") and (oc.mdl_name == "vgrnd" or oc.obj_to_use):
+        d = ps.shape[-1]
+        if oc.obj_one_frm:
+            x = ps.reshape(B * nc_v * nfrm, nppf, d)
+            bx = normalise_boxes(props5, oc.vid_w, oc.vid_h, float(nfrm)).reshape(
+                B * nc_v * nfrm, nppf, 5)
+        else:
+            x = ps.reshape(B * nc_v, NP, d)
+            bx = normalise_boxes(props5, oc.vid_w, oc.vid_h, 1.0).reshape(B * nc_v, NP, 5)
+        x = transformer(x, bx, 1, sd, "obj_txf", "pe_obj_sub_enc.0",
+                        oc.obj_layers, oc.obj_heads, oc.obj_use_rel, quant)
+        ps = x.reshape(B, nc_v, NP, d)
+    st.update(obj_out=ps)
+
+    # ---- vis || lang (a11)
+    lang_v = lang.expand(B, nc_v, nsrl, lang.shape[-1]) if lang.shape[1] != nc_v else lang
+    conc = torch.cat([
+        ps.unsqueeze(2).expand(B, nc_v, nsrl, NP, ps.shape[-1]),
+        lang_v.unsqueeze(3).expand(B, nc_v, nsrl, NP, lang.shape[-1])], dim=-1)
+    vld = conc.shape[-1]
+
+    # ---- multimodal transformer (a9, a10)
+    if oc.mdl_name == "vog":
+        x = conc.reshape(B * nc_v, nsrl, nfrm, nppf, vld).transpose(1, 2).reshape(
+            B * nc_v * nfrm, nsrl * nppf, vld)
+        bx = normalise_boxes(props5, oc.vid_w, oc.vid_h, float(nfrm)).reshape(
+            B * nc_v * nfrm, nppf, 5)
+        x = transformer(x, bx, nsrl, sd, "mult_txf", "pe_mul_sub_enc.0",
+                        oc.mul_layers, oc.mul_heads, oc.mul_use_rel, quant)
+        if keep_stages:
+            st.update(mul_out=x)
+        conc = x.reshape(B * nc_v, nfrm, nsrl, nppf, vld).transpose(1, 2).reshape(
+            B, nc_v, nsrl, NP, vld)
+
+    # ---- score head (a9 tail / a20)
+    h1 = linear(conc, sd, "lin2.0", True, quant, scope="head")
+    outs = linear(h1, sd, "lin2.2", False, quant, scope="head").squeeze(-1)   # [B,nc_v,5,NP]
+
+    # ---- masks (a17)
+    cm = inp["num_cmp_msk"].to(F32)
+    if oc.conc_type == "temp":
+        cmsk = cm.view(B, 1, 1, ncmp, 1).expand(B, 1, nsrl, ncmp, oc.nfrm0 * oc.nppf0)
+    elif oc.conc_type == "spat":
+        cmsk = cm.view(B, 1, 1, 1, ncmp, 1).expand(B, 1, nsrl, oc.nfrm0, ncmp, oc.nppf0)
+    else:
+        cmsk = cm.view(B, ncmp, 1, 1).expand(B, ncmp, nsrl, NP)
+    cmsk = cmsk.reshape(outs.shape)
+    am = inp["srl_arg_inds_msk"].to(F32)
+    if am.shape[1] != nc_v:
+        am = am.expand(B, nc_v, nsrl)
+    outs_eval = torch.sigmoid(outs) * am.unsqueeze(-1) * cmsk
+    res = {"mdl_outs": outs, "mdl_outs_eval": outs_eval}
+
+    # ---- pred_cmp head (a18)
+    if sep:
+        seg_mean = seg.mean(dim=-2)                                # [B,ncmp,256]
+        verb = hid.reshape(B, nv, -1)
+        if verb.shape[1] != ncmp:
+            verb = verb.expand(B, ncmp, verb.shape[-1])
+        sv = torch.cat([verb, seg_mean], dim=-1)
+        vid = linear(linear(sv, sd, "seg_verb_classf.0", True, quant, scope="head"),
+                     sd, "seg_verb_classf.2", False, quant, scope="head").squeeze(-1)
+        s = torch.sigmoid(outs).max(dim=-1).values                 # [B,ncmp,5]
+        vmsk = inp["verb_ind_in_srl"]
+        if vmsk.shape[1] != ncmp:
+            vmsk = vmsk.expand(B, ncmp)
+        s = s.scatter(2, vmsk.unsqueeze(-1), torch.sigmoid(vid).unsqueeze(-1))
+        s = s * am
+        fin = s.sum(-1) / am.sum(-1) * cm
+        res.update(vidf_outs=vid, fin_scores_loss=s * cm.unsqueeze(-1), fin_scores=fin)
+    if keep_stages:
+        res["stages"] = st
+    return res
+
+
+def pred_head(oc: OracleCfg, out: Dict[str, torch.Tensor], inp: Dict[str, torch.Tensor]):
+    """Evaluator{SPAT,TEMP,SEP}.get_out_results_boxes
+    (eval_vsrl_corr.py:357-424, 289-345, 162-220)."""
+    ev = out["mdl_outs_eval"]
+    ncmp = inp["new_srl_idxs"].shape[1]
+    B = ev.shape[0]
+    nsrl = ev.shape[2]
+    nf, np0 = oc.nfrm0, oc.nppf0
+    props = inp["pad_proposals"].to(F32)
+    if oc.conc_type == "spat":
+        r = ev.reshape(B, nsrl, nf, ncmp, np0)
+        sc, ix = r.max(dim=-1)                                     # [B,5,nf,ncmp]
+        pr = props.reshape(B, 1, nf, ncmp, np0, 7).expand(B, nsrl, nf, ncmp, np0, 7)
+        bx = torch.gather(pr, 4, ix[..., None, None].expand(B, nsrl, nf, ncmp, 1, 7)).squeeze(4)
+        return {"boxes": bx.transpose(2, 3).contiguous(),
+                "scores": sc.transpose(2, 3).contiguous(),
+                "indexs": sc.argmax(dim=-1)}
+    if oc.conc_type == "temp":
+        r = ev.reshape(B, nsrl, ncmp, nf, np0)
+        pr = props.reshape(B, 1, ncmp, nf, np0, 7)
+    else:
+        r = ev.transpose(1, 2).reshape(B, nsrl, ncmp, nf, np0)
+        pr = props.reshape(B, 1, ncmp, nf, np0, 7)
+    sc, ix = r.max(dim=-1)                                         # [B,5,ncmp,nf]
+    pr = pr.expand(B, nsrl, ncmp, nf, np0, 7)
+    bx = torch.gather(pr, 4, ix[..., None, None].expand(B, nsrl, ncmp, nf, 1, 7)).squeeze(4)
+    if oc.conc_type == "temp":
+        idx = torch.zeros(B, nsrl, nf, dtype=F32)
+    else:
+        idx = out["fin_scores"].argmax(dim=-1).view(B, 1, 1).expand(B, nsrl, nf).contiguous()
+    return {"boxes": bx, "scores": sc, "indexs": idx}
+
+
+def to_torch(d):
+    return {k: torch.from_numpy(v) if not isinstance(v, torch.Tensor) else v
+            for k, v in d.items()}

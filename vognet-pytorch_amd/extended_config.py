@@ -1,0 +1,210 @@
+"""Config surface of the VOGNet forward path.
+
+Mirrors the *interface* of the reference config layer (reference
+code/extended_config.py:36-81 `update_from_dict`, configs/anet_srl_cfg.yml for
+key names and defaults) without depending on yacs (not installed here): a small
+attribute-dict `CfgNode` with freeze/defrost, dotted-key overrides that assert
+the key exists and that the new value has the type of the default.
+
+Only the keys the forward path, the prediction head and the CLI read are kept
+under the same names; dataset file paths are retained as inert strings so that
+`--ds.some_path=...` overrides of a reference command line still parse.
+"""
+from __future__ import annotations
+
+import ast
+import copy
+from typing import Any, Dict
+
+
+class CfgNode(dict):
+    """Attribute-access dict with yacs-like freeze semantics."""
+
+    _FROZEN = "__frozen__"
+
+    def __init__(self, init: Dict[str, Any] | None = None):
+        super().__init__()
+        object.__setattr__(self, CfgNode._FROZEN, False)
+        for k, v in (init or {}).items():
+            dict.__setitem__(self, k, CfgNode(v) if isinstance(v, dict) else v)
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def __setitem__(self, key, value):
+        if object.__getattribute__(self, CfgNode._FROZEN):
+            raise AttributeError(f"cfg is frozen; cannot set {key!r}")
+        if isinstance(value, dict) and not isinstance(value, CfgNode):
+            value = CfgNode(value)
+        dict.__setitem__(self, key, value)
+
+    def _set_frozen(self, flag: bool):
+        object.__setattr__(self, CfgNode._FROZEN, flag)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v._set_frozen(flag)
+
+    def freeze(self):
+        self._set_frozen(True)
+
+    def defrost(self):
+        self._set_frozen(False)
+
+    def is_frozen(self) -> bool:
+        return object.__getattribute__(self, CfgNode._FROZEN)
+
+    def clone(self) -> "CfgNode":
+        return CfgNode(self.to_dict())
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {k: (v.to_dict() if isinstance(v, CfgNode) else copy.deepcopy(v))
+                for k, v in self.items()}
+
+    def __deepcopy__(self, memo):
+        return self.clone()
+
+
+# Defaults: same keys / values as the reference yaml (configs/anet_srl_cfg.yml:1-131).
+_DEFAULTS: Dict[str, Any] = {
+    "ds_name": "anet",
+    "ds": {
+        "seg_feature_root": "data/anet/rgb_motion_1d",
+        "exp_setting": "gt5",
+        "gt5": {
+            "proposal_h5": "data/anet/anet_detection_vg_fc6_feat_gt5_rois.h5",
+            "feature_root": "data/anet/fc6_feat_5rois",
+            "num_prop_per_frm": 5,
+        },
+        "p100": {
+            "proposal_h5": "data/anet/anet_detection_vg_fc6_feat_100rois_resized.h5",
+            "feature_root": "data/anet/fc6_feat_100rois",
+            "num_prop_per_frm": 100,
+        },
+        "resized_width": 720,
+        "resized_height": 405,
+        "num_sampled_frm": 10,
+        "max_gt_box": 100,
+        "t_attn_size": 480,
+        "max_seq_length": 20,
+        "anet_cap_file": "data/anet_cap_ent_files/anet_captions_all_splits.json",
+        "anet_ent_annot_file": "data/anet_cap_ent_files/anet_ent_cls_bbox_trainval.json",
+        "anet_ent_split_file": "data/anet_cap_ent_files/dic_anet.json",
+        "include_srl_args": ["ARG0", "ARG1", "ARG2", "ARGM-LOC"],
+        "arg_vocab_file": "data/anet_srl_files/arg_vocab.pkl",
+        "trn_ann_file": "data/anet_cap_ent_files/csv_dir/train_postproc.csv",
+        "val_ann_file": "data/anet_cap_ent_files/csv_dir/val_postproc.csv",
+        "trn_ds4_dicts": "data/anet_srl_files/trn_srl_obj_to_index_dict.json",
+        "val_ds4_dicts": "data/anet_srl_files/val_srl_obj_to_index_dict.json",
+        "trn_ds4_inds": "data/anet_srl_files/trn_asrl_annots.csv",
+        "val_ds4_inds": "data/anet_srl_files/val_asrl_annots.csv",
+        "trn_sample": "ds4_random",
+        "val_sample": "ds4",
+        "trn_num_vid_sample": 4,
+        "val_num_vid_sample": 4,
+        "conc_type": "spat",
+        "cs_shuffle": True,
+        "none_word": "<none>",
+    },
+    "mdl": {
+        "name": "vog",
+        "seg_feat_dim": 3072,
+        "prop_feat_dim": 2048,
+        "input_encoding_size": 512,
+        "use_vis_msk": True,
+        "rnn": {"rnn_size": 1024, "num_layers": 2, "drop_prob_lm": 0.5},
+        "vsrl": {"prop_encode_size": 256, "seg_encode_size": 256,
+                 "lang_encode_size": 256},
+        "obj_tx": {"use_ddp": False, "to_use": True, "n_layers": 1,
+                   "n_heads": 3, "attn_drop": 0.2, "use_rel": False,
+                   "one_frm": False},
+        "mul_tx": {"use_ddp": False, "to_use": True, "n_layers": 1,
+                   "n_heads": 3, "attn_drop": 0.2, "use_rel": False,
+                   "one_frm": True, "cross_frm": False},
+    },
+    "loss": {"only_vid_loss": False, "loss_lambda": 1, "loss_margin": 0.1,
+             "loss_margin_vid": 0.5, "loss_type": "bce"},
+    "misc": {"tmp_path": "tmp", "prop_thresh": 0.0, "exclude_bgd_det": False,
+             "add_prop_to_region": False, "ctx_for_seg_feats": 0,
+             "srl_arg_length": 5, "box_per_srl_arg": 4},
+    "train": {"lr": 1e-4, "epochs": 10, "bs": 4, "nw": 4, "bsv": 4, "nwv": 4,
+              "resume": True, "resume_path": "", "load_opt": False,
+              "load_normally": True, "strict_load": True,
+              "use_reduce_lr_plateau": False, "verbose": False,
+              "prob_thresh": 0.2},
+    "log": {"deb_it": 2},
+    "local_rank": 0,
+    "do_dist": False,
+    "do_dp": False,
+    "num_gpus": 1,
+    "only_val": False,
+    "only_test": False,
+    "run_final_val": True,
+    "overfit_batch": False,
+    # build-specific (not in the reference yaml): arithmetic type of the two
+    # transformers' MFMA contractions ("bf16" | "f16"); fp32 accumulate always.
+    "hip": {"tx_dtype": "bf16", "use_graph": True},
+}
+
+key_maps: Dict[str, str] = {}
+
+
+def get_default_cfg() -> CfgNode:
+    """Fresh, unfrozen copy of the default config (reference: module-level
+    `cfg` built at import time, code/extended_config.py:7-11)."""
+    c = CfgNode(copy.deepcopy(_DEFAULTS))
+    c.comm = CfgNode()
+    return c
+
+
+def _decode_cfg_value(v: Any) -> Any:
+    """CLI strings -> python literals (yacs `_decode_cfg_value` behaviour)."""
+    if not isinstance(v, str):
+        return v
+    try:
+        return ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
+
+
+def update_from_dict(cfg: CfgNode, dct: Dict[str, Any],
+                     key_maps: Dict[str, str] | None = None) -> CfgNode:
+    """Dotted-key override with the reference's checks
+    (code/extended_config.py:36-81): unknown key -> AssertionError, type
+    mismatch with the default -> AssertionError."""
+    key_maps = key_maps or {}
+    dct = dict(dct)
+    for full_key in list(dct.keys()):
+        if full_key in key_maps:
+            dct[key_maps[full_key]] = dct.pop(full_key)
+    for full_key, v in dct.items():
+        key_list = full_key.split(".")
+        d = cfg
+        for subkey in key_list[:-1]:
+            assert subkey in d, f"key {full_key} doesnot exist"
+            d = d[subkey]
+        subkey = key_list[-1]
+        assert subkey in d, f"key {full_key} doesnot exist"
+        value = _decode_cfg_value(v)
+        old = d[subkey]
+        if isinstance(old, float) and isinstance(value, int) and not isinstance(value, bool):
+            value = float(value)
+        assert isinstance(value, type(old)), (
+            f"type mismatch for {full_key}: {type(value)} vs {type(old)}")
+        d[subkey] = value
+    return cfg
+
+
+def post_proc_config(cfg: CfgNode) -> CfgNode:
+    return cfg
+
+
+def num_prop_per_frm(cfg: CfgNode) -> int:
+    """comm.num_prop_per_frm as the data layer derives it
+    (reference code/dat_loader_simple.py: cfg.ds[exp_setting].num_prop_per_frm)."""
+    return int(cfg.ds[cfg.ds.exp_setting].num_prop_per_frm)
