@@ -1,0 +1,230 @@
+"""bench.py — queries/sec of the VOGNet forward (gt5, spat, bs=4) on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by
+torch.distributed.run, one rank per GPU over RCCL). A "step" = one pass of the
+whole hot path over ONE batch of 4 synthetic (query, 4-video) pairs already
+resident in HBM: language LSTM -> encoders -> obj_tx -> mul_tx -> score head ->
+per-frame arg-max / box gather (-> all-gather of the packed predictions when
+N>1). Steps are issued round-robin over `--streams` persistent slots (each a
+captured hipGraph with its own inputs, workspace and outputs), so several
+batches are in flight — the regime SURVEY.md section 7 calls for, since one batch is
+~50 dependent launches. `--streams 1` gives the serial latency.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ec = importlib.import_module("vognet-pytorch_amd.extended_config")
+synth = importlib.import_module("vognet-pytorch_amd.synth")
+eng_mod = importlib.import_module("vognet-pytorch_amd.engine")
+D = importlib.import_module("vognet-pytorch_amd.dist")
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(mdl="vog", conc="spat", exp="gt5", B=4, tx="bf16",
+                 desc="VOGNet spat gt5 (obj_tx+mul_tx, use_rel) bs=4"),
+    "cfg3": dict(mdl="vog", conc="temp", exp="gt5", B=8, tx="bf16",
+                 desc="VOGNet temp gt5 bs=8"),
+    "cfg4": dict(mdl="vog", conc="spat", exp="p100", B=4, tx="bf16",
+                 desc="VOGNet spat p100 bs=4"),
+    "cfg5": dict(mdl="vog", conc="svsq", exp="gt5", B=16, tx="f16",
+                 desc="VOGNet svsq gt5 + pred_cmp bs=16 fp16"),
+}
+VOCAB = 5000
+PEAK_MFMA_TFLOPS = 2500.0       # dense bf16/f16, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def make_cfg(w):
+    cfg = ec.get_default_cfg()
+    ec.update_from_dict(cfg, {"mdl.name": w["mdl"], "ds.conc_type": w["conc"], "ds.exp_setting": w["exp"],
+                              "mdl.obj_tx.use_rel": True, "mdl.mul_tx.use_rel": True})
+    cfg.hip.tx_dtype = w["tx"]
+    return cfg
+
+
+def kernel_flops(w, T):
+    """Algorithmic FLOPs per launch of the hot kernels (dense reference
+    formulation, 2*M*N*K) for the gt5/p100 spat/temp/svsq shapes."""
+    nppf0 = 5 if w["exp"] == "gt5" else 100
+    ncmp = 1 if w["conc"] == "svsq" else 4
+    B = w["B"]
+    n_vid = B * (ncmp if w["conc"] in ("sep", "svsq") else 1)
+    nfrm = ncmp * 10 if w["conc"] == "temp" else 10
+    nppf = ncmp * nppf0 if w["conc"] == "spat" else nppf0
+    NP = nfrm * nppf
+    S_mul, N_mul, d_mul = n_vid * nfrm, 5 * nppf, 768
+    S_obj, N_obj, d_obj = n_vid, NP, 512
+    rm, ro = S_mul * N_mul, S_obj * N_obj
+    f = {
+        "mul_qkv": 2.0 * rm * d_mul * 3 * d_mul,
+        "mul_attn": 4.0 * S_mul * N_mul * N_mul * d_mul,
+        "mul_wo": 2.0 * rm * d_mul * d_mul,
+        "mul_ffn1": 2.0 * rm * d_mul * (d_mul // 2),
+        "mul_ffn2": 2.0 * rm * d_mul * (d_mul // 2),
+        "lin2": 2.0 * rm * d_mul * 256,
+        "obj_qkv": 2.0 * ro * d_obj * 3 * d_obj,
+        "obj_attn": 4.0 * S_obj * N_obj * N_obj * d_obj,
+        "obj_wo": 2.0 * ro * d_obj * d_obj,
+        "prop_enc": 2.0 * ro * 2048 * 256,
+    }
+    Bn = B * (ncmp if w["conc"] in ("sep", "svsq") else 1)
+    lstm = 2.0 * Bn * T * (2 * 4096 * 512 + 2 * 4096 * 2048 + 4 * 4096 * 1024)
+    total = sum(f.values()) + f["obj_wo"] * 0 + lstm \
+        + 2.0 * ro * d_obj * (d_obj // 2) * 2 + 2.0 * n_vid * (NP // nppf0) * 3072 * 256 \
+        + 2.0 * Bn * (T + 1) * 2048 * 256
+    return f, total
+
+
+def cpu_baseline(w, cfg, sd, batch, budget_s=15.0):
+    """The CPU oracle (a validated port of the reference forward, oracle/vog_oracle.py)
+    timed on this host, all cores, on the same workload."""
+    from oracle import vog_oracle as vo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oc = vo.OracleCfg.from_cfg(cfg, VOCAB, ec.num_prop_per_frm(cfg))
+    sdt, inp = vo.to_torch(sd), vo.to_torch(batch)
+    times = []
+    with torch.no_grad():
+        t_start = time.time()
+        for i in range(3):
+            vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
+        while len(times) < 20 and time.time() - t_start < budget_s:
+            t0 = time.perf_counter()
+            vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": w["B"] / med, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed forwards of the same batch (bs={w['B']}) after 3 warm-up, median",
+            "ms_per_batch": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=100)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+
+    w = WORKLOADS[args.workload]
+    cfg = make_cfg(w)
+    nppf0 = ec.num_prop_per_frm(cfg)
+    comm = {"vocab_size": VOCAB, "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1},
+            "num_prop_per_frm": nppf0}
+    sd = synth.init_state_dict(cfg, VOCAB, seed=1)
+    eng = eng_mod.VogEngine(cfg, comm)
+    eng.load_state_dict(sd)
+    cfg_id = int(args.workload[3:])
+    nstreams = max(1, args.streams)
+    slots, streams, batches = [], [], []
+    for s in range(nstreams):
+        b = synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=VOCAB,
+                             seed=1000 * cfg_id + rank * 16 + s)
+        batches.append(b)
+        slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
+                                   graph=not args.no_graph))
+        streams.append(torch.cuda.Stream(device=dev))
+    T = slots[0].T
+    gathered = [torch.empty((world * w["B"],) + tuple(slots[0].out["pred_rec"].shape[1:]),
+                            dtype=torch.float32, device=dev) for _ in range(nstreams)]
+
+    def step(i):
+        s = i % nstreams
+        out = slots[s].launch(streams[s])
+        if world > 1:
+            with torch.cuda.stream(streams[s]):
+                dist.all_gather_into_tensor(gathered[s], out["pred_rec"])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    chk = float(slots[0].out["mdl_outs_eval"].sum().item())
+    assert np.isfinite(chk)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    value = world * args.steps * w["B"] / dt
+    res = {
+        "metric": "queries/sec (VOGNet forward, gt5 spat, bs=4)", "value": value, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": w["tx"], "data": "synthetic",
+        "config": {"workload": w["desc"], "global_batch": world * w["B"], "batch_per_gpu": w["B"],
+                   "sentence_len": T, "streams_in_flight": nstreams, "hipgraph": not args.no_graph,
+                   "weights": "seeded default-init-like, vocab 5000",
+                   "parallelism": f"dp{world} (replicated weights, one RCCL all-gather of predictions per step)"},
+    }
+    # ---- roofline of the dominant kernel: HIP-event timing inside libvog_hip on this stream
+    flops, total_flops = kernel_flops(w, T)
+    ktimes = {}
+    for k in flops:
+        try:
+            ktimes[k] = eng.time_kernel(slots[0], k, args.kernel_iters)
+        except Exception as e:      # a kernel name absent for this model variant
+            ktimes[k] = None
+    lstm_us = eng.time_kernel(slots[0], "lstm_step", args.kernel_iters)
+    dom = max((k for k in flops if ktimes[k]), key=lambda k: ktimes[k])
+    ach = flops[dom] / (ktimes[dom] * 1e-6) / 1e12
+    res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
+                       "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None,
+                       "usec_per_launch": ktimes[dom], "flops_per_launch": flops[dom]}
+    res["kernels_usec"] = {k: (round(v, 2) if v else None) for k, v in ktimes.items()}
+    res["kernels_usec"]["lstm_step"] = round(lstm_us, 2)
+    res["forward_roofline"] = {"algorithmic_gflop_per_batch": total_flops / 1e9,
+                               "achieved_tflops": total_flops / (dt / args.steps) / 1e12,
+                               "frac_of_mfma_peak": total_flops / (dt / args.steps) / 1e12 / PEAK_MFMA_TFLOPS}
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(w, cfg, sd, batches[0])
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

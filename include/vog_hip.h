@@ -1,0 +1,250 @@
+/*
+ * vog_hip.h — C ABI of libvog_hip.so: the MI355X (gfx950) engine underneath the
+ * VOGNet forward path.
+ *
+ * The reference (TheShadow29/vognet-pytorch) has no FFI: its plugin boundary is
+ * the Python surface `get_mdl_loss_eval(cfg)` (code/mdl_selector.py:26-69),
+ * `cls(cfg, comm)` (code/mdl_base.py:11-22) and `forward(dict) -> dict`
+ * (code/mdl_conc_single.py:68-127, code/mdl_conc_sep.py:131-217). The build
+ * keeps that surface in `vognet-pytorch_amd/` and binds THIS library under it
+ * with ctypes. Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every entry returns int: 0 = ok, <0 = error (message: vog_last_error()).
+ *   - tensors are raw DEVICE pointers + explicit sizes; the caller owns every
+ *     buffer (inputs, outputs, workspace). No allocation, no hidden sync and no
+ *     global mutable state on the launch path => re-entrant across streams.
+ *   - `stream` is a hipStream_t passed as void* (torch: current_stream().cuda_stream).
+ *   - 16-bit tensors ("t16") are raw bf16 or IEEE f16 bit patterns, selected by
+ *     a vog_dtype argument; accumulation is always fp32.
+ *   - weights are HOST fp32 pointers handed over once (vog_ctx_set_weight) under
+ *     the reference's state_dict key names (utils/trn_utils.py:534-593 loads
+ *     exactly these keys), uploaded / converted / padded by vog_ctx_finalize.
+ */
+#ifndef VOG_HIP_H
+#define VOG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOG_ABI_VERSION 1
+
+typedef enum { VOG_BF16 = 0, VOG_F16 = 1 } vog_dtype;
+typedef enum { VOG_MDL_IGRND = 0, VOG_MDL_VGRND = 1, VOG_MDL_VOG = 2 } vog_mdl_kind;
+/* svsq is SEP with ncmp = 1 */
+typedef enum { VOG_CONC_SEP = 0, VOG_CONC_TEMP = 1, VOG_CONC_SPAT = 2 } vog_conc_type;
+
+int vog_version(void);
+const char* vog_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Operator level (one per hot-path kernel; used by the parity tests and by
+ * vog_forward internally)
+ * ------------------------------------------------------------------------- */
+
+/* C = act(A * W^T + bias) [+ residual]   — replaces nn.Linear everywhere on the
+ * path (transformer_code.py:58-61,77-81,169-172; mdl_vog.py:182-188,202-207,
+ * 224-230). A: [M,K] fp32 (a_is_f32=1) or t16, row pitch lda; optional row
+ * gather a_rows[M] (int32) — the embedding lookup of mdl_srl_utils.py:128.
+ * W: [N,K] t16 row pitch ldw (K % 8 == 0). Outputs (either may be NULL):
+ * c32 fp32 / c16 t16, row pitch ldc; output row = m*rep + j for j < rep
+ * (rep > 1 broadcasts a frame's segment feature onto its proposals,
+ * mdl_conc_single.py:51-66). */
+typedef struct vog_gemm_args {
+  const void* a; int a_is_f32; int64_t lda; const int32_t* a_rows;
+  const void* w; int64_t ldw;
+  const float* bias;           /* [N] or NULL */
+  const float* residual;       /* [M, ldr] fp32 or NULL (rep must be 1) */
+  int64_t ldr;
+  float* c32; void* c16; int64_t ldc; int64_t ldc16;
+  int M, N, K; int relu; int rep; vog_dtype dtype;
+} vog_gemm_args;
+int vog_gemm_bias_act(const vog_gemm_args* g, void* stream);
+
+/* Fused QKV projection for one (Rel)MultiHead (transformer_code.py:64-67,
+ * 180-183): x[S*N, K] * Wqkv_pad^T where Wqkv_pad is [3*H*dp, K] (heads padded
+ * to dp columns with zero rows). Writes q,k as [S,H,N,dp] and v TRANSPOSED as
+ * vt [S,H,dp,npad] (npad = N rounded up to 64; pad region must be zeroed once). */
+typedef struct vog_qkv_args {
+  const void* x16; int64_t ldx; const void* wqkv; int64_t ldw;
+  void* q; void* k; void* vt;
+  int S, N, H, dp, npad, K; vog_dtype dtype;
+} vog_qkv_args;
+int vog_qkv_proj(const vog_qkv_args* a, void* stream);
+
+/* softmax((q k^T + bias)/scale) v per (sequence, head), flash-style, with the
+ * relative-position bias computed on the fly: bias[i,j] = relu(u[i]-u[j]+pe_b[h])
+ * where u[token,h] = W_pe[h,:].box_norm[token,:]  (RelAttention.forward
+ * transformer_code.py:136-160 + compute_pe mdl_vog.py:456-490 + do_cross
+ * mdl_srl_utils.py:30-69 + Linear(5,H)+ReLU mdl_vog.py:446-451,580-585; the
+ * [S,N,N,H] tensor is never materialised). use_rel=0 gives Attention.forward
+ * (transformer_code.py:42-50). u: [n_vid, NP, H] fp32; token j of sequence s
+ * uses row (s / seq_per_vid)*NP + (s % seq_per_vid)*n_box + (j % n_box).
+ * out16: [S*N, H*dp] t16 (heads concatenated, padded). */
+typedef struct vog_attn_args {
+  const void* q; const void* k; const void* vt; void* out16;
+  const float* u; const float* pe_b;
+  int S, N, H, dp, npad; int use_rel; int n_box, seq_per_vid, NP;
+  float inv_scale; vog_dtype dtype;
+} vog_attn_args;
+int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
+
+/* y = LayerNorm(x) * gamma + beta, eps 1e-5 (ResidualBlock.forward
+ * transformer_code.py:30-31; the residual add is fused into the producing
+ * GEMM's epilogue). x,y32: [rows,d] fp32; y16 optional t16 copy. */
+int vog_residual_layernorm(const float* x, const float* gamma, const float* beta,
+                           float* y32, void* y16, int rows, int d, vog_dtype dtype,
+                           void* stream);
+
+/* u[v, r, h] = sum_c W_pe[h,c] * norm(box[v,r,c]), norm = x/vid_w, y/vid_h,
+ * x/vid_w, y/vid_h, frame/nfrm_div (compute_pe mdl_vog.py:456-463).
+ * props: [n_rows, 7] fp32 (pad_proposals). */
+int vog_box_u(const float* props, const float* w_pe, float* u, int n_rows, int H,
+              float vid_w, float vid_h, float nfrm_div, void* stream);
+
+/* Token re-index (get_srl_arg_seq_to_sent_seq mdl_vog.py:67-95):
+ * tok[b*T+t] = words[b, mask[b,t]] if mask[b,t] >= 0 else vocab_size. */
+int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask, int32_t* tok,
+                   int Bn, int T, int nsrl, int seq_len, int vocab_size, void* stream);
+
+/* One time step of one BiLSTM layer, both directions, packed-sequence
+ * semantics (LSTMEncoder.forward mdl_srl_utils.py:134-148; nn.LSTM gate order
+ * i,f,g,o). gx: [Bn*T, 8R] fp32 = x W_ih^T + b_ih + b_hh for (dir,gate,unit);
+ * whh: [2][4R][R] t16; h_in/h_out: [Bn16, 2R] t16 ping-pong state; c: [Bn16,2R]
+ * fp32; out16: [Bn*T, 2R] t16 (zero where t >= len). */
+typedef struct vog_lstm_step_args {
+  const float* gx; const void* whh; const void* h_in; void* h_out; float* c;
+  void* out16; const int64_t* lens; int Bn, T, R, step; vog_dtype dtype;
+} vog_lstm_step_args;
+int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
+
+/* lang[b,a,:] = relu(W [full[b,cap0] || full[b,cap1]] + bias) * msk
+ * (retrieve_srl_arg_from_lang_encode mdl_vog.py:97-140). full: [Bn*T, L] fp32. */
+int vog_srl_argvec(const float* full, const int64_t* capture, const int64_t* inds_msk,
+                   const float* w, const float* bias, float* lang,
+                   int Bn, int T, int nsrl, int L, void* stream);
+
+/* Build the mul_tx token matrix (concate_vis_lang_feats mdl_vog.py:316-344 +
+ * the regroup of conc_encode2 mdl_vog.py:693-699): row (s=(v,f), j=a*nppf+p) =
+ * [vis[v, f*nppf+p, :dv] || lang[lv(v), a, :dl]]; writes fp32 and t16 copies. */
+typedef struct vog_vislang_args {
+  const float* vis; const float* lang; float* x32; void* x16;
+  int n_vid, nfrm, nppf, nsrl, dv, dl; int lang_per_vid; /* 1: lang row = v, 0: v / nc_v */
+  int nc_v; vog_dtype dtype;
+} vog_vislang_args;
+int vog_vislang_layout(const vog_vislang_args* a, void* stream);
+
+/* lin2 second layer + inverse regroup + masks (mdl_vog.py:675-677, 724-737;
+ * mdl_conc_single.py:118-122): logit = w2.h1[row] + b2 scattered to
+ * mdl_outs[v, a, f*nppf+p]; eval = sigmoid * arg_msk * cmp_msk. */
+typedef struct vog_score_args {
+  const float* h1; const float* w2; const float* b2;
+  const int64_t* arg_msk; const int64_t* cmp_msk;
+  float* outs; float* outs_eval;
+  int n_vid, nfrm, nppf, nsrl, dh; int conc_type; int ncmp, nc_v, nvl, nfrm0, nppf0;
+} vog_score_args;
+int vog_score_head(const vog_score_args* a, void* stream);
+
+/* pred_cmp head of SEP (get_seg_verb_feats_to_process / compute_seg_verb_feats_out
+ * mdl_vog.py:365-397, compute_fin_scores mdl_conc_sep.py:64-129). */
+typedef struct vog_predcmp_args {
+  const float* final_hidden;   /* [B*nvl, L] fp32 */
+  const float* prop_seg;       /* [B*ncmp, NP, dps] fp32; seg part = cols [dp0, dps) */
+  const float* w0; const float* b0; const float* w2; const float* b2;
+  const float* outs;           /* mdl_outs [B, ncmp, nsrl, NP] */
+  const int64_t* arg_msk; const int64_t* cmp_msk; const int64_t* verb_ind;
+  float* vidf_outs; float* fin_scores_loss; float* fin_scores;
+  int B, ncmp, nvl, nsrl, NP, nfrm0, nppf0, L, dp0, dps;
+} vog_predcmp_args;
+int vog_pred_cmp_head(const vog_predcmp_args* a, void* stream);
+
+/* Evaluator*.get_out_results_boxes (eval_vsrl_corr.py:162-220,289-345,357-424):
+ * per (query,arg,video,frame) max/argmax over the frame's proposals, gather the
+ * 7-d proposal row, pred_cmp index. Output is ONE packed record per query (the
+ * unit of the cross-rank all-gather that replaces the pickle-file gather of
+ * eval_vsrl_corr.py:125-140):
+ *   float boxes[nsrl][ncmp][nfrm0][7]; float scores[nsrl][ncmp][nfrm0];
+ *   int64 indexs[nsrl][nfrm0]  (temp: zeros; the reference returns float zeros) */
+typedef struct vog_pred_args {
+  const float* outs_eval; const float* props; const float* fin_scores; void* rec;
+  int B, ncmp, nsrl, nfrm0, nppf0; int conc_type;
+} vog_pred_args;
+int64_t vog_pred_record_bytes(int ncmp, int nsrl, int nfrm0);
+int vog_pred_head(const vog_pred_args* a, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)
+ * ------------------------------------------------------------------------- */
+typedef struct vog_model_desc {
+  int mdl_kind, conc_type;
+  int vocab_size, emb_dim, rnn_size, rnn_layers;
+  int prop_dim, seg_dim, prop_enc, seg_enc, lang_enc;
+  int obj_layers, obj_heads, obj_use_rel, obj_one_frm, obj_to_use;
+  int mul_layers, mul_heads, mul_use_rel;
+  int nfrm0, nppf0, nsrl, seq_len;
+  float vid_w, vid_h;
+  int tx_dtype;      /* vog_dtype of the two transformers */
+  int enc_dtype;     /* vog_dtype of LSTM / encoders / score head (default f16) */
+} vog_model_desc;
+
+typedef struct vog_ctx vog_ctx;
+int vog_ctx_create(const vog_model_desc* d, vog_ctx** out);
+int vog_ctx_set_weight(vog_ctx* c, const char* name, const float* host, int64_t numel);
+int vog_ctx_finalize(vog_ctx* c);          /* synchronous; uploads + converts */
+int vog_ctx_destroy(vog_ctx* c);
+int vog_ctx_num_weights(const vog_ctx* c); /* names the model expects */
+const char* vog_ctx_weight_name(const vog_ctx* c, int i);
+int64_t vog_ctx_weight_numel(const vog_ctx* c, int i);
+
+typedef struct vog_batch {
+  int B, ncmp, T;                      /* T = max sentence length of the batch (host) */
+  const int64_t* srl_arg_words_ind;    /* [B,nvl,nsrl,seq_len] */
+  const int64_t* srl_arg_word_mask;    /* [B,nvl,seq_len]  (not modified) */
+  const int64_t* srl_arg_word_mask_len;/* [B,nvl] */
+  const int64_t* srl_arg_words_capture;/* [B,nvl,nsrl,2] */
+  const int64_t* srl_arg_inds_msk;     /* [B,nvl,nsrl] */
+  const int64_t* num_cmp_msk;          /* [B,ncmp] */
+  const int64_t* verb_ind_in_srl;      /* [B,ncmp] (sep) or NULL */
+  const float* pad_region_feature;     /* [B,(ncmp,)NP,prop_dim] */
+  const float* seg_feature_for_frms;   /* [B,(ncmp,)F,seg_dim] */
+  const float* pad_proposals;          /* [B,(ncmp,)NP,7] */
+  /* outputs (device, caller-owned) */
+  float* mdl_outs; float* mdl_outs_eval;           /* [B,nc_v,nsrl,NP] */
+  float* vidf_outs; float* fin_scores_loss; float* fin_scores;  /* sep only */
+  void* pred_rec;                                  /* [B] packed records or NULL */
+} vog_batch;
+
+int64_t vog_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T);
+/* zero the parts of a fresh workspace that kernels rely on (V^T key padding,
+ * LSTM state padding). Call once per (workspace, shape). */
+int vog_workspace_init(const vog_ctx* c, int B, int ncmp, int T, void* ws, size_t ws_bytes,
+                       void* stream);
+int vog_forward(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, void* stream);
+
+/* named intermediate inside the workspace (parity tests): returns offset/bytes */
+int vog_workspace_stage(const vog_ctx* c, int B, int ncmp, int T, const char* stage,
+                        int64_t* offset, int64_t* bytes);
+
+/* hipGraph capture of one forward with fixed pointers (launch-bound regime:
+ * ~50 launches per batch). */
+typedef struct vog_graph vog_graph;
+int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
+                      void* stream, vog_graph** out);
+int vog_graph_launch(vog_graph* g, void* stream);
+int vog_graph_destroy(vog_graph* g);
+
+/* HIP-event timing of `iters` back-to-back launches of ONE hot kernel of the
+ * forward on `stream` (bench.py roofline leg). kernel: "mul_qkv", "mul_attn",
+ * "mul_wo", "mul_ffn1", "mul_ffn2", "lin2", "obj_qkv", "obj_attn", "prop_enc".
+ * Returns average microseconds per launch in *usec. */
+int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
+                    const char* kernel, int iters, void* stream, float* usec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOG_HIP_H */

@@ -1,0 +1,48 @@
+"""Shared helpers of the -m gpu parity tests (product path = libvog_hip via ctypes)."""
+import importlib
+
+import numpy as np
+import torch
+
+from oracle import cases
+from oracle import vog_oracle as vo
+
+pkg = importlib.import_module("vognet-pytorch_amd")
+L = importlib.import_module("vognet-pytorch_amd.lib")
+engine_mod = importlib.import_module("vognet-pytorch_amd.engine")
+
+
+def rnd16(x: torch.Tensor, dtype: str) -> torch.Tensor:
+    t = torch.bfloat16 if dtype == "bf16" else torch.float16
+    return x.to(t)
+
+
+def t16(dtype: str):
+    return torch.bfloat16 if dtype == "bf16" else torch.float16
+
+
+def comm_for(c):
+    return {"vocab_size": c["vocab"], "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1},
+            "num_prop_per_frm": c["nppf0"]}
+
+
+def build_engine(name, tx_dtype="bf16"):
+    cfg, sd, batch, c = cases.build(name)
+    cfg.hip.tx_dtype = tx_dtype
+    eng = engine_mod.VogEngine(cfg, comm_for(c))
+    eng.load_state_dict(sd)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    return eng, cfg, sd, batch, c, dev
+
+
+def oracle_run(cfg, sd, batch, c, keep_stages=False):
+    oc = vo.OracleCfg.from_cfg(cfg, c["vocab"], c["nppf0"])
+    inp = vo.to_torch(batch)
+    with torch.no_grad():
+        out = vo.forward(oc, vo.to_torch(sd), inp, keep_stages=keep_stages)
+        out.update(vo.pred_head(oc, out, inp))
+    return out
+
+
+def rel_err(a: np.ndarray, ref: np.ndarray, floor=1e-6):
+    return np.abs(a - ref) / np.maximum(np.abs(ref), floor)

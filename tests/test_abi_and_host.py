@@ -1,0 +1,143 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header
+declares; host logic (config, selector, sharding, record layout, CLI parsing)."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = importlib.import_module("vognet-pytorch_amd.lib")
+ec = importlib.import_module("vognet-pytorch_amd.extended_config")
+sel = importlib.import_module("vognet-pytorch_amd.mdl_selector")
+D = importlib.import_module("vognet-pytorch_amd.dist")
+synth = importlib.import_module("vognet-pytorch_amd.synth")
+main_dist = importlib.import_module("vognet-pytorch_amd.main_dist")
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "vog_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vog_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = L.load()
+    names = _header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libvog_hip.so does not export {n}"
+        assert n in L.SYMBOLS, f"ctypes binding missing for {n}"
+    assert set(L.SYMBOLS) == set(names)
+    assert lib.vog_version() == 1
+    assert lib.vog_pred_record_bytes(4, 5, 10) == 6800     # 6800 B / query
+    assert lib.vog_pred_record_bytes(1, 5, 10) == 2000
+
+
+def test_ctx_weight_names_match_reference_state_dict_keys():
+    """vog_ctx_create is host-only: the expected weight list must be exactly the
+    keys the reference forward reads (SURVEY 8(b) Checkpoint)."""
+    lib = L.load()
+    eng = importlib.import_module("vognet-pytorch_amd.engine")
+    cfg = ec.get_default_cfg()
+    cfg.mdl.obj_tx.use_rel = True
+    comm = {"vocab_size": 5000, "num_prop_per_frm": 5}
+    d = eng.model_desc_from_cfg(cfg, comm)
+    h = ctypes.c_void_p()
+    assert lib.vog_ctx_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    n = lib.vog_ctx_num_weights(h)
+    exp = {lib.vog_ctx_weight_name(h, i).decode(): lib.vog_ctx_weight_numel(h, i) for i in range(n)}
+    sd = synth.init_state_dict(cfg, 5000)
+    unused = {k for k in sd if k.startswith(("srl_simple_lin", "lin_tmp"))}
+    assert set(exp) == set(sd) - unused
+    for k, v in exp.items():
+        assert v == sd[k].size, k
+    # wrong size / unknown name are rejected with a message
+    a = np.zeros(3, np.float32)
+    assert lib.vog_ctx_set_weight(h, b"lin2.2.bias", a.ctypes.data, 3) != 0
+    assert b"numel" in lib.vog_last_error()
+    assert lib.vog_ctx_set_weight(h, b"nope.weight", a.ctypes.data, 3) != 0
+    # DDP prefix and legacy LayerNorm names are accepted
+    g = np.ones(512, np.float32)
+    assert lib.vog_ctx_set_weight(h, b"module.obj_txf.encoder.layers.0.selfattn.layernorm.gamma",
+                                  g.ctypes.data, 512) == 0
+    assert lib.vog_ctx_finalize(h) != 0 and b"missing weight" in lib.vog_last_error()
+    lib.vog_ctx_destroy(h)
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    eng = importlib.import_module("vognet-pytorch_amd.engine")
+    cfg = ec.get_default_cfg()
+    with pytest.raises(L.VogError):
+        eng.VogEngine(cfg, {"vocab_size": 10, "num_prop_per_frm": 5})
+
+
+def test_selector_contract():
+    cfg = ec.get_default_cfg()
+    for ct in ("sep", "svsq", "temp", "spat"):
+        for m in ("igrnd", "vgrnd", "vog"):
+            cfg.ds.conc_type, cfg.mdl.name = ct, m
+            r = sel.get_mdl_loss_eval(cfg)
+            assert set(r) == {"mdl", "loss", "eval"}
+            want = {"igrnd": "ImgGrnd", "vgrnd": "VidGrnd", "vog": "VOG"}[m] + "_" + \
+                   ("SEP" if ct in ("sep", "svsq") else ct.upper())
+            assert r["mdl"].__name__ == want
+    cfg.mdl.name = "nope"
+    with pytest.raises(NotImplementedError):
+        sel.get_mdl_loss_eval(cfg)
+    cfg.mdl.name, cfg.ds.conc_type = "vog", "nope"
+    with pytest.raises(NotImplementedError):
+        sel.get_mdl_loss_eval(cfg)
+
+
+def test_model_state_dict_keys_and_load():
+    cfg = ec.get_default_cfg()
+    cfg.mdl.rnn.rnn_size = 32
+    cfg.mdl.input_encoding_size = 16
+    comm = {"vocab_size": 50, "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1}, "num_prop_per_frm": 5}
+    mdl = sel.get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm)
+    keys = set(mdl.state_dict().keys())
+    assert keys == set(synth.init_state_dict(cfg, 50).keys())
+    assert "obj_txf.encoder.layers.0.selfattn.layer.wq.weight" in keys
+    assert "lstm_encoder.lstm.weight_hh_l1_reverse" in keys
+    sd = {("module." + k): v for k, v in mdl.state_dict().items()}
+    g = sd.pop("module.mult_txf.encoder.layers.0.feedforward.layernorm.weight")
+    sd["module.mult_txf.encoder.layers.0.feedforward.layernorm.gamma"] = g
+    mdl.load_state_dict(sd, strict=True)
+
+
+def test_cfg_update_from_dict_checks():
+    cfg = ec.get_default_cfg()
+    ec.update_from_dict(cfg, {"mdl.obj_tx.use_rel": "True", "train.lr": "5e-4", "ds.conc_type": "temp"})
+    assert cfg.mdl.obj_tx.use_rel is True and cfg.train.lr == 5e-4 and cfg.ds.conc_type == "temp"
+    with pytest.raises(AssertionError):
+        ec.update_from_dict(cfg, {"mdl.no_such_key": 1})
+    with pytest.raises(AssertionError):
+        ec.update_from_dict(cfg, {"mdl.obj_tx.n_layers": "three"})
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.mdl.name = "igrnd"
+
+
+def test_cli_parse():
+    uid, kw = main_dist.parse_argv(["exp1", "--ds.conc_type=spat", "--mdl.obj_tx.use_rel=True",
+                                    "--local_rank", "3", "--only_val"])
+    assert uid == "exp1" and kw == {"ds.conc_type": "spat", "mdl.obj_tx.use_rel": "True",
+                                    "local_rank": "3", "only_val": "True"}
+
+
+def test_shard_matches_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    for n, w in ((10, 4), (16, 8), (7, 2), (5, 8)):
+        for r in range(w):
+            ds = DistributedSampler(list(range(n)), num_replicas=w, rank=r, shuffle=False)
+            total = ds.total_size
+            idx = list(range(n))
+            idx += idx[: total - n] if total - n <= n else (idx * (total // n + 1))[: total - n]
+            ref = idx[ds.num_samples * r: ds.num_samples * (r + 1)]
+            assert D.shard_indices(n, r, w) == ref, (n, w, r)

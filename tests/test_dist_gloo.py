@@ -1,0 +1,58 @@
+"""world_size-2 gloo run of the N>1 path on CPU: rank-contiguous sharding and
+the single all-gather of packed prediction records (rank-major order, i.e. what
+rank 0 gets by concatenating per-rank results in reference eval_vsrl_corr.py:130-137)."""
+import importlib
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+D = importlib.import_module("vognet-pytorch_amd.dist")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_queries, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = D.shard_indices(n_queries, rank, world)
+    # record of query i = [i, i+0.5, ...] (1700 fp32 words = 6800 B, the gt5 record)
+    rec = torch.stack([torch.full((1700,), float(i)) + torch.arange(1700) * 1e-3 for i in idx])
+    allr = D.all_gather_records(rec)
+    meta = D.all_gather_records(torch.tensor(idx, dtype=torch.int64).view(-1, 1))
+    if rank == 0:
+        q.put((allr[:, 0].tolist(), meta.view(-1).tolist()))
+    D.synchronize()
+    dist.destroy_process_group()
+
+
+def test_allgather_records_world2():
+    world, n = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    first, meta = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = D.shard_indices(n, 0, world) + D.shard_indices(n, 1, world)
+    assert meta == expect == [0, 1, 2, 3, 4, 5, 6, 0]
+    assert [int(x) for x in first] == expect
+
+
+def test_single_process_passthrough():
+    x = torch.randn(4, 1700)
+    assert D.all_gather_records(x) is x
+    assert D.shard_range(8, 1, 2) == (4, 8)

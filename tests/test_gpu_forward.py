@@ -1,0 +1,152 @@
+"""-m gpu: the HIP forward (libvog_hip through the C ABI) against the committed
+reference goldens and the CPU oracle.
+
+Tolerances (north_star: pred_boxes / pred_scores within 1e-3 rel of the
+reference fp32 CPU forward):
+  * pred_scores / mdl_outs_eval: max relative error <= 1e-3 where the reference
+    value is non-zero, exact zero where the reference is masked to zero.
+  * mdl_outs (logits): abs error <= 6e-3 (sigmoid' <= 1/4 maps that to <= 1.5e-3
+    abs on scores ~0.5; the binding bound is the relative one above).
+  * pred_boxes: an arg-max gather. Equal to the reference except where the
+    reference's top-2 proposals of that frame are within 2e-3 of each other
+    (a flip there is inside the score tolerance, SURVEY.md hard-part 2).
+  * indexs: same rule (arg-max over videos).
+Budget: bf16 operands in the two transformers, f16 elsewhere, fp32 accumulate
+— oracle-simulated at 4.5e-4 (tests/test_quant_budget.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from tests.gpu_util import build_engine, oracle_run, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FULL = [n for n in cases.CASES if n.startswith("full/") and "p100" not in n]
+SMALL = [n for n in cases.CASES if n.startswith("small/")]
+
+
+def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
+    msg = []
+    lo = out["mdl_outs"].cpu().numpy()
+    ev = out["mdl_outs_eval"].cpu().numpy()
+    assert lo.shape == g["mdl_outs"].shape
+    e_logit = float(np.abs(lo - g["mdl_outs"]).max())
+    nz = g["mdl_outs_eval"] != 0
+    assert np.all(ev[~nz] == 0), "masked entries must be exactly zero"
+    e_eval = float(rel_err(ev[nz], g["mdl_outs_eval"][nz]).max()) if nz.any() else 0.0
+    sc = pred["scores"].cpu().numpy()
+    snz = g["scores"] != 0
+    e_sc = float(rel_err(sc[snz], g["scores"][snz]).max()) if snz.any() else 0.0
+    msg.append(f"{name}: logit abs {e_logit:.2e} eval rel {e_eval:.2e} scores rel {e_sc:.2e}")
+    for k in ("vidf_outs", "fin_scores", "fin_scores_loss"):
+        if k in g.files:
+            e = float(np.abs(out[k].cpu().numpy() - g[k]).max())
+            msg.append(f"  {k} abs {e:.2e}")
+            assert e <= 4e-3, (k, e)
+    print("\n".join(msg))
+    assert e_logit <= tol_logit, msg
+    assert e_eval <= tol_rel and e_sc <= tol_rel, msg
+    # boxes: equal, or a near-tie flip
+    bx = pred["boxes"].cpu().numpy()
+    diff = np.any(bx != g["boxes"], axis=-1)
+    nflip = int(diff.sum())
+    if nflip:
+        # the score of the box we picked must be within tolerance of the reference max
+        bad = rel_err(sc[diff], g["scores"][diff]) > 2e-3
+        assert not bad.any(), f"{name}: {int(bad.sum())} box flips outside the score tolerance"
+    idx = pred["indexs"].cpu().numpy()
+    assert idx.dtype == g["indexs"].dtype and idx.shape == g["indexs"].shape
+    d_idx = idx != g["indexs"]
+    if d_idx.any():
+        assert d_idx.mean() < 0.05, f"{name}: {d_idx.mean():.3f} of pred_cmp indices differ"
+    return nflip
+
+
+def _run(name, tx_dtype="bf16", graph=False):
+    eng, cfg, sd, batch, c, dev = build_engine(name, tx_dtype)
+    before = {k: v.clone() for k, v in dev.items()}
+    if graph:
+        slot = eng.make_slot(dev, graph=True)
+        slot.launch()
+        torch.cuda.synchronize()
+        out = slot.launch()
+    else:
+        out = eng.forward(dev)
+    torch.cuda.synchronize()
+    for k in before:                       # inputs are borrowed, never modified
+        assert torch.equal(before[k], dev[k]), k
+    ncmp = batch["new_srl_idxs"].shape[1]
+    pred = eng.unpack_pred(out["pred_rec"], ncmp)
+    g = np.load(cases.golden_path(name))
+    return out, pred, g, (cfg, sd, batch, c)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_forward_full_vs_reference_golden(name):
+    out, pred, g, _ = _run(name)
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_forward_small_vs_reference_golden(name):
+    out, pred, g, _ = _run(name)
+    _check_against(name, out, pred, g, None, tol_rel=2e-3, tol_logit=1.2e-2)
+
+
+def test_forward_f16_transformers():
+    """cfg 5 flavour: fp16 MFMA path with fp32 accumulate."""
+    name = "full/cfg5_vog_svsq_gt5_bs16"
+    out, pred, g, _ = _run(name, tx_dtype="f16")
+    _check_against(name, out, pred, g, None, tol_rel=5e-4, tol_logit=3e-3)
+
+
+def test_forward_graph_replay_matches_eager():
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    out_e, pred_e, g, _ = _run(name)
+    out_g, pred_g, _, _ = _run(name, graph=True)
+    assert torch.equal(out_e["mdl_outs"], out_g["mdl_outs"])
+    assert torch.equal(out_e["pred_rec"], out_g["pred_rec"])
+
+
+def test_forward_p100_vs_reference_golden():
+    name = "full/cfg4_vog_spat_p100_bs4"
+    out, pred, g, _ = _run(name)
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+def test_stages_vs_oracle():
+    """Stage-by-stage localisation on cfg 2 (which kernel is off, if any)."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    out = eng.forward(dev)
+    torch.cuda.synchronize()
+    ora = oracle_run(cfg, sd, batch, c, keep_stages=True)
+    st = ora["stages"]
+    B, ncmp, T = 4, 4, int(batch["srl_arg_word_mask_len"].max())
+    tok = eng.stage(B, ncmp, T, "tok", torch.int32, (B, T)).cpu()
+    assert torch.equal(tok.long(), st["tokens"][:, :T])
+    full = eng.stage(B, ncmp, T, "full", torch.float32, (B * T + 16, 256)).cpu()
+    e = (full[: B * T].view(B, T, 256) - st["lstm_full_output"]).abs().max().item()
+    print("lstm_full_output abs err", e)
+    assert e < 5e-3
+    e = (full[B * T: B * T + B] - st["final_hidden"]).abs().max().item()
+    print("final_hidden abs err", e)
+    assert e < 5e-3
+    lang = eng.stage(B, ncmp, T, "lang", torch.float32, (B, 1, 5, 256)).cpu()
+    e = (lang - st["lang"]).abs().max().item()
+    print("lang abs err", e)
+    assert e < 5e-3
+    ps = eng.stage(B, ncmp, T, "prop_seg", torch.float32, (B, 1, 200, 512)).cpu()
+    e = (ps - st["prop_seg"]).abs().max().item()
+    print("prop_seg abs err", e, "max", st["prop_seg"].abs().max().item())
+    assert e < 1e-2
+    oo = eng.stage(B, ncmp, T, "obj_outA", torch.float32, (B, 1, 200, 512)).cpu()
+    e = (oo - st["obj_out"]).abs().max().item()
+    print("obj_out abs err", e)
+    assert e < 3e-2
+    mo = eng.stage(B, ncmp, T, "mul_outA", torch.float32, (40, 100, 768)).cpu()
+    e = (mo - st["mul_out"]).abs().max().item()
+    print("mul_out abs err", e)
+    assert e < 3e-2

@@ -1,0 +1,274 @@
+"""-m gpu: every operator-level entry point of the C ABI against a plain
+fp32 torch reference of the same op on the same (already rounded) operands.
+Inputs are asymmetric random data (a transposed MFMA operand / C layout cannot
+pass). Tolerances are written per test."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vog_oracle as vo
+from tests.gpu_util import L, t16
+
+pytestmark = pytest.mark.gpu
+DT = {"bf16": L.VOG_BF16, "f16": L.VOG_F16}
+
+
+def _lib():
+    return L.load()
+
+
+def _sp():
+    return L.stream_ptr()
+
+
+def _gemm(a, w, bias=None, residual=None, relu=False, rep=1, rows=None, dtype="bf16",
+          want16=False, M=None):
+    lib = _lib()
+    M = M if M is not None else (a.shape[0] if rows is None else rows.numel())
+    N, K = w.shape
+    g = L.GemmArgs()
+    g.a, g.a_is_f32, g.lda = L.ptr(a), int(a.dtype == torch.float32), a.shape[1]
+    g.a_rows = L.ptr(rows)
+    g.w, g.ldw = L.ptr(w), K
+    g.bias, g.residual, g.ldr = L.ptr(bias), L.ptr(residual), N
+    c32 = torch.full((M * rep, N), float("nan"), device="cuda")
+    c16 = torch.zeros((M * rep, N), dtype=t16(dtype), device="cuda") if want16 else None
+    g.c32, g.c16, g.ldc, g.ldc16 = L.ptr(c32), L.ptr(c16), N, N
+    g.M, g.N, g.K, g.relu, g.rep, g.dtype = M, N, K, int(relu), rep, DT[dtype]
+    L.check(lib.vog_gemm_bias_act(C.byref(g), _sp()), "gemm")
+    torch.cuda.synchronize()
+    return c32, c16
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(800, 256, 2048), (4000, 768, 576), (4000, 2304, 768),
+                                   (130, 70, 48), (48, 8192, 512), (52, 256, 2048), (20, 96, 64),
+                                   (333, 200, 72), (1, 16, 32)])
+def test_gemm_t16_operands(M, N, K, dtype):
+    torch.manual_seed(M * 7 + N)
+    a = torch.randn(M, K, device="cuda").to(t16(dtype))
+    w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(t16(dtype))
+    bias = torch.randn(N, device="cuda")
+    c32, c16 = _gemm(a, w, bias=bias, relu=True, dtype=dtype, want16=True)
+    ref = torch.relu(a.float() @ w.float().t() + bias)
+    err = (c32 - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err       # fp32 accumulation order only
+    assert (c16.float() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [40, 160, 800])
+def test_gemm_f32_a_residual_rep_gather(M):
+    torch.manual_seed(3)
+    K, N = 96, 64
+    table = torch.randn(500, K, device="cuda")
+    rows = torch.randint(0, 500, (M,), device="cuda", dtype=torch.int32)
+    w = (torch.randn(N, K, device="cuda") / 8).to(torch.float16)
+    c32, _ = _gemm(table, w, rows=rows, dtype="f16")
+    ref = table[rows.long()].half().float() @ w.float().t()
+    assert (c32 - ref).abs().max().item() <= 2e-3
+    # residual
+    a = torch.randn(M, K, device="cuda")
+    res = torch.randn(M, N, device="cuda")
+    c32, _ = _gemm(a, w, residual=res, dtype="f16")
+    ref = a.half().float() @ w.float().t() + res
+    assert (c32 - ref).abs().max().item() <= 2e-3
+    # row replication (segment feature broadcast onto the frame's proposals)
+    c32, c16 = _gemm(a, w, rep=5, dtype="f16", want16=True)
+    ref = (a.half().float() @ w.float().t()).repeat_interleave(5, dim=0)
+    assert (c32 - ref).abs().max().item() <= 2e-3
+    assert (c16.float() - ref).abs().max().item() <= 2e-2
+
+
+def _attn_ref(q, k, v, u, peb, n_box, inv_scale, use_rel):
+    """q,k,v [S,H,N,dh] fp32 (already rounded); u [S,N,H]"""
+    logits = q @ k.transpose(-1, -2)
+    if use_rel:
+        ub = u.permute(0, 2, 1)                                # [S,H,N]
+        bias = torch.relu(ub.unsqueeze(-1) - ub.unsqueeze(-2) + peb.view(1, -1, 1, 1))
+        logits = logits + bias
+    p = torch.softmax(logits * inv_scale, dim=-1)
+    return p @ v
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("S,N,H,dh,dp,nsrl,use_rel", [
+    (40, 100, 3, 256, 256, 5, 1), (4, 200, 3, 171, 192, 1, 1), (6, 25, 3, 256, 256, 5, 1),
+    (3, 140, 3, 11, 32, 1, 1), (2, 700, 2, 64, 64, 1, 0), (5, 50, 3, 100, 128, 2, 1),
+    (2, 33, 1, 16, 32, 1, 1)])
+def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
+    lib = _lib()
+    torch.manual_seed(S * 1000 + N)
+    td = t16(dtype)
+    npad = (N + 63) // 64 * 64
+    q = torch.zeros(S, H, N, dp, device="cuda")
+    k = torch.zeros(S, H, N, dp, device="cuda")
+    v = torch.zeros(S, H, N, dp, device="cuda")
+    q[..., :dh] = torch.randn(S, H, N, dh, device="cuda") * 2
+    k[..., :dh] = torch.randn(S, H, N, dh, device="cuda") * 2
+    v[..., :dh] = torch.randn(S, H, N, dh, device="cuda")
+    q16, k16 = q.to(td), k.to(td)
+    # V^T with NaN in the key padding: the kernel must mask it, not multiply it
+    vt16 = torch.full((S, H, dp, npad), float("nan"), device="cuda").to(td)
+    vt16[..., :N] = v.transpose(-1, -2).to(td)
+    n_box = N // nsrl
+    NP = n_box                      # one sequence per "video" here
+    u_box = torch.randn(S, n_box, H, device="cuda") * 3
+    peb = torch.randn(H, device="cuda")
+    out = torch.full((S * N, H * dp), float("nan"), device="cuda").to(td)
+    inv_scale = 1.0 / math.sqrt(H * dh)
+    a = L.AttnArgs()
+    a.q, a.k, a.vt, a.out16 = L.ptr(q16), L.ptr(k16), L.ptr(vt16.contiguous()), L.ptr(out)
+    a.u, a.pe_b = L.ptr(u_box.contiguous()), L.ptr(peb)
+    a.S, a.N, a.H, a.dp, a.npad = S, N, H, dp, npad
+    a.use_rel, a.n_box, a.seq_per_vid, a.NP = use_rel, n_box, 1, NP
+    a.inv_scale, a.dtype = inv_scale, DT[dtype]
+    L.check(lib.vog_rel_attention_fwd(C.byref(a), _sp()), "attn")
+    torch.cuda.synchronize()
+    u_tok = u_box.repeat(1, nsrl, 1)                            # token j -> box j % n_box
+    ref = _attn_ref(q16.float(), k16.float(), vt16[..., :N].transpose(-1, -2).float(), u_tok, peb,
+                    n_box, inv_scale, use_rel)                  # [S,H,N,dp]
+    got = out.float().view(S, N, H, dp).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    tol = (2.5e-2 if dtype == "bf16" else 4e-3) * max(1.0, ref.abs().max().item())
+    assert err <= tol, (err, tol)
+    assert (got[..., dh:] == 0).all()                           # padded head columns stay zero
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_qkv_layout(dtype):
+    lib = _lib()
+    torch.manual_seed(5)
+    S, N, H, d = 3, 37, 3, 32
+    heads = vo.chunk_sizes(d, H)                                # 11, 11, 10
+    dp, npad = 32, 64
+    td = t16(dtype)
+    x = torch.randn(S * N, d, device="cuda").to(td)
+    wq, wk, wv = (torch.randn(d, d, device="cuda") / 6 for _ in range(3))
+    wpad = torch.zeros(3 * H * dp, d, device="cuda")
+    off = 0
+    for h, dh in enumerate(heads):
+        for which, w in enumerate((wq, wk, wv)):
+            wpad[(which * H + h) * dp:(which * H + h) * dp + dh] = w[off:off + dh]
+        off += dh
+    wpad = wpad.to(td)
+    q = torch.full((S, H, N, dp), float("nan"), device="cuda").to(td)
+    k = torch.full((S, H, N, dp), float("nan"), device="cuda").to(td)
+    vt = torch.zeros((S, H, dp, npad), device="cuda").to(td)
+    a = L.QkvArgs()
+    a.x16, a.ldx, a.wqkv, a.ldw = L.ptr(x), d, L.ptr(wpad), d
+    a.q, a.k, a.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
+    a.S, a.N, a.H, a.dp, a.npad, a.K, a.dtype = S, N, H, dp, npad, d, DT[dtype]
+    L.check(lib.vog_qkv_proj(C.byref(a), _sp()), "qkv")
+    torch.cuda.synchronize()
+    full = (x.float() @ wpad.float().t()).view(S, N, 3, H, dp)
+    tol = 2e-2
+    assert (q.float() - full[:, :, 0].permute(0, 2, 1, 3)).abs().max().item() <= tol
+    assert (k.float() - full[:, :, 1].permute(0, 2, 1, 3)).abs().max().item() <= tol
+    assert (vt.float()[..., :N] - full[:, :, 2].permute(0, 2, 3, 1)).abs().max().item() <= tol
+
+
+def test_layernorm():
+    lib = _lib()
+    torch.manual_seed(1)
+    for rows, d in ((4000, 768), (801, 512), (7, 48), (5, 32)):
+        x = torch.randn(rows, d, device="cuda") * 3 + 1
+        g = torch.randn(d, device="cuda")
+        b = torch.randn(d, device="cuda")
+        y32 = torch.empty_like(x)
+        y16 = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.vog_residual_layernorm(L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(y32), L.ptr(y16),
+                                           rows, d, L.VOG_BF16, _sp()), "ln")
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)
+        assert (y32 - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) + 2e-5
+        assert torch.equal(y16, y32.to(torch.bfloat16))
+
+
+def test_box_u_and_bias_identity():
+    """u-form of the bias == the reference's Linear(5,H) on box differences."""
+    lib = _lib()
+    torch.manual_seed(2)
+    n, H = 200, 3
+    props = torch.rand(n, 7, device="cuda") * torch.tensor([2880., 405, 2880, 405, 9, 400, 1], device="cuda")
+    w = torch.randn(H, 5, device="cuda")
+    b = torch.randn(H, device="cuda")
+    u = torch.empty(n, H, device="cuda")
+    L.check(lib.vog_box_u(L.ptr(props), L.ptr(w), L.ptr(u), n, H, 720.0, 405.0, 10.0, _sp()), "box_u")
+    torch.cuda.synchronize()
+    bx = vo.normalise_boxes(props[:, :5].cpu(), 720.0, 405.0, 10.0)
+    for h in range(H):
+        ref = vo.box_bias_head(bx.unsqueeze(0), w[h].cpu(), b[h].cpu())[0]
+        got = torch.relu(u[:, h].cpu().unsqueeze(1) - u[:, h].cpu().unsqueeze(0) + b[h].cpu())
+        assert (got - ref).abs().max().item() <= 2e-5
+
+
+def test_srl_gather_and_argvec():
+    lib = _lib()
+    from oracle import cases
+    cfg, sd, batch, c = cases.build("small/vog_sep")
+    words = torch.from_numpy(batch["srl_arg_words_ind"]).cuda()
+    mask = torch.from_numpy(batch["srl_arg_word_mask"]).cuda()
+    B, nv = words.shape[:2]
+    T = int(batch["srl_arg_word_mask_len"].max())
+    tok = torch.empty(B * nv, T, dtype=torch.int32, device="cuda")
+    keep = mask.clone()
+    L.check(lib.vog_srl_gather(L.ptr(words), L.ptr(mask), L.ptr(tok), B * nv, T, 5, 20, c["vocab"], _sp()), "g")
+    torch.cuda.synchronize()
+    ref = vo.srl_arg_seq_to_sent_seq(words.cpu(), mask.cpu(), c["vocab"])[:, :T]
+    assert torch.equal(tok.cpu().long(), ref)
+    assert torch.equal(keep, mask)
+    Ld = 16
+    full = torch.randn(B * nv * T, Ld, device="cuda")
+    cap = torch.from_numpy(batch["srl_arg_words_capture"]).cuda()
+    msk = torch.from_numpy(batch["srl_arg_inds_msk"]).cuda()
+    w = torch.randn(Ld, 2 * Ld, device="cuda")
+    bb = torch.randn(Ld, device="cuda")
+    lang = torch.empty(B * nv, 5, Ld, device="cuda")
+    L.check(lib.vog_srl_argvec(L.ptr(full), L.ptr(cap), L.ptr(msk), L.ptr(w), L.ptr(bb), L.ptr(lang),
+                               B * nv, T, 5, Ld, _sp()), "argvec")
+    torch.cuda.synchronize()
+    sdd = {"srl_arg_words_out_enc.0.weight": w.cpu(), "srl_arg_words_out_enc.0.bias": bb.cpu()}
+    ref = vo.retrieve_srl_args(full.cpu().view(B * nv, T, Ld), cap.cpu(), msk.cpu(), sdd)
+    assert (lang.cpu().view_as(ref) - ref).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("conc", ["spat", "temp", "sep"])
+def test_pred_head_exact(conc):
+    """Integer/index work: bit-exact against the oracle head, ties included."""
+    lib = _lib()
+    torch.manual_seed(4)
+    B, ncmp, nsrl, nf, np0 = 3, 4, 5, 10, 5
+    oc = vo.OracleCfg(conc_type=conc, nppf0=np0)
+    if conc == "sep":
+        ev = torch.rand(B, ncmp, nsrl, nf * np0)
+        props = torch.rand(B, ncmp, nf * np0, 7)
+    else:
+        ev = torch.rand(B, 1, nsrl, ncmp * nf * np0)
+        props = torch.rand(B, ncmp * nf * np0, 7)
+    ev[0, 0, 4] = 0.0                         # masked argument: all ties -> first index
+    ev[1, 0, 1, :7] = 0.5                     # exact ties inside a frame
+    fin = torch.rand(B, ncmp)
+    out = {"mdl_outs_eval": ev, "fin_scores": fin}
+    inp = {"pad_proposals": props, "new_srl_idxs": torch.zeros(B, ncmp, dtype=torch.int64)}
+    ref = vo.pred_head(oc, out, inp)
+    rb = int(lib.vog_pred_record_bytes(ncmp, nsrl, nf))
+    rec = torch.empty(B, rb // 4, device="cuda")
+    a = L.PredArgs()
+    evd, prd, find = ev.cuda(), props.cuda(), fin.cuda()
+    a.outs_eval, a.props, a.fin_scores, a.rec = L.ptr(evd), L.ptr(prd), L.ptr(find), L.ptr(rec)
+    a.B, a.ncmp, a.nsrl, a.nfrm0, a.nppf0, a.conc_type = B, ncmp, nsrl, nf, np0, L.CONC_TYPE[conc]
+    L.check(lib.vog_pred_head(C.byref(a), _sp()), "pred")
+    torch.cuda.synchronize()
+    nb = nsrl * ncmp * nf
+    r = rec.cpu()
+    assert torch.equal(r[:, : nb * 7].reshape(B, nsrl, ncmp, nf, 7), ref["boxes"])
+    assert torch.equal(r[:, nb * 7: nb * 8].reshape(B, nsrl, ncmp, nf), ref["scores"])
+    idx = r[:, nb * 8:].contiguous().view(torch.int64).reshape(B, nsrl, nf)
+    if conc == "temp":
+        assert (idx == 0).all()
+    else:
+        assert torch.equal(idx, ref["indexs"])

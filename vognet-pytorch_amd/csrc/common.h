@@ -1,0 +1,89 @@
+// Shared device/host helpers for libvog_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/vog_hip.h"
+
+namespace vog {
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define VOG_FAIL(code, ...) do { ::vog::set_error(__VA_ARGS__); return (code); } while (0)
+#define VOG_CHECK_ARG(cond) do { if (!(cond)) VOG_FAIL(-1, "%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); } while (0)
+#define VOG_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) VOG_FAIL(-(int)e_ - 1000, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); } while (0)
+#define VOG_LAUNCH_CHECK() VOG_HIP(hipGetLastError())
+#define VOG_TRY(expr) do { int r_ = (expr); if (r_ != 0) return r_; } while (0)
+
+// ---- vector types ------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct BF16 {};   // tags for the 16-bit storage/MFMA type
+struct F16 {};
+
+// fp32 -> 16-bit (round to nearest even) and back; raw bit patterns in memory.
+template <typename T> __device__ __forceinline__ unsigned short to16(float f);
+template <> __device__ __forceinline__ unsigned short to16<BF16>(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <> __device__ __forceinline__ unsigned short to16<F16>(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+template <typename T> __device__ __forceinline__ float from16(unsigned short v);
+template <> __device__ __forceinline__ float from16<BF16>(unsigned short v) {
+  return __uint_as_float(((unsigned int)v) << 16);
+}
+template <> __device__ __forceinline__ float from16<F16>(unsigned short v) {
+  return (float)__builtin_bit_cast(_Float16, v);
+}
+
+// ---- MFMA wrappers (fp32 accumulate) ----------------------------------------------
+// 32x32x16: A lane l holds row (l&31), k = (l>>5)*8+j; B lane l holds col (l&31),
+// same k; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+template <typename T> __device__ __forceinline__ f32x16 mfma32(u16x8 a, u16x8 b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma32<BF16>(u16x8 a, u16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma32<F16>(u16x8 a, u16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// 16x16x32: A lane l holds row (l&15), k = (l>>4)*8+j; B lane l holds col (l&15);
+// C/D: col = l&15, row = (l>>4)*4 + reg.
+template <typename T> __device__ __forceinline__ f32x4 mfma16(u16x8 a, u16x8 b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma16<BF16>(u16x8 a, u16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma16<F16>(u16x8 a, u16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int c32_row(int reg, int lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// dispatch a templated launcher on the runtime 16-bit type
+#define VOG_DISPATCH_DTYPE(dt, ...)                          \
+  do {                                                       \
+    if ((dt) == VOG_BF16) { using T16 = ::vog::BF16; __VA_ARGS__; } \
+    else if ((dt) == VOG_F16) { using T16 = ::vog::F16; __VA_ARGS__; } \
+    else VOG_FAIL(-1, "unknown vog_dtype %d", (int)(dt));    \
+  } while (0)
+
+}  // namespace vog

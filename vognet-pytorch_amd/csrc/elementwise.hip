@@ -1,0 +1,395 @@
+// HBM/latency-bound kernels of the forward path: layernorm, box-bias precursor,
+// token re-index, argument vectors, vis||lang token layout, score head,
+// pred_cmp head, prediction head. fp32 arithmetic throughout (these are exact
+// restatements; only the MFMA contractions run in 16 bit).
+#include "common.h"
+
+namespace vog {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------
+// K3 layernorm: one wave per row, row held in registers (d <= 1024)
+// (ResidualBlock.forward transformer_code.py:30-31, nn.LayerNorm eps 1e-5)
+// ---------------------------------------------------------------------------
+template <typename T16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        float* __restrict__ y32,
+                                                        unsigned short* __restrict__ y16,
+                                                        int rows, int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * d;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < d ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    const float t = c < d ? v[i] - mean : 0.f;
+    q += t * t;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    if (c < d) {
+      const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (y32) y32[(int64_t)row * d + c] = o;
+      if (y16) y16[(int64_t)row * d + c] = to16<T16>(o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// u[row,h] = W_pe[h,:] . norm(box[row,:5])   (compute_pe mdl_vog.py:456-463)
+// ---------------------------------------------------------------------------
+__global__ void box_u_kernel(const float* __restrict__ props, const float* __restrict__ w,
+                             float* __restrict__ u, int n_rows, int H, float vid_w, float vid_h,
+                             float nfrm_div) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * H) return;
+  const int r = i / H, h = i % H;
+  const float* b = props + (int64_t)r * 7;
+  // true divisions, as the reference normalises (not multiplies by a reciprocal)
+  const float b0 = b[0] / vid_w, b1 = b[1] / vid_h, b2 = b[2] / vid_w, b3 = b[3] / vid_h,
+              b4 = b[4] / nfrm_div;
+  const float* wh = w + h * 5;
+  u[i] = wh[0] * b0 + wh[1] * b1 + wh[2] * b2 + wh[3] * b3 + wh[4] * b4;
+}
+
+// ---------------------------------------------------------------------------
+// K6 token re-index (get_srl_arg_seq_to_sent_seq mdl_vog.py:67-95)
+// ---------------------------------------------------------------------------
+__global__ void srl_gather_kernel(const int64_t* __restrict__ words, const int64_t* __restrict__ mask,
+                                  int32_t* __restrict__ tok, int Bn, int T, int nsrl, int seq_len,
+                                  int vocab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bn * T) return;
+  const int b = i / T, t = i % T;
+  const int64_t m = mask[(int64_t)b * seq_len + t];
+  int64_t v = vocab;
+  if (m >= 0 && m < (int64_t)nsrl * seq_len) v = words[(int64_t)b * nsrl * seq_len + m];
+  tok[i] = (int32_t)v;
+}
+
+// ---------------------------------------------------------------------------
+// argument vectors (retrieve_srl_arg_from_lang_encode mdl_vog.py:97-140)
+// one workgroup per (sentence, arg); wave-per-output dot products, fp32 exact
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ full,
+                                                     const int64_t* __restrict__ capture,
+                                                     const int64_t* __restrict__ msk,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ lang, int T, int nsrl, int L) {
+  extern __shared__ float xin[];               // [2L]
+  const int ba = blockIdx.x;                   // b*nsrl + a
+  const int b = ba / nsrl;
+  int64_t c0 = capture[(int64_t)ba * 2], c1 = capture[(int64_t)ba * 2 + 1];
+  c0 = c0 < 0 ? 0 : (c0 >= T ? T - 1 : c0);
+  c1 = c1 < 0 ? 0 : (c1 >= T ? T - 1 : c1);
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    xin[i] = full[((int64_t)b * T + c0) * L + i];
+    xin[L + i] = full[((int64_t)b * T + c1) * L + i];
+  }
+  __syncthreads();
+  const float mk = (float)msk[ba];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int o = wid; o < L; o += nw) {
+    const float* wr = w + (int64_t)o * 2 * L;
+    float acc = 0.f;
+    for (int i = lane; i < 2 * L; i += 64) acc += wr[i] * xin[i];
+    acc = wave_sum(acc);
+    if (lane == 0) lang[(int64_t)ba * L + o] = fmaxf(acc + bias[o], 0.f) * mk;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4 vis||lang token layout (concate_vis_lang_feats mdl_vog.py:316-344 + the
+// regroup of conc_encode2 :693-699). Row (s=(v,f), j=a*nppf+p).
+// ---------------------------------------------------------------------------
+template <typename T16>
+__global__ __launch_bounds__(256) void vislang_kernel(vog_vislang_args a) {
+  const int64_t row = blockIdx.x;
+  const int N = a.nsrl * a.nppf;
+  const int s = (int)(row / N), j = (int)(row % N);
+  const int v = s / a.nfrm, f = s % a.nfrm;
+  const int arg = j / a.nppf, pp = j % a.nppf;
+  const float* vis = a.vis + ((int64_t)v * a.nfrm * a.nppf + (int64_t)f * a.nppf + pp) * a.dv;
+  const int lv = a.lang_per_vid ? v : v / a.nc_v;
+  const float* lang = a.lang + ((int64_t)lv * a.nsrl + arg) * a.dl;
+  const int d = a.dv + a.dl;
+  float* x32 = a.x32 ? a.x32 + row * d : nullptr;
+  unsigned short* x16 = a.x16 ? reinterpret_cast<unsigned short*>(a.x16) + row * d : nullptr;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    const float val = c < a.dv ? vis[c] : lang[c - a.dv];
+    if (x32) x32[c] = val;
+    if (x16) x16[c] = to16<T16>(val);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K7 score head tail: lin2.2 + inverse regroup + masks
+// (mdl_vog.py:675-677,724-737; mdl_conc_single.py:39-49,118-122,144-154;
+//  mdl_conc_sep.py:32-42,205-210). One wave per token row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_kernel(vog_score_args a) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int N = a.nsrl * a.nppf;
+  const int64_t nrows = (int64_t)a.n_vid * a.nfrm * N;
+  if (row >= nrows) return;
+  const float* h = a.h1 + row * a.dh;
+  float acc = 0.f;
+  for (int i = lane; i < a.dh; i += 64) acc += h[i] * a.w2[i];
+  acc = wave_sum(acc);
+  if (lane != 0) return;
+  const float logit = acc + a.b2[0];
+  const int s = (int)(row / N), j = (int)(row % N);
+  const int v = s / a.nfrm, f = s % a.nfrm;
+  const int arg = j / a.nppf, pp = j % a.nppf;
+  const int NP = a.nfrm * a.nppf;
+  const int r = f * a.nppf + pp;                     // proposal row inside the model video
+  const int64_t o = ((int64_t)v * a.nsrl + arg) * NP + r;
+  const int b = v / a.nc_v, c = v % a.nc_v;
+  int cmp;
+  if (a.conc_type == VOG_CONC_TEMP) cmp = r / (a.nfrm0 * a.nppf0);
+  else if (a.conc_type == VOG_CONC_SPAT) cmp = (r / a.nppf0) % a.ncmp;
+  else cmp = c;
+  const int lrow = a.nvl > 1 ? (b * a.nvl + c) : b;  // language copy of this video
+  const float am = (float)a.arg_msk[(int64_t)lrow * a.nsrl + arg];
+  const float cm = (float)a.cmp_msk[(int64_t)b * a.ncmp + cmp];
+  a.outs[o] = logit;
+  a.outs_eval[o] = sigmoidf_(logit) * am * cm;
+}
+
+// ---------------------------------------------------------------------------
+// K8 pred_cmp head (mdl_vog.py:365-397; mdl_conc_sep.py:64-129). One workgroup
+// per (query, video).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void predcmp_kernel(vog_predcmp_args a) {
+  extern __shared__ float sm[];                 // [L + dseg] input, [256] hidden, [nsrl] s
+  const int bc = blockIdx.x, b = bc / a.ncmp, c = bc % a.ncmp;
+  const int dseg = a.dps - a.dp0;
+  const int din = a.L + dseg;
+  float* xin = sm;
+  float* hid = sm + din;
+  float* sarg = hid + 256;
+  const int lrow = a.nvl > 1 ? (b * a.nvl + c) : b;
+  const int Fv = a.NP / a.nppf0;
+  for (int i = threadIdx.x; i < din; i += blockDim.x) {
+    if (i < a.L) xin[i] = a.final_hidden[(int64_t)lrow * a.L + i];
+    else {
+      float s = 0.f;                            // mean over frames of the segment encoding
+      for (int f = 0; f < Fv; ++f)
+        s += a.prop_seg[((int64_t)bc * a.NP + (int64_t)f * a.nppf0) * a.dps + a.dp0 + (i - a.L)];
+      xin[i] = s / (float)Fv;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int o = wid; o < 256; o += nw) {
+    const float* wr = a.w0 + (int64_t)o * din;
+    float acc = 0.f;
+    for (int i = lane; i < din; i += 64) acc += wr[i] * xin[i];
+    acc = wave_sum(acc);
+    if (lane == 0) hid[o] = fmaxf(acc + a.b0[o], 0.f);
+  }
+  __syncthreads();
+  float vid = 0.f;
+  if (wid == 0) {
+    float acc = 0.f;
+    for (int i = lane; i < 256; i += 64) acc += a.w2[i] * hid[i];
+    vid = wave_sum(acc) + a.b2[0];
+    if (lane == 0) a.vidf_outs[bc] = vid;
+  }
+  // per-arg max over proposals of sigmoid(logit) = sigmoid(max logit)
+  for (int arg = wid; arg < a.nsrl; arg += nw) {
+    const float* o = a.outs + ((int64_t)bc * a.nsrl + arg) * a.NP;
+    float m = -3.0e38f;
+    for (int i = lane; i < a.NP; i += 64) m = fmaxf(m, sigmoidf_(o[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) sarg[arg] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int vslot = (int)a.verb_ind[bc];
+    const float cm = (float)a.cmp_msk[bc];
+    float num = 0.f, den = 0.f;
+    for (int arg = 0; arg < a.nsrl; ++arg) {
+      float s = (arg == vslot) ? sigmoidf_(vid) : sarg[arg];
+      const float am = (float)a.arg_msk[(int64_t)lrow * a.nsrl + arg];
+      s *= am;
+      num += s; den += am;
+      a.fin_scores_loss[(int64_t)bc * a.nsrl + arg] = s * cm;
+    }
+    a.fin_scores[bc] = num / den * cm;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// prediction head (eval_vsrl_corr.py:162-220, 289-345, 357-424): one thread per
+// (query, arg, video, frame); packed record per query.
+// ---------------------------------------------------------------------------
+__global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_q = a.nsrl * a.ncmp * a.nfrm0;
+  if (i >= a.B * per_q) return;
+  const int b = i / per_q, rem = i % per_q;
+  const int arg = rem / (a.ncmp * a.nfrm0), c = (rem / a.nfrm0) % a.ncmp, f = rem % a.nfrm0;
+  const int npv = a.nfrm0 * a.nppf0;
+  int64_t e0, p0;     // first proposal of this (video, frame): in outs_eval / in props
+  if (a.conc_type == VOG_CONC_SPAT) {
+    const int r0 = (f * a.ncmp + c) * a.nppf0;
+    e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
+    p0 = (int64_t)b * a.ncmp * npv + r0;
+  } else if (a.conc_type == VOG_CONC_TEMP) {
+    const int r0 = (c * a.nfrm0 + f) * a.nppf0;
+    e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
+    p0 = (int64_t)b * a.ncmp * npv + r0;
+  } else {
+    e0 = (((int64_t)b * a.ncmp + c) * a.nsrl + arg) * npv + (int64_t)f * a.nppf0;
+    p0 = ((int64_t)b * a.ncmp + c) * npv + (int64_t)f * a.nppf0;
+  }
+  float best = a.outs_eval[e0];
+  int bi = 0;
+  for (int k = 1; k < a.nppf0; ++k) {
+    const float v = a.outs_eval[e0 + k];
+    if (v > best) { best = v; bi = k; }          // first maximum wins (torch.max on CPU)
+  }
+  unsigned char* rec = reinterpret_cast<unsigned char*>(a.rec) + (int64_t)b * rec_bytes;
+  float* boxes = reinterpret_cast<float*>(rec);
+  float* scores = boxes + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
+  const int64_t o = ((int64_t)arg * a.ncmp + c) * a.nfrm0 + f;
+  const float* pr = a.props + (p0 + bi) * 7;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) boxes[o * 7 + k] = pr[k];
+  scores[o] = best;
+}
+
+__global__ void pred_index_kernel(vog_pred_args a, int64_t rec_bytes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_q = a.nsrl * a.nfrm0;
+  if (i >= a.B * per_q) return;
+  const int b = i / per_q, arg = (i % per_q) / a.nfrm0, f = i % a.nfrm0;
+  unsigned char* rec = reinterpret_cast<unsigned char*>(a.rec) + (int64_t)b * rec_bytes;
+  const float* scores = reinterpret_cast<const float*>(rec) + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
+  int64_t* idx = reinterpret_cast<int64_t*>(rec + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 8 * 4);
+  int64_t out = 0;
+  if (a.conc_type == VOG_CONC_SPAT) {
+    float best = scores[((int64_t)arg * a.ncmp + 0) * a.nfrm0 + f];
+    for (int c = 1; c < a.ncmp; ++c) {
+      const float v = scores[((int64_t)arg * a.ncmp + c) * a.nfrm0 + f];
+      if (v > best) { best = v; out = c; }
+    }
+  } else if (a.conc_type == VOG_CONC_SEP) {
+    float best = a.fin_scores[(int64_t)b * a.ncmp];
+    for (int c = 1; c < a.ncmp; ++c) {
+      const float v = a.fin_scores[(int64_t)b * a.ncmp + c];
+      if (v > best) { best = v; out = c; }
+    }
+  }
+  idx[(int64_t)arg * a.nfrm0 + f] = out;
+}
+
+}  // namespace vog
+
+using namespace vog;
+
+extern "C" int vog_residual_layernorm(const float* x, const float* gamma, const float* beta,
+                                      float* y32, void* y16, int rows, int d, vog_dtype dtype,
+                                      void* stream) {
+  VOG_CHECK_ARG(x && gamma && beta && (y32 || y16) && rows > 0 && d > 0 && d <= 1024);
+  VOG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_kernel<T16>), dim3(ceil_div(rows, 4)),
+                     dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32, (unsigned short*)y16, rows, d));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_box_u(const float* props, const float* w_pe, float* u, int n_rows, int H,
+                         float vid_w, float vid_h, float nfrm_div, void* stream) {
+  VOG_CHECK_ARG(props && w_pe && u && n_rows > 0 && H > 0);
+  const int n = n_rows * H;
+  hipLaunchKernelGGL(box_u_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     props, w_pe, u, n_rows, H, vid_w, vid_h, nfrm_div);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask, int32_t* tok,
+                              int Bn, int T, int nsrl, int seq_len, int vocab_size, void* stream) {
+  VOG_CHECK_ARG(words_ind && word_mask && tok && Bn > 0 && T > 0 && T <= seq_len);
+  hipLaunchKernelGGL(srl_gather_kernel, dim3(ceil_div(Bn * T, 256)), dim3(256), 0,
+                     (hipStream_t)stream, words_ind, word_mask, tok, Bn, T, nsrl, seq_len, vocab_size);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const int64_t* inds_msk,
+                              const float* w, const float* bias, float* lang,
+                              int Bn, int T, int nsrl, int L, void* stream) {
+  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0);
+  hipLaunchKernelGGL(argvec_kernel, dim3(Bn * nsrl), dim3(256), 2 * L * sizeof(float),
+                     (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_vislang_layout(const vog_vislang_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->vis && a->lang && (a->x32 || a->x16));
+  const int64_t rows = (int64_t)a->n_vid * a->nfrm * a->nsrl * a->nppf;
+  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((vislang_kernel<T16>), dim3((unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, *a));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_score_head(const vog_score_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->h1 && a->w2 && a->b2 && a->arg_msk && a->cmp_msk && a->outs && a->outs_eval);
+  const int64_t rows = (int64_t)a->n_vid * a->nfrm * a->nsrl * a->nppf;
+  hipLaunchKernelGGL(score_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_pred_cmp_head(const vog_predcmp_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->final_hidden && a->prop_seg && a->outs && a->vidf_outs && a->fin_scores &&
+                a->fin_scores_loss && a->verb_ind);
+  const size_t sm = (size_t)(a->L + (a->dps - a->dp0) + 256 + a->nsrl) * sizeof(float);
+  hipLaunchKernelGGL(predcmp_kernel, dim3(a->B * a->ncmp), dim3(256), sm, (hipStream_t)stream, *a);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t vog_pred_record_bytes(int ncmp, int nsrl, int nfrm0) {
+  return (int64_t)nsrl * ncmp * nfrm0 * 8 * 4 + (int64_t)nsrl * nfrm0 * 8;
+}
+
+extern "C" int vog_pred_head(const vog_pred_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->outs_eval && a->props && a->rec && a->B > 0);
+  VOG_CHECK_ARG(a->conc_type != VOG_CONC_SEP || a->fin_scores);
+  const int64_t rb = vog_pred_record_bytes(a->ncmp, a->nsrl, a->nfrm0);
+  const int n1 = a->B * a->nsrl * a->ncmp * a->nfrm0;
+  hipLaunchKernelGGL(pred_kernel, dim3(ceil_div(n1, 128)), dim3(128), 0, (hipStream_t)stream, *a, rb);
+  const int n2 = a->B * a->nsrl * a->nfrm0;
+  hipLaunchKernelGGL(pred_index_kernel, dim3(ceil_div(n2, 128)), dim3(128), 0, (hipStream_t)stream, *a, rb);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,759 @@
+// Whole-forward engine: weight registry, workspace plan, launch sequence,
+// hipGraph capture. Replaces Conc{TEMP,SPAT,SEP}.forward
+// (mdl_conc_single.py:68-127, mdl_conc_sep.py:131-217) and
+// Evaluator*.get_out_results_boxes (eval_vsrl_corr.py:162-424) with ~50 kernel
+// launches on caller-owned buffers; no allocation and no sync on the launch path.
+#include <stdarg.h>
+#include <cmath>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace vog {
+
+// ---- error string -------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int attn_head_pad(int dh);
+
+// ---- host fp32 -> 16 bit ------------------------------------------------------
+static unsigned short h_to16(float f, int dt) {
+  if (dt == VOG_BF16) {
+    unsigned int u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  }
+  _Float16 h = (_Float16)f;
+  unsigned short r;
+  memcpy(&r, &h, 2);
+  return r;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct TxLayer {
+  unsigned short *wqkv, *wo, *w1, *w2;     // 16-bit, padded
+  float *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
+};
+struct TxWeights {
+  int d = 0, H = 0, dp = 0, dh = 0, n_layers = 0, use_rel = 0;
+  std::vector<int> head_off, head_dim;
+  std::vector<TxLayer> layers;
+  float *pe_w = nullptr, *pe_b = nullptr;
+};
+
+}  // namespace vog
+
+using namespace vog;
+
+struct vog_ctx {
+  vog_model_desc d;
+  std::vector<std::string> names;                       // required weights
+  std::map<std::string, int64_t> numel;
+  std::map<std::string, std::vector<float>> host;
+  std::vector<void*> allocs;
+  bool finalized = false;
+  // device weights
+  float* emb = nullptr;
+  std::vector<unsigned short*> wih;                     // [layer] [8R, in]
+  std::vector<unsigned short*> whh;                     // [layer] [2][4R][R]
+  std::vector<float*> bsum;                             // [layer] [8R]
+  unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
+  float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
+  float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
+  float *w_sv0 = nullptr, *b_sv0 = nullptr, *w_sv2 = nullptr, *b_sv2 = nullptr;
+  TxWeights obj, mul;
+};
+
+namespace vog {
+
+static bool has_obj(const vog_model_desc& d) {
+  return d.mdl_kind == VOG_MDL_VGRND || (d.mdl_kind == VOG_MDL_VOG && d.obj_to_use);
+}
+static bool has_obj_weights(const vog_model_desc& d) { return d.mdl_kind != VOG_MDL_IGRND; }
+static bool has_mul(const vog_model_desc& d) { return d.mdl_kind == VOG_MDL_VOG; }
+
+static void add_w(vog_ctx* c, const std::string& n, int64_t numel) {
+  c->names.push_back(n);
+  c->numel[n] = numel;
+}
+
+static void declare_tx(vog_ctx* c, const char* prefix, int d, int n_layers) {
+  const int dh = d / 2;
+  for (int l = 0; l < n_layers; ++l) {
+    std::string p = std::string(prefix) + ".encoder.layers." + std::to_string(l);
+    for (const char* w : {"wq", "wk", "wv", "wo"}) add_w(c, p + ".selfattn.layer." + w + ".weight", (int64_t)d * d);
+    add_w(c, p + ".selfattn.layernorm.weight", d);
+    add_w(c, p + ".selfattn.layernorm.bias", d);
+    add_w(c, p + ".feedforward.layer.linear1.weight", (int64_t)dh * d);
+    add_w(c, p + ".feedforward.layer.linear1.bias", dh);
+    add_w(c, p + ".feedforward.layer.linear2.weight", (int64_t)d * dh);
+    add_w(c, p + ".feedforward.layer.linear2.bias", d);
+    add_w(c, p + ".feedforward.layernorm.weight", d);
+    add_w(c, p + ".feedforward.layernorm.bias", d);
+  }
+}
+
+template <typename T>
+static int upload(vog_ctx* c, const std::vector<T>& h, T** out) {
+  void* p = nullptr;
+  VOG_HIP(hipMalloc(&p, h.size() * sizeof(T) + 64));
+  c->allocs.push_back(p);
+  VOG_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)p;
+  return 0;
+}
+
+static const std::vector<float>& W(vog_ctx* c, const std::string& n) { return c->host.at(n); }
+
+static int up32(vog_ctx* c, const std::string& n, float** out) { return upload<float>(c, W(c, n), out); }
+
+static int up16(vog_ctx* c, const std::string& n, int dt, unsigned short** out) {
+  const auto& w = W(c, n);
+  std::vector<unsigned short> h(w.size());
+  for (size_t i = 0; i < w.size(); ++i) h[i] = h_to16(w[i], dt);
+  return upload<unsigned short>(c, h, out);
+}
+
+static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int d, int H,
+                       int n_layers, int use_rel, TxWeights* tw) {
+  const int dt = c->d.tx_dtype;
+  tw->d = d; tw->H = H; tw->n_layers = n_layers; tw->use_rel = use_rel;
+  const int chunk = (d + H - 1) / H;                     // torch.chunk: ceil(d/H), last shorter
+  int off = 0;
+  for (int h = 0; h < H; ++h) {
+    const int sz = std::min(chunk, d - off);
+    if (sz <= 0) VOG_FAIL(-1, "d_model %d cannot be chunked into %d heads", d, H);
+    tw->head_off.push_back(off);
+    tw->head_dim.push_back(sz);
+    off += sz;
+  }
+  tw->dp = attn_head_pad(chunk);
+  if (tw->dp < 0) VOG_FAIL(-1, "head dim %d > 256 unsupported", chunk);
+  const int dp = tw->dp, dh = d / 2;
+  tw->dh = dh;
+  for (int l = 0; l < n_layers; ++l) {
+    std::string p = std::string(prefix) + ".encoder.layers." + std::to_string(l);
+    TxLayer L{};
+    std::vector<unsigned short> wqkv((size_t)3 * H * dp * d, 0);
+    const char* nm[3] = {"wq", "wk", "wv"};
+    for (int which = 0; which < 3; ++which) {
+      const auto& w = W(c, p + ".selfattn.layer." + nm[which] + ".weight");
+      for (int h = 0; h < H; ++h)
+        for (int dd = 0; dd < tw->head_dim[h]; ++dd) {
+          const float* src = &w[(size_t)(tw->head_off[h] + dd) * d];
+          unsigned short* dst = &wqkv[((size_t)(which * H + h) * dp + dd) * d];
+          for (int k = 0; k < d; ++k) dst[k] = h_to16(src[k], dt);
+        }
+    }
+    VOG_TRY(upload<unsigned short>(c, wqkv, &L.wqkv));
+    std::vector<unsigned short> wo((size_t)d * H * dp, 0);
+    {
+      const auto& w = W(c, p + ".selfattn.layer.wo.weight");
+      for (int o = 0; o < d; ++o)
+        for (int h = 0; h < H; ++h)
+          for (int dd = 0; dd < tw->head_dim[h]; ++dd)
+            wo[(size_t)o * H * dp + (size_t)h * dp + dd] = h_to16(w[(size_t)o * d + tw->head_off[h] + dd], dt);
+    }
+    VOG_TRY(upload<unsigned short>(c, wo, &L.wo));
+    VOG_TRY(up16(c, p + ".feedforward.layer.linear1.weight", dt, &L.w1));
+    VOG_TRY(up16(c, p + ".feedforward.layer.linear2.weight", dt, &L.w2));
+    VOG_TRY(up32(c, p + ".feedforward.layer.linear1.bias", &L.b1));
+    VOG_TRY(up32(c, p + ".feedforward.layer.linear2.bias", &L.b2));
+    VOG_TRY(up32(c, p + ".selfattn.layernorm.weight", &L.ln1g));
+    VOG_TRY(up32(c, p + ".selfattn.layernorm.bias", &L.ln1b));
+    VOG_TRY(up32(c, p + ".feedforward.layernorm.weight", &L.ln2g));
+    VOG_TRY(up32(c, p + ".feedforward.layernorm.bias", &L.ln2b));
+    tw->layers.push_back(L);
+  }
+  VOG_TRY(up32(c, std::string(pe_name) + ".weight", &tw->pe_w));
+  VOG_TRY(up32(c, std::string(pe_name) + ".bias", &tw->pe_b));
+  return 0;
+}
+
+// ---- geometry + workspace plan ---------------------------------------------------
+struct Geo {
+  int B, ncmp, T, sep, nvl, nc_v, nfrm, nppf, NP, Fv, n_vid, Bn, Bn16, R, E, L, d_obj, d_mul;
+  int S_obj, N_obj, spv_obj, npad_obj; float fdiv_obj;
+  int S_mul, N_mul, npad_mul;
+  int64_t rows_obj, rows_mul;
+};
+
+static Geo make_geo(const vog_model_desc& d, int B, int ncmp, int T) {
+  Geo g{};
+  g.B = B; g.ncmp = ncmp; g.T = T;
+  g.sep = d.conc_type == VOG_CONC_SEP;
+  g.nvl = g.sep ? ncmp : 1;
+  g.nc_v = g.sep ? ncmp : 1;
+  g.nfrm = d.conc_type == VOG_CONC_TEMP ? ncmp * d.nfrm0 : d.nfrm0;
+  g.nppf = d.conc_type == VOG_CONC_SPAT ? ncmp * d.nppf0 : d.nppf0;
+  g.NP = g.nfrm * g.nppf;
+  g.Fv = g.NP / d.nppf0;
+  g.n_vid = B * g.nc_v;
+  g.Bn = B * g.nvl;
+  g.Bn16 = (int)round_up64(g.Bn, 16);
+  g.R = d.rnn_size; g.E = d.emb_dim; g.L = d.lang_enc;
+  g.d_obj = d.prop_enc + d.seg_enc;
+  g.d_mul = g.d_obj + d.lang_enc;
+  g.S_obj = d.obj_one_frm ? g.n_vid * g.nfrm : g.n_vid;
+  g.N_obj = d.obj_one_frm ? g.nppf : g.NP;
+  g.spv_obj = d.obj_one_frm ? g.nfrm : 1;
+  g.fdiv_obj = d.obj_one_frm ? (float)g.nfrm : 1.0f;
+  g.npad_obj = (int)round_up64(g.N_obj, 64);
+  g.S_mul = g.n_vid * g.nfrm;
+  g.N_mul = d.nsrl * g.nppf;
+  g.npad_mul = (int)round_up64(g.N_mul, 64);
+  g.rows_obj = (int64_t)g.n_vid * g.NP;
+  g.rows_mul = (int64_t)g.S_mul * g.N_mul;
+  return g;
+}
+
+struct Plan {
+  std::map<std::string, std::pair<int64_t, int64_t>> buf;   // name -> (offset, bytes)
+  int64_t total = 0;
+  int64_t zero_off = 0, zero_bytes = 0;
+  int64_t add(const std::string& n, int64_t bytes) {
+    const int64_t off = total;
+    buf[n] = {off, bytes};
+    total += round_up64(bytes, 256);
+    return off;
+  }
+};
+
+static Plan make_plan(const vog_ctx* c, const Geo& g) {
+  const vog_model_desc& d = c->d;
+  Plan p;
+  const int nl = d.rnn_layers;
+  // ---- zero-initialised region (one memset per forward)
+  p.zero_off = p.total;
+  for (int l = 0; l < nl; ++l) {
+    // out16 of layer l is followed directly by the h buffer that holds the FINAL
+    // state, so [out16 ; h_final] is one contiguous A operand for the out-proj GEMM
+    // (hA lives inside the same allocation: rows [Bn*T, Bn*T + Bn16) )
+    p.add("lstm_out16_" + std::to_string(l), (int64_t)(g.Bn * g.T + g.Bn16) * 2 * g.R * 2);
+    p.add("lstm_hB_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);
+    p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
+  }
+  p.zero_bytes = p.total - p.zero_off;
+  p.add("tok", (int64_t)g.Bn * g.T * 4);
+  p.add("gx", (int64_t)g.Bn * g.T * 8 * g.R * 4);
+  p.add("full", (int64_t)(g.Bn * g.T + g.Bn16) * g.L * 4);
+  p.add("lang", (int64_t)g.Bn * d.nsrl * g.L * 4);
+  p.add("prop_seg", g.rows_obj * g.d_obj * 4);
+  p.add("prop_seg16", g.rows_obj * g.d_obj * 2);
+  auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
+    const std::string n(nm);
+    p.add(n + "_u", g.rows_obj * tw.H * 4);
+    p.add(n + "_q", rows * tw.H * tw.dp * 2);
+    p.add(n + "_k", rows * tw.H * tw.dp * 2);
+    p.add(n + "_vt", (int64_t)S * tw.H * tw.dp * npad * 2);
+    p.add(n + "_attn16", rows * tw.H * tw.dp * 2);
+    p.add(n + "_tmp", rows * tw.d * 4);
+    p.add(n + "_x1", rows * tw.d * 4);
+    p.add(n + "_x1_16", rows * tw.d * 2);
+    p.add(n + "_ffn16", rows * tw.dh * 2);
+    p.add(n + "_outA", rows * tw.d * 4);
+    p.add(n + "_outA16", rows * tw.d * 2);
+    if (tw.n_layers > 1) {
+      p.add(n + "_outB", rows * tw.d * 4);
+      p.add(n + "_outB16", rows * tw.d * 2);
+    }
+  };
+  if (has_obj(d)) tx("obj", c->obj, g.rows_obj, g.S_obj, g.npad_obj);
+  p.add("xmul", g.rows_mul * g.d_mul * 4);
+  p.add("xmul16", g.rows_mul * g.d_mul * 2);
+  if (has_mul(d)) tx("mul", c->mul, g.rows_mul, g.S_mul, g.npad_mul);
+  p.add("h1", g.rows_mul * 256 * 4);
+  return p;
+}
+
+struct Step {
+  std::string name;
+  std::function<int(hipStream_t)> fn;
+};
+
+struct WS {
+  char* base; const Plan* plan;
+  template <typename T> T* at(const std::string& n) const {
+    return reinterpret_cast<T*>(base + plan->buf.at(n).first);
+  }
+};
+
+static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, const Geo& g, const WS& ws,
+                     const vog_batch* b, const float* x_in32, const void* x_in16, int S, int N,
+                     int npad, int spv, int n_box, float fdiv, std::vector<Step>& steps,
+                     const float** out32, const void** out16) {
+  const std::string n(nm);
+  const vog_model_desc& d = c->d;
+  const vog_dtype dt = (vog_dtype)d.tx_dtype;
+  const int64_t rows = (int64_t)S * N;
+  float* u = ws.at<float>(n + "_u");
+  if (tw.use_rel) {
+    const float* props = b->pad_proposals;
+    const int n_rows = (int)g.rows_obj, H = tw.H;
+    const float* pw = tw.pe_w;
+    const float vw = d.vid_w, vh = d.vid_h;
+    steps.push_back({n + "_box_u", [=](hipStream_t st) {
+      return vog_box_u(props, pw, u, n_rows, H, vw, vh, fdiv, st); }});
+  }
+  const float* cur32 = x_in32;
+  const void* cur16 = x_in16;
+  for (int l = 0; l < tw.n_layers; ++l) {
+    const TxLayer& L = tw.layers[l];
+    const bool toA = (l % 2) == 0;
+    float* o32 = ws.at<float>(n + (toA ? "_outA" : "_outB"));
+    void* o16 = ws.at<void>(n + (toA ? "_outA16" : "_outB16"));
+    vog_qkv_args qa{};
+    qa.x16 = cur16; qa.ldx = tw.d; qa.wqkv = L.wqkv; qa.ldw = tw.d;
+    qa.q = ws.at<void>(n + "_q"); qa.k = ws.at<void>(n + "_k"); qa.vt = ws.at<void>(n + "_vt");
+    qa.S = S; qa.N = N; qa.H = tw.H; qa.dp = tw.dp; qa.npad = npad; qa.K = tw.d; qa.dtype = dt;
+    steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
+    vog_attn_args aa{};
+    aa.q = qa.q; aa.k = qa.k; aa.vt = qa.vt; aa.out16 = ws.at<void>(n + "_attn16");
+    aa.u = u; aa.pe_b = tw.pe_b; aa.S = S; aa.N = N; aa.H = tw.H; aa.dp = tw.dp; aa.npad = npad;
+    aa.use_rel = tw.use_rel; aa.n_box = n_box; aa.seq_per_vid = spv; aa.NP = g.NP;
+    aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
+    steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
+    vog_gemm_args wo{};
+    wo.a = aa.out16; wo.a_is_f32 = 0; wo.lda = (int64_t)tw.H * tw.dp; wo.w = L.wo; wo.ldw = (int64_t)tw.H * tw.dp;
+    wo.residual = cur32; wo.ldr = tw.d; wo.c32 = ws.at<float>(n + "_tmp"); wo.ldc = tw.d;
+    wo.M = (int)rows; wo.N = tw.d; wo.K = tw.H * tw.dp; wo.rep = 1; wo.dtype = dt;
+    steps.push_back({n + "_wo", [=](hipStream_t st) { return vog_gemm_bias_act(&wo, st); }});
+    float* x1 = ws.at<float>(n + "_x1");
+    void* x1_16 = ws.at<void>(n + "_x1_16");
+    float* tmp = wo.c32;
+    const int d_ = tw.d;
+    steps.push_back({n + "_ln1", [=](hipStream_t st) {
+      return vog_residual_layernorm(tmp, L.ln1g, L.ln1b, x1, x1_16, (int)rows, d_, dt, st); }});
+    vog_gemm_args f1{};
+    f1.a = x1_16; f1.lda = tw.d; f1.w = L.w1; f1.ldw = tw.d; f1.bias = L.b1; f1.relu = 1;
+    f1.c16 = ws.at<void>(n + "_ffn16"); f1.ldc16 = tw.dh; f1.M = (int)rows; f1.N = tw.dh; f1.K = tw.d;
+    f1.rep = 1; f1.dtype = dt;
+    steps.push_back({n + "_ffn1", [=](hipStream_t st) { return vog_gemm_bias_act(&f1, st); }});
+    vog_gemm_args f2{};
+    f2.a = f1.c16; f2.lda = tw.dh; f2.w = L.w2; f2.ldw = tw.dh; f2.bias = L.b2; f2.residual = x1;
+    f2.ldr = tw.d; f2.c32 = tmp; f2.ldc = tw.d; f2.M = (int)rows; f2.N = tw.d; f2.K = tw.dh; f2.rep = 1;
+    f2.dtype = dt;
+    steps.push_back({n + "_ffn2", [=](hipStream_t st) { return vog_gemm_bias_act(&f2, st); }});
+    steps.push_back({n + "_ln2", [=](hipStream_t st) {
+      return vog_residual_layernorm(tmp, L.ln2g, L.ln2b, o32, o16, (int)rows, d_, dt, st); }});
+    cur32 = o32;
+    cur16 = o16;
+  }
+  *out32 = cur32;
+  *out16 = cur16;
+}
+
+static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t ws_bytes,
+                       Plan& plan, std::vector<Step>& steps) {
+  const vog_model_desc& d = c->d;
+  VOG_CHECK_ARG(c->finalized);
+  VOG_CHECK_ARG(b && b->B > 0 && b->ncmp > 0 && b->T > 0 && b->T <= d.seq_len);
+  VOG_CHECK_ARG(b->srl_arg_words_ind && b->srl_arg_word_mask && b->srl_arg_word_mask_len &&
+                b->srl_arg_words_capture && b->srl_arg_inds_msk && b->num_cmp_msk &&
+                b->pad_region_feature && b->seg_feature_for_frms && b->pad_proposals);
+  VOG_CHECK_ARG(b->mdl_outs && b->mdl_outs_eval);
+  const Geo g = make_geo(d, b->B, b->ncmp, b->T);
+  VOG_CHECK_ARG(!g.sep || (b->verb_ind_in_srl && b->vidf_outs && b->fin_scores && b->fin_scores_loss));
+  plan = make_plan(c, g);
+  if ((int64_t)ws_bytes < plan.total) VOG_FAIL(-2, "workspace too small: %zu < %lld", ws_bytes, (long long)plan.total);
+  WS ws{(char*)wsp, &plan};
+  const vog_dtype et = (vog_dtype)d.enc_dtype;
+  const int R = g.R, T = g.T, Bn = g.Bn;
+
+  // ---- language path (a14-a16)
+  {
+    char* z = ws.base + plan.zero_off;
+    const int64_t zb = plan.zero_bytes;
+    steps.push_back({"zero", [=](hipStream_t st) { VOG_HIP(hipMemsetAsync(z, 0, zb, st)); return 0; }});
+    int32_t* tok = ws.at<int32_t>("tok");
+    const int64_t *wi = b->srl_arg_words_ind, *wm = b->srl_arg_word_mask;
+    const int nsrl = d.nsrl, sl = d.seq_len, V = d.vocab_size;
+    steps.push_back({"srl_gather", [=](hipStream_t st) {
+      return vog_srl_gather(wi, wm, tok, Bn, T, nsrl, sl, V, st); }});
+    float* gx = ws.at<float>("gx");
+    for (int l = 0; l < d.rnn_layers; ++l) {
+      vog_gemm_args ga{};
+      if (l == 0) { ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E; }
+      else { ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R; }
+      ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 8 * R;
+      ga.M = Bn * T; ga.N = 8 * R; ga.rep = 1; ga.dtype = et;
+      steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
+      // final state must land in hA (adjacent to out16): after T steps it is in buf[T % 2]
+      void* hA = ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R;
+      void* hB = ws.at<void>("lstm_hB_" + std::to_string(l));
+      void* hb[2] = {(T % 2) == 0 ? hA : hB, (T % 2) == 0 ? hB : hA};
+      for (int s = 0; s < T; ++s) {
+        vog_lstm_step_args la{};
+        la.gx = gx; la.whh = c->whh[l]; la.h_in = hb[s % 2]; la.h_out = hb[(s + 1) % 2];
+        la.c = ws.at<float>("lstm_c_" + std::to_string(l));
+        la.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
+        la.lens = b->srl_arg_word_mask_len; la.Bn = Bn; la.T = T; la.R = R; la.step = s; la.dtype = et;
+        steps.push_back({"lstm_step", [=](hipStream_t st) { return vog_bilstm_step(&la, st); }});
+      }
+    }
+    vog_gemm_args po{};
+    po.a = ws.at<void>("lstm_out16_" + std::to_string(d.rnn_layers - 1)); po.lda = 2 * R;
+    po.w = c->w_outproj; po.ldw = 2 * R; po.bias = c->b_outproj; po.relu = 1;
+    po.c32 = ws.at<float>("full"); po.ldc = g.L; po.M = Bn * T + Bn; po.N = g.L; po.K = 2 * R;
+    po.rep = 1; po.dtype = et;
+    steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
+    const float* full = po.c32;
+    float* lang = ws.at<float>("lang");
+    const int64_t *cap = b->srl_arg_words_capture, *im = b->srl_arg_inds_msk;
+    const float *wa = c->w_arg, *ba = c->b_arg;
+    const int L = g.L;
+    steps.push_back({"argvec", [=](hipStream_t st) {
+      return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
+  }
+  // ---- visual encoders (a12, a13)
+  float* ps32 = ws.at<float>("prop_seg");
+  void* ps16 = ws.at<void>("prop_seg16");
+  {
+    vog_gemm_args pe{};
+    pe.a = b->pad_region_feature; pe.a_is_f32 = 1; pe.lda = d.prop_dim; pe.w = c->w_prop; pe.ldw = d.prop_dim;
+    pe.bias = c->b_prop; pe.relu = 1; pe.c32 = ps32; pe.c16 = ps16; pe.ldc = g.d_obj; pe.ldc16 = g.d_obj;
+    pe.M = (int)g.rows_obj; pe.N = d.prop_enc; pe.K = d.prop_dim; pe.rep = 1; pe.dtype = et;
+    steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
+    vog_gemm_args se{};
+    se.a = b->seg_feature_for_frms; se.a_is_f32 = 1; se.lda = d.seg_dim; se.w = c->w_seg; se.ldw = d.seg_dim;
+    se.bias = c->b_seg; se.relu = 1; se.c32 = ps32 + d.prop_enc;
+    se.c16 = (unsigned short*)ps16 + d.prop_enc; se.ldc = g.d_obj; se.ldc16 = g.d_obj;
+    se.M = g.n_vid * g.Fv; se.N = d.seg_enc; se.K = d.seg_dim; se.rep = d.nppf0; se.dtype = et;
+    steps.push_back({"seg_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&se, st); }});
+  }
+  // ---- object transformer (a7, a8)
+  const float* vis32 = ps32;
+  const void* vis16 = ps16;
+  if (has_obj(d))
+    tx_steps(c, c->obj, "obj", g, ws, b, ps32, ps16, g.S_obj, g.N_obj, g.npad_obj, g.spv_obj, g.N_obj,
+             g.fdiv_obj, steps, &vis32, &vis16);
+  // ---- vis || lang tokens in mul_tx order (a10, a11)
+  {
+    vog_vislang_args va{};
+    va.vis = vis32; va.lang = ws.at<float>("lang"); va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
+    va.n_vid = g.n_vid; va.nfrm = g.nfrm; va.nppf = g.nppf; va.nsrl = d.nsrl; va.dv = g.d_obj; va.dl = g.L;
+    va.lang_per_vid = g.nvl > 1 ? 1 : 0; va.nc_v = g.nc_v; va.dtype = (vog_dtype)(has_mul(d) ? d.tx_dtype : d.enc_dtype);
+    steps.push_back({"vislang", [=](hipStream_t st) { return vog_vislang_layout(&va, st); }});
+  }
+  const float* x32 = ws.at<float>("xmul");
+  const void* x16 = ws.at<void>("xmul16");
+  int head_dt = has_mul(d) ? d.tx_dtype : d.enc_dtype;   // dtype of the 16-bit copy feeding lin2
+  if (has_mul(d))
+    tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
+             (float)g.nfrm, steps, &x32, &x16);
+  // ---- score head (a9 tail / a20 / a17)
+  {
+    vog_gemm_args l2{};
+    if (head_dt == d.enc_dtype) { l2.a = x16; l2.a_is_f32 = 0; }
+    else { l2.a = x32; l2.a_is_f32 = 1; }               // re-round from fp32 in the head's own type
+    l2.lda = g.d_mul; l2.w = c->w_lin2; l2.ldw = g.d_mul; l2.bias = c->b_lin2; l2.relu = 1;
+    l2.c32 = ws.at<float>("h1"); l2.ldc = 256; l2.M = (int)g.rows_mul; l2.N = 256; l2.K = g.d_mul;
+    l2.rep = 1; l2.dtype = et;
+    steps.push_back({"lin2", [=](hipStream_t st) { return vog_gemm_bias_act(&l2, st); }});
+    vog_score_args sa{};
+    sa.h1 = l2.c32; sa.w2 = c->w_lin2b; sa.b2 = c->b_lin2b; sa.arg_msk = b->srl_arg_inds_msk;
+    sa.cmp_msk = b->num_cmp_msk; sa.outs = b->mdl_outs; sa.outs_eval = b->mdl_outs_eval;
+    sa.n_vid = g.n_vid; sa.nfrm = g.nfrm; sa.nppf = g.nppf; sa.nsrl = d.nsrl; sa.dh = 256;
+    sa.conc_type = d.conc_type; sa.ncmp = g.ncmp; sa.nc_v = g.nc_v; sa.nvl = g.nvl;
+    sa.nfrm0 = d.nfrm0; sa.nppf0 = d.nppf0;
+    steps.push_back({"score", [=](hipStream_t st) { return vog_score_head(&sa, st); }});
+  }
+  if (g.sep) {
+    vog_predcmp_args pa{};
+    pa.final_hidden = ws.at<float>("full") + (int64_t)g.Bn * g.T * g.L;
+    pa.prop_seg = ps32; pa.w0 = c->w_sv0; pa.b0 = c->b_sv0; pa.w2 = c->w_sv2; pa.b2 = c->b_sv2;
+    pa.outs = b->mdl_outs; pa.arg_msk = b->srl_arg_inds_msk; pa.cmp_msk = b->num_cmp_msk;
+    pa.verb_ind = b->verb_ind_in_srl; pa.vidf_outs = b->vidf_outs; pa.fin_scores_loss = b->fin_scores_loss;
+    pa.fin_scores = b->fin_scores; pa.B = g.B; pa.ncmp = g.ncmp; pa.nvl = g.nvl; pa.nsrl = d.nsrl;
+    pa.NP = g.NP; pa.nfrm0 = d.nfrm0; pa.nppf0 = d.nppf0; pa.L = g.L; pa.dp0 = d.prop_enc; pa.dps = g.d_obj;
+    steps.push_back({"pred_cmp", [=](hipStream_t st) { return vog_pred_cmp_head(&pa, st); }});
+  }
+  if (b->pred_rec) {
+    vog_pred_args pr{};
+    pr.outs_eval = b->mdl_outs_eval; pr.props = b->pad_proposals; pr.fin_scores = b->fin_scores;
+    pr.rec = b->pred_rec; pr.B = g.B; pr.ncmp = g.ncmp; pr.nsrl = d.nsrl; pr.nfrm0 = d.nfrm0;
+    pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
+    steps.push_back({"pred_head", [=](hipStream_t st) { return vog_pred_head(&pr, st); }});
+  }
+  return 0;
+}
+
+}  // namespace vog
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" int vog_version(void) { return VOG_ABI_VERSION; }
+extern "C" const char* vog_last_error(void) { return vog::g_err; }
+
+extern "C" int vog_ctx_create(const vog_model_desc* d, vog_ctx** out) {
+  VOG_CHECK_ARG(d && out);
+  VOG_CHECK_ARG(d->mdl_kind >= 0 && d->mdl_kind <= 2 && d->conc_type >= 0 && d->conc_type <= 2);
+  VOG_CHECK_ARG(d->rnn_size % 32 == 0 && d->emb_dim % 8 == 0 && d->prop_dim % 8 == 0 && d->seg_dim % 8 == 0);
+  VOG_CHECK_ARG(d->prop_enc % 8 == 0 && d->seg_enc % 8 == 0 && d->lang_enc % 8 == 0);
+  VOG_CHECK_ARG(((d->prop_enc + d->seg_enc) / 2) % 8 == 0 && ((d->prop_enc + d->seg_enc + d->lang_enc) / 2) % 8 == 0);
+  VOG_CHECK_ARG(d->nsrl > 0 && d->seq_len > 0 && d->nfrm0 > 0 && d->nppf0 > 0 && d->rnn_layers > 0);
+  vog_ctx* c = new vog_ctx();
+  c->d = *d;
+  const int R = d->rnn_size, E = d->emb_dim, L = d->lang_enc;
+  add_w(c, "lstm_encoder.embed_tokens.weight", (int64_t)(d->vocab_size + 1) * E);
+  for (int l = 0; l < d->rnn_layers; ++l)
+    for (const char* sfx : {"", "_reverse"}) {
+      const int in = l == 0 ? E : 2 * R;
+      std::string s = "_l" + std::to_string(l) + sfx;
+      add_w(c, "lstm_encoder.lstm.weight_ih" + s, (int64_t)4 * R * in);
+      add_w(c, "lstm_encoder.lstm.weight_hh" + s, (int64_t)4 * R * R);
+      add_w(c, "lstm_encoder.lstm.bias_ih" + s, 4 * R);
+      add_w(c, "lstm_encoder.lstm.bias_hh" + s, 4 * R);
+    }
+  add_w(c, "lstm_out_feat_proj.0.weight", (int64_t)L * 2 * R);
+  add_w(c, "lstm_out_feat_proj.0.bias", L);
+  add_w(c, "srl_arg_words_out_enc.0.weight", (int64_t)L * 2 * L);
+  add_w(c, "srl_arg_words_out_enc.0.bias", L);
+  add_w(c, "prop_encoder.0.weight", (int64_t)d->prop_enc * d->prop_dim);
+  add_w(c, "prop_encoder.0.bias", d->prop_enc);
+  add_w(c, "seg_encoder.0.weight", (int64_t)d->seg_enc * d->seg_dim);
+  add_w(c, "seg_encoder.0.bias", d->seg_enc);
+  add_w(c, "seg_verb_classf.0.weight", (int64_t)256 * (d->seg_enc + L));
+  add_w(c, "seg_verb_classf.0.bias", 256);
+  add_w(c, "seg_verb_classf.2.weight", 256);
+  add_w(c, "seg_verb_classf.2.bias", 1);
+  const int d_obj = d->prop_enc + d->seg_enc, d_mul = d_obj + L;
+  add_w(c, "lin2.0.weight", (int64_t)256 * d_mul);
+  add_w(c, "lin2.0.bias", 256);
+  add_w(c, "lin2.2.weight", 256);
+  add_w(c, "lin2.2.bias", 1);
+  if (has_obj_weights(*d)) {
+    declare_tx(c, "obj_txf", d_obj, d->obj_layers);
+    add_w(c, "pe_obj_sub_enc.0.weight", (int64_t)d->obj_heads * 5);
+    add_w(c, "pe_obj_sub_enc.0.bias", d->obj_heads);
+  }
+  if (has_mul(*d)) {
+    declare_tx(c, "mult_txf", d_mul, d->mul_layers);
+    add_w(c, "pe_mul_sub_enc.0.weight", (int64_t)d->mul_heads * 5);
+    add_w(c, "pe_mul_sub_enc.0.bias", d->mul_heads);
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int vog_ctx_num_weights(const vog_ctx* c) { return c ? (int)c->names.size() : -1; }
+extern "C" const char* vog_ctx_weight_name(const vog_ctx* c, int i) {
+  return (c && i >= 0 && i < (int)c->names.size()) ? c->names[i].c_str() : nullptr;
+}
+extern "C" int64_t vog_ctx_weight_numel(const vog_ctx* c, int i) {
+  return (c && i >= 0 && i < (int)c->names.size()) ? c->numel.at(c->names[i]) : -1;
+}
+
+extern "C" int vog_ctx_set_weight(vog_ctx* c, const char* name, const float* host, int64_t numel) {
+  VOG_CHECK_ARG(c && name && host);
+  std::string n(name);
+  if (n.rfind("module.", 0) == 0) n = n.substr(7);          // DDP-wrapped checkpoints (trn_utils.py:536-592)
+  // legacy LayerNorm parameter names (trn_utils.py:560-565)
+  for (const char* pr : {".gamma", ".beta"}) {
+    const std::string suf(pr);
+    if (n.size() > suf.size() && n.compare(n.size() - suf.size(), suf.size(), suf) == 0 &&
+        n.find("layernorm") != std::string::npos)
+      n = n.substr(0, n.size() - suf.size()) + (suf == ".gamma" ? ".weight" : ".bias");
+  }
+  auto it = c->numel.find(n);
+  if (it == c->numel.end()) {
+    // parameters that exist in reference checkpoints but are not read by forward
+    if (n.rfind("srl_simple_lin", 0) == 0 || n.rfind("lin_tmp", 0) == 0 ||
+        n.rfind("obj_txf", 0) == 0 || n.rfind("pe_obj_sub_enc", 0) == 0 ||
+        n.rfind("mult_txf", 0) == 0 || n.rfind("pe_mul_sub_enc", 0) == 0)
+      return 0;
+    VOG_FAIL(-3, "unexpected weight '%s'", name);
+  }
+  if (it->second != numel) VOG_FAIL(-3, "weight '%s': numel %lld, expected %lld", name, (long long)numel, (long long)it->second);
+  c->host[n].assign(host, host + numel);
+  c->finalized = false;
+  return 0;
+}
+
+extern "C" int vog_ctx_finalize(vog_ctx* c) {
+  VOG_CHECK_ARG(c);
+  for (auto& n : c->names)
+    if (!c->host.count(n)) VOG_FAIL(-3, "missing weight '%s'", n.c_str());
+  for (void* p : c->allocs) (void)hipFree(p);
+  c->allocs.clear();
+  c->wih.clear(); c->whh.clear(); c->bsum.clear();
+  c->obj = TxWeights(); c->mul = TxWeights();
+  const vog_model_desc& d = c->d;
+  const int R = d.rnn_size, et = d.enc_dtype;
+  VOG_TRY(up32(c, "lstm_encoder.embed_tokens.weight", &c->emb));
+  for (int l = 0; l < d.rnn_layers; ++l) {
+    const int in = l == 0 ? d.emb_dim : 2 * R;
+    std::vector<unsigned short> wih((size_t)8 * R * in), whh((size_t)8 * R * R);
+    std::vector<float> bs((size_t)8 * R);
+    int dir = 0;
+    for (const char* sfx : {"", "_reverse"}) {
+      std::string s = "_l" + std::to_string(l) + sfx;
+      const auto& a = W(c, "lstm_encoder.lstm.weight_ih" + s);
+      const auto& h = W(c, "lstm_encoder.lstm.weight_hh" + s);
+      const auto& bi = W(c, "lstm_encoder.lstm.bias_ih" + s);
+      const auto& bh = W(c, "lstm_encoder.lstm.bias_hh" + s);
+      for (size_t i = 0; i < a.size(); ++i) wih[(size_t)dir * 4 * R * in + i] = h_to16(a[i], et);
+      for (size_t i = 0; i < h.size(); ++i) whh[(size_t)dir * 4 * R * R + i] = h_to16(h[i], et);
+      for (int i = 0; i < 4 * R; ++i) bs[(size_t)dir * 4 * R + i] = bi[i] + bh[i];
+      ++dir;
+    }
+    unsigned short *pw, *ph; float* pb;
+    VOG_TRY(upload<unsigned short>(c, wih, &pw));
+    VOG_TRY(upload<unsigned short>(c, whh, &ph));
+    VOG_TRY(upload<float>(c, bs, &pb));
+    c->wih.push_back(pw); c->whh.push_back(ph); c->bsum.push_back(pb);
+  }
+  VOG_TRY(up16(c, "lstm_out_feat_proj.0.weight", et, &c->w_outproj));
+  VOG_TRY(up32(c, "lstm_out_feat_proj.0.bias", &c->b_outproj));
+  VOG_TRY(up16(c, "prop_encoder.0.weight", et, &c->w_prop));
+  VOG_TRY(up32(c, "prop_encoder.0.bias", &c->b_prop));
+  VOG_TRY(up16(c, "seg_encoder.0.weight", et, &c->w_seg));
+  VOG_TRY(up32(c, "seg_encoder.0.bias", &c->b_seg));
+  VOG_TRY(up16(c, "lin2.0.weight", et, &c->w_lin2));
+  VOG_TRY(up32(c, "lin2.0.bias", &c->b_lin2));
+  VOG_TRY(up32(c, "lin2.2.weight", &c->w_lin2b));
+  VOG_TRY(up32(c, "lin2.2.bias", &c->b_lin2b));
+  VOG_TRY(up32(c, "srl_arg_words_out_enc.0.weight", &c->w_arg));
+  VOG_TRY(up32(c, "srl_arg_words_out_enc.0.bias", &c->b_arg));
+  VOG_TRY(up32(c, "seg_verb_classf.0.weight", &c->w_sv0));
+  VOG_TRY(up32(c, "seg_verb_classf.0.bias", &c->b_sv0));
+  VOG_TRY(up32(c, "seg_verb_classf.2.weight", &c->w_sv2));
+  VOG_TRY(up32(c, "seg_verb_classf.2.bias", &c->b_sv2));
+  const int d_obj = d.prop_enc + d.seg_enc, d_mul = d_obj + d.lang_enc;
+  if (has_obj(d))
+    VOG_TRY(finalize_tx(c, "obj_txf", "pe_obj_sub_enc.0", d_obj, d.obj_heads, d.obj_layers, d.obj_use_rel, &c->obj));
+  if (has_mul(d))
+    VOG_TRY(finalize_tx(c, "mult_txf", "pe_mul_sub_enc.0", d_mul, d.mul_heads, d.mul_layers, d.mul_use_rel, &c->mul));
+  VOG_HIP(hipDeviceSynchronize());
+  c->finalized = true;
+  return 0;
+}
+
+extern "C" int vog_ctx_destroy(vog_ctx* c) {
+  if (!c) return 0;
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+  return 0;
+}
+
+extern "C" int64_t vog_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T) {
+  if (!c || !c->finalized || B <= 0 || ncmp <= 0 || T <= 0) return -1;
+  return make_plan(c, make_geo(c->d, B, ncmp, T)).total;
+}
+
+extern "C" int vog_workspace_init(const vog_ctx* c, int B, int ncmp, int T, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  VOG_CHECK_ARG(c && ws);
+  const int64_t need = vog_workspace_bytes(c, B, ncmp, T);
+  if (need < 0 || (int64_t)ws_bytes < need) VOG_FAIL(-2, "workspace too small");
+  VOG_HIP(hipMemsetAsync(ws, 0, (size_t)need, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int vog_workspace_stage(const vog_ctx* c, int B, int ncmp, int T, const char* stage,
+                                   int64_t* offset, int64_t* bytes) {
+  VOG_CHECK_ARG(c && c->finalized && stage && offset && bytes);
+  Plan p = make_plan(c, make_geo(c->d, B, ncmp, T));
+  auto it = p.buf.find(stage);
+  if (it == p.buf.end()) VOG_FAIL(-4, "no stage '%s'", stage);
+  *offset = it->second.first;
+  *bytes = it->second.second;
+  return 0;
+}
+
+extern "C" int vog_forward(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, void* stream) {
+  VOG_CHECK_ARG(c && b && ws);
+  Plan plan;
+  std::vector<Step> steps;
+  VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
+  for (auto& s : steps) {
+    const int r = s.fn((hipStream_t)stream);
+    if (r != 0) return r;
+  }
+  return 0;
+}
+
+struct vog_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
+                                 void* stream, vog_graph** out) {
+  VOG_CHECK_ARG(c && b && ws && out && stream);
+  Plan plan;
+  std::vector<Step> steps;
+  VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
+  hipStream_t st = (hipStream_t)stream;
+  VOG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (auto& s : steps) {
+    rc = s.fn(st);
+    if (rc != 0) break;
+  }
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) VOG_FAIL(-(int)e - 1000, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  vog_graph* vg = new vog_graph();
+  vg->graph = g;
+  e = hipGraphInstantiate(&vg->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); delete vg; VOG_FAIL(-(int)e - 1000, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  *out = vg;
+  return 0;
+}
+
+extern "C" int vog_graph_launch(vog_graph* g, void* stream) {
+  VOG_CHECK_ARG(g && g->exec);
+  VOG_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int vog_graph_destroy(vog_graph* g) {
+  if (!g) return 0;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
+extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
+                               const char* kernel, int iters, void* stream, float* usec) {
+  VOG_CHECK_ARG(c && b && ws && kernel && iters > 0 && usec);
+  Plan plan;
+  std::vector<Step> steps;
+  VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
+  const Step* s = nullptr;
+  for (auto& x : steps) if (x.name == kernel) { s = &x; break; }
+  if (!s) VOG_FAIL(-4, "no kernel step '%s'", kernel);
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  VOG_HIP(hipEventCreate(&e0));
+  VOG_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) VOG_TRY(s->fn(st));
+  VOG_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) VOG_TRY(s->fn(st));
+  VOG_HIP(hipEventRecord(e1, st));
+  VOG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  VOG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *usec = ms * 1000.0f / (float)iters;
+  return 0;
+}

@@ -1,0 +1,278 @@
+"""Host-side driver of libvog_hip for one model instance.
+
+`VogEngine` owns a `vog_ctx` (weights registered under the reference's
+state-dict key names), per-shape workspaces and captured hipGraphs, and turns a
+batch dict of device tensors into the output dict of the reference `forward`
+(+ the packed prediction records of the evaluator head). torch tensors are
+containers only; every FLOP of the path runs in libvog_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+NSRL_KEYS_I64 = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len",
+                 "srl_arg_words_capture", "srl_arg_inds_msk", "num_cmp_msk")
+F32_KEYS = ("pad_region_feature", "seg_feature_for_frms", "pad_proposals")
+
+
+def model_desc_from_cfg(cfg, comm) -> L.ModelDesc:
+    m = cfg.mdl
+    hip = cfg.get("hip", {}) if hasattr(cfg, "get") else {}
+    tx = hip.get("tx_dtype", "bf16") if hasattr(hip, "get") else "bf16"
+    d = L.ModelDesc()
+    d.mdl_kind = L.MDL_KIND[m.name]
+    d.conc_type = L.CONC_TYPE[cfg.ds.conc_type]
+    d.vocab_size = int(comm["vocab_size"])
+    d.emb_dim = m.input_encoding_size
+    d.rnn_size = m.rnn.rnn_size
+    d.rnn_layers = m.rnn.num_layers
+    d.prop_dim, d.seg_dim = m.prop_feat_dim, m.seg_feat_dim
+    d.prop_enc, d.seg_enc, d.lang_enc = (m.vsrl.prop_encode_size, m.vsrl.seg_encode_size,
+                                         m.vsrl.lang_encode_size)
+    d.obj_layers, d.obj_heads = m.obj_tx.n_layers, m.obj_tx.n_heads
+    d.obj_use_rel, d.obj_one_frm, d.obj_to_use = (int(m.obj_tx.use_rel), int(m.obj_tx.one_frm),
+                                                  int(m.obj_tx.to_use))
+    d.mul_layers, d.mul_heads, d.mul_use_rel = (m.mul_tx.n_layers, m.mul_tx.n_heads,
+                                                int(m.mul_tx.use_rel))
+    d.nfrm0 = cfg.ds.num_sampled_frm
+    d.nppf0 = int(comm["num_prop_per_frm"])
+    d.nsrl = cfg.misc.srl_arg_length
+    d.seq_len = cfg.ds.max_seq_length
+    d.vid_w, d.vid_h = float(cfg.ds.resized_width), float(cfg.ds.resized_height)
+    d.tx_dtype = L.DTYPE[tx]
+    d.enc_dtype = L.VOG_F16
+    return d
+
+
+class VogEngine:
+    def __init__(self, cfg, comm, device: Optional[torch.device] = None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.VogError("VogEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                             "there is no CPU fallback on the product path")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.cfg = cfg
+        self.desc = model_desc_from_cfg(cfg, comm)
+        self.conc_type = cfg.ds.conc_type
+        self.sep = self.conc_type in ("sep", "svsq")
+        h = C.c_void_p()
+        L.check(self.lib.vog_ctx_create(C.byref(self.desc), C.byref(h)), "vog_ctx_create")
+        self.ctx = h
+        self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._graphs: Dict[tuple, C.c_void_p] = {}
+        self._finalized = False
+        self.use_graph = bool(cfg.hip.use_graph) if "hip" in cfg else True
+
+    # ---- weights -------------------------------------------------------------
+    def expected_weights(self) -> Dict[str, int]:
+        n = self.lib.vog_ctx_num_weights(self.ctx)
+        return {self.lib.vog_ctx_weight_name(self.ctx, i).decode():
+                int(self.lib.vog_ctx_weight_numel(self.ctx, i)) for i in range(n)}
+
+    def load_state_dict(self, sd) -> None:
+        """Register weights (torch tensors or numpy arrays) under the reference's
+        key names (utils/trn_utils.py:534-593 semantics: `module.` prefix and
+        legacy LayerNorm gamma/beta names are accepted by the library)."""
+        for k, v in sd.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            L.check(self.lib.vog_ctx_set_weight(self.ctx, k.encode(), a.ctypes.data, a.size),
+                    f"vog_ctx_set_weight({k})")
+        self._drop_graphs()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.vog_ctx_finalize(self.ctx), "vog_ctx_finalize")
+        self._finalized = True
+
+    # ---- workspace -----------------------------------------------------------
+    def workspace(self, B: int, ncmp: int, T: int) -> torch.Tensor:
+        key = (B, ncmp, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = self.lib.vog_workspace_bytes(self.ctx, B, ncmp, T)
+            if n < 0:
+                raise L.VogError("vog_workspace_bytes failed (weights not finalized?)")
+            ws = torch.empty(int(n), dtype=torch.uint8, device=self.device)
+            L.check(self.lib.vog_workspace_init(self.ctx, B, ncmp, T, ws.data_ptr(), ws.numel(),
+                                                L.stream_ptr()), "vog_workspace_init")
+            self._ws[key] = ws
+        return ws
+
+    def stage(self, B, ncmp, T, name, dtype, shape) -> torch.Tensor:
+        """View of a named intermediate inside the workspace (parity tests)."""
+        off, nb = C.c_int64(), C.c_int64()
+        L.check(self.lib.vog_workspace_stage(self.ctx, B, ncmp, T, name.encode(), C.byref(off),
+                                             C.byref(nb)), f"stage {name}")
+        ws = self.workspace(B, ncmp, T)
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        assert n <= nb.value, (name, n, nb.value)
+        return ws[off.value: off.value + n].view(dtype).view(*shape)
+
+    # ---- forward -------------------------------------------------------------
+    def _geometry(self, inp):
+        B = inp["srl_arg_words_ind"].shape[0]
+        ncmp = inp["new_srl_idxs"].shape[1] if "new_srl_idxs" in inp else inp["num_cmp_msk"].shape[1]
+        d = self.desc
+        nc_v = ncmp if self.sep else 1
+        NP = ncmp * d.nfrm0 * d.nppf0 if not self.sep else d.nfrm0 * d.nppf0
+        return B, ncmp, nc_v, NP
+
+    def make_batch(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
+                   with_pred: bool = True):
+        """Validate a batch dict, allocate outputs, fill the C struct."""
+        d = self.desc
+        B, ncmp, nc_v, NP = self._geometry(inp)
+        for k in NSRL_KEYS_I64:
+            assert inp[k].dtype == torch.int64 and inp[k].is_cuda, k
+        for k in F32_KEYS:
+            assert inp[k].dtype == torch.float32 and inp[k].is_cuda, k
+        nv = inp["srl_arg_words_ind"].shape[1]
+        assert nv == (ncmp if self.sep else 1), "language axis does not match conc_type"
+        assert inp["srl_arg_words_ind"].shape[2:] == (d.nsrl, d.seq_len)
+        assert inp["srl_tag_word_ind"].shape == inp["srl_arg_word_mask"].shape \
+            if "srl_tag_word_ind" in inp else True
+        vis_lead = (B, ncmp) if self.sep else (B,)
+        assert tuple(inp["pad_region_feature"].shape) == vis_lead + (NP, d.prop_dim)
+        assert tuple(inp["pad_proposals"].shape) == vis_lead + (NP, 7)
+        assert tuple(inp["seg_feature_for_frms"].shape) == vis_lead + (NP // d.nppf0, d.seg_dim)
+        if T is None:
+            # the reference does the same host read (mdl_vog.py:257 `.max().item()`)
+            T = int(inp["srl_arg_word_mask_len"].max().item())
+        dev = self.device
+        out = {
+            "mdl_outs": torch.empty(B, nc_v, d.nsrl, NP, device=dev),
+            "mdl_outs_eval": torch.empty(B, nc_v, d.nsrl, NP, device=dev),
+        }
+        if self.sep:
+            out["vidf_outs"] = torch.empty(B, ncmp, device=dev)
+            out["fin_scores_loss"] = torch.empty(B, ncmp, d.nsrl, device=dev)
+            out["fin_scores"] = torch.empty(B, ncmp, device=dev)
+        rec = None
+        if with_pred:
+            rb = int(self.lib.vog_pred_record_bytes(ncmp, d.nsrl, d.nfrm0))
+            rec = torch.empty(B, rb // 4, dtype=torch.float32, device=dev)
+            out["pred_rec"] = rec
+        b = L.Batch()
+        b.B, b.ncmp, b.T = B, ncmp, T
+        for k in NSRL_KEYS_I64 + F32_KEYS:
+            setattr(b, k, L.ptr(inp[k]))
+        if self.sep:
+            v = inp["verb_ind_in_srl"]
+            if v.shape[1] == 1 and ncmp > 1:
+                v = v.expand(-1, ncmp).contiguous()
+            out["_verb"] = v
+            b.verb_ind_in_srl = L.ptr(v)
+            b.vidf_outs = L.ptr(out["vidf_outs"])
+            b.fin_scores_loss = L.ptr(out["fin_scores_loss"])
+            b.fin_scores = L.ptr(out["fin_scores"])
+        b.mdl_outs = L.ptr(out["mdl_outs"])
+        b.mdl_outs_eval = L.ptr(out["mdl_outs_eval"])
+        b.pred_rec = L.ptr(rec)
+        return b, out, (B, ncmp, T)
+
+    def forward(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
+                with_pred: bool = True) -> Dict[str, torch.Tensor]:
+        """Eager launch sequence on the current stream (fresh output tensors)."""
+        assert self._finalized, "load_state_dict first"
+        with torch.cuda.device(self.device):
+            b, out, (B, ncmp, T) = self.make_batch(inp, T, with_pred)
+            ws = self.workspace(B, ncmp, T)
+            L.check(self.lib.vog_forward(self.ctx, C.byref(b), ws.data_ptr(), ws.numel(),
+                                         L.stream_ptr()), "vog_forward")
+        out["_keepalive"] = (inp, ws)
+        return out
+
+    # ---- persistent slots (graph replay; what bench.py and the evaluator use) ----
+    def make_slot(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
+                  with_pred: bool = True, graph: Optional[bool] = None) -> "Slot":
+        return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph)
+
+    def time_kernel(self, slot: "Slot", name: str, iters: int = 50) -> float:
+        us = C.c_float()
+        L.check(self.lib.vog_time_kernel(self.ctx, C.byref(slot.batch), slot.ws.data_ptr(),
+                                         slot.ws.numel(), name.encode(), iters, L.stream_ptr(),
+                                         C.byref(us)), f"vog_time_kernel({name})")
+        return float(us.value)
+
+    def _drop_graphs(self):
+        for g in self._graphs.values():
+            self.lib.vog_graph_destroy(g)
+        self._graphs.clear()
+
+    def unpack_pred(self, rec: torch.Tensor, ncmp: int):
+        """Packed records -> the reference's {'boxes','scores','indexs'} tensors
+        (eval_vsrl_corr.py:216-220). TEMP returns float zeros for indexs (:338-340)."""
+        d = self.desc
+        B = rec.shape[0]
+        nb = d.nsrl * ncmp * d.nfrm0
+        boxes = rec[:, : nb * 7].reshape(B, d.nsrl, ncmp, d.nfrm0, 7)
+        scores = rec[:, nb * 7: nb * 8].reshape(B, d.nsrl, ncmp, d.nfrm0)
+        idx = rec[:, nb * 8:].contiguous().view(torch.int64).reshape(B, d.nsrl, d.nfrm0)
+        if self.conc_type == "temp":
+            idx = torch.zeros(B, d.nsrl, d.nfrm0, dtype=torch.float32, device=rec.device)
+        return {"boxes": boxes, "scores": scores, "indexs": idx}
+
+    def __del__(self):
+        try:
+            self._drop_graphs()
+            if getattr(self, "ctx", None):
+                self.lib.vog_ctx_destroy(self.ctx)
+        except Exception:
+            pass
+
+
+class Slot:
+    """Persistent device buffers for one batch shape + a captured hipGraph.
+
+    Inputs live at fixed addresses (H2D copies land here directly), so one
+    forward is a single hipGraphLaunch of ~50 kernel nodes."""
+
+    def __init__(self, eng: VogEngine, inp, T, with_pred, graph):
+        self.eng = eng
+        self.inp = {k: (v.to(eng.device).contiguous() if isinstance(v, torch.Tensor)
+                        else torch.from_numpy(np.ascontiguousarray(v)).to(eng.device))
+                    for k, v in inp.items()}
+        with torch.cuda.device(eng.device):
+            self.batch, self.out, (self.B, self.ncmp, self.T) = eng.make_batch(self.inp, T, with_pred)
+            n = eng.lib.vog_workspace_bytes(eng.ctx, self.B, self.ncmp, self.T)
+            self.ws = torch.empty(int(n), dtype=torch.uint8, device=eng.device)
+            L.check(eng.lib.vog_workspace_init(eng.ctx, self.B, self.ncmp, self.T, self.ws.data_ptr(),
+                                               self.ws.numel(), L.stream_ptr()), "vog_workspace_init")
+            self.graph = None
+            if graph:
+                torch.cuda.synchronize()
+                cap = torch.cuda.Stream(device=eng.device)
+                g = C.c_void_p()
+                L.check(eng.lib.vog_graph_capture(eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
+                                                  self.ws.numel(), cap.cuda_stream, C.byref(g)),
+                        "vog_graph_capture")
+                self.graph = g
+                torch.cuda.synchronize()
+
+    def update_inputs(self, inp):
+        """Copy a new batch (same shapes, same T) into the slot's buffers."""
+        for k, v in inp.items():
+            if k in self.inp:
+                self.inp[k].copy_(v if isinstance(v, torch.Tensor) else torch.from_numpy(v),
+                                  non_blocking=True)
+
+    def launch(self, stream: Optional[torch.cuda.Stream] = None):
+        sp = L.stream_ptr(stream)
+        if self.graph is not None:
+            L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
+        else:
+            L.check(self.eng.lib.vog_forward(self.eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
+                                             self.ws.numel(), sp), "vog_forward")
+        return self.out
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.eng.lib.vog_graph_destroy(self.graph)
+        except Exception:
+            pass

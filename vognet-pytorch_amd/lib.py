@@ -1,0 +1,180 @@
+"""ctypes binding of libvog_hip.so (C ABI: include/vog_hip.h).
+
+The product path has NO fallback: if the library is missing or an entry point
+fails, an exception is raised. Tensors cross this boundary as raw device
+pointers (`tensor.data_ptr()`); torch is only the container.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvog_hip.so")
+
+VOG_BF16, VOG_F16 = 0, 1
+MDL_KIND = {"igrnd": 0, "vgrnd": 1, "vog": 2}
+CONC_TYPE = {"sep": 0, "svsq": 0, "temp": 1, "spat": 2}
+DTYPE = {"bf16": VOG_BF16, "f16": VOG_F16, "fp16": VOG_F16}
+
+c_i32, c_i64, c_f32, c_vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class VogError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("a", c_vp), ("a_is_f32", c_i32), ("lda", c_i64), ("a_rows", c_vp),
+                ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
+                ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
+                ("dtype", c_i32)]
+
+
+class QkvArgs(C.Structure):
+    _fields_ = [("x16", c_vp), ("ldx", c_i64), ("wqkv", c_vp), ("ldw", c_i64),
+                ("q", c_vp), ("k", c_vp), ("vt", c_vp),
+                ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
+                ("K", c_i32), ("dtype", c_i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", c_vp), ("k", c_vp), ("vt", c_vp), ("out16", c_vp), ("u", c_vp), ("pe_b", c_vp),
+                ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
+                ("use_rel", c_i32), ("n_box", c_i32), ("seq_per_vid", c_i32), ("NP", c_i32),
+                ("inv_scale", c_f32), ("dtype", c_i32)]
+
+
+class LstmStepArgs(C.Structure):
+    _fields_ = [("gx", c_vp), ("whh", c_vp), ("h_in", c_vp), ("h_out", c_vp), ("c", c_vp),
+                ("out16", c_vp), ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32),
+                ("step", c_i32), ("dtype", c_i32)]
+
+
+class VislangArgs(C.Structure):
+    _fields_ = [("vis", c_vp), ("lang", c_vp), ("x32", c_vp), ("x16", c_vp),
+                ("n_vid", c_i32), ("nfrm", c_i32), ("nppf", c_i32), ("nsrl", c_i32),
+                ("dv", c_i32), ("dl", c_i32), ("lang_per_vid", c_i32), ("nc_v", c_i32),
+                ("dtype", c_i32)]
+
+
+class ScoreArgs(C.Structure):
+    _fields_ = [("h1", c_vp), ("w2", c_vp), ("b2", c_vp), ("arg_msk", c_vp), ("cmp_msk", c_vp),
+                ("outs", c_vp), ("outs_eval", c_vp),
+                ("n_vid", c_i32), ("nfrm", c_i32), ("nppf", c_i32), ("nsrl", c_i32), ("dh", c_i32),
+                ("conc_type", c_i32), ("ncmp", c_i32), ("nc_v", c_i32), ("nvl", c_i32),
+                ("nfrm0", c_i32), ("nppf0", c_i32)]
+
+
+class PredcmpArgs(C.Structure):
+    _fields_ = [("final_hidden", c_vp), ("prop_seg", c_vp), ("w0", c_vp), ("b0", c_vp),
+                ("w2", c_vp), ("b2", c_vp), ("outs", c_vp), ("arg_msk", c_vp), ("cmp_msk", c_vp),
+                ("verb_ind", c_vp), ("vidf_outs", c_vp), ("fin_scores_loss", c_vp),
+                ("fin_scores", c_vp),
+                ("B", c_i32), ("ncmp", c_i32), ("nvl", c_i32), ("nsrl", c_i32), ("NP", c_i32),
+                ("nfrm0", c_i32), ("nppf0", c_i32), ("L", c_i32), ("dp0", c_i32), ("dps", c_i32)]
+
+
+class PredArgs(C.Structure):
+    _fields_ = [("outs_eval", c_vp), ("props", c_vp), ("fin_scores", c_vp), ("rec", c_vp),
+                ("B", c_i32), ("ncmp", c_i32), ("nsrl", c_i32), ("nfrm0", c_i32), ("nppf0", c_i32),
+                ("conc_type", c_i32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("mdl_kind", c_i32), ("conc_type", c_i32),
+                ("vocab_size", c_i32), ("emb_dim", c_i32), ("rnn_size", c_i32), ("rnn_layers", c_i32),
+                ("prop_dim", c_i32), ("seg_dim", c_i32), ("prop_enc", c_i32), ("seg_enc", c_i32),
+                ("lang_enc", c_i32),
+                ("obj_layers", c_i32), ("obj_heads", c_i32), ("obj_use_rel", c_i32),
+                ("obj_one_frm", c_i32), ("obj_to_use", c_i32),
+                ("mul_layers", c_i32), ("mul_heads", c_i32), ("mul_use_rel", c_i32),
+                ("nfrm0", c_i32), ("nppf0", c_i32), ("nsrl", c_i32), ("seq_len", c_i32),
+                ("vid_w", c_f32), ("vid_h", c_f32), ("tx_dtype", c_i32), ("enc_dtype", c_i32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", c_i32), ("ncmp", c_i32), ("T", c_i32),
+                ("srl_arg_words_ind", c_vp), ("srl_arg_word_mask", c_vp),
+                ("srl_arg_word_mask_len", c_vp), ("srl_arg_words_capture", c_vp),
+                ("srl_arg_inds_msk", c_vp), ("num_cmp_msk", c_vp), ("verb_ind_in_srl", c_vp),
+                ("pad_region_feature", c_vp), ("seg_feature_for_frms", c_vp), ("pad_proposals", c_vp),
+                ("mdl_outs", c_vp), ("mdl_outs_eval", c_vp), ("vidf_outs", c_vp),
+                ("fin_scores_loss", c_vp), ("fin_scores", c_vp), ("pred_rec", c_vp)]
+
+
+# every symbol include/vog_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "vog_version": (c_i32, []),
+    "vog_last_error": (C.c_char_p, []),
+    "vog_gemm_bias_act": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
+    "vog_rel_attention_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
+    "vog_residual_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vog_box_u": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp]),
+    "vog_srl_gather": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vog_bilstm_step": (c_i32, [C.POINTER(LstmStepArgs), c_vp]),
+    "vog_srl_argvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vog_vislang_layout": (c_i32, [C.POINTER(VislangArgs), c_vp]),
+    "vog_score_head": (c_i32, [C.POINTER(ScoreArgs), c_vp]),
+    "vog_pred_cmp_head": (c_i32, [C.POINTER(PredcmpArgs), c_vp]),
+    "vog_pred_record_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "vog_pred_head": (c_i32, [C.POINTER(PredArgs), c_vp]),
+    "vog_ctx_create": (c_i32, [C.POINTER(ModelDesc), C.POINTER(c_vp)]),
+    "vog_ctx_set_weight": (c_i32, [c_vp, C.c_char_p, c_vp, c_i64]),
+    "vog_ctx_finalize": (c_i32, [c_vp]),
+    "vog_ctx_destroy": (c_i32, [c_vp]),
+    "vog_ctx_num_weights": (c_i32, [c_vp]),
+    "vog_ctx_weight_name": (C.c_char_p, [c_vp, c_i32]),
+    "vog_ctx_weight_numel": (c_i64, [c_vp, c_i32]),
+    "vog_workspace_bytes": (c_i64, [c_vp, c_i32, c_i32, c_i32]),
+    "vog_workspace_init": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, C.c_size_t, c_vp]),
+    "vog_forward": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp]),
+    "vog_workspace_stage": (c_i32, [c_vp, c_i32, c_i32, c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "vog_graph_capture": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp, C.POINTER(c_vp)]),
+    "vog_graph_launch": (c_i32, [c_vp, c_vp]),
+    "vog_graph_destroy": (c_i32, [c_vp]),
+    "vog_time_kernel": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.c_char_p, c_i32, c_vp, C.POINTER(c_f32)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen libvog_hip.so and type every entry point. Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise VogError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+            "(or vognet-pytorch_amd/csrc/build.py). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)           # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().vog_last_error()
+        raise VogError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> Optional[int]:
+    """torch tensor (or None) -> raw pointer value."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libvog_hip takes contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr(stream=None) -> int:
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream

@@ -1,0 +1,137 @@
+"""Base model contract of the plugin surface.
+
+Same constructor contract and hook names as the reference `AnetBaseMdl`
+(code/mdl_base.py:11-107): `cls(cfg=cfg, comm=comm)`, `set_args` reading the
+same cfg/comm fields, `build_lang_model / build_vis_model / build_conc_model`
+hooks, and a `state_dict()` with the reference's key names — but the module
+tree holds parameters only; `forward` hands raw device pointers to
+libvog_hip.so (engine.py). There is no torch compute on the path.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import synth
+from .engine import VogEngine
+
+
+class _Node(nn.Module):
+    """Pure parameter container (never called)."""
+
+
+def _register(root: nn.Module, dotted: str, value: torch.Tensor):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Node())
+        m = getattr(m, p)
+    m.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+
+
+class AnetBaseMdl(nn.Module):
+    def __init__(self, cfg, comm):
+        super().__init__()
+        self.cfg = cfg
+        if comm is not None:
+            assert isinstance(comm, dict)
+            self.comm = dict(comm)
+        else:
+            self.comm = {}
+        self._engine = None
+        self._weights_dirty = True
+        self.set_args()
+        self.after_init()
+
+    def after_init(self):
+        self.build_model()
+
+    def build_model(self):
+        self._init_sd = synth.init_state_dict(
+            self.cfg, self.vocab_size, seed=int(torch.initial_seed() % (2 ** 31)))
+        self.build_lang_model()
+        self.build_vis_model()
+        self.build_conc_model()
+        del self._init_sd
+
+    def _take(self, prefixes):
+        for k in list(self._init_sd.keys()):
+            if k.startswith(tuple(prefixes)):
+                _register(self, k, torch.from_numpy(np.ascontiguousarray(self._init_sd.pop(k))))
+
+    def set_args(self):
+        """Same fields as reference mdl_base.py:32-75."""
+        c = self.comm
+        self.vocab_size = c["vocab_size"]
+        self.detect_size = c["detect_size"]
+        self.input_encoding_size = self.cfg.mdl.input_encoding_size
+        self.rnn_size = self.cfg.mdl.rnn.rnn_size
+        self.num_layers = self.cfg.mdl.rnn.num_layers
+        self.drop_prob_lm = self.cfg.mdl.rnn.drop_prob_lm
+        self.itod = c["itod"]
+        self.num_sampled_frm = self.cfg.ds.num_sampled_frm
+        self.num_prop_per_frm = c["num_prop_per_frm"]
+        self.unk_idx = int(c["wtoi"]["UNK"])
+        self.t_attn_size = self.cfg.ds.t_attn_size
+        self.srl_arg_len = self.cfg.misc.srl_arg_length
+        self.set_args_mdl()
+        self.set_args_conc()
+
+    def set_args_mdl(self):
+        return
+
+    def set_args_conc(self):
+        return
+
+    def build_lang_model(self):
+        raise NotImplementedError
+
+    def build_vis_model(self):
+        raise NotImplementedError
+
+    def build_conc_model(self):
+        raise NotImplementedError
+
+    # ---- weights -> engine ------------------------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts reference checkpoints: optional `module.` prefix and legacy
+        LayerNorm gamma/beta names (utils/trn_utils.py:536-592)."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k[7:] if k.startswith("module.") else k
+            if "layernorm" in k and k.endswith(".gamma"):
+                k = k[:-6] + ".weight"
+            if "layernorm" in k and k.endswith(".beta"):
+                k = k[:-5] + ".bias"
+            sd[k] = v
+        r = super().load_state_dict(sd, strict=strict)
+        self._weights_dirty = True
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._weights_dirty = True
+        return r
+
+    def engine(self) -> VogEngine:
+        if self._engine is None:
+            self._engine = VogEngine(self.cfg, self.comm)
+        if self._weights_dirty:
+            self._engine.load_state_dict(self.state_dict())
+            self._weights_dirty = False
+        return self._engine
+
+    def forward(self, inp: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """`forward(inp) -> {'mdl_outs', 'mdl_outs_eval'[, 'vidf_outs',
+        'fin_scores_loss', 'fin_scores']}` as Conc{TEMP,SPAT,SEP}.forward
+        (mdl_conc_single.py:68-127; mdl_conc_sep.py:131-217). Inputs are
+        borrowed and NOT modified (the reference overwrites srl_arg_word_mask).
+        Adds '_pred_rec': packed prediction records of the evaluator head."""
+        out = self.engine().forward(inp, with_pred=True)
+        res = {k: v for k, v in out.items() if not k.startswith("_") and k != "pred_rec"}
+        res["_pred_rec"] = out["pred_rec"]
+        return res
