@@ -91,26 +91,39 @@ def kernel_flops(w, T):
     return f, total
 
 
-def cpu_baseline(w, cfg, sd, batch, budget_s=15.0):
+def cpu_baseline(w, cfg, sd, batch, budget_s=24.0):
     """The CPU oracle (a validated port of the reference forward, oracle/vog_oracle.py)
-    timed on this host, all cores, on the same workload."""
+    timed on this host on the same workload. The forward is a chain of small
+    GEMMs (M = 4..4000), so more threads is not faster: a few thread counts are
+    tried inside the time budget and the best one is reported, `cores` = the
+    thread count it used."""
     from oracle import vog_oracle as vo
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     oc = vo.OracleCfg.from_cfg(cfg, VOCAB, ec.num_prop_per_frm(cfg))
     sdt, inp = vo.to_torch(sd), vo.to_torch(batch)
-    times = []
+    tried = {}
+    cands = [t for t in (8, 32) if t <= ncpu] or [ncpu]
     with torch.no_grad():
-        t_start = time.time()
-        for i in range(3):
+        for nt in cands:
+            torch.set_num_threads(nt)
+            t_start = time.time()
             vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
-        while len(times) < 20 and time.time() - t_start < budget_s:
-            t0 = time.perf_counter()
-            vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
-            times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": w["B"] / med, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed forwards of the same batch (bs={w['B']}) after 3 warm-up, median",
+            times = []
+            while len(times) < 12 and time.time() - t_start < budget_s / len(cands):
+                t0 = time.perf_counter()
+                vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
+                times.append(time.perf_counter() - t0)
+            if times:
+                tried[nt] = (float(np.median(times)), len(times))
+    if not tried:
+        return {"value": None, "unit": "queries/s", "cores": ncpu, "kind": "port",
+                "sample": "no forward finished inside the time budget"}
+    best = min(tried, key=lambda k: tried[k][0])
+    med, n = tried[best]
+    return {"value": w["B"] / med, "unit": "queries/s", "cores": best, "kind": "port",
+            "sample": f"{n} timed forwards of the same batch (bs={w['B']}) after 1 warm-up, median; "
+                      f"host has {ncpu} logical cpus; threads tried: "
+                      + ", ".join(f"{k}: {w['B'] / v[0]:.1f} q/s" for k, v in tried.items()),
             "ms_per_batch": med * 1e3}
 
 

@@ -51,7 +51,7 @@ const char* vog_last_error(void);
  * 224-230). A: [M,K] fp32 (a_is_f32=1) or t16, row pitch lda; optional row
  * gather a_rows[M] (int32) — the embedding lookup of mdl_srl_utils.py:128.
  * W: [N,K] t16 row pitch ldw (K % 8 == 0). Outputs (either may be NULL):
- * c32 fp32 / c16 t16, row pitch ldc; output row = m*rep + j for j < rep
+ * c32 fp32 / c16 t16 (type c16_dtype), row pitch ldc; output row = m*rep + j for j < rep
  * (rep > 1 broadcasts a frame's segment feature onto its proposals,
  * mdl_conc_single.py:51-66). */
 typedef struct vog_gemm_args {
@@ -62,6 +62,7 @@ typedef struct vog_gemm_args {
   int64_t ldr;
   float* c32; void* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; vog_dtype dtype;
+  int c16_dtype;               /* vog_dtype of c16, or -1 = same as dtype */
 } vog_gemm_args;
 int vog_gemm_bias_act(const vog_gemm_args* g, void* stream);
 

@@ -327,7 +327,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.use_rel = tw.use_rel; aa.n_box = n_box; aa.seq_per_vid = spv; aa.NP = g.NP;
     aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
     steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
-    vog_gemm_args wo{};
+    vog_gemm_args wo{}; wo.c16_dtype = -1;
     wo.a = aa.out16; wo.a_is_f32 = 0; wo.lda = (int64_t)tw.H * tw.dp; wo.w = L.wo; wo.ldw = (int64_t)tw.H * tw.dp;
     wo.residual = cur32; wo.ldr = tw.d; wo.c32 = ws.at<float>(n + "_tmp"); wo.ldc = tw.d;
     wo.M = (int)rows; wo.N = tw.d; wo.K = tw.H * tw.dp; wo.rep = 1; wo.dtype = dt;
@@ -338,12 +338,12 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     const int d_ = tw.d;
     steps.push_back({n + "_ln1", [=](hipStream_t st) {
       return vog_residual_layernorm(tmp, L.ln1g, L.ln1b, x1, x1_16, (int)rows, d_, dt, st); }});
-    vog_gemm_args f1{};
+    vog_gemm_args f1{}; f1.c16_dtype = -1;
     f1.a = x1_16; f1.lda = tw.d; f1.w = L.w1; f1.ldw = tw.d; f1.bias = L.b1; f1.relu = 1;
     f1.c16 = ws.at<void>(n + "_ffn16"); f1.ldc16 = tw.dh; f1.M = (int)rows; f1.N = tw.dh; f1.K = tw.d;
     f1.rep = 1; f1.dtype = dt;
     steps.push_back({n + "_ffn1", [=](hipStream_t st) { return vog_gemm_bias_act(&f1, st); }});
-    vog_gemm_args f2{};
+    vog_gemm_args f2{}; f2.c16_dtype = -1;
     f2.a = f1.c16; f2.lda = tw.dh; f2.w = L.w2; f2.ldw = tw.dh; f2.bias = L.b2; f2.residual = x1;
     f2.ldr = tw.d; f2.c32 = tmp; f2.ldc = tw.d; f2.M = (int)rows; f2.N = tw.d; f2.K = tw.dh; f2.rep = 1;
     f2.dtype = dt;
@@ -386,7 +386,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       return vog_srl_gather(wi, wm, tok, Bn, T, nsrl, sl, V, st); }});
     float* gx = ws.at<float>("gx");
     for (int l = 0; l < d.rnn_layers; ++l) {
-      vog_gemm_args ga{};
+      vog_gemm_args ga{}; ga.c16_dtype = -1;
       if (l == 0) { ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E; }
       else { ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R; }
       ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 8 * R;
@@ -405,7 +405,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         steps.push_back({"lstm_step", [=](hipStream_t st) { return vog_bilstm_step(&la, st); }});
       }
     }
-    vog_gemm_args po{};
+    vog_gemm_args po{}; po.c16_dtype = -1;
     po.a = ws.at<void>("lstm_out16_" + std::to_string(d.rnn_layers - 1)); po.lda = 2 * R;
     po.w = c->w_outproj; po.ldw = 2 * R; po.bias = c->b_outproj; po.relu = 1;
     po.c32 = ws.at<float>("full"); po.ldc = g.L; po.M = Bn * T + Bn; po.N = g.L; po.K = 2 * R;
@@ -423,12 +423,12 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   float* ps32 = ws.at<float>("prop_seg");
   void* ps16 = ws.at<void>("prop_seg16");
   {
-    vog_gemm_args pe{};
+    vog_gemm_args pe{}; pe.c16_dtype = d.tx_dtype;
     pe.a = b->pad_region_feature; pe.a_is_f32 = 1; pe.lda = d.prop_dim; pe.w = c->w_prop; pe.ldw = d.prop_dim;
     pe.bias = c->b_prop; pe.relu = 1; pe.c32 = ps32; pe.c16 = ps16; pe.ldc = g.d_obj; pe.ldc16 = g.d_obj;
     pe.M = (int)g.rows_obj; pe.N = d.prop_enc; pe.K = d.prop_dim; pe.rep = 1; pe.dtype = et;
     steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
-    vog_gemm_args se{};
+    vog_gemm_args se{}; se.c16_dtype = d.tx_dtype;
     se.a = b->seg_feature_for_frms; se.a_is_f32 = 1; se.lda = d.seg_dim; se.w = c->w_seg; se.ldw = d.seg_dim;
     se.bias = c->b_seg; se.relu = 1; se.c32 = ps32 + d.prop_enc;
     se.c16 = (unsigned short*)ps16 + d.prop_enc; se.ldc = g.d_obj; se.ldc16 = g.d_obj;
@@ -457,7 +457,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
              (float)g.nfrm, steps, &x32, &x16);
   // ---- score head (a9 tail / a20 / a17)
   {
-    vog_gemm_args l2{};
+    vog_gemm_args l2{}; l2.c16_dtype = -1;
     if (head_dt == d.enc_dtype) { l2.a = x16; l2.a_is_f32 = 0; }
     else { l2.a = x32; l2.a_is_f32 = 1; }               // re-round from fp32 in the head's own type
     l2.lda = g.d_mul; l2.w = c->w_lin2; l2.ldw = g.d_mul; l2.bias = c->b_lin2; l2.relu = 1;

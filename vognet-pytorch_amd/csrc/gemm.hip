@@ -24,7 +24,7 @@ struct GemmParams {
   const unsigned short* w; int64_t ldw;
   const float* bias; const float* residual; int64_t ldr;
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
-  int M, N, K; int relu; int rep;
+  int M, N, K; int relu; int rep; int c16_bf16;
   // QKV epilogue
   unsigned short* q; unsigned short* k; unsigned short* vt;
   int ntok, H, dp, npad;
@@ -45,30 +45,50 @@ __device__ __forceinline__ u16x8 load_a_chunk(const void* a, int64_t row_off, in
   return r;
 }
 
-template <typename T16, int EPI>
+template <typename T16>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int col, float v) {
   if (row >= p.M || col >= p.N) return;
-  if constexpr (EPI == EPI_PLAIN) {
+  {
     if (p.bias) v += p.bias[col];
     if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
     if (p.relu) v = fmaxf(v, 0.f);
     for (int j = 0; j < p.rep; ++j) {
       int64_t orow = (int64_t)row * p.rep + j;
       if (p.c32) p.c32[orow * p.ldc + col] = v;
-      if (p.c16) p.c16[orow * p.ldc16 + col] = to16<T16>(v);
+      if (p.c16) p.c16[orow * p.ldc16 + col] = p.c16_bf16 ? to16<BF16>(v) : to16<F16>(v);
     }
-  } else {
-    const int hd = p.H * p.dp;
-    const int which = col / hd;
-    const int h = (col - which * hd) / p.dp;
-    const int dd = col % p.dp;
+  }
+}
+
+// QKV epilogue for one 32x32 accumulator fragment. dp % 32 == 0 and fragment
+// column bases are multiples of 32, so (which, head) is WAVE-UNIFORM: derive it
+// from the fragment base through readfirstlane and branch on scalars. (A
+// per-lane 3-way pointer select here was miscompiled by hipcc 7.2: the V^T
+// stores went through the K base pointer.)
+template <typename T16>
+__device__ __forceinline__ void qkv_store_frag(const GemmParams& p, int row0, int col0, int lane,
+                                               const f32x16& acc) {
+  col0 = __builtin_amdgcn_readfirstlane(col0);
+  if (col0 >= p.N) return;
+  const int hd = p.H * p.dp;
+  const int which = col0 / hd;
+  const int h = (col0 - which * hd) / p.dp;
+  const int dd = (col0 % p.dp) + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + c32_row(r, lane);
+    if (row >= p.M) continue;
     const int s = row / p.ntok;
     const int i = row - s * p.ntok;
-    const unsigned short o = to16<T16>(v);
     const int64_t sh = (int64_t)s * p.H + h;
-    if (which == 0) p.q[(sh * p.ntok + i) * p.dp + dd] = o;
-    else if (which == 1) p.k[(sh * p.ntok + i) * p.dp + dd] = o;
-    else p.vt[(sh * p.dp + dd) * p.npad + i] = o;
+    const unsigned short o = to16<T16>(acc[r]);
+    if (which == 0) {
+      p.q[(sh * p.ntok + i) * p.dp + dd] = o;
+    } else if (which == 1) {
+      p.k[(sh * p.ntok + i) * p.dp + dd] = o;
+    } else {
+      p.vt[(sh * p.dp + dd) * p.npad + i] = o;
+    }
   }
 }
 
@@ -165,10 +185,14 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if constexpr (EPI == EPI_QKV) {
+        qkv_store_frag<T16>(p, m0 + wm * (BM / 2) + i * 32, n0 + wn * (BN / 2) + j * 32, lane, acc[i][j]);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + c32_row(r, lane);
-        epilogue_store<T16, EPI>(p, row, col, acc[i][j][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 32 + c32_row(r, lane);
+          epilogue_store<T16>(p, row, col, acc[i][j][r]);
+        }
       }
     }
 }
@@ -236,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
     for (int r = 0; r < 4; ++r) {
       const float v = red[0][mt][lane][r] + red[1][mt][lane][r] + red[2][mt][lane][r] + red[3][mt][lane][r];
       const int row = mt * 16 + (lane >> 4) * 4 + r;
-      epilogue_store<T16, EPI_PLAIN>(p, row, n, v);
+      epilogue_store<T16>(p, row, n, v);
     }
   }
 }
@@ -266,6 +290,7 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   p.bias = g->bias; p.residual = g->residual; p.ldr = g->ldr;
   p.c32 = g->c32; p.c16 = (unsigned short*)g->c16; p.ldc = g->ldc; p.ldc16 = g->ldc16;
   p.M = g->M; p.N = g->N; p.K = g->K; p.relu = g->relu; p.rep = g->rep < 1 ? 1 : g->rep;
+  p.c16_bf16 = (g->c16_dtype < 0 ? (int)g->dtype : g->c16_dtype) == VOG_BF16;
   if (p.M <= 64 && (p.K % 32) == 0) {
     dim3 grid(ceil_div(p.N, 16));
     if (g->a_is_f32) hipLaunchKernelGGL((gemm_skinny<T16, true>), grid, dim3(256), 0, st, p);

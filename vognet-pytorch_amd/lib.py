@@ -30,7 +30,11 @@ class GemmArgs(C.Structure):
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32)]
+                ("dtype", c_i32), ("c16_dtype", c_i32)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.c16_dtype = -1
 
 
 class QkvArgs(C.Structure):
@@ -147,6 +151,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; load it FIRST so that libvog_hip binds to
+    # the same HIP runtime (a second runtime instance sees no devices / no streams)
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise VogError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
