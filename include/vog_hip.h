@@ -63,6 +63,10 @@ typedef struct vog_gemm_args {
   float* c32; void* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; vog_dtype dtype;
   int c16_dtype;               /* vog_dtype of c16, or -1 = same as dtype */
+  /* optional output-row scatter: column n belongs to segment n / out_rows_ncol and
+   * row m of that segment is written to row out_rows[seg*M + m] (< 0: dropped).
+   * Used to emit the LSTM input projections directly in (direction, step) order. */
+  const int32_t* out_rows; int out_rows_ncol;
 } vog_gemm_args;
 int vog_gemm_bias_act(const vog_gemm_args* g, void* stream);
 
@@ -101,6 +105,13 @@ int vog_residual_layernorm(const float* x, const float* gamma, const float* beta
                            float* y32, void* y16, int rows, int d, vog_dtype dtype,
                            void* stream);
 
+/* dst[i] = (t16) src[i] for two arrays in one launch (raw proposal / segment
+ * features -> the encoders' MFMA operand type; replaces the implicit fp32 read
+ * of nn.Linear in prop_feats_encode / seg_feats_encode mdl_vog.py:291-314).
+ * n0, n1 multiples of 4; src1 may be NULL. */
+int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, const float* src1, void* dst1,
+                        int64_t n1, vog_dtype dtype, void* stream);
+
 /* u[v, r, h] = sum_c W_pe[h,c] * norm(box[v,r,c]), norm = x/vid_w, y/vid_h,
  * x/vid_w, y/vid_h, frame/nfrm_div (compute_pe mdl_vog.py:456-463).
  * props: [n_rows, 7] fp32 (pad_proposals). */
@@ -111,17 +122,27 @@ int vog_box_u(const float* props, const float* w_pe, float* u, int n_rows, int H
  * tok[b*T+t] = words[b, mask[b,t]] if mask[b,t] >= 0 else vocab_size. */
 int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask, int32_t* tok,
                    int Bn, int T, int nsrl, int seq_len, int vocab_size, void* stream);
+/* Packed-sequence schedule of the BiLSTM, as GEMM out_rows (pitch 4R, segment
+ * width 4R): rows[dir*Bn*T + b*T + t] = dir*(T*Bn - 1) + step*Bn + b with step = t
+ * (dir 0) or len_b-1-t (dir 1), so that row*4R + col lands in gxs[dir][step][b][:];
+ * -1 for t >= len_b. */
+int vog_lstm_schedule(const int64_t* lens, int32_t* rows, int Bn, int T, void* stream);
 
 /* One time step of one BiLSTM layer, both directions, packed-sequence
  * semantics (LSTMEncoder.forward mdl_srl_utils.py:134-148; nn.LSTM gate order
- * i,f,g,o). gx: [Bn*T, 8R] fp32 = x W_ih^T + b_ih + b_hh for (dir,gate,unit);
- * whh: [2][4R][R] t16; h_in/h_out: [Bn16, 2R] t16 ping-pong state; c: [Bn16,2R]
- * fp32; out16: [Bn*T, 2R] t16 (zero where t >= len). */
+ * i,f,g,o). gxs: [2][T][Bn][4R] fp32 = x W_ih^T + b_ih + b_hh in (direction, step)
+ * order (vog_lstm_schedule + the GEMM's out_rows scatter); whh: the 16-bit
+ * recurrent weights in MFMA-fragment order as packed by vog_lstm_pack_whh;
+ * h_in/h_out: [Bn16, 2R] t16 ping-pong state; c: [Bn16,2R] fp32; out16:
+ * [Bn*T, 2R] t16 (zero where t >= len). */
 typedef struct vog_lstm_step_args {
   const float* gx; const void* whh; const void* h_in; void* h_out; float* c;
   void* out16; const int64_t* lens; int Bn, T, R, step; vog_dtype dtype;
 } vog_lstm_step_args;
 int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
+/* host: [2][4R][R] fp32 (weight_hh_l*, weight_hh_l*_reverse) -> fragment order, 16 bit.
+ * dst holds 2*4R*R halfwords: [dir][unit/4][k/32][lane 64][8]. */
+int vog_lstm_pack_whh(const float* whh_fwd, const float* whh_bwd, void* dst_host, int R, vog_dtype dtype);
 
 /* lang[b,a,:] = relu(W [full[b,cap0] || full[b,cap1]] + bias) * msk
  * (retrieve_srl_arg_from_lang_encode mdl_vog.py:97-140). full: [Bn*T, L] fp32. */

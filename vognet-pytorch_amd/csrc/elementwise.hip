@@ -57,6 +57,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// fp32 -> 16-bit cast of the raw feature blocks (HBM-bound: 16 B in, 8 B out per lane)
+// ---------------------------------------------------------------------------
+template <typename T16>
+__global__ __launch_bounds__(256) void cast2_kernel(const float4* __restrict__ s0, u16x4* __restrict__ d0,
+                                                    int64_t n0, const float4* __restrict__ s1,
+                                                    u16x4* __restrict__ d1, int64_t n1) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += stride) {
+    const bool first = i < n0;
+    const float4 v = first ? s0[i] : s1[i - n0];
+    u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
+    if (first) d0[i] = o; else d1[i - n0] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // u[row,h] = W_pe[h,:] . norm(box[row,:5])   (compute_pe mdl_vog.py:456-463)
 // ---------------------------------------------------------------------------
 __global__ void box_u_kernel(const float* __restrict__ props, const float* __restrict__ w,
@@ -98,25 +114,29 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias,
                                                      float* __restrict__ lang, int T, int nsrl, int L) {
-  extern __shared__ float xin[];               // [2L]
+  // grid (sentence*arg, L/16): each wave owns 4 outputs with 4 independent
+  // accumulators, so all of its weight-row loads are in flight together
   const int ba = blockIdx.x;                   // b*nsrl + a
   const int b = ba / nsrl;
   int64_t c0 = capture[(int64_t)ba * 2], c1 = capture[(int64_t)ba * 2 + 1];
   c0 = c0 < 0 ? 0 : (c0 >= T ? T - 1 : c0);
   c1 = c1 < 0 ? 0 : (c1 >= T ? T - 1 : c1);
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
-    xin[i] = full[((int64_t)b * T + c0) * L + i];
-    xin[L + i] = full[((int64_t)b * T + c1) * L + i];
-  }
-  __syncthreads();
+  const float* x0 = full + ((int64_t)b * T + c0) * L;
+  const float* x1 = full + ((int64_t)b * T + c1) * L;
   const float mk = (float)msk[ba];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int o = wid; o < L; o += nw) {
-    const float* wr = w + (int64_t)o * 2 * L;
-    float acc = 0.f;
-    for (int i = lane; i < 2 * L; i += 64) acc += wr[i] * xin[i];
-    acc = wave_sum(acc);
-    if (lane == 0) lang[(int64_t)ba * L + o] = fmaxf(acc + bias[o], 0.f) * mk;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int o0 = blockIdx.y * 16 + wid * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < 2 * L; i += 64) {
+    const float xv = i < L ? x0[i] : x1[i - L];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (o0 + k < L) acc[k] += w[(int64_t)(o0 + k) * 2 * L + i] * xv;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0 && o0 + k < L) lang[(int64_t)ba * L + o0 + k] = fmaxf(v + bias[o0 + k], 0.f) * mk;
   }
 }
 
@@ -323,6 +343,17 @@ extern "C" int vog_residual_layernorm(const float* x, const float* gamma, const 
   return 0;
 }
 
+extern "C" int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, const float* src1,
+                                   void* dst1, int64_t n1, vog_dtype dtype, void* stream) {
+  VOG_CHECK_ARG(src0 && dst0 && n0 > 0 && (n0 % 4) == 0 && n1 >= 0 && (n1 % 4) == 0 && (n1 == 0 || (src1 && dst1)));
+  const int64_t q = (n0 + n1) / 4;
+  const int grid = (int)((q + 255) / 256 < 2048 ? (q + 255) / 256 : 2048);
+  VOG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cast2_kernel<T16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)src0, (u16x4*)dst0, n0 / 4, (const float4*)src1, (u16x4*)dst1, n1 / 4));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vog_box_u(const float* props, const float* w_pe, float* u, int n_rows, int H,
                          float vid_w, float vid_h, float nfrm_div, void* stream) {
   VOG_CHECK_ARG(props && w_pe && u && n_rows > 0 && H > 0);
@@ -346,7 +377,7 @@ extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const i
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
   VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0);
-  hipLaunchKernelGGL(argvec_kernel, dim3(Bn * nsrl), dim3(256), 2 * L * sizeof(float),
+  hipLaunchKernelGGL(argvec_kernel, dim3(Bn * nsrl, ceil_div(L, 16)), dim3(256), 0,
                      (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L);
   VOG_LAUNCH_CHECK();
   return 0;

@@ -249,9 +249,12 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
   }
   p.zero_bytes = p.total - p.zero_off;
   p.add("tok", (int64_t)g.Bn * g.T * 4);
+  p.add("lstm_rows", (int64_t)2 * g.Bn * g.T * 4);
   p.add("gx", (int64_t)g.Bn * g.T * 8 * g.R * 4);
   p.add("full", (int64_t)(g.Bn * g.T + g.Bn16) * g.L * 4);
   p.add("lang", (int64_t)g.Bn * d.nsrl * g.L * 4);
+  p.add("prop16", g.rows_obj * d.prop_dim * 2);
+  p.add("seg16", (int64_t)g.n_vid * g.Fv * d.seg_dim * 2);
   p.add("prop_seg", g.rows_obj * g.d_obj * 4);
   p.add("prop_seg16", g.rows_obj * g.d_obj * 2);
   auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
@@ -294,7 +297,7 @@ struct WS {
 
 static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, const Geo& g, const WS& ws,
                      const vog_batch* b, const float* x_in32, const void* x_in16, int S, int N,
-                     int npad, int spv, int n_box, float fdiv, std::vector<Step>& steps,
+                     int npad, int spv, int n_box, float fdiv, int last_dt, std::vector<Step>& steps,
                      const float** out32, const void** out16) {
   const std::string n(nm);
   const vog_model_desc& d = c->d;
@@ -348,8 +351,13 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     f2.ldr = tw.d; f2.c32 = tmp; f2.ldc = tw.d; f2.M = (int)rows; f2.N = tw.d; f2.K = tw.dh; f2.rep = 1;
     f2.dtype = dt;
     steps.push_back({n + "_ffn2", [=](hipStream_t st) { return vog_gemm_bias_act(&f2, st); }});
+    // 16-bit copy of the LAST layer's output: typed for its consumer (none for obj_tx,
+    // the f16 score head for mul_tx)
+    const bool last = l == tw.n_layers - 1;
+    void* o16w = (last && last_dt < 0) ? nullptr : o16;
+    const vog_dtype odt = last && last_dt >= 0 ? (vog_dtype)last_dt : dt;
     steps.push_back({n + "_ln2", [=](hipStream_t st) {
-      return vog_residual_layernorm(tmp, L.ln2g, L.ln2b, o32, o16, (int)rows, d_, dt, st); }});
+      return vog_residual_layernorm(tmp, L.ln2g, L.ln2b, o32, o16w, (int)rows, d_, odt, st); }});
     cur32 = o32;
     cur16 = o16;
   }
@@ -385,12 +393,19 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     steps.push_back({"srl_gather", [=](hipStream_t st) {
       return vog_srl_gather(wi, wm, tok, Bn, T, nsrl, sl, V, st); }});
     float* gx = ws.at<float>("gx");
+    int32_t* lrows = ws.at<int32_t>("lstm_rows");
+    {
+      const int64_t* lens = b->srl_arg_word_mask_len;
+      steps.push_back({"lstm_schedule", [=](hipStream_t st) { return vog_lstm_schedule(lens, lrows, Bn, T, st); }});
+    }
     for (int l = 0; l < d.rnn_layers; ++l) {
       vog_gemm_args ga{}; ga.c16_dtype = -1;
       if (l == 0) { ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E; }
       else { ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R; }
-      ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 8 * R;
+      // output rows land in (direction, step) order: gxs[dir][step][b][4R]
+      ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 4 * R;
       ga.M = Bn * T; ga.N = 8 * R; ga.rep = 1; ga.dtype = et;
+      ga.out_rows = lrows; ga.out_rows_ncol = 4 * R;
       steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
       // final state must land in hA (adjacent to out16): after T steps it is in buf[T % 2]
       void* hA = ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R;
@@ -423,13 +438,22 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   float* ps32 = ws.at<float>("prop_seg");
   void* ps16 = ws.at<void>("prop_seg16");
   {
+    // raw features -> encoder operand type once (then both encoders run on the
+    // LDS-DMA GEMM, which cannot convert in flight)
+    {
+      const float *s0 = b->pad_region_feature, *s1 = b->seg_feature_for_frms;
+      void *d0 = ws.at<void>("prop16"), *d1 = ws.at<void>("seg16");
+      const int64_t n0 = g.rows_obj * d.prop_dim, n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
+      steps.push_back({"cast_feats", [=](hipStream_t st) {
+        return vog_cast_f32_to_t16(s0, d0, n0, s1, d1, n1, et, st); }});
+    }
     vog_gemm_args pe{}; pe.c16_dtype = d.tx_dtype;
-    pe.a = b->pad_region_feature; pe.a_is_f32 = 1; pe.lda = d.prop_dim; pe.w = c->w_prop; pe.ldw = d.prop_dim;
+    pe.a = ws.at<void>("prop16"); pe.a_is_f32 = 0; pe.lda = d.prop_dim; pe.w = c->w_prop; pe.ldw = d.prop_dim;
     pe.bias = c->b_prop; pe.relu = 1; pe.c32 = ps32; pe.c16 = ps16; pe.ldc = g.d_obj; pe.ldc16 = g.d_obj;
     pe.M = (int)g.rows_obj; pe.N = d.prop_enc; pe.K = d.prop_dim; pe.rep = 1; pe.dtype = et;
     steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
     vog_gemm_args se{}; se.c16_dtype = d.tx_dtype;
-    se.a = b->seg_feature_for_frms; se.a_is_f32 = 1; se.lda = d.seg_dim; se.w = c->w_seg; se.ldw = d.seg_dim;
+    se.a = ws.at<void>("seg16"); se.a_is_f32 = 0; se.lda = d.seg_dim; se.w = c->w_seg; se.ldw = d.seg_dim;
     se.bias = c->b_seg; se.relu = 1; se.c32 = ps32 + d.prop_enc;
     se.c16 = (unsigned short*)ps16 + d.prop_enc; se.ldc = g.d_obj; se.ldc16 = g.d_obj;
     se.M = g.n_vid * g.Fv; se.N = d.seg_enc; se.K = d.seg_dim; se.rep = d.nppf0; se.dtype = et;
@@ -440,7 +464,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   const void* vis16 = ps16;
   if (has_obj(d))
     tx_steps(c, c->obj, "obj", g, ws, b, ps32, ps16, g.S_obj, g.N_obj, g.npad_obj, g.spv_obj, g.N_obj,
-             g.fdiv_obj, steps, &vis32, &vis16);
+             g.fdiv_obj, -1, steps, &vis32, &vis16);
   // ---- vis || lang tokens in mul_tx order (a10, a11)
   {
     vog_vislang_args va{};
@@ -451,10 +475,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   }
   const float* x32 = ws.at<float>("xmul");
   const void* x16 = ws.at<void>("xmul16");
-  int head_dt = has_mul(d) ? d.tx_dtype : d.enc_dtype;   // dtype of the 16-bit copy feeding lin2
+  int head_dt = d.enc_dtype;   // the 16-bit copy feeding lin2 is always written in the head's type
   if (has_mul(d))
     tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
-             (float)g.nfrm, steps, &x32, &x16);
+             (float)g.nfrm, d.enc_dtype, steps, &x32, &x16);
   // ---- score head (a9 tail / a20 / a17)
   {
     vog_gemm_args l2{}; l2.c16_dtype = -1;
@@ -608,9 +632,14 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
       const auto& bi = W(c, "lstm_encoder.lstm.bias_ih" + s);
       const auto& bh = W(c, "lstm_encoder.lstm.bias_hh" + s);
       for (size_t i = 0; i < a.size(); ++i) wih[(size_t)dir * 4 * R * in + i] = h_to16(a[i], et);
-      for (size_t i = 0; i < h.size(); ++i) whh[(size_t)dir * 4 * R * R + i] = h_to16(h[i], et);
+      (void)h;
       for (int i = 0; i < 4 * R; ++i) bs[(size_t)dir * 4 * R + i] = bi[i] + bh[i];
       ++dir;
+    }
+    {
+      std::string s0 = "_l" + std::to_string(l), s1 = s0 + "_reverse";
+      VOG_TRY(vog_lstm_pack_whh(W(c, "lstm_encoder.lstm.weight_hh" + s0).data(),
+                                W(c, "lstm_encoder.lstm.weight_hh" + s1).data(), whh.data(), R, (vog_dtype)et));
     }
     unsigned short *pw, *ph; float* pb;
     VOG_TRY(upload<unsigned short>(c, wih, &pw));

@@ -13,18 +13,27 @@
 //
 // Both read W as [N,K] row-major 16-bit (K contiguous), which is exactly the
 // MFMA B-operand fragment order (8 consecutive k per lane): no transposes.
+#include <stdlib.h>
 #include "common.h"
 
 namespace vog {
 
 enum { EPI_PLAIN = 0, EPI_QKV = 1 };
 
+// VOG_GEMM_DEBUG (ablation, perf experiments only): 1 = no DMA, 2 = no MFMA, 4 = no epilogue
+static int gemm_debug_flags() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VOG_GEMM_DEBUG"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 struct GemmParams {
   const void* a; const int32_t* a_rows; int64_t lda;
   const unsigned short* w; int64_t ldw;
   const float* bias; const float* residual; int64_t ldr;
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
-  int M, N, K; int relu; int rep; int c16_bf16;
+  int M, N, K; int relu; int rep; int c16_bf16; int debug;
+  const int32_t* out_rows; int out_rows_ncol;
   // QKV epilogue
   unsigned short* q; unsigned short* k; unsigned short* vt;
   int ntok, H, dp, npad;
@@ -52,6 +61,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
     if (p.bias) v += p.bias[col];
     if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
     if (p.relu) v = fmaxf(v, 0.f);
+    if (p.out_rows) {
+      const int orow = p.out_rows[(int64_t)(col / p.out_rows_ncol) * p.M + row];
+      if (orow < 0) return;
+      if (p.c32) p.c32[(int64_t)orow * p.ldc + col] = v;
+      if (p.c16) p.c16[(int64_t)orow * p.ldc16 + col] = p.c16_bf16 ? to16<BF16>(v) : to16<F16>(v);
+      return;
+    }
     for (int j = 0; j < p.rep; ++j) {
       int64_t orow = (int64_t)row * p.rep + j;
       if (p.c32) p.c32[orow * p.ldc + col] = v;
@@ -197,6 +213,297 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmParams p) {
     }
 }
 
+// ---- epilogues for the swapped (C^T) accumulator layout -------------------------
+// acc[4*g + e] = C[m][nb + 8*g + 4*hi + e]
+template <typename T16>
+__device__ __forceinline__ void plain_store_swapped(const GemmParams& p, int m, int nb, int hi,
+                                                    const f32x16& acc) {
+  if (m >= p.M) return;
+  const bool vec = (p.N & 3) == 0;
+  const float* res = p.residual ? p.residual + (int64_t)m * p.ldr : nullptr;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = nb + 8 * g + 4 * hi;
+    if (n >= p.N) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (vec) {
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      u16x4 h;
+      if (p.c16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = p.c16_bf16 ? to16<BF16>(v[e]) : to16<F16>(v[e]);
+      }
+      for (int j = 0; j < p.rep; ++j) {
+        const int64_t orow = (int64_t)m * p.rep + j;
+        if (p.c32) *reinterpret_cast<float4*>(p.c32 + orow * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.c16) *reinterpret_cast<u16x4*>(p.c16 + orow * p.ldc16 + n) = h;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) epilogue_store<T16>(p, m, n + e, v[e]);
+    }
+  }
+}
+
+template <typename T16>
+__device__ __forceinline__ void qkv_store_swapped(const GemmParams& p, int m, int nb, int hi,
+                                                  const f32x16& acc) {
+  nb = __builtin_amdgcn_readfirstlane(nb);
+  if (nb >= p.N || m >= p.M) return;
+  const int hd = p.H * p.dp;
+  const int which = nb / hd;                          // wave-uniform (dp % 32 == 0)
+  const int h = (nb - which * hd) / p.dp;
+  const int dd0 = nb % p.dp;
+  const int s = m / p.ntok;
+  const int i = m - s * p.ntok;
+  const int64_t sh = (int64_t)s * p.H + h;
+  if (which < 2) {
+    unsigned short* dst = (which == 0 ? p.q : p.k) + (sh * p.ntok + i) * p.dp + dd0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = to16<T16>(acc[4 * g + e]);
+      *reinterpret_cast<u16x4*>(dst + 8 * g + 4 * hi) = v;
+    }
+  } else {
+    // V^T[dd][token]: for a fixed dd the 32 lanes of a half-wave hold consecutive tokens
+    unsigned short* dst = p.vt + (sh * p.dp + dd0) * p.npad + i;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dst[(int64_t)(8 * g + 4 * hi + e) * p.npad] = to16<T16>(acc[4 * g + e]);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// pipelined kernel: K % 64 == 0, 16-bit A. Global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), STAGES-deep
+// ring, ONE raw s_barrier per K tile, counted vmcnt so the next tile's DMA stays
+// in flight across the barrier (the tiled kernel above exposes a full L2/HBM
+// round trip per 64-deep step; at M = 4000 that, not MFMA issue, set its time).
+//
+// LDS image: rows of 128 B (64 halfwords), lane-linear per DMA instruction
+// (1 KiB = 8 rows). Bank-conflict-free ds_read_b128 needs 16 consecutive rows on
+// 16 distinct 16-B slots of the 256-B bank row: slot = (row&1)*8 + (chunk ^
+// ((row>>1)&7)). The DMA destination cannot be permuted, so the permutation is
+// applied to the per-lane SOURCE chunk and, identically, to the read address
+// (same involution on both sides).
+// ----------------------------------------------------------------------------
+template <typename T16, int BM, int BN, int STAGES, int EPI>
+__global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE_BYTES = ROWS * 128;
+  constexpr int LPT = ROWS / 32;                   // DMA instructions per wave per tile
+  constexpr int FM = BM / 64, FN = BN / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / nbn, bn = bid % nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // per-lane source pointers of this wave's DMA instructions (advance by 64 halfwords per tile)
+  const unsigned short* gsrc[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int rr = (wid * LPT + i) * 8 + (lane >> 3);        // row in the combined [A | W] tile
+    const int c = (lane & 7) ^ ((rr >> 1) & 7);              // source chunk for LDS chunk lane&7
+    if (rr < BM) {
+      int m = m0 + rr;
+      m = m < p.M ? m : p.M - 1;                             // clamp: rows >= M are discarded later
+      const int64_t src = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
+      gsrc[i] = reinterpret_cast<const unsigned short*>(p.a) + src * p.lda + c * 8;
+    } else {
+      int n = n0 + rr - BM;
+      n = n < p.N ? n : p.N - 1;
+      gsrc[i] = p.w + (int64_t)n * p.ldw + c * 8;
+    }
+  }
+  auto issue = [&](int kt, int stage) {
+    if (p.debug & 1) return;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(gsrc[i] + (int64_t)kt * 64),
+          (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (wid * LPT + i) * 1024),
+          16, 0, 0);
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int a_row[FM], b_row[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_row[i] = wm * (BM / 2) + i * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) b_row[j] = BM + wn * (BN / 2) + j * 32 + (lane & 31);
+  const int hi = lane >> 5;
+
+  const int nk = p.K / 64;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles in flight now: kt .. min(kt+STAGES-2, nk-1). Retire tile kt only.
+    const int ahead = (nk - 1 - kt) < (STAGES - 2) ? (nk - 1 - kt) : (STAGES - 2);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
+    if (p.debug & 2) continue;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u16x8 fa[FM], fb[FN];
+      const int g = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        fa[i] = *reinterpret_cast<const u16x8*>(st + a_row[i] * 128 + ((g ^ ((a_row[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        fb[j] = *reinterpret_cast<const u16x8*>(st + b_row[j] * 128 + ((g ^ ((b_row[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma32<T16>(fb[j], fa[i], acc[i][j]);   // C^T: D[n][m]
+    }
+  }
+  if (p.debug & 4) { if (acc[0][0][0] != 123.456f) return; }
+  // ---- epilogue through LDS -------------------------------------------------------
+  // The MFMA C layout gives a lane 4-element column strips of many rows; stores
+  // straight from it touch 32-64 distinct cache lines per instruction (measured:
+  // 26 us of a 62 us QKV launch). Each wave parks its (BM/2 x BN/2) fp32 tile in
+  // the (now idle) stage buffers and re-reads it row-wise, so every global
+  // load/store instruction covers whole 128-256 B row segments.
+  constexpr int WTM = BM / 2, WTN = BN / 2, EP_LD = WTN + 4;
+  static_assert(4 * WTM * EP_LD * 4 <= STAGES * STAGE_BYTES, "epilogue tile must fit the stage ring");
+  __builtin_amdgcn_s_barrier();                       // all waves done with the last stage
+  asm volatile("" ::: "memory");
+  float* ep = reinterpret_cast<float*>(smem) + wid * (WTM * EP_LD);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(&ep[(i * 32 + (lane & 31)) * EP_LD + j * 32 + 8 * g + 4 * hi]) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;   // wave tile origin
+  if constexpr (EPI == EPI_PLAIN) {
+    constexpr int CPR = WTN / 4, RPP = 64 / CPR;      // 16-B chunks per row, rows per pass
+    const int c = lane % CPR, rsub = lane / CPR;
+    const int n = nw + 4 * c;
+    const bool vec = (p.N & 3) == 0;
+    if (n < p.N) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && vec) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+      for (int ps = 0; ps < WTM / RPP; ++ps) {
+        const int rl = ps * RPP + rsub;
+        const int m = mw + rl;
+        if (m >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + 4 * c]);
+        if (vec) {
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          if (p.residual) {
+            const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldr + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          u16x4 h;
+          if (p.c16) {
+            if (p.c16_bf16) h = u16x4{to16<BF16>(v.x), to16<BF16>(v.y), to16<BF16>(v.z), to16<BF16>(v.w)};
+            else h = u16x4{to16<F16>(v.x), to16<F16>(v.y), to16<F16>(v.z), to16<F16>(v.w)};
+          }
+          if (p.out_rows) {
+            const int orow = p.out_rows[(int64_t)(n / p.out_rows_ncol) * p.M + m];
+            if (orow >= 0) {
+              if (p.c32) *reinterpret_cast<float4*>(p.c32 + (int64_t)orow * p.ldc + n) = v;
+              if (p.c16) *reinterpret_cast<u16x4*>(p.c16 + (int64_t)orow * p.ldc16 + n) = h;
+            }
+            continue;
+          }
+          for (int j = 0; j < p.rep; ++j) {
+            const int64_t orow = (int64_t)m * p.rep + j;
+            if (p.c32) *reinterpret_cast<float4*>(p.c32 + orow * p.ldc + n) = v;
+            if (p.c16) *reinterpret_cast<u16x4*>(p.c16 + orow * p.ldc16 + n) = h;
+          }
+        } else {
+          epilogue_store<T16>(p, m, n, v.x); epilogue_store<T16>(p, m, n + 1, v.y);
+          epilogue_store<T16>(p, m, n + 2, v.z); epilogue_store<T16>(p, m, n + 3, v.w);
+        }
+      }
+    }
+  } else {
+    // QKV: handle the wave tile in 32-column groups; (which, head) is uniform per group
+    const int hd = p.H * p.dp;
+#pragma unroll
+    for (int cg = 0; cg < WTN / 32; ++cg) {
+      const int nb = __builtin_amdgcn_readfirstlane(nw + cg * 32);
+      if (nb >= p.N) continue;
+      const int which = nb / hd;
+      const int h = (nb - which * hd) / p.dp;
+      const int dd0 = nb % p.dp;
+      if (which < 2) {
+        unsigned short* base = which == 0 ? p.q : p.k;
+        const int c = lane & 7, rsub = lane >> 3;     // 8 chunks of 4 columns per row, 8 rows per pass
+#pragma unroll 4
+        for (int ps = 0; ps < WTM / 8; ++ps) {
+          const int rl = ps * 8 + rsub;
+          const int m = mw + rl;
+          if (m >= p.M) continue;
+          const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
+          const int sq = m / p.ntok, tok = m - sq * p.ntok;
+          const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
+          *reinterpret_cast<u16x4*>(base + (((int64_t)sq * p.H + h) * p.ntok + tok) * p.dp + dd0 + 4 * c) = o;
+        }
+      } else {
+        // V^T[dd][token]: lane = token, so each store instruction writes a token-contiguous run
+#pragma unroll
+        for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
+          const int rl = th * 64 + lane;
+          const int m = mw + rl;
+          if (rl < WTM && m < p.M) {
+            const int sq = m / p.ntok, tok = m - sq * p.ntok;
+            unsigned short* dst = p.vt + (((int64_t)sq * p.H + h) * p.dp + dd0) * p.npad + tok;
+#pragma unroll 8
+            for (int dd = 0; dd < 32; ++dd)
+              dst[(int64_t)dd * p.npad] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------
 // skinny kernel (M <= 64, K % 32 == 0)
 // ----------------------------------------------------------------------------
@@ -268,8 +575,43 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
 // ----------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------
+template <typename T16, int BM, int BN, int STAGES, int EPI>
+static int launch_pipe_cfg(const GemmParams& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  auto kern = gemm_pipe<T16, BM, BN, STAGES, EPI>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T16, int EPI>
+static int launch_pipe(const GemmParams& p, hipStream_t st) {
+  // largest tile that still gives every CU a workgroup (256 CUs)
+  auto ntiles = [&](int bm, int bn) { return (int64_t)ceil_div(p.M, bm) * ceil_div(p.N, bn); };
+  if (ntiles(128, 128) >= 256) return launch_pipe_cfg<T16, 128, 128, 3, EPI>(p, st);
+  if (ntiles(128, 64) >= 256) return launch_pipe_cfg<T16, 128, 64, 3, EPI>(p, st);
+  return launch_pipe_cfg<T16, 64, 64, 4, EPI>(p, st);
+}
+
+static bool pipe_ok(const GemmParams& p, bool a_f32) {
+  const bool out_ok = (!p.c32 || ((p.ldc % 4) == 0 && ((uintptr_t)p.c32 % 16) == 0)) &&
+                      (!p.c16 || ((p.ldc16 % 4) == 0 && ((uintptr_t)p.c16 % 8) == 0)) &&
+                      (!p.residual || ((p.ldr % 4) == 0 && ((uintptr_t)p.residual % 16) == 0)) &&
+                      (!p.bias || ((uintptr_t)p.bias % 16) == 0);
+  return !a_f32 && p.M > 64 && (p.K % 64) == 0 && (p.lda % 8) == 0 && (p.ldw % 8) == 0 &&
+         ((uintptr_t)p.a % 16) == 0 && ((uintptr_t)p.w % 16) == 0 && out_ok;
+}
+
 template <typename T16, bool A_F32, int EPI>
 static int launch_tiled(const GemmParams& p, hipStream_t st) {
+  if (pipe_ok(p, A_F32)) return launch_pipe<T16, EPI>(p, st);
   const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   if (p.M > 64 && t128 >= 192) {
     dim3 grid(ceil_div(p.M, 128) * ceil_div(p.N, 128));
@@ -291,6 +633,8 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   p.c32 = g->c32; p.c16 = (unsigned short*)g->c16; p.ldc = g->ldc; p.ldc16 = g->ldc16;
   p.M = g->M; p.N = g->N; p.K = g->K; p.relu = g->relu; p.rep = g->rep < 1 ? 1 : g->rep;
   p.c16_bf16 = (g->c16_dtype < 0 ? (int)g->dtype : g->c16_dtype) == VOG_BF16;
+  p.debug = gemm_debug_flags();
+  p.out_rows = g->out_rows; p.out_rows_ncol = g->out_rows_ncol;
   if (p.M <= 64 && (p.K % 32) == 0) {
     dim3 grid(ceil_div(p.N, 16));
     if (g->a_is_f32) hipLaunchKernelGGL((gemm_skinny<T16, true>), grid, dim3(256), 0, st, p);
@@ -307,6 +651,7 @@ int gemm_run(const vog_gemm_args* g, hipStream_t st) {
   VOG_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0 && (g->K % 8) == 0);
   VOG_CHECK_ARG((g->lda % (g->a_is_f32 ? 4 : 8)) == 0 && (g->ldw % 8) == 0);
   VOG_CHECK_ARG(!(g->residual && g->rep > 1));
+  VOG_CHECK_ARG(!g->out_rows || (g->rep <= 1 && g->out_rows_ncol > 0 && (g->out_rows_ncol % 4) == 0));
   VOG_DISPATCH_DTYPE(g->dtype, return gemm_dispatch<T16>(g, st));
   return 0;
 }
@@ -319,6 +664,7 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
   p.M = a->S * a->N; p.N = 3 * a->H * a->dp; p.K = a->K; p.rep = 1;
   p.q = (unsigned short*)a->q; p.k = (unsigned short*)a->k; p.vt = (unsigned short*)a->vt;
   p.ntok = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad;
+  p.debug = gemm_debug_flags();
   VOG_DISPATCH_DTYPE(a->dtype, return (launch_tiled<T16, false, EPI_QKV>(p, st)));
   return 0;
 }

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32), ("c16_dtype", c_i32)]
+                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -117,8 +117,11 @@ SYMBOLS = {
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_rel_attention_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
     "vog_residual_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vog_cast_f32_to_t16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "vog_box_u": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp]),
     "vog_srl_gather": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "vog_lstm_pack_whh": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32]),
     "vog_bilstm_step": (c_i32, [C.POINTER(LstmStepArgs), c_vp]),
     "vog_srl_argvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vog_vislang_layout": (c_i32, [C.POINTER(VislangArgs), c_vp]),
