@@ -72,7 +72,10 @@ def kernel_flops(w, T):
     S_obj, N_obj, d_obj = n_vid, NP, 512
     rm, ro = S_mul * N_mul, S_obj * N_obj
     f = {
-        "mul_qkv": 2.0 * rm * d_mul * 3 * d_mul,
+        "mul_qkv": 2.0 * rm * d_mul * 3 * d_mul,          # dense form (layers >= 1 / unstructured input)
+        "mul_pv": 2.0 * ro * d_obj * 3 * d_mul,           # structured layer 0: vis part
+        "mul_pl": 2.0 * (B * (ncmp if w["conc"] in ("sep", "svsq") else 1) * 5) * 256 * 3 * d_mul,
+        "mul_combine": 0.0,
         "mul_attn": 4.0 * S_mul * N_mul * N_mul * d_mul,
         "mul_wo": 2.0 * rm * d_mul * d_mul,
         "mul_ffn1": 2.0 * rm * d_mul * (d_mul // 2),
@@ -85,7 +88,8 @@ def kernel_flops(w, T):
     }
     Bn = B * (ncmp if w["conc"] in ("sep", "svsq") else 1)
     lstm = 2.0 * Bn * T * (2 * 4096 * 512 + 2 * 4096 * 2048 + 4 * 4096 * 1024)
-    total = sum(f.values()) + f["obj_wo"] * 0 + lstm \
+    dense = {k: v for k, v in f.items() if k not in ("mul_pv", "mul_pl", "mul_combine")}
+    total = sum(dense.values()) + lstm \
         + 2.0 * ro * d_obj * (d_obj // 2) * 2 + 2.0 * n_vid * (NP // nppf0) * 3072 * 256 \
         + 2.0 * Bn * (T + 1) * 2048 * 256
     return f, total
@@ -222,7 +226,7 @@ def main():
         except Exception as e:      # a kernel name absent for this model variant
             ktimes[k] = None
     lstm_us = eng.time_kernel(slots[0], "lstm_step", args.kernel_iters)
-    dom = max((k for k in flops if ktimes[k]), key=lambda k: ktimes[k])
+    dom = max((k for k in flops if ktimes[k] and flops[k] > 0), key=lambda k: ktimes[k])
     ach = flops[dom] / (ktimes[dom] * 1e-6) / 1e12
     res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
                        "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None,

@@ -54,6 +54,7 @@ const char* vog_last_error(void);
  * c32 fp32 / c16 t16 (type c16_dtype), row pitch ldc; output row = m*rep + j for j < rep
  * (rep > 1 broadcasts a frame's segment feature onto its proposals,
  * mdl_conc_single.py:51-66). */
+struct vog_vislang_args;
 typedef struct vog_gemm_args {
   const void* a; int a_is_f32; int64_t lda; const int32_t* a_rows;
   const void* w; int64_t ldw;
@@ -67,13 +68,21 @@ typedef struct vog_gemm_args {
    * row m of that segment is written to row out_rows[seg*M + m] (< 0: dropped).
    * Used to emit the LSTM input projections directly in (direction, step) order. */
   const int32_t* out_rows; int out_rows_ncol;
+  /* optional implicit residual: the residual row of output row m is the vis||lang
+   * token m of this layout (never materialised); `residual` must then be NULL. */
+  const struct vog_vislang_args* res_vislang;
 } vog_gemm_args;
 int vog_gemm_bias_act(const vog_gemm_args* g, void* stream);
 
 /* Fused QKV projection for one (Rel)MultiHead (transformer_code.py:64-67,
  * 180-183): x[S*N, K] * Wqkv_pad^T where Wqkv_pad is [3*H*dp, K] (heads padded
- * to dp columns with zero rows). Writes q,k as [S,H,N,dp] and v TRANSPOSED as
- * vt [S,H,dp,npad] (npad = N rounded up to 64; pad region must be zeroed once). */
+ * to dp columns with zero rows, dp % 32 == 0). Writes q, k, v per (sequence, head)
+ * in MFMA-FRAGMENT ORDER, npad*dp halfwords each, npad = N rounded up to 32:
+ *   q/k : [token/32][dd/16][lane = ((dd/8)&1)*32 + token%32][dd%8]
+ *   v   : [token/32][dd/32][(token%32)/16][lane = hi*32 + dd%32][j],
+ *         token%16 = 8*(j>>2) + 4*hi + (j&3)
+ * (csrc/common.h frag_qk / frag_v). Pad tokens are never written: zero the
+ * buffers once (vog_workspace_init does). */
 typedef struct vog_qkv_args {
   const void* x16; int64_t ldx; const void* wqkv; int64_t ldw;
   void* q; void* k; void* vt;
@@ -81,15 +90,29 @@ typedef struct vog_qkv_args {
 } vog_qkv_args;
 int vog_qkv_proj(const vog_qkv_args* a, void* stream);
 
+/* Layer-0 QKV of mul_tx through the token structure: every token is
+ * [vis[v, f*nppf+p] || lang[l, a]], so x Wqkv^T = PV[vis row] + PL[lang row] with
+ * PV = vis Wqkv[:, :dv]^T ([n_vid*NP, 3*H*dp] fp32) and PL = lang Wqkv[:, dv:]^T
+ * ([n_lang*nsrl, 3*H*dp] fp32): 5x fewer projection FLOPs than the dense
+ * [tokens, d] GEMM of transformer_code.py:180 and no token matrix in HBM. This
+ * entry adds the two parts (one rounding to 16 bit) and emits q, k, v in the
+ * fragment order of vog_qkv_proj. */
+typedef struct vog_qkvcomb_args {
+  const float* pv; const float* pl; void* q; void* k; void* vt;
+  int n_vid, nfrm, nppf, nsrl, H, dp, npad; int lang_per_vid, nc_v; vog_dtype dtype;
+} vog_qkvcomb_args;
+int vog_qkv_combine(const vog_qkvcomb_args* a, void* stream);
+
 /* softmax((q k^T + bias)/scale) v per (sequence, head), flash-style, with the
  * relative-position bias computed on the fly: bias[i,j] = relu(u[i]-u[j]+pe_b[h])
  * where u[token,h] = W_pe[h,:].box_norm[token,:]  (RelAttention.forward
  * transformer_code.py:136-160 + compute_pe mdl_vog.py:456-490 + do_cross
  * mdl_srl_utils.py:30-69 + Linear(5,H)+ReLU mdl_vog.py:446-451,580-585; the
  * [S,N,N,H] tensor is never materialised). use_rel=0 gives Attention.forward
- * (transformer_code.py:42-50). u: [n_vid, NP, H] fp32; token j of sequence s
- * uses row (s / seq_per_vid)*NP + (s % seq_per_vid)*n_box + (j % n_box).
- * out16: [S*N, H*dp] t16 (heads concatenated, padded). */
+ * (transformer_code.py:42-50). q, k, vt: fragment order of vog_qkv_proj (npad = N up
+ * to 32). u: [n_vid, NP, H] fp32; token j of sequence s uses row
+ * (s / seq_per_vid)*NP + (s % seq_per_vid)*n_box + (j % n_box).
+ * out16: [S*N, H*dp] t16 row-major (heads concatenated, padded). */
 typedef struct vog_attn_args {
   const void* q; const void* k; const void* vt; void* out16;
   const float* u; const float* pe_b;

@@ -82,6 +82,37 @@ def test_gemm_f32_a_residual_rep_gather(M):
     assert (c16.float() - ref).abs().max().item() <= 2e-2
 
 
+def frag_index(N, dp, kind):
+    """Flat offsets of (token i, column dd) inside one (sequence, head) block of the
+    fragment-ordered q/k ('qk') or v ('v') layout (csrc/common.h frag_qk / frag_v)."""
+    i = torch.arange(N).view(N, 1)
+    dd = torch.arange(dp).view(1, dp)
+    if kind == "qk":
+        return ((i >> 5) * (dp >> 4) + (dd >> 4)) * 512 + ((((dd >> 3) & 1) << 5) + (i & 31)) * 8 + (dd & 7)
+    kl = i & 31
+    r = kl & 15
+    j = ((r >> 3) << 2) + (r & 3)
+    hi = (r >> 2) & 1
+    return ((((i >> 5) * (dp >> 5) + (dd >> 5)) * 2 + (kl >> 4)) * 64 + (hi << 5) + (dd & 31)) * 8 + j
+
+
+def to_frag(x, kind):
+    """[S,H,N,dp] row-major -> [S,H,npad*dp] fragment order (pad tokens zero)."""
+    S, H, N, dp = x.shape
+    npad = (N + 31) // 32 * 32
+    idx = frag_index(N, dp, kind).reshape(-1).to(x.device)
+    assert idx.unique().numel() == N * dp and int(idx.max()) < npad * dp
+    out = torch.zeros(S, H, npad * dp, dtype=x.dtype, device=x.device)
+    out[:, :, idx] = x.reshape(S, H, N * dp)
+    return out
+
+
+def from_frag(f, N, dp, kind):
+    idx = frag_index(N, dp, kind).reshape(-1).to(f.device)
+    S, H = f.shape[:2]
+    return f[:, :, idx].reshape(S, H, N, dp)
+
+
 def _attn_ref(q, k, v, u, peb, n_box, inv_scale, use_rel):
     """q,k,v [S,H,N,dh] fp32 (already rounded); u [S,N,H]"""
     logits = q @ k.transpose(-1, -2)
@@ -102,17 +133,16 @@ def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
     lib = _lib()
     torch.manual_seed(S * 1000 + N)
     td = t16(dtype)
-    npad = (N + 63) // 64 * 64
+    npad = (N + 31) // 32 * 32
     q = torch.zeros(S, H, N, dp, device="cuda")
     k = torch.zeros(S, H, N, dp, device="cuda")
     v = torch.zeros(S, H, N, dp, device="cuda")
     q[..., :dh] = torch.randn(S, H, N, dh, device="cuda") * 2
     k[..., :dh] = torch.randn(S, H, N, dh, device="cuda") * 2
     v[..., :dh] = torch.randn(S, H, N, dh, device="cuda")
-    q16, k16 = q.to(td), k.to(td)
-    # V^T with NaN in the key padding: the kernel must mask it, not multiply it
-    vt16 = torch.full((S, H, dp, npad), float("nan"), device="cuda").to(td)
-    vt16[..., :N] = v.transpose(-1, -2).to(td)
+    q16, k16, v16 = q.to(td), k.to(td), v.to(td)
+    qf, kf, vf = to_frag(q16, "qk"), to_frag(k16, "qk"), to_frag(v16, "v")
+    # pad keys: K may hold anything (masked); V pad must be finite (contract)
     n_box = N // nsrl
     NP = n_box                      # one sequence per "video" here
     u_box = torch.randn(S, n_box, H, device="cuda") * 3
@@ -120,7 +150,7 @@ def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
     out = torch.full((S * N, H * dp), float("nan"), device="cuda").to(td)
     inv_scale = 1.0 / math.sqrt(H * dh)
     a = L.AttnArgs()
-    a.q, a.k, a.vt, a.out16 = L.ptr(q16), L.ptr(k16), L.ptr(vt16.contiguous()), L.ptr(out)
+    a.q, a.k, a.vt, a.out16 = L.ptr(qf), L.ptr(kf), L.ptr(vf), L.ptr(out)
     a.u, a.pe_b = L.ptr(u_box.contiguous()), L.ptr(peb)
     a.S, a.N, a.H, a.dp, a.npad = S, N, H, dp, npad
     a.use_rel, a.n_box, a.seq_per_vid, a.NP = use_rel, n_box, 1, NP
@@ -128,7 +158,7 @@ def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
     L.check(lib.vog_rel_attention_fwd(C.byref(a), _sp()), "attn")
     torch.cuda.synchronize()
     u_tok = u_box.repeat(1, nsrl, 1)                            # token j -> box j % n_box
-    ref = _attn_ref(q16.float(), k16.float(), vt16[..., :N].transpose(-1, -2).float(), u_tok, peb,
+    ref = _attn_ref(q16.float(), k16.float(), v16.float(), u_tok, peb,
                     n_box, inv_scale, use_rel)                  # [S,H,N,dp]
     got = out.float().view(S, N, H, dp).permute(0, 2, 1, 3)
     assert torch.isfinite(got).all()
@@ -155,9 +185,9 @@ def test_qkv_layout(dtype):
             wpad[(which * H + h) * dp:(which * H + h) * dp + dh] = w[off:off + dh]
         off += dh
     wpad = wpad.to(td)
-    q = torch.full((S, H, N, dp), float("nan"), device="cuda").to(td)
-    k = torch.full((S, H, N, dp), float("nan"), device="cuda").to(td)
-    vt = torch.zeros((S, H, dp, npad), device="cuda").to(td)
+    q = torch.zeros((S, H, npad * dp), device="cuda").to(td)
+    k = torch.zeros((S, H, npad * dp), device="cuda").to(td)
+    vt = torch.zeros((S, H, npad * dp), device="cuda").to(td)
     a = L.QkvArgs()
     a.x16, a.ldx, a.wqkv, a.ldw = L.ptr(x), d, L.ptr(wpad), d
     a.q, a.k, a.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
@@ -166,9 +196,44 @@ def test_qkv_layout(dtype):
     torch.cuda.synchronize()
     full = (x.float() @ wpad.float().t()).view(S, N, 3, H, dp)
     tol = 2e-2
-    assert (q.float() - full[:, :, 0].permute(0, 2, 1, 3)).abs().max().item() <= tol
-    assert (k.float() - full[:, :, 1].permute(0, 2, 1, 3)).abs().max().item() <= tol
-    assert (vt.float()[..., :N] - full[:, :, 2].permute(0, 2, 3, 1)).abs().max().item() <= tol
+    for which, (buf, kind) in enumerate(((q, "qk"), (k, "qk"), (vt, "v"))):
+        got = from_frag(buf.float(), N, dp, kind)
+        ref = full[:, :, which].permute(0, 2, 1, 3)
+        assert (got - ref).abs().max().item() <= tol, which
+        # nothing outside the N*dp valid slots was touched
+        msk = torch.ones(npad * dp, dtype=torch.bool, device="cuda")
+        msk[frag_index(N, dp, kind).reshape(-1).cuda()] = False
+        assert (buf[:, :, msk] == 0).all()
+
+
+@pytest.mark.parametrize("nppf,nsrl,dp,H", [(20, 5, 256, 3), (5, 5, 64, 3), (7, 5, 32, 2)])
+def test_qkv_combine_structured(nppf, nsrl, dp, H):
+    """vog_qkv_combine == dense projection of the [vis || lang] token matrix."""
+    lib = _lib()
+    torch.manual_seed(9)
+    n_vid, nfrm = 3, 4
+    N = nsrl * nppf
+    npad = (N + 31) // 32 * 32
+    ncol = 3 * H * dp
+    pv = torch.randn(n_vid * nfrm * nppf, ncol, device="cuda")
+    pl = torch.randn(n_vid * nsrl, ncol, device="cuda")
+    q = torch.zeros(n_vid * nfrm, H, npad * dp, dtype=torch.bfloat16, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros_like(q)
+    a = L.QkvCombArgs()
+    a.pv, a.pl, a.q, a.k, a.vt = L.ptr(pv), L.ptr(pl), L.ptr(q), L.ptr(k), L.ptr(vt)
+    a.n_vid, a.nfrm, a.nppf, a.nsrl, a.H, a.dp, a.npad = n_vid, nfrm, nppf, nsrl, H, dp, npad
+    a.lang_per_vid, a.nc_v, a.dtype = 1, 1, L.VOG_BF16
+    L.check(lib.vog_qkv_combine(C.byref(a), _sp()), "combine")
+    torch.cuda.synchronize()
+    # token (s=(v,f), j=a*nppf+p) = PV[v, f*nppf+p] + PL[v, a]
+    pvr = pv.view(n_vid, nfrm, 1, nppf, 3, H, dp)
+    plr = pl.view(n_vid, 1, nsrl, 1, 3, H, dp)
+    tok = (pvr + plr).reshape(n_vid * nfrm, N, 3, H, dp)
+    for which, (buf, kind) in enumerate(((q, "qk"), (k, "qk"), (vt, "v"))):
+        got = from_frag(buf.float(), N, dp, kind)
+        ref = tok[:, :, which].permute(0, 2, 1, 3)
+        assert torch.equal(got, ref.to(torch.bfloat16).float()), which
 
 
 def test_layernorm():

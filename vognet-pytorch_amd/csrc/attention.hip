@@ -1,6 +1,6 @@
 // K1: rel_attention_fwd — softmax((Q K^T + bias)/sqrt(d_model)) V per
 // (sequence, head), flash-style on gfx950, with the reference's relative
-// position bias recomputed per tile instead of materialised.
+// position bias recomputed per block instead of materialised.
 //
 // Replaces RelAttention.forward / Attention.forward (transformer_code.py:136-160,
 // 42-50) and the whole of compute_pe (mdl_vog.py:456-490): the reference builds
@@ -8,21 +8,26 @@
 // the Linear is affine in the box, so pe[i,j,h] = relu(u[i,h] - u[j,h] + b[h])
 // with u = W_pe . box — three VALU ops per (i,j), nothing stored.
 //
-// Mapping (wave64, v_mfma_f32_32x32x16):
-//   * one wave owns 32 query rows; a workgroup of NW waves shares LDS K / V^T tiles
-//     of 64 keys.
-//   * "swapped" products so the softmax row lives in one lane:
-//       S^T[key][q] = K_tile . Q^T        (A = K rows from LDS, B = Q from registers)
-//       O^T[d][q]  += V^T_tile . P^T      (A = V^T rows from LDS, B = P from registers)
-//     C/D layout has col = lane&31 = query for both, so the running max / sum /
-//     rescale are per-lane scalars, and P goes from the S accumulator registers
-//     straight into the B operand: the MFMA k index is a free summation index,
-//     so register r of half hi is declared to be k = hi*8 + (r&7) of k-step r>>3
-//     and the V^T fragment is read with the same key permutation
-//     (key = 16*ks + 8*(j>>2) + 4*hi + (j&3)). No cross-lane movement, no LDS
-//     round trip for P.
-//   * V arrives already transposed ([S,H,dp,npad], written by the QKV GEMM
-//     epilogue), so both LDS tiles are filled with 16-byte row chunks.
+// Mapping (wave64, v_mfma_f32_32x32x16), one WAVE = one workgroup = 32 queries:
+//   * "swapped" products so a query's softmax row lives in one lane:
+//       S^T[key][q] = K_blk . Q^T        (A = K fragment, B = Q fragment)
+//       O^T[d][q]  += V^T_blk . P^T      (A = V fragment, B = P from registers)
+//     C/D has col = lane&31 = query for both, so running max / sum / rescale are
+//     per-lane scalars, and P goes from the S accumulator registers straight into
+//     the B operand: the MFMA k index is a free summation index, so register r
+//     of half hi is declared to be k = hi*8 + (r&7) of k-step r>>3 and V is stored
+//     with the matching key permutation (common.h frag_v). No cross-lane
+//     movement, no LDS round trip for P.
+//   * q, k, v arrive in MFMA-fragment order (written that way by the QKV GEMM
+//     epilogue / vog_qkv_combine): every operand fragment is one contiguous KiB,
+//     loaded straight into registers with a 16-byte-per-lane coalesced load. No
+//     LDS staging, no barriers: at the sequence lengths of this model (25..200
+//     tokens, K+V = 100..200 KB per head, L2-resident) the shared-tile kernel
+//     this replaces spent its time in stage->barrier->compute serialisation on
+//     24..120 workgroups; here every 32-query block is an independent wave
+//     (84..480 of them) with all loads of a key block in flight at once.
+//     (For p100, N = 2000..4000, K/V are re-read once per 32-query block from L2;
+//     an LDS-DMA shared-tile variant over the same fragment layout is the next step.)
 #include "common.h"
 
 namespace vog {
@@ -35,41 +40,32 @@ struct AttnParams {
   float inv_scale;
 };
 
-constexpr int KT = 64;               // keys per LDS tile
-
-template <typename T16, int NDB, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
-  constexpr int DP = NDB * 32;
-  constexpr int KLD = DP + 8;        // K tile row pitch (halfwords): 16B-aligned, conflict-free b128
-  constexpr int VLD = KT + 4;        // V^T tile row pitch: 8B-aligned, conflict-free b64
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* Ks = reinterpret_cast<unsigned short*>(smem);                 // [KT][KLD]
-  unsigned short* Vs = Ks + KT * KLD;                                           // [DP][VLD]
-  float* us = reinterpret_cast<float*>(Vs + DP * VLD);                          // [KT]
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+template <typename T16, int NDB>
+__global__ __launch_bounds__(64) void attn_frag_kernel(AttnParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  extern __shared__ float us[];                      // [npad] bias precursor of every key
+  const int lane = threadIdx.x;
   const int hi = lane >> 5, ql = lane & 31;
-  const int s = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * NW + wid) * 32;
-  const int qi = q0 + ql;
+  const int s = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  const int qi = qb * 32 + ql;
   const bool q_ok = qi < p.N;
-  const int64_t sh = (int64_t)s * p.H + h;
-  const unsigned short* Qg = p.q + sh * p.N * DP;
-  const unsigned short* Kg = p.k + sh * p.N * DP;
-  const unsigned short* Vg = p.vt + sh * DP * (int64_t)p.npad;
+  const int nkb = (p.N + 31) >> 5;
+  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
+  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + lane;
 
-  // Q fragments (B operand of S^T): lane (q, hi) holds Q[q][ks*16 + hi*8 .. +8]
-  u16x8 qf[DP / 16];
+  u16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < DP / 16; ++ks) {
-    u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    qf[ks] = q_ok ? *reinterpret_cast<const u16x8*>(Qg + (int64_t)qi * DP + ks * 16 + hi * 8) : z;
-  }
-  const int64_t u_base = p.use_rel
-      ? ((int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box) : 0;
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
+
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
     peb = p.pe_b[h];
+    for (int key = lane; key < p.npad; key += 64)
+      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    // same wave wrote and reads us[]: DS ops of one wave are processed in order
     if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
   }
 
@@ -80,103 +76,63 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  const int ntiles = (p.N + KT - 1) / KT;
-  for (int t = 0; t < ntiles; ++t) {
-    const int kt0 = t * KT;
-    __syncthreads();                      // previous tile fully consumed
-    // ---- stage K tile: KT rows x DP halfwords, 16-byte chunks
-    for (int c = tid; c < KT * (DP / 8); c += NW * 64) {
-      const int row = c / (DP / 8), cc = c % (DP / 8);
-      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (kt0 + row < p.N) v = *reinterpret_cast<const u16x8*>(Kg + (int64_t)(kt0 + row) * DP + cc * 8);
-      *reinterpret_cast<u16x8*>(&Ks[row * KLD + cc * 8]) = v;
+  for (int kb = 0; kb < nkb; ++kb) {
+    // ---- all operand fragments of this key block: 32 independent 1-KiB loads
+    u16x8 kf[KS], vf[NDB * 2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
+#pragma unroll
+    for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
+    // ---- S^T block [32 keys x 32 queries]
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sacc = mfma32<T16>(kf[ks], qf[ks], sacc);
+    // ---- bias, scale, mask, block max
+    float mloc = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + c32_row(r, lane);
+      float x = sacc[r];
+      if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
+      x *= p.inv_scale;
+      x = key < p.N ? x : -1e30f;
+      sacc[r] = x;
+      mloc = fmaxf(mloc, x);
     }
-    // ---- stage V^T tile: DP rows x KT keys; keys >= N forced to zero
-    for (int c = tid; c < DP * (KT / 8); c += NW * 64) {
-      const int row = c / (KT / 8), cc = c % (KT / 8);
-      const int key = kt0 + cc * 8;
-      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (key < p.N) {
-        v = *reinterpret_cast<const u16x8*>(Vg + (int64_t)row * p.npad + key);
-        if (key + 8 > p.N) {
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) if (key + e >= p.N) v[e] = 0;
-        }
-      }
-      u16x4 lo = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
-      *reinterpret_cast<u16x4*>(&Vs[row * VLD + cc * 8]) = lo;
-      *reinterpret_cast<u16x4*>(&Vs[row * VLD + cc * 8 + 4]) = hi4;
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(sacc[r] - m_new);
+      sacc[r] = e;
+      lsum += e;
     }
-    if (p.use_rel) {
-      for (int c = tid; c < KT; c += NW * 64) {
-        const int key = kt0 + c;
-        us[c] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
-      }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+    if (kb > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
-    __syncthreads();
-
+    // ---- P^T fragments straight from the accumulator registers
+    u16x8 pf[2];
 #pragma unroll
-    for (int kb = 0; kb < KT / 32; ++kb) {
-      if (kt0 + kb * 32 >= p.N) break;                 // wave-uniform
-      // ---- S^T block [32 keys x 32 queries]
-      f32x16 sacc;
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
+    // pad keys of the last block carry p = 0 but their V fragment entries are
+    // whatever the (zero-initialised, never written) buffer holds: finite by contract
+    // ---- O^T += V^T_blk . P^T
 #pragma unroll
-      for (int ks = 0; ks < DP / 16; ++ks) {
-        const u16x8 kf = *reinterpret_cast<const u16x8*>(&Ks[(kb * 32 + ql) * KLD + ks * 16 + hi * 8]);
-        sacc = mfma32<T16>(kf, qf[ks], sacc);
-      }
-      // ---- bias, scale, mask, block max
-      float mloc = -1e30f;
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = kb * 32 + c32_row(r, lane);     // key within tile
-        float x = sacc[r];
-        if (p.use_rel) x += fmaxf(uq - us[kl] + peb, 0.f);
-        x *= p.inv_scale;
-        x = (kt0 + kl < p.N) ? x : -1e30f;
-        sacc[r] = x;
-        mloc = fmaxf(mloc, x);
-      }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __expf(m_run - m_new);
-      float lsum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __expf(sacc[r] - m_new);
-        sacc[r] = e;
-        lsum += e;
-      }
-      lsum += __shfl_xor(lsum, 32);
-      l_run = l_run * alpha + lsum;
-      m_run = m_new;
-      if (!__all(alpha == 1.0f)) {
-#pragma unroll
-        for (int i = 0; i < NDB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-      }
-      // ---- P^T fragments straight from the accumulator registers
-      u16x8 pf[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
-      // ---- O^T += V^T_tile . P^T
-#pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const unsigned short* vr = &Vs[(db * 32 + ql) * VLD + kb * 32 + ks * 16 + hi * 4];
-          const u16x4 v0 = *reinterpret_cast<const u16x4*>(vr);
-          const u16x4 v1 = *reinterpret_cast<const u16x4*>(vr + 8);
-          const u16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          o[db] = mfma32<T16>(vf, pf[ks], o[db]);
-        }
-      }
-    }
+      for (int ks = 0; ks < 2; ++ks) o[db] = mfma32<T16>(vf[db * 2 + ks], pf[ks], o[db]);
   }
   // ---- normalise and store: O^T[d][q] -> out[(s*N+q), h*DP + d], 4 consecutive d per store
   if (q_ok) {
@@ -194,38 +150,24 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   }
 }
 
-template <typename T16, int NDB, int NW>
+template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
-  constexpr int DP = NDB * 32;
-  const size_t lds = (size_t)KT * (DP + 8) * 2 + (size_t)DP * (KT + 4) * 2 + KT * 4;
-  auto kern = attn_kernel<T16, NDB, NW>;
-  static bool attr_set = false;       // benign race: idempotent
-  if (!attr_set && lds > 48 * 1024) {
-    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  dim3 grid(ceil_div(p.N, 32 * NW), p.H, p.S);
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p);
+  const size_t lds = p.use_rel ? (size_t)p.npad * sizeof(float) : 0;
+  if (lds > 60 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the bias staging buffer", p.N);
+  dim3 grid(ceil_div(p.N, 32), p.H, p.S);
+  hipLaunchKernelGGL((attn_frag_kernel<T16, NDB>), grid, dim3(64), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
-}
-
-template <typename T16, int NDB>
-static int launch_attn_nw(const AttnParams& p, hipStream_t st) {
-  if (p.N <= 32) return launch_attn<T16, NDB, 1>(p, st);
-  if (p.N <= 64) return launch_attn<T16, NDB, 2>(p, st);
-  return launch_attn<T16, NDB, 4>(p, st);
 }
 
 template <typename T16>
 static int attn_dispatch(const AttnParams& p, hipStream_t st) {
   switch (p.dp) {
-    case 32: return launch_attn_nw<T16, 1>(p, st);
-    case 64: return launch_attn_nw<T16, 2>(p, st);
-    case 128: return launch_attn_nw<T16, 4>(p, st);
-    case 192: return launch_attn_nw<T16, 6>(p, st);
-    case 256: return launch_attn_nw<T16, 8>(p, st);
+    case 32: return launch_attn<T16, 1>(p, st);
+    case 64: return launch_attn<T16, 2>(p, st);
+    case 128: return launch_attn<T16, 4>(p, st);
+    case 192: return launch_attn<T16, 6>(p, st);
+    case 256: return launch_attn<T16, 8>(p, st);
     default: VOG_FAIL(-1, "rel_attention: unsupported padded head dim %d (32/64/128/192/256)", p.dp);
   }
 }
@@ -238,7 +180,7 @@ int attn_head_pad(int dh) {
 
 int attn_run(const vog_attn_args* a, hipStream_t st) {
   VOG_CHECK_ARG(a && a->q && a->k && a->vt && a->out16);
-  VOG_CHECK_ARG(a->S > 0 && a->N > 0 && a->H > 0 && a->npad >= a->N && (a->npad % KT) == 0);
+  VOG_CHECK_ARG(a->S > 0 && a->N > 0 && a->H > 0 && a->npad >= a->N && (a->npad % 32) == 0);
   VOG_CHECK_ARG(!a->use_rel || (a->u && a->pe_b && a->n_box > 0 && a->seq_per_vid > 0));
   AttnParams p{};
   p.q = (const unsigned short*)a->q; p.k = (const unsigned short*)a->k;

@@ -75,6 +75,24 @@ __device__ __forceinline__ int c32_row(int reg, int lane) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 
+// ---- fragment-ordered attention operands ---------------------------------------------
+// q, k and v of one (sequence, head) are stored in the order the attention kernel's MFMA
+// operands consume them, npad = N rounded up to 32 tokens, npad*dp halfwords each:
+//   q/k : [token/32][dd/16][lane = ((dd/8)&1)*32 + token%32][dd%8]
+//         (= A/B fragment of v_mfma_f32_32x32x16: row token%32, k = dd%16)
+//   v   : [token/32][dd/32][ks = (token%32)/16][lane = hi*32 + dd%32][j]
+//         with token%16 = 8*(j>>2) + 4*hi + (j&3)  (the key permutation under which the
+//         S^T accumulator registers are directly the P^T operand, attention.hip)
+// Every fragment is one contiguous KiB: wave loads and LDS-DMA need no swizzle.
+__host__ __device__ __forceinline__ int64_t frag_qk(int i, int dd, int dp) {
+  return ((int64_t)(i >> 5) * (dp >> 4) + (dd >> 4)) * 512 + ((((dd >> 3) & 1) << 5) + (i & 31)) * 8 + (dd & 7);
+}
+__host__ __device__ __forceinline__ int64_t frag_v(int i, int dd, int dp) {
+  const int kl = i & 31, r = kl & 15;
+  const int j = ((r >> 3) << 2) + (r & 3), hi = (r >> 2) & 1;
+  return ((((int64_t)(i >> 5) * (dp >> 5) + (dd >> 5)) * 2 + (kl >> 4)) * 64 + (hi << 5) + (dd & 31)) * 8 + j;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

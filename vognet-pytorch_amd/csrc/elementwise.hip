@@ -165,6 +165,66 @@ __global__ __launch_bounds__(256) void vislang_kernel(vog_vislang_args a) {
 }
 
 // ---------------------------------------------------------------------------
+// structured layer-0 QKV of mul_tx: q/k/v[token(a,p)] = PV[vis row p] + PL[lang row a]
+// (see vog_qkvcomb_args). grid (sequence, head, {q,k,v}); each PV element is read
+// once and fanned out to the nsrl tokens that share it.
+// ---------------------------------------------------------------------------
+template <typename T16>
+__global__ __launch_bounds__(256) void qkv_combine_kernel(vog_qkvcomb_args a) {
+  const int s = blockIdx.x, h = blockIdx.y, which = blockIdx.z;
+  const int v = s / a.nfrm, f = s - v * a.nfrm;
+  const int ldp = 3 * a.H * a.dp;
+  const int col0 = (which * a.H + h) * a.dp;
+  const int lv = a.lang_per_vid ? v : v / a.nc_v;
+  const float* pv = a.pv + ((int64_t)v * a.nfrm * a.nppf + (int64_t)f * a.nppf) * ldp + col0;
+  const float* pl = a.pl + (int64_t)lv * a.nsrl * ldp + col0;
+  const int64_t sh = (int64_t)s * a.H + h;
+  if (which < 2) {
+    unsigned short* dst = reinterpret_cast<unsigned short*>(which == 0 ? a.q : a.k) + sh * a.npad * a.dp;
+    const int cpr = a.dp / 8;                       // 8-column chunks per row
+    for (int it = threadIdx.x; it < a.nppf * cpr; it += blockDim.x) {
+      const int pp = it / cpr, c = it - pp * cpr;
+      const float4 x0 = *reinterpret_cast<const float4*>(pv + (int64_t)pp * ldp + c * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(pv + (int64_t)pp * ldp + c * 8 + 4);
+      for (int ar = 0; ar < a.nsrl; ++ar) {
+        const float4 l0 = *reinterpret_cast<const float4*>(pl + (int64_t)ar * ldp + c * 8);
+        const float4 l1 = *reinterpret_cast<const float4*>(pl + (int64_t)ar * ldp + c * 8 + 4);
+        u16x8 o = {to16<T16>(x0.x + l0.x), to16<T16>(x0.y + l0.y), to16<T16>(x0.z + l0.z), to16<T16>(x0.w + l0.w),
+                   to16<T16>(x1.x + l1.x), to16<T16>(x1.y + l1.y), to16<T16>(x1.z + l1.z), to16<T16>(x1.w + l1.w)};
+        *reinterpret_cast<u16x8*>(dst + frag_qk(ar * a.nppf + pp, c * 8, a.dp)) = o;
+      }
+    }
+  } else {
+    // V^T[dd][token]: thread = (dd, group of 4 proposals); lanes run along dd so the PV
+    // reads are coalesced; each thread emits nsrl 8-byte stores
+    unsigned short* dst = reinterpret_cast<unsigned short*>(a.vt) + sh * a.npad * a.dp;
+    const int ng = (a.nppf + 3) / 4;
+    const bool vec = (a.nppf & 3) == 0;
+    for (int it = threadIdx.x; it < a.dp * ng; it += blockDim.x) {
+      const int g = it / a.dp, dd = it - g * a.dp;
+      float x[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pp = g * 4 + e;
+        x[e] = pp < a.nppf ? pv[(int64_t)pp * ldp + dd] : 0.f;
+      }
+      for (int ar = 0; ar < a.nsrl; ++ar) {
+        const float l = pl[(int64_t)ar * ldp + dd];
+        const int tok = ar * a.nppf + g * 4;
+        if (vec) {   // 4 consecutive tokens, tok % 4 == 0 -> 4 consecutive j of one fragment lane
+          u16x4 o = {to16<T16>(x[0] + l), to16<T16>(x[1] + l), to16<T16>(x[2] + l), to16<T16>(x[3] + l)};
+          *reinterpret_cast<u16x4*>(dst + frag_v(tok, dd, a.dp)) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (g * 4 + e < a.nppf) dst[frag_v(tok + e, dd, a.dp)] = to16<T16>(x[e] + l);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K7 score head tail: lin2.2 + inverse regroup + masks
 // (mdl_vog.py:675-677,724-737; mdl_conc_single.py:39-49,118-122,144-154;
 //  mdl_conc_sep.py:32-42,205-210). One wave per token row.
@@ -387,6 +447,16 @@ extern "C" int vog_vislang_layout(const vog_vislang_args* a, void* stream) {
   VOG_CHECK_ARG(a && a->vis && a->lang && (a->x32 || a->x16));
   const int64_t rows = (int64_t)a->n_vid * a->nfrm * a->nsrl * a->nppf;
   VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((vislang_kernel<T16>), dim3((unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, *a));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_qkv_combine(const vog_qkvcomb_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->pv && a->pl && a->q && a->k && a->vt);
+  VOG_CHECK_ARG((a->dp % 32) == 0 && a->npad >= a->nsrl * a->nppf && (a->npad % 32) == 0);
+  dim3 grid(a->n_vid * a->nfrm, a->H, 3);
+  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((qkv_combine_kernel<T16>), grid, dim3(256), 0,
                      (hipStream_t)stream, *a));
   VOG_LAUNCH_CHECK();
   return 0;

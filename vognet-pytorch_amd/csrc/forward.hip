@@ -212,10 +212,10 @@ static Geo make_geo(const vog_model_desc& d, int B, int ncmp, int T) {
   g.N_obj = d.obj_one_frm ? g.nppf : g.NP;
   g.spv_obj = d.obj_one_frm ? g.nfrm : 1;
   g.fdiv_obj = d.obj_one_frm ? (float)g.nfrm : 1.0f;
-  g.npad_obj = (int)round_up64(g.N_obj, 64);
+  g.npad_obj = (int)round_up64(g.N_obj, 32);
   g.S_mul = g.n_vid * g.nfrm;
   g.N_mul = d.nsrl * g.nppf;
-  g.npad_mul = (int)round_up64(g.N_mul, 64);
+  g.npad_mul = (int)round_up64(g.N_mul, 32);
   g.rows_obj = (int64_t)g.n_vid * g.NP;
   g.rows_mul = (int64_t)g.S_mul * g.N_mul;
   return g;
@@ -260,8 +260,8 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
   auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
     const std::string n(nm);
     p.add(n + "_u", g.rows_obj * tw.H * 4);
-    p.add(n + "_q", rows * tw.H * tw.dp * 2);
-    p.add(n + "_k", rows * tw.H * tw.dp * 2);
+    p.add(n + "_q", (int64_t)S * tw.H * tw.dp * npad * 2);      // fragment order, npad = N up to 32
+    p.add(n + "_k", (int64_t)S * tw.H * tw.dp * npad * 2);
     p.add(n + "_vt", (int64_t)S * tw.H * tw.dp * npad * 2);
     p.add(n + "_attn16", rows * tw.H * tw.dp * 2);
     p.add(n + "_tmp", rows * tw.d * 4);
@@ -278,7 +278,11 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
   if (has_obj(d)) tx("obj", c->obj, g.rows_obj, g.S_obj, g.npad_obj);
   p.add("xmul", g.rows_mul * g.d_mul * 4);
   p.add("xmul16", g.rows_mul * g.d_mul * 2);
-  if (has_mul(d)) tx("mul", c->mul, g.rows_mul, g.S_mul, g.npad_mul);
+  if (has_mul(d)) {
+    tx("mul", c->mul, g.rows_mul, g.S_mul, g.npad_mul);
+    p.add("mul_pv", g.rows_obj * 3 * c->mul.H * c->mul.dp * 4);
+    p.add("mul_pl", (int64_t)g.Bn * d.nsrl * 3 * c->mul.H * c->mul.dp * 4);
+  }
   p.add("h1", g.rows_mul * 256 * 4);
   return p;
 }
@@ -298,7 +302,8 @@ struct WS {
 static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, const Geo& g, const WS& ws,
                      const vog_batch* b, const float* x_in32, const void* x_in16, int S, int N,
                      int npad, int spv, int n_box, float fdiv, int last_dt, std::vector<Step>& steps,
-                     const float** out32, const void** out16) {
+                     const float** out32, const void** out16,
+                     const vog_vislang_args* structured = nullptr, const void* vis16 = nullptr) {
   const std::string n(nm);
   const vog_model_desc& d = c->d;
   const vog_dtype dt = (vog_dtype)d.tx_dtype;
@@ -323,7 +328,28 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     qa.x16 = cur16; qa.ldx = tw.d; qa.wqkv = L.wqkv; qa.ldw = tw.d;
     qa.q = ws.at<void>(n + "_q"); qa.k = ws.at<void>(n + "_k"); qa.vt = ws.at<void>(n + "_vt");
     qa.S = S; qa.N = N; qa.H = tw.H; qa.dp = tw.dp; qa.npad = npad; qa.K = tw.d; qa.dtype = dt;
-    steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
+    const bool fact = structured && l == 0;
+    if (fact) {
+      // layer 0 of mul_tx: tokens are [vis[p] || lang[a]] -> project the two parts once each
+      const vog_vislang_args sv = *structured;
+      const int ncol = 3 * tw.H * tw.dp;
+      vog_gemm_args gv{}; gv.c16_dtype = -1;
+      gv.a = vis16; gv.lda = sv.dv; gv.w = L.wqkv; gv.ldw = tw.d; gv.c32 = ws.at<float>(n + "_pv"); gv.ldc = ncol;
+      gv.M = (int)g.rows_obj; gv.N = ncol; gv.K = sv.dv; gv.rep = 1; gv.dtype = dt;
+      steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_gemm_bias_act(&gv, st); }});
+      vog_gemm_args gl{}; gl.c16_dtype = -1;
+      gl.a = sv.lang; gl.a_is_f32 = 1; gl.lda = sv.dl; gl.w = L.wqkv + sv.dv; gl.ldw = tw.d;
+      gl.c32 = ws.at<float>(n + "_pl"); gl.ldc = ncol; gl.M = g.Bn * sv.nsrl; gl.N = ncol; gl.K = sv.dl;
+      gl.rep = 1; gl.dtype = dt;
+      steps.push_back({n + "_pl", [=](hipStream_t st) { return vog_gemm_bias_act(&gl, st); }});
+      vog_qkvcomb_args ca{};
+      ca.pv = gv.c32; ca.pl = gl.c32; ca.q = qa.q; ca.k = qa.k; ca.vt = qa.vt;
+      ca.n_vid = sv.n_vid; ca.nfrm = sv.nfrm; ca.nppf = sv.nppf; ca.nsrl = sv.nsrl; ca.H = tw.H; ca.dp = tw.dp;
+      ca.npad = npad; ca.lang_per_vid = sv.lang_per_vid; ca.nc_v = sv.nc_v; ca.dtype = dt;
+      steps.push_back({n + "_combine", [=](hipStream_t st) { return vog_qkv_combine(&ca, st); }});
+    } else {
+      steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
+    }
     vog_attn_args aa{};
     aa.q = qa.q; aa.k = qa.k; aa.vt = qa.vt; aa.out16 = ws.at<void>(n + "_attn16");
     aa.u = u; aa.pe_b = tw.pe_b; aa.S = S; aa.N = N; aa.H = tw.H; aa.dp = tw.dp; aa.npad = npad;
@@ -334,7 +360,14 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     wo.a = aa.out16; wo.a_is_f32 = 0; wo.lda = (int64_t)tw.H * tw.dp; wo.w = L.wo; wo.ldw = (int64_t)tw.H * tw.dp;
     wo.residual = cur32; wo.ldr = tw.d; wo.c32 = ws.at<float>(n + "_tmp"); wo.ldc = tw.d;
     wo.M = (int)rows; wo.N = tw.d; wo.K = tw.H * tw.dp; wo.rep = 1; wo.dtype = dt;
-    steps.push_back({n + "_wo", [=](hipStream_t st) { return vog_gemm_bias_act(&wo, st); }});
+    if (fact) {
+      const vog_vislang_args sv = *structured;       // residual = the (unmaterialised) token matrix
+      wo.residual = nullptr;
+      steps.push_back({n + "_wo", [=](hipStream_t st) {
+        vog_gemm_args w2 = wo; w2.res_vislang = &sv; return vog_gemm_bias_act(&w2, st); }});
+    } else {
+      steps.push_back({n + "_wo", [=](hipStream_t st) { return vog_gemm_bias_act(&wo, st); }});
+    }
     float* x1 = ws.at<float>(n + "_x1");
     void* x1_16 = ws.at<void>(n + "_x1_16");
     float* tmp = wo.c32;
@@ -464,21 +497,23 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   const void* vis16 = ps16;
   if (has_obj(d))
     tx_steps(c, c->obj, "obj", g, ws, b, ps32, ps16, g.S_obj, g.N_obj, g.npad_obj, g.spv_obj, g.N_obj,
-             g.fdiv_obj, -1, steps, &vis32, &vis16);
+             g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16);
   // ---- vis || lang tokens in mul_tx order (a10, a11)
-  {
-    vog_vislang_args va{};
-    va.vis = vis32; va.lang = ws.at<float>("lang"); va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
-    va.n_vid = g.n_vid; va.nfrm = g.nfrm; va.nppf = g.nppf; va.nsrl = d.nsrl; va.dv = g.d_obj; va.dl = g.L;
-    va.lang_per_vid = g.nvl > 1 ? 1 : 0; va.nc_v = g.nc_v; va.dtype = (vog_dtype)(has_mul(d) ? d.tx_dtype : d.enc_dtype);
+  vog_vislang_args va{};
+  va.vis = vis32; va.lang = ws.at<float>("lang"); va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
+  va.n_vid = g.n_vid; va.nfrm = g.nfrm; va.nppf = g.nppf; va.nsrl = d.nsrl; va.dv = g.d_obj; va.dl = g.L;
+  va.lang_per_vid = g.nvl > 1 ? 1 : 0; va.nc_v = g.nc_v; va.dtype = (vog_dtype)(has_mul(d) ? d.tx_dtype : d.enc_dtype);
+  // mul_tx consumes the token structure directly (layer-0 QKV and its residual), so the
+  // token matrix is only materialised for ImgGrnd / VidGrnd, whose lin2 reads it
+  const bool structured = has_mul(d) && (g.d_obj % 64) == 0 && (g.L % 32) == 0;
+  if (!structured)
     steps.push_back({"vislang", [=](hipStream_t st) { return vog_vislang_layout(&va, st); }});
-  }
   const float* x32 = ws.at<float>("xmul");
   const void* x16 = ws.at<void>("xmul16");
   int head_dt = d.enc_dtype;   // the 16-bit copy feeding lin2 is always written in the head's type
   if (has_mul(d))
     tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
-             (float)g.nfrm, d.enc_dtype, steps, &x32, &x16);
+             (float)g.nfrm, d.enc_dtype, steps, &x32, &x16, structured ? &va : nullptr, vis16);
   // ---- score head (a9 tail / a20 / a17)
   {
     vog_gemm_args l2{}; l2.c16_dtype = -1;

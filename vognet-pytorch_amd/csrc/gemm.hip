@@ -34,6 +34,8 @@ struct GemmParams {
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; int c16_bf16; int debug;
   const int32_t* out_rows; int out_rows_ncol;
+  // implicit vis||lang residual (res_vis != nullptr)
+  const float* res_vis; const float* res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
   // QKV epilogue
   unsigned short* q; unsigned short* k; unsigned short* vt;
   int ntok, H, dp, npad;
@@ -54,12 +56,26 @@ __device__ __forceinline__ u16x8 load_a_chunk(const void* a, int64_t row_off, in
   return r;
 }
 
+// residual pointer of token row m, column n, for the implicit vis||lang token matrix
+// (row m = (s=(v,f), j=a*nppf+p); a 4-column chunk never straddles dv since dv % 4 == 0)
+__device__ __forceinline__ const float* vislang_res_ptr(const GemmParams& p, int m, int n) {
+  const int N = p.rv_nsrl * p.rv_nppf;
+  const int s = m / N, j = m - s * N;
+  const int v = s / p.rv_nfrm, f = s - v * p.rv_nfrm;
+  const int a = j / p.rv_nppf, pp = j - a * p.rv_nppf;
+  if (n < p.rv_dv)
+    return p.res_vis + ((int64_t)v * p.rv_nfrm * p.rv_nppf + (int64_t)f * p.rv_nppf + pp) * p.rv_dv + n;
+  const int lv = p.rv_lpv ? v : v / p.rv_ncv;
+  return p.res_lang + ((int64_t)lv * p.rv_nsrl + a) * p.rv_dl + (n - p.rv_dv);
+}
+
 template <typename T16>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int col, float v) {
   if (row >= p.M || col >= p.N) return;
   {
     if (p.bias) v += p.bias[col];
     if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
+    if (p.res_vis) v += *vislang_res_ptr(p, row, col);
     if (p.relu) v = fmaxf(v, 0.f);
     if (p.out_rows) {
       const int orow = p.out_rows[(int64_t)(col / p.out_rows_ncol) * p.M + row];
@@ -96,14 +112,14 @@ __device__ __forceinline__ void qkv_store_frag(const GemmParams& p, int row0, in
     if (row >= p.M) continue;
     const int s = row / p.ntok;
     const int i = row - s * p.ntok;
-    const int64_t sh = (int64_t)s * p.H + h;
+    const int64_t base = ((int64_t)s * p.H + h) * p.npad * p.dp;
     const unsigned short o = to16<T16>(acc[r]);
     if (which == 0) {
-      p.q[(sh * p.ntok + i) * p.dp + dd] = o;
+      p.q[base + frag_qk(i, dd, p.dp)] = o;
     } else if (which == 1) {
-      p.k[(sh * p.ntok + i) * p.dp + dd] = o;
+      p.k[base + frag_qk(i, dd, p.dp)] = o;
     } else {
-      p.vt[(sh * p.dp + dd) * p.npad + i] = o;
+      p.vt[base + frag_v(i, dd, p.dp)] = o;
     }
   }
 }
@@ -211,81 +227,6 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmParams p) {
         }
       }
     }
-}
-
-// ---- epilogues for the swapped (C^T) accumulator layout -------------------------
-// acc[4*g + e] = C[m][nb + 8*g + 4*hi + e]
-template <typename T16>
-__device__ __forceinline__ void plain_store_swapped(const GemmParams& p, int m, int nb, int hi,
-                                                    const f32x16& acc) {
-  if (m >= p.M) return;
-  const bool vec = (p.N & 3) == 0;
-  const float* res = p.residual ? p.residual + (int64_t)m * p.ldr : nullptr;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int n = nb + 8 * g + 4 * hi;
-    if (n >= p.N) continue;
-    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    if (vec) {
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (res) {
-        const float4 r = *reinterpret_cast<const float4*>(res + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      u16x4 h;
-      if (p.c16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = p.c16_bf16 ? to16<BF16>(v[e]) : to16<F16>(v[e]);
-      }
-      for (int j = 0; j < p.rep; ++j) {
-        const int64_t orow = (int64_t)m * p.rep + j;
-        if (p.c32) *reinterpret_cast<float4*>(p.c32 + orow * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (p.c16) *reinterpret_cast<u16x4*>(p.c16 + orow * p.ldc16 + n) = h;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) epilogue_store<T16>(p, m, n + e, v[e]);
-    }
-  }
-}
-
-template <typename T16>
-__device__ __forceinline__ void qkv_store_swapped(const GemmParams& p, int m, int nb, int hi,
-                                                  const f32x16& acc) {
-  nb = __builtin_amdgcn_readfirstlane(nb);
-  if (nb >= p.N || m >= p.M) return;
-  const int hd = p.H * p.dp;
-  const int which = nb / hd;                          // wave-uniform (dp % 32 == 0)
-  const int h = (nb - which * hd) / p.dp;
-  const int dd0 = nb % p.dp;
-  const int s = m / p.ntok;
-  const int i = m - s * p.ntok;
-  const int64_t sh = (int64_t)s * p.H + h;
-  if (which < 2) {
-    unsigned short* dst = (which == 0 ? p.q : p.k) + (sh * p.ntok + i) * p.dp + dd0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      u16x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = to16<T16>(acc[4 * g + e]);
-      *reinterpret_cast<u16x4*>(dst + 8 * g + 4 * hi) = v;
-    }
-  } else {
-    // V^T[dd][token]: for a fixed dd the 32 lanes of a half-wave hold consecutive tokens
-    unsigned short* dst = p.vt + (sh * p.dp + dd0) * p.npad + i;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        dst[(int64_t)(8 * g + 4 * hi + e) * p.npad] = to16<T16>(acc[4 * g + e]);
-  }
 }
 
 // ----------------------------------------------------------------------------
@@ -404,7 +345,6 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
   // the (now idle) stage buffers and re-reads it row-wise, so every global
   // load/store instruction covers whole 128-256 B row segments.
   constexpr int WTM = BM / 2, WTN = BN / 2, EP_LD = WTN + 4;
-  static_assert(4 * WTM * EP_LD * 4 <= STAGES * STAGE_BYTES, "epilogue tile must fit the stage ring");
   __builtin_amdgcn_s_barrier();                       // all waves done with the last stage
   asm volatile("" ::: "memory");
   float* ep = reinterpret_cast<float*>(smem) + wid * (WTM * EP_LD);
@@ -435,6 +375,10 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           if (p.residual) {
             const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldr + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          if (p.res_vis) {
+            const float4 r = *reinterpret_cast<const float4*>(vislang_res_ptr(p, m, n));
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
           }
           if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -483,20 +427,22 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
           const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
           const int sq = m / p.ntok, tok = m - sq * p.ntok;
           const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
-          *reinterpret_cast<u16x4*>(base + (((int64_t)sq * p.H + h) * p.ntok + tok) * p.dp + dd0 + 4 * c) = o;
+          *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * p.npad * p.dp +
+                                    frag_qk(tok, dd0 + 4 * c, p.dp)) = o;
         }
       } else {
-        // V^T[dd][token]: lane = token, so each store instruction writes a token-contiguous run
+        // V fragments: lane = token; 2-byte stores inside this token's fragment block
 #pragma unroll
         for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
           const int rl = th * 64 + lane;
           const int m = mw + rl;
           if (rl < WTM && m < p.M) {
             const int sq = m / p.ntok, tok = m - sq * p.ntok;
-            unsigned short* dst = p.vt + (((int64_t)sq * p.H + h) * p.dp + dd0) * p.npad + tok;
+            // dd0 % 32 == 0: the 32 columns of this group are one d-block of the V fragment
+            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp + frag_v(tok, dd0, p.dp);
 #pragma unroll 8
             for (int dd = 0; dd < 32; ++dd)
-              dst[(int64_t)dd * p.npad] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd]);
+              dst[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd]);
           }
         }
       }
@@ -577,7 +523,9 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
 // ----------------------------------------------------------------------------
 template <typename T16, int BM, int BN, int STAGES, int EPI>
 static int launch_pipe_cfg(const GemmParams& p, hipStream_t st) {
-  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * 128;
+  constexpr size_t epi = (size_t)4 * (BM / 2) * (BN / 2 + 4) * 4;   // LDS-staged epilogue tile
+  constexpr size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_pipe<T16, BM, BN, STAGES, EPI>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
@@ -593,11 +541,27 @@ static int launch_pipe_cfg(const GemmParams& p, hipStream_t st) {
 
 template <typename T16, int EPI>
 static int launch_pipe(const GemmParams& p, hipStream_t st) {
-  // largest tile that still gives every CU a workgroup (256 CUs)
+  // VOG_GEMM_TILE (perf experiments only) forces a tile configuration
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("VOG_GEMM_TILE"); force = e ? atoi(e) : -1; }
+  switch (force) {
+    case 0: return launch_pipe_cfg<T16, 128, 128, 3, EPI>(p, st);
+    case 1: return launch_pipe_cfg<T16, 128, 64, 3, EPI>(p, st);
+    case 2: return launch_pipe_cfg<T16, 64, 64, 4, EPI>(p, st);
+    case 3: return launch_pipe_cfg<T16, 128, 128, 2, EPI>(p, st);
+    case 4: return launch_pipe_cfg<T16, 128, 64, 2, EPI>(p, st);
+    case 5: return launch_pipe_cfg<T16, 64, 64, 2, EPI>(p, st);
+    case 6: return launch_pipe_cfg<T16, 64, 128, 3, EPI>(p, st);
+    default: break;
+  }
+  // Measured on MI355X (scratch/mb_gemm.py, M = 800..8192): occupancy beats pipeline
+  // depth — 2-stage rings (2-5 workgroups per CU hide each other's barrier and
+  // LDS-latency stalls) are faster than 3-4-stage rings at one workgroup per CU
+  // for every shape of this model. 128x128 only when there are >= 8 tiles per CU.
   auto ntiles = [&](int bm, int bn) { return (int64_t)ceil_div(p.M, bm) * ceil_div(p.N, bn); };
-  if (ntiles(128, 128) >= 256) return launch_pipe_cfg<T16, 128, 128, 3, EPI>(p, st);
-  if (ntiles(128, 64) >= 256) return launch_pipe_cfg<T16, 128, 64, 3, EPI>(p, st);
-  return launch_pipe_cfg<T16, 64, 64, 4, EPI>(p, st);
+  if (ntiles(128, 128) >= 2048) return launch_pipe_cfg<T16, 128, 128, 2, EPI>(p, st);
+  if (ntiles(128, 64) >= 512) return launch_pipe_cfg<T16, 128, 64, 2, EPI>(p, st);
+  return launch_pipe_cfg<T16, 64, 64, 2, EPI>(p, st);
 }
 
 static bool pipe_ok(const GemmParams& p, bool a_f32) {
@@ -635,6 +599,11 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   p.c16_bf16 = (g->c16_dtype < 0 ? (int)g->dtype : g->c16_dtype) == VOG_BF16;
   p.debug = gemm_debug_flags();
   p.out_rows = g->out_rows; p.out_rows_ncol = g->out_rows_ncol;
+  if (g->res_vislang) {
+    const vog_vislang_args* r = g->res_vislang;
+    p.res_vis = r->vis; p.res_lang = r->lang; p.rv_nfrm = r->nfrm; p.rv_nppf = r->nppf; p.rv_nsrl = r->nsrl;
+    p.rv_dv = r->dv; p.rv_dl = r->dl; p.rv_lpv = r->lang_per_vid; p.rv_ncv = r->nc_v;
+  }
   if (p.M <= 64 && (p.K % 32) == 0) {
     dim3 grid(ceil_div(p.N, 16));
     if (g->a_is_f32) hipLaunchKernelGGL((gemm_skinny<T16, true>), grid, dim3(256), 0, st, p);
@@ -651,6 +620,9 @@ int gemm_run(const vog_gemm_args* g, hipStream_t st) {
   VOG_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0 && (g->K % 8) == 0);
   VOG_CHECK_ARG((g->lda % (g->a_is_f32 ? 4 : 8)) == 0 && (g->ldw % 8) == 0);
   VOG_CHECK_ARG(!(g->residual && g->rep > 1));
+  VOG_CHECK_ARG(!g->res_vislang || (!g->residual && g->res_vislang->vis && g->res_vislang->lang &&
+                                    (g->res_vislang->dv % 4) == 0 && (g->res_vislang->dl % 4) == 0 &&
+                                    g->res_vislang->dv + g->res_vislang->dl == g->N));
   VOG_CHECK_ARG(!g->out_rows || (g->rep <= 1 && g->out_rows_ncol > 0 && (g->out_rows_ncol % 4) == 0));
   VOG_DISPATCH_DTYPE(g->dtype, return gemm_dispatch<T16>(g, st));
   return 0;
@@ -658,7 +630,7 @@ int gemm_run(const vog_gemm_args* g, hipStream_t st) {
 
 int qkv_run(const vog_qkv_args* a, hipStream_t st) {
   VOG_CHECK_ARG(a && a->x16 && a->wqkv && a->q && a->k && a->vt);
-  VOG_CHECK_ARG(a->K % 8 == 0 && a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->npad >= a->N);
+  VOG_CHECK_ARG(a->K % 8 == 0 && a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->npad >= a->N && (a->npad % 32) == 0 && (a->dp % 32) == 0);
   GemmParams p{};
   p.a = a->x16; p.lda = a->ldx; p.w = (const unsigned short*)a->wqkv; p.ldw = a->ldw;
   p.M = a->S * a->N; p.N = 3 * a->H * a->dp; p.K = a->K; p.rep = 1;

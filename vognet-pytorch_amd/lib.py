@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32)]
+                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -42,6 +42,13 @@ class QkvArgs(C.Structure):
                 ("q", c_vp), ("k", c_vp), ("vt", c_vp),
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
                 ("K", c_i32), ("dtype", c_i32)]
+
+
+class QkvCombArgs(C.Structure):
+    _fields_ = [("pv", c_vp), ("pl", c_vp), ("q", c_vp), ("k", c_vp), ("vt", c_vp),
+                ("n_vid", c_i32), ("nfrm", c_i32), ("nppf", c_i32), ("nsrl", c_i32), ("H", c_i32),
+                ("dp", c_i32), ("npad", c_i32), ("lang_per_vid", c_i32), ("nc_v", c_i32),
+                ("dtype", c_i32)]
 
 
 class AttnArgs(C.Structure):
@@ -115,6 +122,7 @@ SYMBOLS = {
     "vog_last_error": (C.c_char_p, []),
     "vog_gemm_bias_act": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
+    "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),
     "vog_rel_attention_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
     "vog_residual_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vog_cast_f32_to_t16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp]),
