@@ -71,8 +71,21 @@ typedef struct vog_gemm_args {
   /* optional implicit residual: the residual row of output row m is the vis||lang
    * token m of this layout (never materialised); `residual` must then be NULL. */
   const struct vog_vislang_args* res_vislang;
+  /* split-K (> 1): the K range is cut into `splitk` slices, slice s writes its raw
+   * partial product to c32 + s*M*ldc (fp32 slabs, plain stores); bias / relu /
+   * residual / c16 / rep must be unset — apply them with vog_splitk_finish. For
+   * GEMMs with fewer output tiles than CUs and a long K (the two feature encoders). */
+  int splitk;
 } vog_gemm_args;
 int vog_gemm_bias_act(const vog_gemm_args* g, void* stream);
+
+/* out[m*rep + j, n] = act(sum_s slab[s][m][n] + bias[n]) for up to two problems in
+ * one launch (prop_encoder + seg_encoder), fp32 and/or 16-bit outputs. */
+typedef struct vog_splitk_prob {
+  const float* slabs; int splits; int M, N; const float* bias; int relu; int rep;
+  float* c32; void* c16; int64_t ldc, ldc16; int c16_dtype;
+} vog_splitk_prob;
+int vog_splitk_finish(const vog_splitk_prob* p0, const vog_splitk_prob* p1, void* stream);
 
 /* Fused QKV projection for one (Rel)MultiHead (transformer_code.py:64-67,
  * 180-183): x[S*N, K] * Wqkv_pad^T where Wqkv_pad is [3*H*dp, K] (heads padded

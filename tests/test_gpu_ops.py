@@ -113,6 +113,31 @@ def from_frag(f, N, dp, kind):
     return f[:, :, idx].reshape(S, H, N, dp)
 
 
+@pytest.mark.parametrize("M,N,K,splits,rep", [(800, 256, 2048, 8, 1), (160, 256, 3072, 12, 5), (130, 64, 256, 3, 1)])
+def test_gemm_splitk_and_finish(M, N, K, splits, rep):
+    lib = _lib()
+    torch.manual_seed(M + splits)
+    a = torch.randn(M, K, device="cuda").half()
+    w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
+    bias = torch.randn(N, device="cuda")
+    slabs = torch.full((splits, M, N), float("nan"), device="cuda")
+    g = L.GemmArgs()
+    g.a, g.a_is_f32, g.lda, g.w, g.ldw = L.ptr(a), 0, K, L.ptr(w), K
+    g.c32, g.ldc, g.M, g.N, g.K, g.rep, g.dtype, g.splitk = L.ptr(slabs), N, M, N, K, 1, L.VOG_F16, splits
+    L.check(lib.vog_gemm_bias_act(C.byref(g), _sp()), "splitk gemm")
+    out32 = torch.full((M * rep, N + 8), float("nan"), device="cuda")
+    out16 = torch.zeros((M * rep, N + 8), dtype=torch.bfloat16, device="cuda")
+    f = L.SplitkProb()
+    f.slabs, f.splits, f.M, f.N, f.bias, f.relu, f.rep = L.ptr(slabs), splits, M, N, L.ptr(bias), 1, rep
+    f.c32, f.c16, f.ldc, f.ldc16, f.c16_dtype = L.ptr(out32), L.ptr(out16), N + 8, N + 8, L.VOG_BF16
+    L.check(lib.vog_splitk_finish(C.byref(f), None, _sp()), "finish")
+    torch.cuda.synchronize()
+    ref = torch.relu(a.float() @ w.float().t() + bias).repeat_interleave(rep, dim=0)
+    assert (out32[:, :N] - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out16[:, :N], out32[:, :N].to(torch.bfloat16))
+    assert torch.isnan(out32[:, N:]).all()
+
+
 def _attn_ref(q, k, v, u, peb, n_box, inv_scale, use_rel):
     """q,k,v [S,H,N,dh] fp32 (already rounded); u [S,N,H]"""
     logits = q @ k.transpose(-1, -2)

@@ -73,6 +73,40 @@ __global__ __launch_bounds__(256) void cast2_kernel(const float4* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------
+// split-K finish: sum the slabs, bias, ReLU, row replication, fp32 + 16-bit copies
+// ---------------------------------------------------------------------------
+struct SplitkProbs { vog_splitk_prob p[2]; int blocks0; };
+
+__global__ __launch_bounds__(256) void splitk_finish_kernel(SplitkProbs a) {
+  const bool second = (int)blockIdx.x >= a.blocks0;
+  const vog_splitk_prob& q = a.p[second ? 1 : 0];
+  const int64_t i4 = (int64_t)(blockIdx.x - (second ? a.blocks0 : 0)) * 256 + threadIdx.x;   // float4 index
+  const int n4 = q.N / 4;
+  if (i4 >= (int64_t)q.M * n4) return;
+  const int m = (int)(i4 / n4), n = (int)(i4 - (int64_t)m * n4) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < q.splits; ++s) {
+    const float4 x = *reinterpret_cast<const float4*>(q.slabs + ((int64_t)s * q.M + m) * q.N + n);
+    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+  }
+  if (q.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(q.bias + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (q.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  u16x4 h;
+  if (q.c16) {
+    if (q.c16_dtype == VOG_BF16) h = u16x4{to16<BF16>(v.x), to16<BF16>(v.y), to16<BF16>(v.z), to16<BF16>(v.w)};
+    else h = u16x4{to16<F16>(v.x), to16<F16>(v.y), to16<F16>(v.z), to16<F16>(v.w)};
+  }
+  for (int j = 0; j < q.rep; ++j) {
+    const int64_t orow = (int64_t)m * q.rep + j;
+    if (q.c32) *reinterpret_cast<float4*>(q.c32 + orow * q.ldc + n) = v;
+    if (q.c16) *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(q.c16) + orow * q.ldc16 + n) = h;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // u[row,h] = W_pe[h,:] . norm(box[row,:5])   (compute_pe mdl_vog.py:456-463)
 // ---------------------------------------------------------------------------
 __global__ void box_u_kernel(const float* __restrict__ props, const float* __restrict__ w,
@@ -127,12 +161,22 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int o0 = blockIdx.y * 16 + wid * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = lane; i < 2 * L; i += 64) {
-    const float xv = i < L ? x0[i] : x1[i - L];
+  // 2L <= 1024: up to 16 strided elements per lane, all loads issued before the FMAs
+  constexpr int MAXI = 16;
+  float xv[MAXI], wv[4][MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int i = lane + it * 64;
+    const bool ok = i < 2 * L;
+    xv[it] = ok ? (i < L ? x0[i] : x1[i - L]) : 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (o0 + k < L) acc[k] += w[(int64_t)(o0 + k) * 2 * L + i] * xv;
+      wv[k][it] = (ok && o0 + k < L) ? w[(int64_t)(o0 + k) * 2 * L + i] : 0.f;
   }
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += wv[k][it] * xv[it];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float v = wave_sum(acc[k]);
@@ -170,8 +214,11 @@ __global__ __launch_bounds__(256) void vislang_kernel(vog_vislang_args a) {
 // once and fanned out to the nsrl tokens that share it.
 // ---------------------------------------------------------------------------
 template <typename T16>
-__global__ __launch_bounds__(256) void qkv_combine_kernel(vog_qkvcomb_args a) {
-  const int s = blockIdx.x, h = blockIdx.y, which = blockIdx.z;
+__global__ __launch_bounds__(256) void qkv_combine_kernel(vog_qkvcomb_args a, int chunks) {
+  // grid.x = sequence * chunks: one work item per thread so that every load of the
+  // launch is in flight at once (this is a pure L2 -> HBM streaming pass)
+  const int s = blockIdx.x / chunks, chunk = blockIdx.x - s * chunks;
+  const int h = blockIdx.y, which = blockIdx.z;
   const int v = s / a.nfrm, f = s - v * a.nfrm;
   const int ldp = 3 * a.H * a.dp;
   const int col0 = (which * a.H + h) * a.dp;
@@ -179,46 +226,47 @@ __global__ __launch_bounds__(256) void qkv_combine_kernel(vog_qkvcomb_args a) {
   const float* pv = a.pv + ((int64_t)v * a.nfrm * a.nppf + (int64_t)f * a.nppf) * ldp + col0;
   const float* pl = a.pl + (int64_t)lv * a.nsrl * ldp + col0;
   const int64_t sh = (int64_t)s * a.H + h;
+  const int it = chunk * 256 + threadIdx.x;
   if (which < 2) {
     unsigned short* dst = reinterpret_cast<unsigned short*>(which == 0 ? a.q : a.k) + sh * a.npad * a.dp;
     const int cpr = a.dp / 8;                       // 8-column chunks per row
-    for (int it = threadIdx.x; it < a.nppf * cpr; it += blockDim.x) {
-      const int pp = it / cpr, c = it - pp * cpr;
-      const float4 x0 = *reinterpret_cast<const float4*>(pv + (int64_t)pp * ldp + c * 8);
-      const float4 x1 = *reinterpret_cast<const float4*>(pv + (int64_t)pp * ldp + c * 8 + 4);
-      for (int ar = 0; ar < a.nsrl; ++ar) {
-        const float4 l0 = *reinterpret_cast<const float4*>(pl + (int64_t)ar * ldp + c * 8);
-        const float4 l1 = *reinterpret_cast<const float4*>(pl + (int64_t)ar * ldp + c * 8 + 4);
-        u16x8 o = {to16<T16>(x0.x + l0.x), to16<T16>(x0.y + l0.y), to16<T16>(x0.z + l0.z), to16<T16>(x0.w + l0.w),
-                   to16<T16>(x1.x + l1.x), to16<T16>(x1.y + l1.y), to16<T16>(x1.z + l1.z), to16<T16>(x1.w + l1.w)};
-        *reinterpret_cast<u16x8*>(dst + frag_qk(ar * a.nppf + pp, c * 8, a.dp)) = o;
-      }
+    if (it >= a.nppf * cpr) return;
+    const int pp = it / cpr, c = it - pp * cpr;
+    const float4 x0 = *reinterpret_cast<const float4*>(pv + (int64_t)pp * ldp + c * 8);
+    const float4 x1 = *reinterpret_cast<const float4*>(pv + (int64_t)pp * ldp + c * 8 + 4);
+#pragma unroll 5
+    for (int ar = 0; ar < a.nsrl; ++ar) {
+      const float4 l0 = *reinterpret_cast<const float4*>(pl + (int64_t)ar * ldp + c * 8);
+      const float4 l1 = *reinterpret_cast<const float4*>(pl + (int64_t)ar * ldp + c * 8 + 4);
+      u16x8 o = {to16<T16>(x0.x + l0.x), to16<T16>(x0.y + l0.y), to16<T16>(x0.z + l0.z), to16<T16>(x0.w + l0.w),
+                 to16<T16>(x1.x + l1.x), to16<T16>(x1.y + l1.y), to16<T16>(x1.z + l1.z), to16<T16>(x1.w + l1.w)};
+      *reinterpret_cast<u16x8*>(dst + frag_qk(ar * a.nppf + pp, c * 8, a.dp)) = o;
     }
   } else {
-    // V^T[dd][token]: thread = (dd, group of 4 proposals); lanes run along dd so the PV
+    // V fragments: thread = (dd, group of 4 proposals); lanes run along dd so the PV
     // reads are coalesced; each thread emits nsrl 8-byte stores
     unsigned short* dst = reinterpret_cast<unsigned short*>(a.vt) + sh * a.npad * a.dp;
     const int ng = (a.nppf + 3) / 4;
     const bool vec = (a.nppf & 3) == 0;
-    for (int it = threadIdx.x; it < a.dp * ng; it += blockDim.x) {
-      const int g = it / a.dp, dd = it - g * a.dp;
-      float x[4];
+    if (it >= a.dp * ng) return;
+    const int g = it / a.dp, dd = it - g * a.dp;
+    float x[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pp = g * 4 + e;
-        x[e] = pp < a.nppf ? pv[(int64_t)pp * ldp + dd] : 0.f;
-      }
-      for (int ar = 0; ar < a.nsrl; ++ar) {
-        const float l = pl[(int64_t)ar * ldp + dd];
-        const int tok = ar * a.nppf + g * 4;
-        if (vec) {   // 4 consecutive tokens, tok % 4 == 0 -> 4 consecutive j of one fragment lane
-          u16x4 o = {to16<T16>(x[0] + l), to16<T16>(x[1] + l), to16<T16>(x[2] + l), to16<T16>(x[3] + l)};
-          *reinterpret_cast<u16x4*>(dst + frag_v(tok, dd, a.dp)) = o;
-        } else {
+    for (int e = 0; e < 4; ++e) {
+      const int pp = g * 4 + e;
+      x[e] = pp < a.nppf ? pv[(int64_t)pp * ldp + dd] : 0.f;
+    }
+#pragma unroll 5
+    for (int ar = 0; ar < a.nsrl; ++ar) {
+      const float l = pl[(int64_t)ar * ldp + dd];
+      const int tok = ar * a.nppf + g * 4;
+      if (vec) {   // 4 consecutive tokens, tok % 4 == 0 -> 4 consecutive j of one fragment lane
+        u16x4 o = {to16<T16>(x[0] + l), to16<T16>(x[1] + l), to16<T16>(x[2] + l), to16<T16>(x[3] + l)};
+        *reinterpret_cast<u16x4*>(dst + frag_v(tok, dd, a.dp)) = o;
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (g * 4 + e < a.nppf) dst[frag_v(tok + e, dd, a.dp)] = to16<T16>(x[e] + l);
-        }
+        for (int e = 0; e < 4; ++e)
+          if (g * 4 + e < a.nppf) dst[frag_v(tok + e, dd, a.dp)] = to16<T16>(x[e] + l);
       }
     }
   }
@@ -414,6 +462,19 @@ extern "C" int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, co
   return 0;
 }
 
+extern "C" int vog_splitk_finish(const vog_splitk_prob* p0, const vog_splitk_prob* p1, void* stream) {
+  VOG_CHECK_ARG(p0 && p0->slabs && p0->splits > 0 && (p0->N % 4) == 0 && (p0->c32 || p0->c16) && p0->rep >= 1);
+  VOG_CHECK_ARG(!p1 || (p1->slabs && p1->splits > 0 && (p1->N % 4) == 0 && (p1->c32 || p1->c16) && p1->rep >= 1));
+  SplitkProbs a{};
+  a.p[0] = *p0;
+  a.blocks0 = (int)(((int64_t)p0->M * (p0->N / 4) + 255) / 256);
+  int blocks1 = 0;
+  if (p1) { a.p[1] = *p1; blocks1 = (int)(((int64_t)p1->M * (p1->N / 4) + 255) / 256); }
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(a.blocks0 + blocks1), dim3(256), 0, (hipStream_t)stream, a);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vog_box_u(const float* props, const float* w_pe, float* u, int n_rows, int H,
                          float vid_w, float vid_h, float nfrm_div, void* stream) {
   VOG_CHECK_ARG(props && w_pe && u && n_rows > 0 && H > 0);
@@ -436,7 +497,7 @@ extern "C" int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask
 extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const int64_t* inds_msk,
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
-  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0);
+  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512);
   hipLaunchKernelGGL(argvec_kernel, dim3(Bn * nsrl, ceil_div(L, 16)), dim3(256), 0,
                      (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L);
   VOG_LAUNCH_CHECK();
@@ -455,9 +516,11 @@ extern "C" int vog_vislang_layout(const vog_vislang_args* a, void* stream) {
 extern "C" int vog_qkv_combine(const vog_qkvcomb_args* a, void* stream) {
   VOG_CHECK_ARG(a && a->pv && a->pl && a->q && a->k && a->vt);
   VOG_CHECK_ARG((a->dp % 32) == 0 && a->npad >= a->nsrl * a->nppf && (a->npad % 32) == 0);
-  dim3 grid(a->n_vid * a->nfrm, a->H, 3);
+  const int items_qk = a->nppf * (a->dp / 8), items_v = a->dp * ((a->nppf + 3) / 4);
+  const int chunks = ceil_div(items_qk > items_v ? items_qk : items_v, 256);
+  dim3 grid(a->n_vid * a->nfrm * chunks, a->H, 3);
   VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((qkv_combine_kernel<T16>), grid, dim3(256), 0,
-                     (hipStream_t)stream, *a));
+                     (hipStream_t)stream, *a, chunks));
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -255,6 +255,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
   p.add("lang", (int64_t)g.Bn * d.nsrl * g.L * 4);
   p.add("prop16", g.rows_obj * d.prop_dim * 2);
   p.add("seg16", (int64_t)g.n_vid * g.Fv * d.seg_dim * 2);
+  p.add("enc_slabs", (int64_t)16 * (g.rows_obj * d.prop_enc + (int64_t)g.n_vid * g.Fv * d.seg_enc) * 4);
   p.add("prop_seg", g.rows_obj * g.d_obj * 4);
   p.add("prop_seg16", g.rows_obj * g.d_obj * 2);
   auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
@@ -480,17 +481,48 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       steps.push_back({"cast_feats", [=](hipStream_t st) {
         return vog_cast_f32_to_t16(s0, d0, n0, s1, d1, n1, et, st); }});
     }
+    // the two encoders have 52 / 12 output tiles and K = 2048 / 3072: split K so every CU
+    // gets a slice, partial products go to fp32 slabs, one finishing pass for both
+    auto pick_split = [](int M, int N, int K) {
+      const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 64);
+      int sp = (int)((511 + tiles) / tiles);
+      const int nk = K / 64;
+      if (sp > nk / 4) sp = nk / 4;
+      if (sp > 16) sp = 16;
+      return sp < 1 ? 1 : sp;
+    };
+    const int Mp = (int)g.rows_obj, Ms = g.n_vid * g.Fv;
+    const bool can_split = (d.prop_dim % 64) == 0 && (d.seg_dim % 64) == 0 && Mp > 64 && Ms > 64 &&
+                           (d.prop_enc % 4) == 0 && (d.seg_enc % 4) == 0;
+    const int sp_p = can_split ? pick_split(Mp, d.prop_enc, d.prop_dim) : 1;
+    const int sp_s = can_split ? pick_split(Ms, d.seg_enc, d.seg_dim) : 1;
+    float* slab_p = ws.at<float>("enc_slabs");
+    float* slab_s = slab_p + (int64_t)16 * Mp * d.prop_enc;
     vog_gemm_args pe{}; pe.c16_dtype = d.tx_dtype;
     pe.a = ws.at<void>("prop16"); pe.a_is_f32 = 0; pe.lda = d.prop_dim; pe.w = c->w_prop; pe.ldw = d.prop_dim;
-    pe.bias = c->b_prop; pe.relu = 1; pe.c32 = ps32; pe.c16 = ps16; pe.ldc = g.d_obj; pe.ldc16 = g.d_obj;
-    pe.M = (int)g.rows_obj; pe.N = d.prop_enc; pe.K = d.prop_dim; pe.rep = 1; pe.dtype = et;
-    steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
+    pe.M = Mp; pe.N = d.prop_enc; pe.K = d.prop_dim; pe.rep = 1; pe.dtype = et;
     vog_gemm_args se{}; se.c16_dtype = d.tx_dtype;
     se.a = ws.at<void>("seg16"); se.a_is_f32 = 0; se.lda = d.seg_dim; se.w = c->w_seg; se.ldw = d.seg_dim;
-    se.bias = c->b_seg; se.relu = 1; se.c32 = ps32 + d.prop_enc;
-    se.c16 = (unsigned short*)ps16 + d.prop_enc; se.ldc = g.d_obj; se.ldc16 = g.d_obj;
-    se.M = g.n_vid * g.Fv; se.N = d.seg_enc; se.K = d.seg_dim; se.rep = d.nppf0; se.dtype = et;
-    steps.push_back({"seg_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&se, st); }});
+    se.M = Ms; se.N = d.seg_enc; se.K = d.seg_dim; se.dtype = et;
+    if (can_split && sp_p > 1 && sp_s > 1) {
+      pe.c32 = slab_p; pe.ldc = d.prop_enc; pe.splitk = sp_p;
+      se.c32 = slab_s; se.ldc = d.seg_enc; se.splitk = sp_s; se.rep = 1;
+      steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
+      steps.push_back({"seg_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&se, st); }});
+      vog_splitk_prob f0{}, f1{};
+      f0.slabs = slab_p; f0.splits = sp_p; f0.M = Mp; f0.N = d.prop_enc; f0.bias = c->b_prop; f0.relu = 1; f0.rep = 1;
+      f0.c32 = ps32; f0.c16 = ps16; f0.ldc = g.d_obj; f0.ldc16 = g.d_obj; f0.c16_dtype = d.tx_dtype;
+      f1.slabs = slab_s; f1.splits = sp_s; f1.M = Ms; f1.N = d.seg_enc; f1.bias = c->b_seg; f1.relu = 1; f1.rep = d.nppf0;
+      f1.c32 = ps32 + d.prop_enc; f1.c16 = (unsigned short*)ps16 + d.prop_enc; f1.ldc = g.d_obj; f1.ldc16 = g.d_obj;
+      f1.c16_dtype = d.tx_dtype;
+      steps.push_back({"enc_finish", [=](hipStream_t st) { return vog_splitk_finish(&f0, &f1, st); }});
+    } else {
+      pe.bias = c->b_prop; pe.relu = 1; pe.c32 = ps32; pe.c16 = ps16; pe.ldc = g.d_obj; pe.ldc16 = g.d_obj;
+      steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
+      se.bias = c->b_seg; se.relu = 1; se.c32 = ps32 + d.prop_enc;
+      se.c16 = (unsigned short*)ps16 + d.prop_enc; se.ldc = g.d_obj; se.ldc16 = g.d_obj; se.rep = d.nppf0;
+      steps.push_back({"seg_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&se, st); }});
+    }
   }
   // ---- object transformer (a7, a8)
   const float* vis32 = ps32;

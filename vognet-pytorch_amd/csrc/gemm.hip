@@ -34,6 +34,7 @@ struct GemmParams {
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; int c16_bf16; int debug;
   const int32_t* out_rows; int out_rows_ncol;
+  int splitk;
   // implicit vis||lang residual (res_vis != nullptr)
   const float* res_vis; const float* res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
   // QKV epilogue
@@ -306,7 +307,18 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
   for (int j = 0; j < FN; ++j) b_row[j] = BM + wn * (BN / 2) + j * 32 + (lane & 31);
   const int hi = lane >> 5;
 
-  const int nk = p.K / 64;
+  // split-K: blockIdx.y owns k tiles [kbeg, kbeg + nk) and its own fp32 output slab
+  int nk = p.K / 64;
+  int kbeg = 0;
+  if (p.splitk > 1) {
+    const int per = (nk + p.splitk - 1) / p.splitk;
+    kbeg = blockIdx.y * per;
+    nk = nk - kbeg < per ? nk - kbeg : per;
+    if (nk < 0) nk = 0;
+    p.c32 += (int64_t)blockIdx.y * p.M * p.ldc;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) gsrc[i] += (int64_t)kbeg * 64;
+  }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue(s, s);
@@ -533,7 +545,7 @@ static int launch_pipe_cfg(const GemmParams& p, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN), p.splitk > 1 ? p.splitk : 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -561,6 +573,8 @@ static int launch_pipe(const GemmParams& p, hipStream_t st) {
   auto ntiles = [&](int bm, int bn) { return (int64_t)ceil_div(p.M, bm) * ceil_div(p.N, bn); };
   if (ntiles(128, 128) >= 2048) return launch_pipe_cfg<T16, 128, 128, 2, EPI>(p, st);
   if (ntiles(128, 64) >= 512) return launch_pipe_cfg<T16, 128, 64, 2, EPI>(p, st);
+  if (ntiles(64, 64) * (p.splitk > 1 ? p.splitk : 1) < 256)
+    return launch_pipe_cfg<T16, 64, 64, 4, EPI>(p, st);                            // <1 tile per CU: go deep
   return launch_pipe_cfg<T16, 64, 64, 2, EPI>(p, st);
 }
 
@@ -599,10 +613,17 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   p.c16_bf16 = (g->c16_dtype < 0 ? (int)g->dtype : g->c16_dtype) == VOG_BF16;
   p.debug = gemm_debug_flags();
   p.out_rows = g->out_rows; p.out_rows_ncol = g->out_rows_ncol;
+  p.splitk = g->splitk;
   if (g->res_vislang) {
     const vog_vislang_args* r = g->res_vislang;
     p.res_vis = r->vis; p.res_lang = r->lang; p.rv_nfrm = r->nfrm; p.rv_nppf = r->nppf; p.rv_nsrl = r->nsrl;
     p.rv_dv = r->dv; p.rv_dl = r->dl; p.rv_lpv = r->lang_per_vid; p.rv_ncv = r->nc_v;
+  }
+  if (p.splitk > 1) {
+    if (!pipe_ok(p, g->a_is_f32 != 0) || g->bias || g->residual || g->relu || g->c16 || p.rep != 1 ||
+        g->out_rows || g->res_vislang || !g->c32 || g->splitk > p.K / 64)
+      VOG_FAIL(-1, "split-K GEMM needs the LDS-DMA path (16-bit A, K %% 64 == 0, M > 64) and a bare fp32 output");
+    return launch_pipe<T16, EPI_PLAIN>(p, st);
   }
   if (p.M <= 64 && (p.K % 32) == 0) {
     dim3 grid(ceil_div(p.N, 16));
