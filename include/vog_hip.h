@@ -76,7 +76,14 @@ typedef struct vog_gemm_args {
    * residual / c16 / rep must be unset — apply them with vog_splitk_finish. For
    * GEMMs with fewer output tiles than CUs and a long K (the two feature encoders). */
   int splitk;
+  /* w_frag = 1: `w` is in MFMA-fragment order (vog_pack_w_frag: [N/16][K/32][64 lanes][8],
+   * one contiguous KiB per fragment) — only for the M <= 64 weight-streaming kernel
+   * (K % 32 == 0, N % 16 == 0), where the row-major layout makes every wave load touch
+   * 16 half-used cache lines. */
+  int w_frag;
 } vog_gemm_args;
+/* host: fp32 [N, ld] (first K columns) -> 16-bit fragment order, N*K halfwords. */
+int vog_pack_w_frag(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);
 int vog_gemm_bias_act(const vog_gemm_args* g, void* stream);
 
 /* out[m*rep + j, n] = act(sum_s slab[s][m][n] + bias[n]) for up to two problems in

@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, '.')
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, torch, math, json
 from tests.gpu_util import L
 lib = L.load()

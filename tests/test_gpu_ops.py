@@ -113,6 +113,28 @@ def from_frag(f, N, dp, kind):
     return f[:, :, idx].reshape(S, H, N, dp)
 
 
+@pytest.mark.parametrize("M,N,K", [(48, 8192, 2048), (52, 256, 2048), (20, 2304, 256), (7, 32, 64)])
+def test_gemm_skinny_fragment_ordered_weights(M, N, K):
+    import numpy as np
+    lib = _lib()
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda")
+    w = (torch.randn(N, K) / math.sqrt(K)).contiguous()
+    wf = np.zeros(N * K, np.uint16)
+    wn = w.numpy()
+    L.check(lib.vog_pack_w_frag(wn.ctypes.data, K, N, K, wf.ctypes.data, L.VOG_F16), "pack")
+    wfd = torch.from_numpy(wf.view(np.int16)).cuda()
+    bias = torch.randn(N, device="cuda")
+    g = L.GemmArgs()
+    g.a, g.a_is_f32, g.lda, g.w, g.ldw, g.w_frag = L.ptr(a), 1, K, L.ptr(wfd), K, 1
+    c32 = torch.full((M, N), float("nan"), device="cuda")
+    g.bias, g.c32, g.ldc, g.M, g.N, g.K, g.relu, g.rep, g.dtype = L.ptr(bias), L.ptr(c32), N, M, N, K, 1, 1, L.VOG_F16
+    L.check(lib.vog_gemm_bias_act(C.byref(g), _sp()), "gemm")
+    torch.cuda.synchronize()
+    ref = torch.relu(a.half().float() @ w.cuda().half().float().t() + bias)
+    assert (c32 - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,K,splits,rep", [(800, 256, 2048, 8, 1), (160, 256, 3072, 12, 5), (130, 64, 256, 3, 1)])
 def test_gemm_splitk_and_finish(M, N, K, splits, rep):
     lib = _lib()

@@ -8,7 +8,8 @@
 // the Linear is affine in the box, so pe[i,j,h] = relu(u[i,h] - u[j,h] + b[h])
 // with u = W_pe . box — three VALU ops per (i,j), nothing stored.
 //
-// Mapping (wave64, v_mfma_f32_32x32x16), one WAVE = one workgroup = 32 queries:
+// Mapping (wave64, v_mfma_f32_32x32x16): one workgroup = 32 queries; its 4 waves split
+// the key blocks and merge their partial (max, sum, O^T) through LDS at the end:
 //   * "swapped" products so a query's softmax row lives in one lane:
 //       S^T[key][q] = K_blk . Q^T        (A = K fragment, B = Q fragment)
 //       O^T[d][q]  += V^T_blk . P^T      (A = V fragment, B = P from registers)
@@ -28,6 +29,7 @@
 //     (84..480 of them) with all loads of a key block in flight at once.
 //     (For p100, N = 2000..4000, K/V are re-read once per 32-query block from L2;
 //     an LDS-DMA shared-tile variant over the same fragment layout is the next step.)
+#include <stdlib.h>
 #include "common.h"
 
 namespace vog {
@@ -41,33 +43,47 @@ struct AttnParams {
 };
 
 template <typename T16, int NDB>
-__global__ __launch_bounds__(64) void attn_frag_kernel(AttnParams p) {
+__global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
-  extern __shared__ float us[];                      // [npad] bias precursor of every key
-  const int lane = threadIdx.x;
+  constexpr int OSLOT = NDB * 16 * 64;               // floats of one wave's O^T partial
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* obuf = smem;                                // [2][OSLOT]
+  float* mlbuf = smem + 2 * OSLOT;                   // [4][2][64]  (m, l) per wave
+  float* us = mlbuf + 4 * 2 * 64;                    // [npad] bias precursor of every key
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ql = lane & 31;
-  const int s = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  // 1-D grid. Workgroup b runs on XCD b % 8 (observed; speed only): give the 8 XCDs 8
+  // different (sequence, head) pairs and keep all query blocks of a pair on ONE XCD, so
+  // its K/V fragments are fetched into one L2 instead of up to eight.
+  const int nqb = (p.N + 31) >> 5;
+  const int npair = p.S * p.H;
+  int pair, qb;
+  {
+    const int b = blockIdx.x;
+    const int full = (npair / 8) * 8;                 // pairs that form complete groups of 8
+    const int grp = b / (8 * nqb);
+    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qb = (b >> 3) % nqb; }
+    else { const int r = b - full * nqb; pair = full + r / nqb; qb = r % nqb; }
+  }
+  const int s = pair / p.H, h = pair - s * p.H;
   const int qi = qb * 32 + ql;
   const bool q_ok = qi < p.N;
-  const int nkb = (p.N + 31) >> 5;
+  const int nkb = nqb;
   const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
   const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
   const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + lane;
   const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + lane;
 
-  u16x8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
-
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
     peb = p.pe_b[h];
-    for (int key = lane; key < p.npad; key += 64)
+    for (int key = tid; key < p.npad; key += 256)
       us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
-    // same wave wrote and reads us[]: DS ops of one wave are processed in order
     if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
   }
+  __syncthreads();
 
   f32x16 o[NDB];
 #pragma unroll
@@ -76,25 +92,37 @@ __global__ __launch_bounds__(64) void attn_frag_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  for (int kb = 0; kb < nkb; ++kb) {
-    // ---- all operand fragments of this key block: 32 independent 1-KiB loads
-    u16x8 kf[KS], vf[NDB * 2];
+  // ---- the 4 waves of the workgroup split the KEY blocks of this query block (wave w
+  // takes kb = w, w+4, ...): at N = 100 every wave has exactly one block, so the whole
+  // attention is one round of loads + 32 MFMAs per wave, then a merge. No wave waits on
+  // another until the merge. (Variants measured and rejected on MI355X: one wave per
+  // query block walking all key blocks 23.8 us; + software-prefetched next K block 30 us
+  // — the extra 64 registers spill; K/V register-resident across 2 query blocks with Q
+  // shared through LDS 25-31 us — spills again. This form: 21.9 us mul, 10.5 us obj.)
+  for (int kb = wid; kb < nkb; kb += 4) {
+    u16x8 kf[KS], qf[KS], vf[NDB * 2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
 #pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
+#pragma unroll
     for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
-    // ---- S^T block [32 keys x 32 queries]
-    f32x16 sacc;
+    // ---- S^T block [32 keys x 32 queries]; two chains halve the dependent-MFMA latency
+    f32x16 s0, s1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) sacc = mfma32<T16>(kf[ks], qf[ks], sacc);
+    for (int ks = 0; ks < KS; ks += 2) {
+      s0 = mfma32<T16>(kf[ks], qf[ks], s0);
+      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+    }
     // ---- bias, scale, mask, block max
+    f32x16 sacc;
     float mloc = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kb * 32 + c32_row(r, lane);
-      float x = sacc[r];
+      float x = s0[r] + s1[r];
       if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
       x *= p.inv_scale;
       x = key < p.N ? x : -1e30f;
@@ -114,7 +142,7 @@ __global__ __launch_bounds__(64) void attn_frag_kernel(AttnParams p) {
     lsum += __shfl_xor(lsum, 32);
     l_run = l_run * alpha + lsum;
     m_run = m_new;
-    if (kb > 0 && !__all(alpha == 1.0f)) {
+    if (kb >= 4 && !__all(alpha == 1.0f)) {
 #pragma unroll
       for (int i = 0; i < NDB; ++i)
 #pragma unroll
@@ -128,14 +156,47 @@ __global__ __launch_bounds__(64) void attn_frag_kernel(AttnParams p) {
       for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
     // pad keys of the last block carry p = 0 but their V fragment entries are
     // whatever the (zero-initialised, never written) buffer holds: finite by contract
-    // ---- O^T += V^T_blk . P^T
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) o[db] = mfma32<T16>(vf[db * 2 + ks], pf[ks], o[db]);
   }
+
+  // ---- merge the 4 partial (m, l, O^T) with a two-level tree through LDS
+  auto publish = [&](int slot) {
+    float* ob = obuf + slot * OSLOT;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(i * 16 + r) * 64 + lane] = o[i][r];
+    mlbuf[(wid * 2 + 0) * 64 + lane] = m_run;
+    mlbuf[(wid * 2 + 1) * 64 + lane] = l_run;
+  };
+  auto absorb = [&](int slot, int other) {
+    const float* ob = obuf + slot * OSLOT;
+    const float mb = mlbuf[(other * 2 + 0) * 64 + lane], lb = mlbuf[(other * 2 + 1) * 64 + lane];
+    const float m = fmaxf(m_run, mb);
+    const float fa = __expf(m_run - m), fb = __expf(mb - m);
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * fa + ob[(i * 16 + r) * 64 + lane] * fb;
+    l_run = l_run * fa + lb * fb;
+    m_run = m;
+  };
+  if (nkb > 2) {                      // waves 2,3 hold something only then
+    if (wid >= 2) publish(wid - 2);
+    __syncthreads();
+    if (wid < 2) absorb(wid, wid + 2);
+    __syncthreads();
+  }
+  if (nkb > 1) {
+    if (wid == 1) publish(0);
+    __syncthreads();
+    if (wid == 0) absorb(0, 1);
+  }
   // ---- normalise and store: O^T[d][q] -> out[(s*N+q), h*DP + d], 4 consecutive d per store
-  if (q_ok) {
+  if (wid == 0 && q_ok) {
     const float inv_l = 1.0f / l_run;
     unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
 #pragma unroll
@@ -152,10 +213,17 @@ __global__ __launch_bounds__(64) void attn_frag_kernel(AttnParams p) {
 
 template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
-  const size_t lds = p.use_rel ? (size_t)p.npad * sizeof(float) : 0;
-  if (lds > 60 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the bias staging buffer", p.N);
-  dim3 grid(ceil_div(p.N, 32), p.H, p.S);
-  hipLaunchKernelGGL((attn_frag_kernel<T16, NDB>), grid, dim3(64), lds, st, p);
+  const size_t lds = ((size_t)2 * NDB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);
+  if (lds > 150 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the LDS budget", p.N);
+  auto kern = attn_frag_kernel<T16, NDB>;
+  static bool attr_set = false;       // benign race: idempotent
+  if (!attr_set && lds > 48 * 1024) {
+    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -30,10 +30,9 @@ struct F16 {};
 // fp32 -> 16-bit (round to nearest even) and back; raw bit patterns in memory.
 template <typename T> __device__ __forceinline__ unsigned short to16(float f);
 template <> __device__ __forceinline__ unsigned short to16<BF16>(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  // gfx950 has a hardware RNE convert (v_cvt_pk_bf16_f32); the cast lowers to it.
+  // (A bit-twiddled RNE costs ~6 VALU per element: measured 4.2k VALU per attention wave.)
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 template <> __device__ __forceinline__ unsigned short to16<F16>(float f) {
   _Float16 h = (_Float16)f;

@@ -46,6 +46,7 @@ struct DevBuf {
 
 struct TxLayer {
   unsigned short *wqkv, *wo, *w1, *w2;     // 16-bit, padded
+  unsigned short* wqkv_lang_f;             // Wqkv[:, d_vis:] in fragment order (structured layer 0)
   float *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 struct TxWeights {
@@ -69,6 +70,8 @@ struct vog_ctx {
   // device weights
   float* emb = nullptr;
   std::vector<unsigned short*> wih;                     // [layer] [8R, in]
+  std::vector<unsigned short*> wih_f;                   // same, fragment order (M <= 64 kernel)
+  unsigned short* w_outproj_f = nullptr;
   std::vector<unsigned short*> whh;                     // [layer] [2][4R][R]
   std::vector<float*> bsum;                             // [layer] [8R]
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
@@ -160,6 +163,24 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
         }
     }
     VOG_TRY(upload<unsigned short>(c, wqkv, &L.wqkv));
+    L.wqkv_lang_f = nullptr;
+    {
+      const int dl = c->d.lang_enc, dv = d - dl;
+      if (l == 0 && std::string(prefix) == "mult_txf" && dv > 0 && dl % 32 == 0) {
+        // fp32 image of the padded lang columns, then fragment order
+        std::vector<float> wl((size_t)3 * H * dp * dl, 0.f);
+        for (int which = 0; which < 3; ++which) {
+          const auto& w = W(c, p + ".selfattn.layer." + nm[which] + ".weight");
+          for (int h = 0; h < H; ++h)
+            for (int dd = 0; dd < tw->head_dim[h]; ++dd)
+              memcpy(&wl[((size_t)(which * H + h) * dp + dd) * dl], &w[(size_t)(tw->head_off[h] + dd) * d + dv],
+                     dl * sizeof(float));
+        }
+        std::vector<unsigned short> wf(wl.size());
+        VOG_TRY(vog_pack_w_frag(wl.data(), dl, 3 * H * dp, dl, wf.data(), (vog_dtype)dt));
+        VOG_TRY(upload<unsigned short>(c, wf, &L.wqkv_lang_f));
+      }
+    }
     std::vector<unsigned short> wo((size_t)d * H * dp, 0);
     {
       const auto& w = W(c, p + ".selfattn.layer.wo.weight");
@@ -342,6 +363,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       gl.a = sv.lang; gl.a_is_f32 = 1; gl.lda = sv.dl; gl.w = L.wqkv + sv.dv; gl.ldw = tw.d;
       gl.c32 = ws.at<float>(n + "_pl"); gl.ldc = ncol; gl.M = g.Bn * sv.nsrl; gl.N = ncol; gl.K = sv.dl;
       gl.rep = 1; gl.dtype = dt;
+      if (gl.M <= 64 && L.wqkv_lang_f) { gl.w = L.wqkv_lang_f; gl.ldw = sv.dl; gl.w_frag = 1; }
       steps.push_back({n + "_pl", [=](hipStream_t st) { return vog_gemm_bias_act(&gl, st); }});
       vog_qkvcomb_args ca{};
       ca.pv = gv.c32; ca.pl = gl.c32; ca.q = qa.q; ca.k = qa.k; ca.vt = qa.vt;
@@ -440,6 +462,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 4 * R;
       ga.M = Bn * T; ga.N = 8 * R; ga.rep = 1; ga.dtype = et;
       ga.out_rows = lrows; ga.out_rows_ncol = 4 * R;
+      if (ga.M <= 64 && c->wih_f[l]) { ga.w = c->wih_f[l]; ga.w_frag = 1; }
       steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
       // final state must land in hA (adjacent to out16): after T steps it is in buf[T % 2]
       void* hA = ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R;
@@ -459,6 +482,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     po.w = c->w_outproj; po.ldw = 2 * R; po.bias = c->b_outproj; po.relu = 1;
     po.c32 = ws.at<float>("full"); po.ldc = g.L; po.M = Bn * T + Bn; po.N = g.L; po.K = 2 * R;
     po.rep = 1; po.dtype = et;
+    if (po.M <= 64 && c->w_outproj_f) { po.w = c->w_outproj_f; po.w_frag = 1; }
     steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
     const float* full = po.c32;
     float* lang = ws.at<float>("lang");
@@ -682,7 +706,7 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
     if (!c->host.count(n)) VOG_FAIL(-3, "missing weight '%s'", n.c_str());
   for (void* p : c->allocs) (void)hipFree(p);
   c->allocs.clear();
-  c->wih.clear(); c->whh.clear(); c->bsum.clear();
+  c->wih.clear(); c->wih_f.clear(); c->whh.clear(); c->bsum.clear();
   c->obj = TxWeights(); c->mul = TxWeights();
   const vog_model_desc& d = c->d;
   const int R = d.rnn_size, et = d.enc_dtype;
@@ -709,12 +733,34 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
                                 W(c, "lstm_encoder.lstm.weight_hh" + s1).data(), whh.data(), R, (vog_dtype)et));
     }
     unsigned short *pw, *ph; float* pb;
+    {
+      std::vector<float> cat((size_t)8 * R * in);
+      int dd = 0;
+      for (const char* sfx : {"", "_reverse"}) {
+        const auto& a = W(c, "lstm_encoder.lstm.weight_ih_l" + std::to_string(l) + sfx);
+        memcpy(&cat[(size_t)dd * 4 * R * in], a.data(), a.size() * sizeof(float));
+        ++dd;
+      }
+      std::vector<unsigned short> wf((size_t)8 * R * in);
+      unsigned short* pf = nullptr;
+      if (in % 32 == 0) {
+        VOG_TRY(vog_pack_w_frag(cat.data(), in, 8 * R, in, wf.data(), (vog_dtype)et));
+        VOG_TRY(upload<unsigned short>(c, wf, &pf));
+      }
+      c->wih_f.push_back(pf);
+    }
     VOG_TRY(upload<unsigned short>(c, wih, &pw));
     VOG_TRY(upload<unsigned short>(c, whh, &ph));
     VOG_TRY(upload<float>(c, bs, &pb));
     c->wih.push_back(pw); c->whh.push_back(ph); c->bsum.push_back(pb);
   }
   VOG_TRY(up16(c, "lstm_out_feat_proj.0.weight", et, &c->w_outproj));
+  c->w_outproj_f = nullptr;
+  if (d.lang_enc % 16 == 0) {
+    std::vector<unsigned short> wf((size_t)d.lang_enc * 2 * R);
+    VOG_TRY(vog_pack_w_frag(W(c, "lstm_out_feat_proj.0.weight").data(), 2 * R, d.lang_enc, 2 * R, wf.data(), (vog_dtype)et));
+    VOG_TRY(upload<unsigned short>(c, wf, &c->w_outproj_f));
+  }
   VOG_TRY(up32(c, "lstm_out_feat_proj.0.bias", &c->b_outproj));
   VOG_TRY(up16(c, "prop_encoder.0.weight", et, &c->w_prop));
   VOG_TRY(up32(c, "prop_encoder.0.bias", &c->b_prop));

@@ -34,7 +34,7 @@ struct GemmParams {
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; int c16_bf16; int debug;
   const int32_t* out_rows; int out_rows_ncol;
-  int splitk;
+  int splitk; int w_frag;
   // implicit vis||lang residual (res_vis != nullptr)
   const float* res_vis; const float* res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
   // QKV epilogue
@@ -475,7 +475,11 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
   const int n = n0 + (lane & 15);
   const bool n_ok = n < p.N;
   const int kg = (lane >> 4) * 8;
-  const int mt_n = (p.M + 15) / 16;           // <= 4
+  const int mt_all = (p.M + 15) / 16;         // <= 4
+  // grid.y > 1: one 16-row tile of A per workgroup (few output columns: parallelism
+  // matters more than re-reading the small W panel)
+  const int mt_lo = gridDim.y > 1 ? blockIdx.y : 0;
+  const int mt_n = gridDim.y > 1 ? mt_lo + 1 : mt_all;
   const int ksteps = p.K / 32;
   f32x4 acc[4];
 #pragma unroll
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = mt * 16 + (lane & 15);
-    a_ok[mt] = (mt < mt_n) && (m < p.M);
+    a_ok[mt] = (mt >= mt_lo) && (mt < mt_n) && (m < p.M);
     const int64_t src = a_ok[mt] ? (p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m) : 0;
     a_off[mt] = src * p.lda;
   }
@@ -497,11 +501,17 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
 #pragma unroll
     for (int c = 0; c < SK_CH; ++c) {
       const int ks = base + c * 4;
-      fw[c] = load_a_chunk<T16, false>(p.w, w_off, ks * 32 + kg, n_ok && ks < ksteps);
+      if (p.w_frag) {   // one contiguous KiB per (column tile, k-step)
+        u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        fw[c] = ks < ksteps ? *reinterpret_cast<const u16x8*>(
+                                  p.w + (((int64_t)blockIdx.x * ksteps + ks) * 64 + lane) * 8) : z;
+      } else {
+        fw[c] = load_a_chunk<T16, false>(p.w, w_off, ks * 32 + kg, n_ok && ks < ksteps);
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      if (mt < mt_n) {
+      if (mt >= mt_lo && mt < mt_n) {
         u16x8 fa[SK_CH];
 #pragma unroll
         for (int c = 0; c < SK_CH; ++c) {
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
   __syncthreads();
   // wave w finishes m-tile w
   const int mt = wid;
-  if (mt < mt_n) {
+  if (mt >= mt_lo && mt < mt_n) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = red[0][mt][lane][r] + red[1][mt][lane][r] + red[2][mt][lane][r] + red[3][mt][lane][r];
@@ -625,8 +635,12 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
       VOG_FAIL(-1, "split-K GEMM needs the LDS-DMA path (16-bit A, K %% 64 == 0, M > 64) and a bare fp32 output");
     return launch_pipe<T16, EPI_PLAIN>(p, st);
   }
+  p.w_frag = g->w_frag;
+  if (p.w_frag && !(p.M <= 64 && (p.K % 32) == 0 && (p.N % 16) == 0))
+    VOG_FAIL(-1, "w_frag weights are only valid for the M <= 64 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);
   if (p.M <= 64 && (p.K % 32) == 0) {
-    dim3 grid(ceil_div(p.N, 16));
+    const int ncol = ceil_div(p.N, 16);
+    dim3 grid(ncol, ncol < 128 ? ceil_div(p.M, 16) : 1);
     if (g->a_is_f32) hipLaunchKernelGGL((gemm_skinny<T16, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_skinny<T16, false>), grid, dim3(256), 0, st, p);
     VOG_LAUNCH_CHECK();
@@ -663,6 +677,29 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
 }
 
 }  // namespace vog
+
+extern "C" int vog_pack_w_frag(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype) {
+  VOG_CHECK_ARG(w && dst_host && N > 0 && K > 0 && (N % 16) == 0 && (K % 32) == 0 && ld >= K);
+  unsigned short* dst = (unsigned short*)dst_host;
+  const int ksteps = K / 32;
+  for (int nt = 0; nt < N / 16; ++nt)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int lane = 0; lane < 64; ++lane) {
+        const float* src = w + (int64_t)(nt * 16 + (lane & 15)) * ld + ks * 32 + (lane >> 4) * 8;
+        unsigned short* d = dst + (((int64_t)nt * ksteps + ks) * 64 + lane) * 8;
+        for (int j = 0; j < 8; ++j) {
+          if (dtype == VOG_BF16) {
+            unsigned int u; memcpy(&u, &src[j], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            d[j] = (unsigned short)(u >> 16);
+          } else {
+            _Float16 h = (_Float16)src[j];
+            memcpy(&d[j], &h, 2);
+          }
+        }
+      }
+  return 0;
+}
 
 extern "C" int vog_gemm_bias_act(const vog_gemm_args* g, void* stream) {
   return vog::gemm_run(g, (hipStream_t)stream);

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32)]
+                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -127,6 +127,7 @@ SYMBOLS = {
     "vog_version": (c_i32, []),
     "vog_last_error": (C.c_char_p, []),
     "vog_gemm_bias_act": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "vog_pack_w_frag": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),
