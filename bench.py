@@ -85,13 +85,19 @@ def kernel_flops(w, T):
         "obj_attn": 4.0 * S_obj * N_obj * N_obj * d_obj,
         "obj_wo": 2.0 * ro * d_obj * d_obj,
         "prop_enc": 2.0 * ro * 2048 * 256,
+        "seg_enc": 2.0 * n_vid * (NP // nppf0) * 3072 * 256,
+        "lstm_ih0": 2.0 * B * (ncmp if w["conc"] in ("sep", "svsq") else 1) * T * 8192 * 512,
+        "lstm_ih1": 2.0 * B * (ncmp if w["conc"] in ("sep", "svsq") else 1) * T * 8192 * 2048,
+        "lstm_outproj": 2.0 * B * (ncmp if w["conc"] in ("sep", "svsq") else 1) * (T + 1) * 2048 * 256,
+        "obj_ffn1": 2.0 * ro * d_obj * (d_obj // 2), "obj_ffn2": 2.0 * ro * d_obj * (d_obj // 2),
+        "argvec": 0.0, "enc_finish": 0.0, "cast_feats": 0.0, "mul_ln1": 0.0, "mul_ln2": 0.0,
+        "obj_ln1": 0.0, "obj_ln2": 0.0, "score": 0.0, "pred_head": 0.0,
     }
     Bn = B * (ncmp if w["conc"] in ("sep", "svsq") else 1)
     lstm = 2.0 * Bn * T * (2 * 4096 * 512 + 2 * 4096 * 2048 + 4 * 4096 * 1024)
-    dense = {k: v for k, v in f.items() if k not in ("mul_pv", "mul_pl", "mul_combine")}
-    total = sum(dense.values()) + lstm \
-        + 2.0 * ro * d_obj * (d_obj // 2) * 2 + 2.0 * n_vid * (NP // nppf0) * 3072 * 256 \
-        + 2.0 * Bn * (T + 1) * 2048 * 256
+    dense = {k: v for k, v in f.items() if k not in ("mul_pv", "mul_pl", "mul_combine", "lstm_ih0", "lstm_ih1",
+                                                     "lstm_outproj")}
+    total = sum(dense.values()) + lstm + f["lstm_outproj"]
     return f, total
 
 

@@ -30,6 +30,7 @@
 //     (For p100, N = 2000..4000, K/V are re-read once per 32-query block from L2;
 //     an LDS-DMA shared-tile variant over the same fragment layout is the next step.)
 #include <stdlib.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace vog {
@@ -211,8 +212,187 @@ __global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
   }
 }
 
+// ----------------------------------------------------------------------------
+// Single-pass variant for N <= 128 (<= 4 key blocks: every mul_tx shape of gt5, where this
+// kernel is the largest single item of the forward). Wave w owns key block w, so nothing
+// has to persist across key blocks, and the kernel is shaped around OCCUPANCY: the general
+// kernel needs 462 registers per wave = one workgroup per CU, i.e. 480 workgroups run as
+// two serial rounds of ~8.5 us that are each >50 % load wait (measured: SQ_WAIT_ANY 53 %).
+// Here the softmax is made global BEFORE the PV product (the 4 waves exchange (max, sum)
+// through LDS and fold exp(m_w - m*) into P), so the partial O^T of the waves are plain
+// summands; PV runs in two head-dim halves that reuse the same 32 + 64 registers, and the
+// 4 waves reduce the halves in parallel (wave w sums and stores d-block w). <= 256
+// registers => two workgroups per CU overlap each other's load round trip.
+// ----------------------------------------------------------------------------
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  constexpr int HB = (NDB + 1) / 2;                  // d-blocks per half
+  constexpr int SLOT = HB * 16 * 64;                 // floats of one wave's half partial
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* slots = smem;                               // [4][SLOT]
+  float* mlbuf = smem + 4 * SLOT;                    // [4][2][64]
+  float* us = mlbuf + 4 * 2 * 64;                    // [npad]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int nqb = (p.N + 31) >> 5;                   // = number of key blocks <= 4
+  const int npair = p.S * p.H;
+  int pair, qb;
+  {
+    const int b = blockIdx.x;
+    const int full = (npair / 8) * 8;
+    const int grp = b / (8 * nqb);
+    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qb = (b >> 3) % nqb; }
+    else { const int r = b - full * nqb; pair = full + r / nqb; qb = r % nqb; }
+  }
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = qi < p.N;
+  const bool active = wid < nqb;                     // wave-uniform: has a key block
+  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
+  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + (int64_t)wid * KS * 64 + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + (int64_t)wid * NDB * 2 * 64 + lane;
+
+  // requests first: K and Q (needed at once), then the first V half
+  u16x8 kf[KS], qf[KS], vf[HB * 2];
+  if (active) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { kf[ks] = Kf[ks * 64]; qf[ks] = Qf[ks * 64]; }
+#pragma unroll
+    for (int i = 0; i < HB * 2; ++i) vf[i] = Vf[i * 64];
+  }
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
+    peb = p.pe_b[h];
+    for (int key = tid; key < p.npad; key += 256)
+      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
+  }
+  __syncthreads();
+
+  float m_w = -1e30f, l_w = 0.f;
+  f32x16 sacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+  if (active) {
+    f32x16 s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      sacc = mfma32<T16>(kf[ks], qf[ks], sacc);
+      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = wid * 32 + c32_row(r, lane);
+      float x = sacc[r] + s1[r];
+      if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
+      x *= p.inv_scale;
+      x = key < p.N ? x : -1e30f;
+      sacc[r] = x;
+      m_w = fmaxf(m_w, x);
+    }
+    m_w = fmaxf(m_w, __shfl_xor(m_w, 32));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(sacc[r] - m_w);
+      sacc[r] = e;
+      l_w += e;
+    }
+    l_w += __shfl_xor(l_w, 32);
+  }
+  mlbuf[(wid * 2 + 0) * 64 + lane] = m_w;
+  mlbuf[(wid * 2 + 1) * 64 + lane] = l_w;
+  __syncthreads();
+  // global softmax statistics of this query (same in every wave)
+  float m_all = -1e30f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, mlbuf[(w * 2) * 64 + lane]);
+  float l_all = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) l_all += mlbuf[(w * 2 + 1) * 64 + lane] * __expf(mlbuf[(w * 2) * 64 + lane] - m_all);
+  const float f_w = __expf(m_w - m_all);
+  const float inv_l = 1.0f / l_all;
+  // P^T fragments, already on the global scale
+  u16x8 pf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j] * f_w);
+
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int nb = half == 0 ? HB : NDB - HB;        // d-blocks in this half
+    if (nb <= 0) break;
+    if (half == 1) {
+      __syncthreads();                               // slots consumed by the previous half
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < (NDB - HB) * 2; ++i) vf[i] = Vf[(HB * 2 + i) * 64];
+      }
+    }
+    float* mine = slots + wid * SLOT;
+    if (active) {
+#pragma unroll
+      for (int db = 0; db < HB; ++db) {
+        if (db < nb) {
+          f32x16 o;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[r] = 0.f;
+          o = mfma32<T16>(vf[db * 2], pf[0], o);
+          o = mfma32<T16>(vf[db * 2 + 1], pf[1], o);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64 + lane] = o[r];
+        }
+      }
+    }
+    __syncthreads();
+    // wave w reduces and stores d-block w (w + 4, ...) of this half
+    for (int db = wid; db < nb; db += 4) {
+      float acc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int w = 0; w < nqb; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += slots[w * SLOT + (db * 16 + r) * 64 + lane];
+      if (q_ok) {
+        unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP +
+                               (half * HB + db) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = to16<T16>(acc[g * 4 + e] * inv_l);
+          *reinterpret_cast<u16x4*>(orow + g * 8 + hi * 4) = v;
+        }
+      }
+    }
+  }
+}
+
 template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
+  static int force_general = -2;      // VOG_ATTN_GENERAL=1: perf experiments only
+  if (force_general == -2) { const char* e = getenv("VOG_ATTN_GENERAL"); force_general = e ? atoi(e) : 0; }
+  if (p.N <= 128 && !force_general) {
+    constexpr int HB = (NDB + 1) / 2;
+    const size_t lds = ((size_t)4 * HB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);
+    auto kern = attn_sb_kernel<T16, NDB>;
+    static bool attr_sb = false;
+    if (!attr_sb && lds > 48 * 1024) {
+      VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      attr_sb = true;
+    }
+    dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    VOG_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = ((size_t)2 * NDB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);
   if (lds > 150 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the LDS budget", p.N);
   auto kern = attn_frag_kernel<T16, NDB>;

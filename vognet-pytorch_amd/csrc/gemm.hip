@@ -465,9 +465,10 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
 // ----------------------------------------------------------------------------
 // skinny kernel (M <= 64, K % 32 == 0)
 // ----------------------------------------------------------------------------
-constexpr int SK_CH = 8;   // k-steps (of 32) per register chunk
-
-template <typename T16, bool A_F32>
+// SK_CH = k-steps (of 32) per register chunk. The W panel is the HBM-bound stream of this
+// kernel: with K = 2048 a wave owns 16 k-steps, and all 16 of its weight fragments are
+// requested before anything else (one round trip instead of two).
+template <typename T16, bool A_F32, int SK_CH>
 __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
   __shared__ float red[4][4][64][4];          // [wave][mtile][lane][reg]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -641,8 +642,14 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   if (p.M <= 64 && (p.K % 32) == 0) {
     const int ncol = ceil_div(p.N, 16);
     dim3 grid(ncol, ncol < 128 ? ceil_div(p.M, 16) : 1);
-    if (g->a_is_f32) hipLaunchKernelGGL((gemm_skinny<T16, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_skinny<T16, false>), grid, dim3(256), 0, st, p);
+    const bool deep = false;   // 16-deep weight prefetch measured SLOWER (26 vs 18.6 us at M=48,N=8192,K=2048: 230 VGPRs)
+    if (g->a_is_f32) {
+      if (deep) hipLaunchKernelGGL((gemm_skinny<T16, true, 16>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_skinny<T16, true, 8>), grid, dim3(256), 0, st, p);
+    } else {
+      if (deep) hipLaunchKernelGGL((gemm_skinny<T16, false, 16>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_skinny<T16, false, 8>), grid, dim3(256), 0, st, p);
+    }
     VOG_LAUNCH_CHECK();
     return 0;
   }
