@@ -171,6 +171,23 @@ int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask, int32_t* 
  * -1 for t >= len_b. */
 int vog_lstm_schedule(const int64_t* lens, int32_t* rows, int Bn, int T, void* stream);
 
+/* Fused prologue of the language path (one launch instead of memset + vog_srl_gather +
+ * vog_lstm_schedule): zero `zero_bytes` at `zero` (multiple of 16), token re-index and the
+ * packed-sequence schedule. */
+int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+                  const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
+                  int seq_len, int vocab_size, void* stream);
+
+/* Fused prologue of the visual path (one launch instead of vog_cast_f32_to_t16 + up to two
+ * vog_box_u): u0/u1 = bias precursors for obj_tx / mul_tx (either w_pe may be NULL). */
+typedef struct vog_visprep_args {
+  const float* src0; void* dst0; int64_t n0; const float* src1; void* dst1; int64_t n1; vog_dtype dtype;
+  const float* props; int n_rows; float vid_w, vid_h;
+  const float* w_pe0; float* u0; int H0; float nfrm_div0;
+  const float* w_pe1; float* u1; int H1; float nfrm_div1;
+} vog_visprep_args;
+int vog_vis_prep(const vog_visprep_args* a, void* stream);
+
 /* One time step of one BiLSTM layer, both directions, packed-sequence
  * semantics (LSTMEncoder.forward mdl_srl_utils.py:134-148; nn.LSTM gate order
  * i,f,g,o). gxs: [2][T][Bn][4R] fp32 = x W_ih^T + b_ih + b_hh in (direction, step)

@@ -377,64 +377,110 @@ __global__ __launch_bounds__(256) void predcmp_kernel(vog_predcmp_args a) {
 // (query, arg, video, frame); packed record per query.
 // ---------------------------------------------------------------------------
 __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int per_q = a.nsrl * a.ncmp * a.nfrm0;
-  if (i >= a.B * per_q) return;
-  const int b = i / per_q, rem = i % per_q;
-  const int arg = rem / (a.ncmp * a.nfrm0), c = (rem / a.nfrm0) % a.ncmp, f = rem % a.nfrm0;
-  const int npv = a.nfrm0 * a.nppf0;
-  int64_t e0, p0;     // first proposal of this (video, frame): in outs_eval / in props
-  if (a.conc_type == VOG_CONC_SPAT) {
-    const int r0 = (f * a.ncmp + c) * a.nppf0;
-    e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
-    p0 = (int64_t)b * a.ncmp * npv + r0;
-  } else if (a.conc_type == VOG_CONC_TEMP) {
-    const int r0 = (c * a.nfrm0 + f) * a.nppf0;
-    e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
-    p0 = (int64_t)b * a.ncmp * npv + r0;
-  } else {
-    e0 = (((int64_t)b * a.ncmp + c) * a.nsrl + arg) * npv + (int64_t)f * a.nppf0;
-    p0 = ((int64_t)b * a.ncmp + c) * npv + (int64_t)f * a.nppf0;
-  }
-  float best = a.outs_eval[e0];
-  int bi = 0;
-  for (int k = 1; k < a.nppf0; ++k) {
-    const float v = a.outs_eval[e0 + k];
-    if (v > best) { best = v; bi = k; }          // first maximum wins (torch.max on CPU)
-  }
-  unsigned char* rec = reinterpret_cast<unsigned char*>(a.rec) + (int64_t)b * rec_bytes;
-  float* boxes = reinterpret_cast<float*>(rec);
-  float* scores = boxes + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
-  const int64_t o = ((int64_t)arg * a.ncmp + c) * a.nfrm0 + f;
-  const float* pr = a.props + (p0 + bi) * 7;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) boxes[o * 7 + k] = pr[k];
-  scores[o] = best;
-}
-
-__global__ void pred_index_kernel(vog_pred_args a, int64_t rec_bytes) {
+  // one thread per (query, arg, frame): the ncmp videos of that frame, then pred_cmp
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_q = a.nsrl * a.nfrm0;
   if (i >= a.B * per_q) return;
   const int b = i / per_q, arg = (i % per_q) / a.nfrm0, f = i % a.nfrm0;
+  const int npv = a.nfrm0 * a.nppf0;
   unsigned char* rec = reinterpret_cast<unsigned char*>(a.rec) + (int64_t)b * rec_bytes;
-  const float* scores = reinterpret_cast<const float*>(rec) + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
+  float* boxes = reinterpret_cast<float*>(rec);
+  float* scores = boxes + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
   int64_t* idx = reinterpret_cast<int64_t*>(rec + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 8 * 4);
-  int64_t out = 0;
-  if (a.conc_type == VOG_CONC_SPAT) {
-    float best = scores[((int64_t)arg * a.ncmp + 0) * a.nfrm0 + f];
-    for (int c = 1; c < a.ncmp; ++c) {
-      const float v = scores[((int64_t)arg * a.ncmp + c) * a.nfrm0 + f];
-      if (v > best) { best = v; out = c; }
+  float best_c = -3.0e38f;
+  int64_t arg_c = 0;
+  for (int c = 0; c < a.ncmp; ++c) {
+    int64_t e0, p0;   // first proposal of this (video, frame): in outs_eval / in props
+    if (a.conc_type == VOG_CONC_SPAT) {
+      const int r0 = (f * a.ncmp + c) * a.nppf0;
+      e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
+      p0 = (int64_t)b * a.ncmp * npv + r0;
+    } else if (a.conc_type == VOG_CONC_TEMP) {
+      const int r0 = (c * a.nfrm0 + f) * a.nppf0;
+      e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
+      p0 = (int64_t)b * a.ncmp * npv + r0;
+    } else {
+      e0 = (((int64_t)b * a.ncmp + c) * a.nsrl + arg) * npv + (int64_t)f * a.nppf0;
+      p0 = ((int64_t)b * a.ncmp + c) * npv + (int64_t)f * a.nppf0;
     }
-  } else if (a.conc_type == VOG_CONC_SEP) {
-    float best = a.fin_scores[(int64_t)b * a.ncmp];
+    float best = a.outs_eval[e0];
+    int bi = 0;
+    for (int k = 1; k < a.nppf0; ++k) {
+      const float v = a.outs_eval[e0 + k];
+      if (v > best) { best = v; bi = k; }          // first maximum wins (torch.max on CPU)
+    }
+    const int64_t o = ((int64_t)arg * a.ncmp + c) * a.nfrm0 + f;
+    const float* pr = a.props + (p0 + bi) * 7;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) boxes[o * 7 + k] = pr[k];
+    scores[o] = best;
+    if (best > best_c) { best_c = best; arg_c = c; }   // first maximum over the videos
+  }
+  int64_t out = 0;
+  if (a.conc_type == VOG_CONC_SPAT) out = arg_c;
+  else if (a.conc_type == VOG_CONC_SEP) {
+    float bf = a.fin_scores[(int64_t)b * a.ncmp];
     for (int c = 1; c < a.ncmp; ++c) {
       const float v = a.fin_scores[(int64_t)b * a.ncmp + c];
-      if (v > best) { best = v; out = c; }
+      if (v > bf) { bf = v; out = c; }
     }
   }
   idx[(int64_t)arg * a.nfrm0 + f] = out;
+}
+
+// ---------------------------------------------------------------------------
+// fused prologues (one graph node each instead of 3)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lang_prep_kernel(uint4* __restrict__ zero, int64_t zero16,
+                                                        const int64_t* __restrict__ words,
+                                                        const int64_t* __restrict__ mask,
+                                                        const int64_t* __restrict__ lens,
+                                                        int32_t* __restrict__ tok, int32_t* __restrict__ rows,
+                                                        int Bn, int T, int nsrl, int seq_len, int vocab) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gid; i < zero16; i += stride) zero[i] = make_uint4(0, 0, 0, 0);
+  if (gid < (int64_t)Bn * T) {
+    const int i = (int)gid, b = i / T, t = i % T;
+    const int64_t m = mask[(int64_t)b * seq_len + t];
+    int64_t v = vocab;
+    if (m >= 0 && m < (int64_t)nsrl * seq_len) v = words[(int64_t)b * nsrl * seq_len + m];
+    tok[i] = (int32_t)v;
+    const int len = (int)lens[b];
+    rows[i] = t < len ? t * Bn + b : -1;
+    rows[Bn * T + i] = t < len ? T * Bn - 1 + (len - 1 - t) * Bn + b : -1;
+  }
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void vis_prep_kernel(vog_visprep_args a, int cast_blocks) {
+  if ((int)blockIdx.x < cast_blocks) {
+    const int64_t q0 = a.n0 / 4, q1 = a.n1 / 4;
+    const int64_t stride = (int64_t)cast_blocks * blockDim.x;
+    const float4* s0 = reinterpret_cast<const float4*>(a.src0);
+    const float4* s1 = reinterpret_cast<const float4*>(a.src1);
+    u16x4* d0 = reinterpret_cast<u16x4*>(a.dst0);
+    u16x4* d1 = reinterpret_cast<u16x4*>(a.dst1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q0 + q1; i += stride) {
+      const bool first = i < q0;
+      const float4 v = first ? s0[i] : s1[i - q0];
+      u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
+      if (first) d0[i] = o; else d1[i - q0] = o;
+    }
+    return;
+  }
+  const int i = ((int)blockIdx.x - cast_blocks) * blockDim.x + threadIdx.x;
+  const int n0 = a.w_pe0 ? a.n_rows * a.H0 : 0, n1 = a.w_pe1 ? a.n_rows * a.H1 : 0;
+  if (i >= n0 + n1) return;
+  const bool second = i >= n0;
+  const int k = second ? i - n0 : i;
+  const int H = second ? a.H1 : a.H0;
+  const float fd = second ? a.nfrm_div1 : a.nfrm_div0;
+  const float* w = (second ? a.w_pe1 : a.w_pe0) + (k % H) * 5;
+  const float* b = a.props + (int64_t)(k / H) * 7;
+  const float v = w[0] * (b[0] / a.vid_w) + w[1] * (b[1] / a.vid_h) + w[2] * (b[2] / a.vid_w) +
+                  w[3] * (b[3] / a.vid_h) + w[4] * (b[4] / fd);
+  (second ? a.u1 : a.u0)[k] = v;
 }
 
 }  // namespace vog
@@ -458,6 +504,38 @@ extern "C" int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, co
   const int grid = (int)((q + 255) / 256 < 2048 ? (q + 255) / 256 : 2048);
   VOG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cast2_kernel<T16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)src0, (u16x4*)dst0, n0 / 4, (const float4*)src1, (u16x4*)dst1, n1 / 4));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+                             const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
+                             int seq_len, int vocab_size, void* stream) {
+  VOG_CHECK_ARG(words_ind && word_mask && lens && tok && rows && Bn > 0 && T > 0 && T <= seq_len);
+  VOG_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && (zero_bytes == 0 || zero));
+  const int64_t z16 = zero_bytes / 16;
+  int64_t blocks = (z16 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  const int64_t need = ((int64_t)Bn * T + 255) / 256;
+  if (blocks < need) blocks = need;
+  hipLaunchKernelGGL(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_vis_prep(const vog_visprep_args* a, void* stream) {
+  VOG_CHECK_ARG(a && (a->n0 % 4) == 0 && (a->n1 % 4) == 0 && (a->n0 == 0 || (a->src0 && a->dst0)) &&
+                (a->n1 == 0 || (a->src1 && a->dst1)));
+  VOG_CHECK_ARG((!a->w_pe0 && !a->w_pe1) || (a->props && a->n_rows > 0));
+  VOG_CHECK_ARG((!a->w_pe0 || (a->u0 && a->H0 > 0)) && (!a->w_pe1 || (a->u1 && a->H1 > 0)));
+  const int64_t q = (a->n0 + a->n1) / 4;
+  int cast_blocks = (int)((q + 255) / 256 < 2048 ? (q + 255) / 256 : 2048);
+  const int nu = (a->w_pe0 ? a->n_rows * a->H0 : 0) + (a->w_pe1 ? a->n_rows * a->H1 : 0);
+  const int u_blocks = ceil_div(nu, 256);
+  if (cast_blocks + u_blocks == 0) return 0;
+  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((vis_prep_kernel<T16>), dim3(cast_blocks + u_blocks), dim3(256), 0,
+                     (hipStream_t)stream, *a, cast_blocks));
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -550,10 +628,8 @@ extern "C" int vog_pred_head(const vog_pred_args* a, void* stream) {
   VOG_CHECK_ARG(a && a->outs_eval && a->props && a->rec && a->B > 0);
   VOG_CHECK_ARG(a->conc_type != VOG_CONC_SEP || a->fin_scores);
   const int64_t rb = vog_pred_record_bytes(a->ncmp, a->nsrl, a->nfrm0);
-  const int n1 = a->B * a->nsrl * a->ncmp * a->nfrm0;
-  hipLaunchKernelGGL(pred_kernel, dim3(ceil_div(n1, 128)), dim3(128), 0, (hipStream_t)stream, *a, rb);
-  const int n2 = a->B * a->nsrl * a->nfrm0;
-  hipLaunchKernelGGL(pred_index_kernel, dim3(ceil_div(n2, 128)), dim3(128), 0, (hipStream_t)stream, *a, rb);
+  const int n1 = a->B * a->nsrl * a->nfrm0;
+  hipLaunchKernelGGL(pred_kernel, dim3(ceil_div(n1, 64)), dim3(64), 0, (hipStream_t)stream, *a, rb);
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -331,14 +331,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
   const vog_dtype dt = (vog_dtype)d.tx_dtype;
   const int64_t rows = (int64_t)S * N;
   float* u = ws.at<float>(n + "_u");
-  if (tw.use_rel) {
-    const float* props = b->pad_proposals;
-    const int n_rows = (int)g.rows_obj, H = tw.H;
-    const float* pw = tw.pe_w;
-    const float vw = d.vid_w, vh = d.vid_h;
-    steps.push_back({n + "_box_u", [=](hipStream_t st) {
-      return vog_box_u(props, pw, u, n_rows, H, vw, vh, fdiv, st); }});
-  }
+  (void)fdiv;   // the bias precursors u are produced by the fused visual prologue (vis_prep)
   const float* cur32 = x_in32;
   const void* cur16 = x_in16;
   for (int l = 0; l < tw.n_layers; ++l) {
@@ -442,17 +435,15 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   {
     char* z = ws.base + plan.zero_off;
     const int64_t zb = plan.zero_bytes;
-    steps.push_back({"zero", [=](hipStream_t st) { VOG_HIP(hipMemsetAsync(z, 0, zb, st)); return 0; }});
     int32_t* tok = ws.at<int32_t>("tok");
     const int64_t *wi = b->srl_arg_words_ind, *wm = b->srl_arg_word_mask;
     const int nsrl = d.nsrl, sl = d.seq_len, V = d.vocab_size;
-    steps.push_back({"srl_gather", [=](hipStream_t st) {
-      return vog_srl_gather(wi, wm, tok, Bn, T, nsrl, sl, V, st); }});
     float* gx = ws.at<float>("gx");
     int32_t* lrows = ws.at<int32_t>("lstm_rows");
     {
       const int64_t* lens = b->srl_arg_word_mask_len;
-      steps.push_back({"lstm_schedule", [=](hipStream_t st) { return vog_lstm_schedule(lens, lrows, Bn, T, st); }});
+      steps.push_back({"lang_prep", [=](hipStream_t st) {
+        return vog_lang_prep(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, st); }});
     }
     for (int l = 0; l < d.rnn_layers; ++l) {
       vog_gemm_args ga{}; ga.c16_dtype = -1;
@@ -496,14 +487,20 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   float* ps32 = ws.at<float>("prop_seg");
   void* ps16 = ws.at<void>("prop_seg16");
   {
-    // raw features -> encoder operand type once (then both encoders run on the
-    // LDS-DMA GEMM, which cannot convert in flight)
+    // fused visual prologue: raw features -> encoder operand type (the LDS-DMA GEMM cannot
+    // convert in flight) + the box-bias precursors of both transformers
     {
-      const float *s0 = b->pad_region_feature, *s1 = b->seg_feature_for_frms;
-      void *d0 = ws.at<void>("prop16"), *d1 = ws.at<void>("seg16");
-      const int64_t n0 = g.rows_obj * d.prop_dim, n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
-      steps.push_back({"cast_feats", [=](hipStream_t st) {
-        return vog_cast_f32_to_t16(s0, d0, n0, s1, d1, n1, et, st); }});
+      vog_visprep_args vp{};
+      vp.src0 = b->pad_region_feature; vp.dst0 = ws.at<void>("prop16"); vp.n0 = g.rows_obj * d.prop_dim;
+      vp.src1 = b->seg_feature_for_frms; vp.dst1 = ws.at<void>("seg16"); vp.n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
+      vp.dtype = et; vp.props = b->pad_proposals; vp.n_rows = (int)g.rows_obj; vp.vid_w = d.vid_w; vp.vid_h = d.vid_h;
+      if (has_obj(d) && c->obj.use_rel) {
+        vp.w_pe0 = c->obj.pe_w; vp.u0 = ws.at<float>("obj_u"); vp.H0 = c->obj.H; vp.nfrm_div0 = g.fdiv_obj;
+      }
+      if (has_mul(d) && c->mul.use_rel) {
+        vp.w_pe1 = c->mul.pe_w; vp.u1 = ws.at<float>("mul_u"); vp.H1 = c->mul.H; vp.nfrm_div1 = (float)g.nfrm;
+      }
+      steps.push_back({"vis_prep", [=](hipStream_t st) { return vog_vis_prep(&vp, st); }});
     }
     // the two encoders have 52 / 12 output tiles and K = 2048 / 3072: split K so every CU
     // gets a slice, partial products go to fp32 slabs, one finishing pass for both

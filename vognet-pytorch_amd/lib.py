@@ -43,6 +43,13 @@ class SplitkProb(C.Structure):
                 ("ldc16", c_i64), ("c16_dtype", c_i32)]
 
 
+class VisprepArgs(C.Structure):
+    _fields_ = [("src0", c_vp), ("dst0", c_vp), ("n0", c_i64), ("src1", c_vp), ("dst1", c_vp), ("n1", c_i64),
+                ("dtype", c_i32), ("props", c_vp), ("n_rows", c_i32), ("vid_w", c_f32), ("vid_h", c_f32),
+                ("w_pe0", c_vp), ("u0", c_vp), ("H0", c_i32), ("nfrm_div0", c_f32),
+                ("w_pe1", c_vp), ("u1", c_vp), ("H1", c_i32), ("nfrm_div1", c_f32)]
+
+
 class QkvArgs(C.Structure):
     _fields_ = [("x16", c_vp), ("ldx", c_i64), ("wqkv", c_vp), ("ldw", c_i64),
                 ("q", c_vp), ("k", c_vp), ("vt", c_vp),
@@ -138,6 +145,8 @@ SYMBOLS = {
     "vog_srl_gather": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vog_lstm_pack_whh": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32]),
+    "vog_lang_prep": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vog_vis_prep": (c_i32, [C.POINTER(VisprepArgs), c_vp]),
     "vog_bilstm_step": (c_i32, [C.POINTER(LstmStepArgs), c_vp]),
     "vog_srl_argvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vog_vislang_layout": (c_i32, [C.POINTER(VislangArgs), c_vp]),
