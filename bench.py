@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dag", action="store_true", help="capture the language chain as a parallel graph branch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=100)
     args = ap.parse_args()
@@ -174,7 +175,7 @@ def main():
                              seed=1000 * cfg_id + rank * 16 + s)
         batches.append(b)
         slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
-                                   graph=not args.no_graph))
+                                   graph=not args.no_graph, dag=args.dag))
         streams.append(torch.cuda.Stream(device=dev))
     T = slots[0].T
     gathered = [torch.empty((world * w["B"],) + tuple(slots[0].out["pred_rec"].shape[1:]),

@@ -107,6 +107,13 @@ typedef struct vog_qkv_args {
   const void* x16; int64_t ldx; const void* wqkv; int64_t ldw;
   void* q; void* k; void* vt;
   int S, N, H, dp, npad, K; vog_dtype dtype;
+  /* structured layer 0 of mul_tx (pl != NULL): x16 holds the n_vid*nfrm*nppf VISUAL rows
+   * only ([rows, K = d_vis]), wqkv its first K columns (row pitch ldw); pl = lang Wqkv[:, d_vis:]^T
+   * ([n_lang*nsrl, 3*H*dp] fp32). The epilogue emits, for every visual row and every one of
+   * the nsrl arguments, token (arg*nppf + p) = projection + pl[lang row of that arg]:
+   * S = n_vid*nfrm sequences of N = nsrl*nppf tokens, no [tokens, d] matrix and no fp32
+   * intermediate in HBM (see vog_qkv_combine for the unfused form). */
+  const float* pl; int nsrl, nppf, nfrm, lang_per_vid, nc_v;
 } vog_qkv_args;
 int vog_qkv_proj(const vog_qkv_args* a, void* stream);
 
@@ -317,6 +324,11 @@ typedef struct vog_graph vog_graph;
 int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
                       void* stream, vog_graph** out);
 int vog_graph_launch(vog_graph* g, void* stream);
+/* Integer options of a context. "graph_dag" (default 0): capture the language chain as a
+ * parallel branch of the graph (forked beside the encoders + obj_tx, joined before mul_tx).
+ * Measured on MI355X: lower single-batch latency (381 -> 332 us at cfg 2) but lower
+ * throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in. */
+int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 
 /* HIP-event timing of `iters` back-to-back launches of ONE hot kernel of the

@@ -283,6 +283,40 @@ def test_qkv_combine_structured(nppf, nsrl, dp, H):
         assert torch.equal(got, ref.to(torch.bfloat16).float()), which
 
 
+def test_qkv_proj_structured_fused():
+    """vog_qkv_proj with pl: visual rows x W[:, :dv]^T + pl[arg], fanned out over the args,
+    straight into fragment order == dense projection of the [vis || lang] tokens."""
+    lib = _lib()
+    torch.manual_seed(11)
+    n_vid, nfrm, nppf, nsrl, H, dp, dv, dl = 2, 10, 20, 5, 3, 256, 512, 256
+    d = dv + dl
+    N = nsrl * nppf
+    npad = (N + 31) // 32 * 32
+    ncol = 3 * H * dp
+    td = torch.bfloat16
+    vis = torch.randn(n_vid * nfrm * nppf, dv, device="cuda").to(td)
+    lang = torch.randn(n_vid * nsrl, dl, device="cuda")
+    w = (torch.randn(ncol, d, device="cuda") / math.sqrt(d)).to(td)
+    pl = (lang.to(td).float() @ w[:, dv:].float().t()).contiguous()
+    S = n_vid * nfrm
+    q = torch.zeros(S, H, npad * dp, dtype=td, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros_like(q)
+    a = L.QkvArgs()
+    a.x16, a.ldx, a.wqkv, a.ldw = L.ptr(vis), dv, L.ptr(w), d
+    a.q, a.k, a.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
+    a.S, a.N, a.H, a.dp, a.npad, a.K, a.dtype = S, N, H, dp, npad, dv, L.VOG_BF16
+    a.pl, a.nsrl, a.nppf, a.nfrm, a.lang_per_vid, a.nc_v = L.ptr(pl), nsrl, nppf, nfrm, 1, 1
+    L.check(lib.vog_qkv_proj(C.byref(a), _sp()), "qkv structured")
+    torch.cuda.synchronize()
+    pv = (vis.float() @ w[:, :dv].float().t()).view(n_vid, nfrm, 1, nppf, 3, H, dp)
+    tok = (pv + pl.view(n_vid, 1, nsrl, 1, 3, H, dp)).reshape(S, N, 3, H, dp)
+    for which, (buf, kind) in enumerate(((q, "qk"), (k, "qk"), (vt, "v"))):
+        got = from_frag(buf.float(), N, dp, kind)
+        ref = tok[:, :, which].permute(0, 2, 1, 3)
+        assert (got - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item()), which
+
+
 def test_layernorm():
     lib = _lib()
     torch.manual_seed(1)

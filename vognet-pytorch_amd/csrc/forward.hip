@@ -67,6 +67,9 @@ struct vog_ctx {
   std::map<std::string, std::vector<float>> host;
   std::vector<void*> allocs;
   bool finalized = false;
+  int graph_dag = 0;                    // capture the language chain as a parallel branch
+  hipStream_t side = nullptr;           // language branch during graph capture
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
   float* emb = nullptr;
   std::vector<unsigned short*> wih;                     // [layer] [8R, in]
@@ -309,9 +312,12 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
   return p;
 }
 
+// branch 0 = visual + joint path (caller's stream), 1 = language path (captured as a
+// parallel branch of the graph), -1 = join marker: everything after it needs both.
 struct Step {
   std::string name;
   std::function<int(hipStream_t)> fn;
+  int branch = 0;
 };
 
 struct WS {
@@ -347,22 +353,11 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     if (fact) {
       // layer 0 of mul_tx: tokens are [vis[p] || lang[a]] -> project the two parts once each
       const vog_vislang_args sv = *structured;
-      const int ncol = 3 * tw.H * tw.dp;
-      vog_gemm_args gv{}; gv.c16_dtype = -1;
-      gv.a = vis16; gv.lda = sv.dv; gv.w = L.wqkv; gv.ldw = tw.d; gv.c32 = ws.at<float>(n + "_pv"); gv.ldc = ncol;
-      gv.M = (int)g.rows_obj; gv.N = ncol; gv.K = sv.dv; gv.rep = 1; gv.dtype = dt;
-      steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_gemm_bias_act(&gv, st); }});
-      vog_gemm_args gl{}; gl.c16_dtype = -1;
-      gl.a = sv.lang; gl.a_is_f32 = 1; gl.lda = sv.dl; gl.w = L.wqkv + sv.dv; gl.ldw = tw.d;
-      gl.c32 = ws.at<float>(n + "_pl"); gl.ldc = ncol; gl.M = g.Bn * sv.nsrl; gl.N = ncol; gl.K = sv.dl;
-      gl.rep = 1; gl.dtype = dt;
-      if (gl.M <= 64 && L.wqkv_lang_f) { gl.w = L.wqkv_lang_f; gl.ldw = sv.dl; gl.w_frag = 1; }
-      steps.push_back({n + "_pl", [=](hipStream_t st) { return vog_gemm_bias_act(&gl, st); }});
-      vog_qkvcomb_args ca{};
-      ca.pv = gv.c32; ca.pl = gl.c32; ca.q = qa.q; ca.k = qa.k; ca.vt = qa.vt;
-      ca.n_vid = sv.n_vid; ca.nfrm = sv.nfrm; ca.nppf = sv.nppf; ca.nsrl = sv.nsrl; ca.H = tw.H; ca.dp = tw.dp;
-      ca.npad = npad; ca.lang_per_vid = sv.lang_per_vid; ca.nc_v = sv.nc_v; ca.dtype = dt;
-      steps.push_back({n + "_combine", [=](hipStream_t st) { return vog_qkv_combine(&ca, st); }});
+      vog_qkv_args qs = qa;
+      qs.x16 = vis16; qs.ldx = sv.dv; qs.K = sv.dv;          // visual rows x first d_vis weight columns
+      qs.pl = ws.at<float>(n + "_pl"); qs.nsrl = sv.nsrl; qs.nppf = sv.nppf; qs.nfrm = sv.nfrm;
+      qs.lang_per_vid = sv.lang_per_vid; qs.nc_v = sv.nc_v;
+      steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_qkv_proj(&qs, st); }});
     } else {
       steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
     }
@@ -431,7 +426,9 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   const vog_dtype et = (vog_dtype)d.enc_dtype;
   const int R = g.R, T = g.T, Bn = g.Bn;
 
-  // ---- language path (a14-a16)
+  // ---- language path (a14-a16): branch 1
+  const size_t lang_begin = steps.size();
+  const bool structured = has_mul(d) && (g.d_obj % 64) == 0 && (g.L % 32) == 0 && g.rows_obj > 64;
   {
     char* z = ws.base + plan.zero_off;
     const int64_t zb = plan.zero_bytes;
@@ -482,7 +479,20 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     const int L = g.L;
     steps.push_back({"argvec", [=](hipStream_t st) {
       return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
+    if (structured) {
+      // language half of mul_tx's layer-0 QKV: depends on `lang` only, so it rides on this branch
+      const TxWeights& tw = c->mul;
+      const TxLayer& L0 = tw.layers[0];
+      const int ncol = 3 * tw.H * tw.dp;
+      vog_gemm_args gl{}; gl.c16_dtype = -1;
+      gl.a = lang; gl.a_is_f32 = 1; gl.lda = g.L; gl.w = L0.wqkv + g.d_obj; gl.ldw = tw.d;
+      gl.c32 = ws.at<float>("mul_pl"); gl.ldc = ncol; gl.M = g.Bn * d.nsrl; gl.N = ncol; gl.K = g.L;
+      gl.rep = 1; gl.dtype = (vog_dtype)d.tx_dtype;
+      if (gl.M <= 64 && L0.wqkv_lang_f) { gl.w = L0.wqkv_lang_f; gl.ldw = g.L; gl.w_frag = 1; }
+      steps.push_back({"mul_pl", [=](hipStream_t st) { return vog_gemm_bias_act(&gl, st); }});
+    }
   }
+  for (size_t i = lang_begin; i < steps.size(); ++i) steps[i].branch = 1;
   // ---- visual encoders (a12, a13)
   float* ps32 = ws.at<float>("prop_seg");
   void* ps16 = ws.at<void>("prop_seg16");
@@ -558,7 +568,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   va.lang_per_vid = g.nvl > 1 ? 1 : 0; va.nc_v = g.nc_v; va.dtype = (vog_dtype)(has_mul(d) ? d.tx_dtype : d.enc_dtype);
   // mul_tx consumes the token structure directly (layer-0 QKV and its residual), so the
   // token matrix is only materialised for ImgGrnd / VidGrnd, whose lin2 reads it
-  const bool structured = has_mul(d) && (g.d_obj % 64) == 0 && (g.L % 32) == 0;
+  { Step j; j.name = "join"; j.branch = -1; steps.push_back(j); }
   if (!structured)
     steps.push_back({"vislang", [=](hipStream_t st) { return vog_vislang_layout(&va, st); }});
   const float* x32 = ws.at<float>("xmul");
@@ -785,6 +795,7 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
 
 extern "C" int vog_ctx_destroy(vog_ctx* c) {
   if (!c) return 0;
+  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
   return 0;
@@ -820,7 +831,8 @@ extern "C" int vog_forward(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_b
   Plan plan;
   std::vector<Step> steps;
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
-  for (auto& s : steps) {
+  for (auto& s : steps) {               // eager: one stream, program order (re-entrant)
+    if (s.branch < 0) continue;
     const int r = s.fn((hipStream_t)stream);
     if (r != 0) return r;
   }
@@ -839,11 +851,37 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
   std::vector<Step> steps;
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
   hipStream_t st = (hipStream_t)stream;
+  if (!c->side) {
+    VOG_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    VOG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    VOG_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  // The graph is a DAG: the language chain (prep -> 2 x (input GEMM + T steps) -> projections)
+  // is captured on a side stream forked from `st` and joined before the first kernel that
+  // needs the argument vectors, so it runs beside the encoders + obj_tx instead of ahead of them.
   VOG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int rc = 0;
+  hipError_t fe = hipEventRecord(c->ev_fork, st);
+  if (fe == hipSuccess) fe = hipStreamWaitEvent(c->side, c->ev_fork, 0);
+  bool joined = false;
+  if (fe != hipSuccess) rc = -(int)fe - 1000;
   for (auto& s : steps) {
-    rc = s.fn(st);
     if (rc != 0) break;
+    if (s.branch < 0) {
+      if (!joined) {
+        fe = hipEventRecord(c->ev_join, c->side);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(st, c->ev_join, 0);
+        if (fe != hipSuccess) rc = -(int)fe - 1000;
+        joined = true;
+      }
+      continue;
+    }
+    rc = s.fn(c->graph_dag && s.branch == 1 && !joined ? c->side : st);
+  }
+  if (rc == 0 && !joined) {             // no join marker (cannot happen today): join at the end
+    fe = hipEventRecord(c->ev_join, c->side);
+    if (fe == hipSuccess) fe = hipStreamWaitEvent(st, c->ev_join, 0);
+    if (fe != hipSuccess) rc = -(int)fe - 1000;
   }
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(st, &g);
@@ -855,6 +893,12 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
   if (e != hipSuccess) { (void)hipGraphDestroy(g); delete vg; VOG_FAIL(-(int)e - 1000, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
   *out = vg;
   return 0;
+}
+
+extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
+  VOG_CHECK_ARG(c && name);
+  if (strcmp(name, "graph_dag") == 0) { c->graph_dag = value ? 1 : 0; return 0; }
+  VOG_FAIL(-4, "unknown option '%s'", name);
 }
 
 extern "C" int vog_graph_launch(vog_graph* g, void* stream) {
@@ -878,7 +922,7 @@ extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t 
   std::vector<Step> steps;
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
   const Step* s = nullptr;
-  for (auto& x : steps) if (x.name == kernel) { s = &x; break; }
+  for (auto& x : steps) if (x.name == kernel && x.branch >= 0) { s = &x; break; }
   if (!s) VOG_FAIL(-4, "no kernel step '%s'", kernel);
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t e0, e1;

@@ -19,6 +19,8 @@
 namespace vog {
 
 enum { EPI_PLAIN = 0, EPI_QKV = 1 };
+struct GemmParams;
+static bool pipe_ok(const GemmParams& p, bool a_f32);
 
 // VOG_GEMM_DEBUG (ablation, perf experiments only): 1 = no DMA, 2 = no MFMA, 4 = no epilogue
 static int gemm_debug_flags() {
@@ -40,6 +42,8 @@ struct GemmParams {
   // QKV epilogue
   unsigned short* q; unsigned short* k; unsigned short* vt;
   int ntok, H, dp, npad;
+  // structured QKV (pl != nullptr): rows are visual rows, fan out over nsrl arguments
+  const float* pl; int st_nsrl, st_nppf, st_nfrm, st_lpv, st_ncv;
 };
 
 template <typename T16, bool A_F32>
@@ -428,7 +432,74 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
       const int which = nb / hd;
       const int h = (nb - which * hd) / p.dp;
       const int dd0 = nb % p.dp;
-      if (which < 2) {
+      if (p.pl) {
+        // structured layer 0: row m = visual row (v, f, p'); token(arg) = arg*nppf + p'
+        const int ldp = 3 * hd;
+        if (which < 2) {
+          unsigned short* base = which == 0 ? p.q : p.k;
+          const int c = lane & 7, rsub = lane >> 3;
+#pragma unroll 2
+          for (int ps = 0; ps < WTM / 8; ++ps) {
+            const int rl = ps * 8 + rsub;
+            const int m = mw + rl;
+            if (m >= p.M) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
+            const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
+            const int vid = sq / p.st_nfrm;
+            const int lv = p.st_lpv ? vid : vid / p.st_ncv;
+            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + 4 * c;
+            unsigned short* dst = base + ((int64_t)sq * p.H + h) * p.npad * p.dp;
+            for (int ar = 0; ar < p.st_nsrl; ++ar) {
+              const float4 l = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp);
+              const u16x4 o = {to16<T16>(v.x + l.x), to16<T16>(v.y + l.y), to16<T16>(v.z + l.z), to16<T16>(v.w + l.w)};
+              *reinterpret_cast<u16x4*>(dst + frag_qk(ar * p.st_nppf + pp, dd0 + 4 * c, p.dp)) = o;
+            }
+          }
+        } else if ((p.st_nppf & 3) == 0) {
+          // V fragments, vector form: an aligned group of 4 visual rows = 4 consecutive tokens of
+          // every argument = 4 consecutive j of one fragment lane -> one 8-byte store. Lanes run
+          // along dd: conflict-free LDS column reads, 16-byte-strided global stores.
+          const int dd = lane & 31, gsub = lane >> 5;
+          for (int rg = gsub; rg < WTM / 4; rg += 2) {
+            const int rl = rg * 4;
+            const int m = mw + rl;
+            if (m >= p.M) continue;                    // M % 4 == 0 here (nppf % 4 == 0)
+            const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
+            const int vid = sq / p.st_nfrm;
+            const int lv = p.st_lpv ? vid : vid / p.st_ncv;
+            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + dd;
+            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp;
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = ep[(rl + e) * EP_LD + cg * 32 + dd];
+            for (int ar = 0; ar < p.st_nsrl; ++ar) {
+              const float l = plr[(int64_t)ar * ldp];
+              const u16x4 o = {to16<T16>(x[0] + l), to16<T16>(x[1] + l), to16<T16>(x[2] + l), to16<T16>(x[3] + l)};
+              *reinterpret_cast<u16x4*>(dst + frag_v(ar * p.st_nppf + pp, dd0 + dd, p.dp)) = o;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
+            const int rl = th * 64 + lane;
+            const int m = mw + rl;
+            if (rl < WTM && m < p.M) {
+              const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
+              const int vid = sq / p.st_nfrm;
+              const int lv = p.st_lpv ? vid : vid / p.st_ncv;
+              const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb;
+              unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp;
+              for (int ar = 0; ar < p.st_nsrl; ++ar) {
+                unsigned short* d2 = dst + frag_v(ar * p.st_nppf + pp, dd0, p.dp);
+                const float* l = plr + (int64_t)ar * ldp;
+#pragma unroll 8
+                for (int dd = 0; dd < 32; ++dd)
+                  d2[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd] + l[dd]);
+              }
+            }
+          }
+        }
+      } else if (which < 2) {
         unsigned short* base = which == 0 ? p.q : p.k;
         const int c = lane & 7, rsub = lane >> 3;     // 8 chunks of 4 columns per row, 8 rows per pass
 #pragma unroll 4
@@ -676,6 +747,15 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
   GemmParams p{};
   p.a = a->x16; p.lda = a->ldx; p.w = (const unsigned short*)a->wqkv; p.ldw = a->ldw;
   p.M = a->S * a->N; p.N = 3 * a->H * a->dp; p.K = a->K; p.rep = 1;
+  if (a->pl) {
+    VOG_CHECK_ARG(a->nsrl > 0 && a->nppf > 0 && a->nfrm > 0 && a->nc_v > 0 && a->N == a->nsrl * a->nppf &&
+                  (a->S % a->nfrm) == 0);
+    p.pl = a->pl; p.st_nsrl = a->nsrl; p.st_nppf = a->nppf; p.st_nfrm = a->nfrm; p.st_lpv = a->lang_per_vid;
+    p.st_ncv = a->nc_v;
+    p.M = a->S * a->nppf;                        // visual rows
+    if (!pipe_ok(p, false) || p.M <= 64)
+      VOG_FAIL(-1, "structured QKV needs the LDS-DMA GEMM (K %% 64 == 0, > 64 visual rows)");
+  }
   p.q = (unsigned short*)a->q; p.k = (unsigned short*)a->k; p.vt = (unsigned short*)a->vt;
   p.ntok = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad;
   p.debug = gemm_debug_flags();

@@ -189,7 +189,10 @@ class VogEngine:
 
     # ---- persistent slots (graph replay; what bench.py and the evaluator use) ----
     def make_slot(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
-                  with_pred: bool = True, graph: Optional[bool] = None) -> "Slot":
+                  with_pred: bool = True, graph: Optional[bool] = None, dag: bool = False) -> "Slot":
+        """dag=True captures the language chain as a parallel graph branch (lower latency of a
+        single batch, lower throughput with several slots in flight)."""
+        L.check(self.lib.vog_ctx_set_int(self.ctx, b"graph_dag", int(dag)), "vog_ctx_set_int")
         return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph)
 
     def time_kernel(self, slot: "Slot", name: str, iters: int = 50) -> float:

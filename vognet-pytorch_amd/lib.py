@@ -54,7 +54,9 @@ class QkvArgs(C.Structure):
     _fields_ = [("x16", c_vp), ("ldx", c_i64), ("wqkv", c_vp), ("ldw", c_i64),
                 ("q", c_vp), ("k", c_vp), ("vt", c_vp),
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
-                ("K", c_i32), ("dtype", c_i32)]
+                ("K", c_i32), ("dtype", c_i32),
+                ("pl", c_vp), ("nsrl", c_i32), ("nppf", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32),
+                ("nc_v", c_i32)]
 
 
 class QkvCombArgs(C.Structure):
@@ -166,6 +168,7 @@ SYMBOLS = {
     "vog_forward": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp]),
     "vog_workspace_stage": (c_i32, [c_vp, c_i32, c_i32, c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "vog_graph_capture": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp, C.POINTER(c_vp)]),
+    "vog_ctx_set_int": (c_i32, [c_vp, C.c_char_p, c_i32]),
     "vog_graph_launch": (c_i32, [c_vp, c_vp]),
     "vog_graph_destroy": (c_i32, [c_vp]),
     "vog_time_kernel": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.c_char_p, c_i32, c_vp, C.POINTER(c_f32)]),
