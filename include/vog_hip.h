@@ -207,6 +207,26 @@ typedef struct vog_lstm_step_args {
   void* out16; const int64_t* lens; int Bn, T, R, step; vog_dtype dtype;
 } vog_lstm_step_args;
 int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
+/* ALL T steps of one BiLSTM layer in ONE launch (persistent workgroups): 2 x R/32
+ * workgroups, each keeps its 128 rows of W_hh in registers for the whole sequence; the
+ * hidden state is exchanged between steps through `hx` with 8-byte agent-scope
+ * (write-through / L1-bypassing) atomics and a per-direction arrival counter in `sync`.
+ * Alternative to T launches of vog_bilstm_step. MEASURED SLOWER on MI355X and therefore
+ * opt-in (vog_ctx_set_int "lstm_persistent"): a software all-to-all step barrier (write-
+ * through store -> counter -> poll -> L1-bypassing reload) costs ~9.8 us per step against
+ * ~5.1 us for a dependent graph node (cfg 2: 117 us vs 61 us per layer). Kept because it is
+ * parity-tested and is the right shape once the exchange is cheaper (fewer, fatter
+ * workgroups per XCD). Requires Bn <= 16 and R/32 in {1,2,4,32}
+ * (vog_bilstm_layer_supported); hx ([2][2][16][R] t16) and sync (16 x u32) must be zero at
+ * launch; every wait is bounded (on timeout sync[2] is set and the kernel drains).
+ * Launch at most 4 instances concurrently (64 workgroups x 1 per CU each). */
+typedef struct vog_lstm_layer_args {
+  const float* gxs; const void* whh; void* hx; uint32_t* sync; void* out16;
+  const int64_t* lens; int Bn, T, R; vog_dtype dtype;
+} vog_lstm_layer_args;
+int vog_bilstm_layer_supported(int Bn, int R);
+int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream);
+
 /* host: [2][4R][R] fp32 (weight_hh_l*, weight_hh_l*_reverse) -> fragment order, 16 bit.
  * dst holds 2*4R*R halfwords: [dir][unit/4][k/32][lane 64][8]. */
 int vog_lstm_pack_whh(const float* whh_fwd, const float* whh_bwd, void* dst_host, int R, vog_dtype dtype);
@@ -326,6 +346,7 @@ int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
 int vog_graph_launch(vog_graph* g, void* stream);
 /* Integer options of a context. "graph_dag" (default 0): capture the language chain as a
  * parallel branch of the graph (forked beside the encoders + obj_tx, joined before mul_tx).
+ * "lstm_persistent" (default 0): use vog_bilstm_layer instead of T step launches.
  * Measured on MI355X: lower single-batch latency (381 -> 332 us at cfg 2) but lower
  * throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);

@@ -85,6 +85,15 @@ CASES["small/vog_spat_p7"] = _case(       # nppf0 = 7 -> N = 140 / 28: not tile 
     B=2, nppf0=7, vocab=50, ragged=True, perturb_ln=True)
 
 
+# wider LSTMs: 2 / 4 workgroups per direction in the persistent layer kernel (cross-CU hand-off)
+CASES["small/vog_spat_r128"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, **SMALL_DIMS, "mdl.rnn.rnn_size": 128},
+    B=3, vocab=50, ragged=True, perturb_ln=True, dseed=31)
+CASES["small/vog_sep_r64"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "sep", **REL, **SMALL_DIMS, "mdl.rnn.rnn_size": 64},
+    B=2, vocab=50, ragged=True, perturb_ln=True, dseed=32)
+
+
 def build(name: str):
     """-> (cfg, state_dict(np), batch(np), case)."""
     c = CASES[name]

@@ -95,6 +95,22 @@ def test_forward_small_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=2e-3, tol_logit=1.2e-2)
 
 
+@pytest.mark.parametrize("name", ["full/cfg2_ragged", "small/vog_spat_r128", "small/vog_sep_r64"])
+def test_forward_persistent_lstm_layer(name):
+    """The opt-in one-launch-per-layer LSTM (cross-workgroup hand-off through agent-scope
+    atomics; 64 / 4 / 2 workgroups per direction here) must agree with the T-launch path."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    a = eng.forward(dev)
+    eng.set_option("lstm_persistent", 1)
+    b = eng.forward(dev)
+    torch.cuda.synchronize()
+    # same arithmetic, different fp32 summation order of the recurrent dot products
+    assert (a["mdl_outs"] - b["mdl_outs"]).abs().max().item() < 5e-4
+    ncmp = batch["new_srl_idxs"].shape[1]
+    pa, pb = eng.unpack_pred(a["pred_rec"], ncmp), eng.unpack_pred(b["pred_rec"], ncmp)
+    assert (pa["scores"] - pb["scores"]).abs().max().item() < 2e-4
+
+
 def test_forward_f16_transformers():
     """cfg 5 flavour: fp16 MFMA path with fp32 accumulate."""
     name = "full/cfg5_vog_svsq_gt5_bs16"

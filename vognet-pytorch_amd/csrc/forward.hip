@@ -68,6 +68,7 @@ struct vog_ctx {
   std::vector<void*> allocs;
   bool finalized = false;
   int graph_dag = 0;                    // capture the language chain as a parallel branch
+  int lstm_persistent = 0;              // one launch per BiLSTM layer (opt-in: measured slower, see vog_hip.h)
   hipStream_t side = nullptr;           // language branch during graph capture
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
@@ -270,6 +271,8 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
     p.add("lstm_out16_" + std::to_string(l), (int64_t)(g.Bn * g.T + g.Bn16) * 2 * g.R * 2);
     p.add("lstm_hB_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
+    p.add("lstm_hx_" + std::to_string(l), (int64_t)2 * 2 * 16 * g.R * 2);
+    p.add("lstm_sync_" + std::to_string(l), 64);
   }
   p.zero_bytes = p.total - p.zero_off;
   p.add("tok", (int64_t)g.Bn * g.T * 4);
@@ -456,6 +459,15 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       void* hA = ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R;
       void* hB = ws.at<void>("lstm_hB_" + std::to_string(l));
       void* hb[2] = {(T % 2) == 0 ? hA : hB, (T % 2) == 0 ? hB : hA};
+      if (c->lstm_persistent && vog_bilstm_layer_supported(Bn, R)) {
+        vog_lstm_layer_args pa{};
+        pa.gxs = gx; pa.whh = c->whh[l]; pa.hx = ws.at<void>("lstm_hx_" + std::to_string(l));
+        pa.sync = ws.at<uint32_t>("lstm_sync_" + std::to_string(l));
+        pa.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
+        pa.lens = b->srl_arg_word_mask_len; pa.Bn = Bn; pa.T = T; pa.R = R; pa.dtype = et;
+        steps.push_back({"lstm_layer", [=](hipStream_t st) { return vog_bilstm_layer(&pa, st); }});
+        continue;
+      }
       for (int s = 0; s < T; ++s) {
         vog_lstm_step_args la{};
         la.gx = gx; la.whh = c->whh[l]; la.h_in = hb[s % 2]; la.h_out = hb[(s + 1) % 2];
@@ -898,6 +910,7 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
 extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   VOG_CHECK_ARG(c && name);
   if (strcmp(name, "graph_dag") == 0) { c->graph_dag = value ? 1 : 0; return 0; }
+  if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 

@@ -195,6 +195,10 @@ class VogEngine:
         L.check(self.lib.vog_ctx_set_int(self.ctx, b"graph_dag", int(dag)), "vog_ctx_set_int")
         return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph)
 
+    def set_option(self, name: str, value: int) -> None:
+        """Integer options of the context: 'graph_dag', 'lstm_persistent' (include/vog_hip.h)."""
+        L.check(self.lib.vog_ctx_set_int(self.ctx, name.encode(), int(value)), f"vog_ctx_set_int({name})")
+
     def time_kernel(self, slot: "Slot", name: str, iters: int = 50) -> float:
         us = C.c_float()
         L.check(self.lib.vog_time_kernel(self.ctx, C.byref(slot.batch), slot.ws.data_ptr(),

@@ -79,6 +79,11 @@ class LstmStepArgs(C.Structure):
                 ("step", c_i32), ("dtype", c_i32)]
 
 
+class LstmLayerArgs(C.Structure):
+    _fields_ = [("gxs", c_vp), ("whh", c_vp), ("hx", c_vp), ("sync", c_vp), ("out16", c_vp),
+                ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32)]
+
+
 class VislangArgs(C.Structure):
     _fields_ = [("vis", c_vp), ("lang", c_vp), ("x32", c_vp), ("x16", c_vp),
                 ("n_vid", c_i32), ("nfrm", c_i32), ("nppf", c_i32), ("nsrl", c_i32),
@@ -145,6 +150,8 @@ SYMBOLS = {
     "vog_cast_f32_to_t16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "vog_box_u": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp]),
     "vog_srl_gather": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vog_bilstm_layer_supported": (c_i32, [c_i32, c_i32]),
+    "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vog_lstm_pack_whh": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32]),
     "vog_lang_prep": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
