@@ -81,6 +81,10 @@ typedef struct vog_gemm_args {
    * (K % 32 == 0, N % 16 == 0), where the row-major layout makes every wave load touch
    * 16 half-used cache lines. */
   int w_frag;
+  /* a_frag = 1 (M <= 64 kernel only, 16-bit A): `a` is in fragment order
+   * [m/16][K/32][lane = ((k%32)/8)*16 + m%16][k%8] — written that way by vog_bilstm_step
+   * (out_frag) so that the LSTM -> projection hand-off needs no strided fragment loads. */
+  int a_frag;
 } vog_gemm_args;
 /* host: fp32 [N, ld] (first K columns) -> 16-bit fragment order, N*K halfwords. */
 int vog_pack_w_frag(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);
@@ -205,6 +209,10 @@ int vog_vis_prep(const vog_visprep_args* a, void* stream);
 typedef struct vog_lstm_step_args {
   const float* gx; const void* whh; const void* h_in; void* h_out; float* c;
   void* out16; const int64_t* lens; int Bn, T, R, step; vog_dtype dtype;
+  /* out_frag = 1: out16 is written in the A-fragment order of vog_gemm_args.a_frag
+   * (K = 2R, rows m = b*T + pos) and every active step also writes h into row
+   * final_row0 + b (the final hidden state ends up there). 0: row-major [.., 2R]. */
+  int out_frag; int final_row0;
 } vog_lstm_step_args;
 int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
 /* ALL T steps of one BiLSTM layer in ONE launch (persistent workgroups): 2 x R/32

@@ -135,6 +135,32 @@ def test_gemm_skinny_fragment_ordered_weights(M, N, K):
     assert (c32 - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(48, 8192, 2048), (52, 256, 2048), (20, 96, 64)])
+def test_gemm_skinny_fragment_ordered_activations(M, N, K):
+    """a_frag: A in [m/16][K/32][lane][8] order (what vog_bilstm_step writes with out_frag)."""
+    lib = _lib()
+    torch.manual_seed(M + N + 1)
+    a = torch.randn(M, K, device="cuda").half()
+    w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
+    m = torch.arange(M, device="cuda").view(-1, 1)
+    k = torch.arange(K, device="cuda").view(1, -1)
+    idx = ((((m >> 4) * (K >> 5) + (k >> 5)) * 64) + (((k >> 3) & 3) << 4) + (m & 15)) * 8 + (k & 7)
+    mp = (M + 15) // 16 * 16
+    af = torch.zeros(mp * K, dtype=torch.float16, device="cuda")
+    af[idx.reshape(-1)] = a.reshape(-1)
+    bias = torch.randn(N, device="cuda")
+    g = L.GemmArgs()
+    g.a, g.a_is_f32, g.lda, g.w, g.ldw, g.a_frag = L.ptr(af), 0, K, L.ptr(w), K, 1
+    c32 = torch.full((M, N), float("nan"), device="cuda")
+    g.bias, g.c32, g.ldc, g.M, g.N, g.K, g.relu, g.rep, g.dtype = L.ptr(bias), L.ptr(c32), N, M, N, K, 0, 1, L.VOG_F16
+    L.check(lib.vog_gemm_bias_act(C.byref(g), _sp()), "gemm")
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + bias
+    assert (c32 - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    g.M = 100   # not the M <= 64 kernel: must be refused, not silently misread
+    assert lib.vog_gemm_bias_act(C.byref(g), _sp()) != 0
+
+
 @pytest.mark.parametrize("M,N,K,splits,rep", [(800, 256, 2048, 8, 1), (160, 256, 3072, 12, 5), (130, 64, 256, 3, 1)])
 def test_gemm_splitk_and_finish(M, N, K, splits, rep):
     lib = _lib()

@@ -92,6 +92,11 @@ __host__ __device__ __forceinline__ int64_t frag_v(int i, int dd, int dp) {
   return ((((int64_t)(i >> 5) * (dp >> 5) + (dd >> 5)) * 2 + (kl >> 4)) * 64 + (hi << 5) + (dd & 31)) * 8 + j;
 }
 
+// A operand of the M <= 64 GEMM in fragment order (K = number of columns)
+__host__ __device__ __forceinline__ int64_t frag_a(int m, int k, int K) {
+  return ((((int64_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64) + (((k >> 3) & 3) << 4) + (m & 15)) * 8 + (k & 7);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

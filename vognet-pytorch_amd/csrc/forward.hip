@@ -268,8 +268,9 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
     // out16 of layer l is followed directly by the h buffer that holds the FINAL
     // state, so [out16 ; h_final] is one contiguous A operand for the out-proj GEMM
     // (hA lives inside the same allocation: rows [Bn*T, Bn*T + Bn16) )
-    p.add("lstm_out16_" + std::to_string(l), (int64_t)(g.Bn * g.T + g.Bn16) * 2 * g.R * 2);
+    p.add("lstm_out16_" + std::to_string(l), (int64_t)(round_up64(g.Bn * g.T + g.Bn, 16) + g.Bn16) * 2 * g.R * 2);
     p.add("lstm_hB_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);
+    p.add("lstm_hA2_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);   // ping buffer when out16 is fragment-ordered
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
     p.add("lstm_hx_" + std::to_string(l), (int64_t)2 * 2 * 16 * g.R * 2);
     p.add("lstm_sync_" + std::to_string(l), 64);
@@ -447,8 +448,14 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     }
     for (int l = 0; l < d.rnn_layers; ++l) {
       vog_gemm_args ga{}; ga.c16_dtype = -1;
+      // LSTM outputs feed M <= 64 GEMMs (next layer's input projection, final projection): then the
+      // step kernel writes them in A-fragment order and those GEMMs load contiguous fragments
+      const bool ofrag = (Bn * T + Bn) <= 64 && !(c->lstm_persistent && vog_bilstm_layer_supported(Bn, R));
       if (l == 0) { ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E; }
-      else { ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R; }
+      else {
+        ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R;
+        ga.a_frag = ofrag ? 1 : 0;
+      }
       // output rows land in (direction, step) order: gxs[dir][step][b][4R]
       ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 4 * R;
       ga.M = Bn * T; ga.N = 8 * R; ga.rep = 1; ga.dtype = et;
@@ -456,7 +463,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       if (ga.M <= 64 && c->wih_f[l]) { ga.w = c->wih_f[l]; ga.w_frag = 1; }
       steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
       // final state must land in hA (adjacent to out16): after T steps it is in buf[T % 2]
-      void* hA = ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R;
+      void* hA = ofrag ? ws.at<void>("lstm_hA2_" + std::to_string(l))
+                       : (void*)(ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R);
       void* hB = ws.at<void>("lstm_hB_" + std::to_string(l));
       void* hb[2] = {(T % 2) == 0 ? hA : hB, (T % 2) == 0 ? hB : hA};
       if (c->lstm_persistent && vog_bilstm_layer_supported(Bn, R)) {
@@ -474,6 +482,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         la.c = ws.at<float>("lstm_c_" + std::to_string(l));
         la.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
         la.lens = b->srl_arg_word_mask_len; la.Bn = Bn; la.T = T; la.R = R; la.step = s; la.dtype = et;
+        la.out_frag = ofrag ? 1 : 0; la.final_row0 = Bn * T;
         steps.push_back({"lstm_step", [=](hipStream_t st) { return vog_bilstm_step(&la, st); }});
       }
     }
@@ -483,6 +492,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     po.c32 = ws.at<float>("full"); po.ldc = g.L; po.M = Bn * T + Bn; po.N = g.L; po.K = 2 * R;
     po.rep = 1; po.dtype = et;
     if (po.M <= 64 && c->w_outproj_f) { po.w = c->w_outproj_f; po.w_frag = 1; }
+    po.a_frag = ((Bn * T + Bn) <= 64 && !(c->lstm_persistent && vog_bilstm_layer_supported(Bn, R))) ? 1 : 0;
     steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
     const float* full = po.c32;
     float* lang = ws.at<float>("lang");

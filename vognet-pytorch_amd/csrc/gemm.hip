@@ -36,7 +36,7 @@ struct GemmParams {
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; int c16_bf16; int debug;
   const int32_t* out_rows; int out_rows_ncol;
-  int splitk; int w_frag;
+  int splitk; int w_frag; int a_frag;
   // implicit vis||lang residual (res_vis != nullptr)
   const float* res_vis; const float* res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
   // QKV epilogue
@@ -588,7 +588,13 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
 #pragma unroll
         for (int c = 0; c < SK_CH; ++c) {
           const int ks = base + c * 4;
-          fa[c] = load_a_chunk<T16, A_F32>(p.a, a_off[mt], ks * 32 + kg, a_ok[mt] && ks < ksteps);
+          if (!A_F32 && p.a_frag) {   // contiguous KiB per (row tile, k-step); pad rows are zero-filled
+            u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            fa[c] = ks < ksteps ? *reinterpret_cast<const u16x8*>(reinterpret_cast<const unsigned short*>(p.a) +
+                                      (((int64_t)mt * ksteps + ks) * 64 + lane) * 8) : z;
+          } else {
+            fa[c] = load_a_chunk<T16, A_F32>(p.a, a_off[mt], ks * 32 + kg, a_ok[mt] && ks < ksteps);
+          }
         }
 #pragma unroll
         for (int c = 0; c < SK_CH; ++c) acc[mt] = mfma16<T16>(fa[c], fw[c], acc[mt]);
@@ -707,7 +713,9 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
       VOG_FAIL(-1, "split-K GEMM needs the LDS-DMA path (16-bit A, K %% 64 == 0, M > 64) and a bare fp32 output");
     return launch_pipe<T16, EPI_PLAIN>(p, st);
   }
-  p.w_frag = g->w_frag;
+  p.w_frag = g->w_frag; p.a_frag = g->a_frag;
+  if (p.a_frag && !(p.M <= 64 && (p.K % 32) == 0 && !g->a_is_f32 && !g->a_rows))
+    VOG_FAIL(-1, "a_frag activations are only valid for the M <= 64 kernel with a 16-bit A (M=%d K=%d)", p.M, p.K);
   if (p.w_frag && !(p.M <= 64 && (p.K % 32) == 0 && (p.N % 16) == 0))
     VOG_FAIL(-1, "w_frag weights are only valid for the M <= 64 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);
   if (p.M <= 64 && (p.K % 32) == 0) {

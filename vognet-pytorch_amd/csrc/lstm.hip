@@ -31,7 +31,7 @@ namespace vog {
 struct LstmParams {
   const float* gxs; const unsigned short* whh; const unsigned short* h_in; unsigned short* h_out;
   float* c; unsigned short* out16; const int64_t* lens;
-  int Bn, T, R, step;
+  int Bn, T, R, step; int out_frag, final_row0;
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -109,7 +109,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
         p.c[st] = cn;
         const unsigned short h16 = to16<T16>(hn);
         p.h_out[st] = h16;
-        p.out16[((int64_t)b * p.T + pos) * 2 * R + (int64_t)dir * R + unit] = h16;
+        if (p.out_frag) {
+          p.out16[frag_a(b * p.T + pos, dir * R + unit, 2 * R)] = h16;
+          p.out16[frag_a(p.final_row0 + b, dir * R + unit, 2 * R)] = h16;   // last active step wins
+        } else {
+          p.out16[((int64_t)b * p.T + pos) * 2 * R + (int64_t)dir * R + unit] = h16;
+        }
       } else {
         p.h_out[st] = h_prev;
       }
@@ -253,7 +258,7 @@ int lstm_step_run(const vog_lstm_step_args* a, hipStream_t st) {
   VOG_CHECK_ARG(a->h_in != a->h_out);
   LstmParams p{a->gx, (const unsigned short*)a->whh, (const unsigned short*)a->h_in,
                (unsigned short*)a->h_out, a->c, (unsigned short*)a->out16, a->lens,
-               a->Bn, a->T, a->R, a->step};
+               a->Bn, a->T, a->R, a->step, a->out_frag, a->final_row0};
   dim3 grid(ceil_div(a->R, 4), 2);
   VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((lstm_step_kernel<T16>), grid, dim3(256), 0, st, p));
   VOG_LAUNCH_CHECK();

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32)]
+                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32), ("a_frag", c_i32)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -76,7 +76,7 @@ class AttnArgs(C.Structure):
 class LstmStepArgs(C.Structure):
     _fields_ = [("gx", c_vp), ("whh", c_vp), ("h_in", c_vp), ("h_out", c_vp), ("c", c_vp),
                 ("out16", c_vp), ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32),
-                ("step", c_i32), ("dtype", c_i32)]
+                ("step", c_i32), ("dtype", c_i32), ("out_frag", c_i32), ("final_row0", c_i32)]
 
 
 class LstmLayerArgs(C.Structure):
