@@ -360,6 +360,37 @@ int vog_graph_launch(vog_graph* g, void* stream);
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 
+/* ---- AQL programs: the forward as pre-built dispatch packets on user-mode queues ---------------
+ * The steady-state path of the validation loop (replaces `for batch in dl: mdl(batch)` of
+ * utils/trn_utils.py:497-501 for a fixed batch shape). One forward is ~50 short dependent
+ * kernels; through a stream or a hipGraph every dependent kernel costs >= 4.2 us on MI355X.
+ * A program is the launch sequence of vog_forward recorded once (same buffers as given here,
+ * which must stay alive), stored as AQL kernel-dispatch packets with device-resident kernargs,
+ * and submitted by copying them into an HSA queue owned by the library: agent-scope fences
+ * between the kernels of a forward, the barrier bit only at the head of each ROW of mutually
+ * independent kernels (csrc/aql.hip).
+ *
+ * vog_aql_open(n)           create n hardware queues on the current HIP device (idempotent, grows).
+ * vog_aql_program_create    split_chains = 1: the language chain and the vision chain of the
+ *                           forward share rows until they join (fewer barrier packets); 0: one
+ *                           kernel per row, program order.
+ * vog_aql_submit(progs,n,q) enqueue n distinct idle programs on queue q, row-interleaved: row r of
+ *                           every program is dispatched behind ONE barrier packet. Inputs must be
+ *                           complete (synchronise the stream that staged them). Not stream ordered.
+ * vog_aql_wait(p, us)       block (spinning) until p's last kernel has completed and its outputs are
+ *                           visible system-wide; error -2008 after `us` microseconds, -2006 if the
+ *                           queue reported an error.
+ * The HIP path (vog_forward / vog_graph_*) computes exactly the same thing from the same kernels;
+ * tests/test_gpu_forward.py holds the bit-equality check. */
+typedef struct vog_aql_program vog_aql_program;
+int vog_aql_open(int n_queues);
+int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* workspace, size_t ws_bytes,
+                           int split_chains, vog_aql_program** out);
+int vog_aql_program_info(const vog_aql_program* p, int* packets, int* rows);
+int vog_aql_submit(vog_aql_program* const* progs, int n, int queue);
+int vog_aql_wait(vog_aql_program* p, uint64_t timeout_us);
+int vog_aql_program_destroy(vog_aql_program* p);
+
 /* HIP-event timing of `iters` back-to-back launches of ONE hot kernel of the
  * forward on `stream` (bench.py roofline leg). kernel: "mul_qkv", "mul_attn",
  * "mul_wo", "mul_ffn1", "mul_ffn2", "lin2", "obj_qkv", "obj_attn", "prop_enc".

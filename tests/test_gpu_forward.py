@@ -166,3 +166,68 @@ def test_stages_vs_oracle():
     e = (mo - st["mul_out"]).abs().max().item()
     print("mul_out abs err", e)
     assert e < 3e-2
+
+
+# ---- AQL submission path (csrc/aql.hip): same kernels, own queue, pre-built packets --------------
+def _aql_outputs(eng, dev, split, n_slots=1, queue=0, reps=2):
+    slots = [eng.make_slot(dev, graph=False).build_aql(split_chains=split) for _ in range(n_slots)]
+    for _ in range(reps):                      # replays must be idempotent (state re-zeroed in-program)
+        for s in slots:
+            for k in ("mdl_outs", "mdl_outs_eval", "pred_rec"):
+                s.out[k].fill_(float("nan"))
+        torch.cuda.synchronize()
+        eng.aql_submit(slots, queue)
+        for s in slots:
+            s.wait(timeout_us=5_000_000)
+    return slots
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8",
+                                  "full/vog_sep_gt5_bs4_ragged", "full/cfg1_igrnd_spat_gt5_bs2",
+                                  "small/vgrnd_temp", "small/vog_spat_p7"])
+@pytest.mark.parametrize("split", [False, True])
+def test_aql_program_equals_stream_forward(name, split):
+    """Raw AQL dispatch of the recorded forward == the HIP-stream forward, bit for bit."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    eng.aql_open(1)
+    (slot,) = _aql_outputs(eng, dev, split)
+    assert slot.aql_packets >= slot.aql_rows >= 3
+    if split and cfg.mdl.name != "igrnd":
+        assert slot.aql_rows < slot.aql_packets          # language and vision chains share rows
+    for k in ref:
+        assert torch.equal(ref[k], slot.out[k]), (name, k)
+
+
+def test_aql_interleaved_programs_and_queues():
+    """Four forwards row-interleaved behind shared barrier packets, on two queues at once."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    eng.aql_open(2)
+    slots = [eng.make_slot(dev, graph=False).build_aql(split_chains=True) for _ in range(6)]
+    for rep in range(3):
+        for s in slots:
+            s.out["pred_rec"].fill_(float("nan"))
+        torch.cuda.synchronize()
+        eng.aql_submit(slots[:4], 0)
+        eng.aql_submit(slots[4:], 1)
+        with pytest.raises(Exception):
+            eng.aql_submit(slots[:1], 1)         # still in flight: refused, not re-queued
+        for s in slots:
+            out = s.wait(timeout_us=5_000_000)
+            for k in ref:
+                assert torch.equal(ref[k], out[k]), (rep, k)
+
+
+def test_aql_golden_parity():
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.aql_open(1)
+    (slot,) = _aql_outputs(eng, dev, True)
+    ncmp = batch["new_srl_idxs"].shape[1]
+    pred = eng.unpack_pred(slot.out["pred_rec"], ncmp)
+    g = np.load(cases.golden_path(name))
+    _check_against(name, slot.out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)

@@ -389,7 +389,7 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
       attr_sb = true;
     }
     dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    ::vog::launch(kern, grid, dim3(256), lds, st, p);
     VOG_LAUNCH_CHECK();
     return 0;
   }
@@ -403,7 +403,7 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  ::vog::launch(kern, grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }

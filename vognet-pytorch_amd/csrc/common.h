@@ -97,6 +97,50 @@ __host__ __device__ __forceinline__ int64_t frag_a(int m, int k, int K) {
   return ((((int64_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64) + (((k >> 3) & 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
 
+// ---- kernel launch: HIP stream, or recorded into an AQL program (aql.hip) -----------------------
+// Every kernel of the library is launched through vog::launch. With an ordinary stream it is
+// hipLaunchKernelGGL. With the recorder pseudo-stream (vog_aql_program_create) nothing is
+// launched: the kernel's host stub, geometry and packed kernarg bytes are appended to the
+// active recording, from which aql.hip builds raw AQL dispatch packets.
+struct LaunchRecord {
+  const void* host_fn;
+  unsigned grid[3], block[3];      // grid in workgroups
+  unsigned dyn_lds;
+  unsigned arg_bytes;              // explicit kernarg bytes (natural alignment packing)
+  unsigned char args[1024];
+};
+struct LaunchRecorder {
+  virtual void add(const LaunchRecord& r) = 0;
+  virtual ~LaunchRecorder() {}
+};
+extern thread_local LaunchRecorder* g_recorder;
+static inline hipStream_t recorder_stream() { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(0x7e0c0de1)); }
+
+template <typename T>
+inline void pack_arg(LaunchRecord& r, const T& v) {
+  unsigned off = (r.arg_bytes + alignof(T) - 1) / alignof(T) * alignof(T);
+  static_assert(sizeof(T) <= sizeof(r.args), "kernel argument too large");
+  if (off + sizeof(T) > sizeof(r.args)) { r.arg_bytes = 0xffffffffu; return; }
+  memcpy(r.args + off, &v, sizeof(T));
+  r.arg_bytes = off + (unsigned)sizeof(T);
+}
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count mismatch");
+  if (st == recorder_stream() && g_recorder) {
+    LaunchRecord r;
+    r.host_fn = reinterpret_cast<const void*>(kern);
+    r.grid[0] = grid.x; r.grid[1] = grid.y; r.grid[2] = grid.z;
+    r.block[0] = block.x; r.block[1] = block.y; r.block[2] = block.z;
+    r.dyn_lds = (unsigned)lds; r.arg_bytes = 0;
+    (pack_arg<KArgs>(r, static_cast<KArgs>(args)), ...);
+    g_recorder->add(r);
+    return;
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<KArgs>(args)...);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

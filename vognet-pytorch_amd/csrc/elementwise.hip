@@ -491,7 +491,7 @@ extern "C" int vog_residual_layernorm(const float* x, const float* gamma, const 
                                       float* y32, void* y16, int rows, int d, vog_dtype dtype,
                                       void* stream) {
   VOG_CHECK_ARG(x && gamma && beta && (y32 || y16) && rows > 0 && d > 0 && d <= 1024);
-  VOG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_kernel<T16>), dim3(ceil_div(rows, 4)),
+  VOG_DISPATCH_DTYPE(dtype, ::vog::launch((layernorm_kernel<T16>), dim3(ceil_div(rows, 4)),
                      dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32, (unsigned short*)y16, rows, d));
   VOG_LAUNCH_CHECK();
   return 0;
@@ -502,7 +502,7 @@ extern "C" int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, co
   VOG_CHECK_ARG(src0 && dst0 && n0 > 0 && (n0 % 4) == 0 && n1 >= 0 && (n1 % 4) == 0 && (n1 == 0 || (src1 && dst1)));
   const int64_t q = (n0 + n1) / 4;
   const int grid = (int)((q + 255) / 256 < 2048 ? (q + 255) / 256 : 2048);
-  VOG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cast2_kernel<T16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+  VOG_DISPATCH_DTYPE(dtype, ::vog::launch((cast2_kernel<T16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)src0, (u16x4*)dst0, n0 / 4, (const float4*)src1, (u16x4*)dst1, n1 / 4));
   VOG_LAUNCH_CHECK();
   return 0;
@@ -518,7 +518,7 @@ extern "C" int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* word
   if (blocks > 1024) blocks = 1024;
   const int64_t need = ((int64_t)Bn * T + 255) / 256;
   if (blocks < need) blocks = need;
-  hipLaunchKernelGGL(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+  ::vog::launch(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -534,7 +534,7 @@ extern "C" int vog_vis_prep(const vog_visprep_args* a, void* stream) {
   const int nu = (a->w_pe0 ? a->n_rows * a->H0 : 0) + (a->w_pe1 ? a->n_rows * a->H1 : 0);
   const int u_blocks = ceil_div(nu, 256);
   if (cast_blocks + u_blocks == 0) return 0;
-  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((vis_prep_kernel<T16>), dim3(cast_blocks + u_blocks), dim3(256), 0,
+  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_prep_kernel<T16>), dim3(cast_blocks + u_blocks), dim3(256), 0,
                      (hipStream_t)stream, *a, cast_blocks));
   VOG_LAUNCH_CHECK();
   return 0;
@@ -548,7 +548,7 @@ extern "C" int vog_splitk_finish(const vog_splitk_prob* p0, const vog_splitk_pro
   a.blocks0 = (int)(((int64_t)p0->M * (p0->N / 4) + 255) / 256);
   int blocks1 = 0;
   if (p1) { a.p[1] = *p1; blocks1 = (int)(((int64_t)p1->M * (p1->N / 4) + 255) / 256); }
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3(a.blocks0 + blocks1), dim3(256), 0, (hipStream_t)stream, a);
+  ::vog::launch(splitk_finish_kernel, dim3(a.blocks0 + blocks1), dim3(256), 0, (hipStream_t)stream, a);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -557,7 +557,7 @@ extern "C" int vog_box_u(const float* props, const float* w_pe, float* u, int n_
                          float vid_w, float vid_h, float nfrm_div, void* stream) {
   VOG_CHECK_ARG(props && w_pe && u && n_rows > 0 && H > 0);
   const int n = n_rows * H;
-  hipLaunchKernelGGL(box_u_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+  ::vog::launch(box_u_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      props, w_pe, u, n_rows, H, vid_w, vid_h, nfrm_div);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -566,7 +566,7 @@ extern "C" int vog_box_u(const float* props, const float* w_pe, float* u, int n_
 extern "C" int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask, int32_t* tok,
                               int Bn, int T, int nsrl, int seq_len, int vocab_size, void* stream) {
   VOG_CHECK_ARG(words_ind && word_mask && tok && Bn > 0 && T > 0 && T <= seq_len);
-  hipLaunchKernelGGL(srl_gather_kernel, dim3(ceil_div(Bn * T, 256)), dim3(256), 0,
+  ::vog::launch(srl_gather_kernel, dim3(ceil_div(Bn * T, 256)), dim3(256), 0,
                      (hipStream_t)stream, words_ind, word_mask, tok, Bn, T, nsrl, seq_len, vocab_size);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -576,7 +576,7 @@ extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const i
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
   VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512);
-  hipLaunchKernelGGL(argvec_kernel, dim3(Bn * nsrl, ceil_div(L, 16)), dim3(256), 0,
+  ::vog::launch(argvec_kernel, dim3(Bn * nsrl, ceil_div(L, 16)), dim3(256), 0,
                      (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -585,7 +585,7 @@ extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const i
 extern "C" int vog_vislang_layout(const vog_vislang_args* a, void* stream) {
   VOG_CHECK_ARG(a && a->vis && a->lang && (a->x32 || a->x16));
   const int64_t rows = (int64_t)a->n_vid * a->nfrm * a->nsrl * a->nppf;
-  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((vislang_kernel<T16>), dim3((unsigned)rows), dim3(256), 0,
+  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vislang_kernel<T16>), dim3((unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, *a));
   VOG_LAUNCH_CHECK();
   return 0;
@@ -597,7 +597,7 @@ extern "C" int vog_qkv_combine(const vog_qkvcomb_args* a, void* stream) {
   const int items_qk = a->nppf * (a->dp / 8), items_v = a->dp * ((a->nppf + 3) / 4);
   const int chunks = ceil_div(items_qk > items_v ? items_qk : items_v, 256);
   dim3 grid(a->n_vid * a->nfrm * chunks, a->H, 3);
-  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((qkv_combine_kernel<T16>), grid, dim3(256), 0,
+  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((qkv_combine_kernel<T16>), grid, dim3(256), 0,
                      (hipStream_t)stream, *a, chunks));
   VOG_LAUNCH_CHECK();
   return 0;
@@ -606,7 +606,7 @@ extern "C" int vog_qkv_combine(const vog_qkvcomb_args* a, void* stream) {
 extern "C" int vog_score_head(const vog_score_args* a, void* stream) {
   VOG_CHECK_ARG(a && a->h1 && a->w2 && a->b2 && a->arg_msk && a->cmp_msk && a->outs && a->outs_eval);
   const int64_t rows = (int64_t)a->n_vid * a->nfrm * a->nsrl * a->nppf;
-  hipLaunchKernelGGL(score_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  ::vog::launch(score_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -615,7 +615,7 @@ extern "C" int vog_pred_cmp_head(const vog_predcmp_args* a, void* stream) {
   VOG_CHECK_ARG(a && a->final_hidden && a->prop_seg && a->outs && a->vidf_outs && a->fin_scores &&
                 a->fin_scores_loss && a->verb_ind);
   const size_t sm = (size_t)(a->L + (a->dps - a->dp0) + 256 + a->nsrl) * sizeof(float);
-  hipLaunchKernelGGL(predcmp_kernel, dim3(a->B * a->ncmp), dim3(256), sm, (hipStream_t)stream, *a);
+  ::vog::launch(predcmp_kernel, dim3(a->B * a->ncmp), dim3(256), sm, (hipStream_t)stream, *a);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -629,7 +629,7 @@ extern "C" int vog_pred_head(const vog_pred_args* a, void* stream) {
   VOG_CHECK_ARG(a->conc_type != VOG_CONC_SEP || a->fin_scores);
   const int64_t rb = vog_pred_record_bytes(a->ncmp, a->nsrl, a->nfrm0);
   const int n1 = a->B * a->nsrl * a->nfrm0;
-  hipLaunchKernelGGL(pred_kernel, dim3(ceil_div(n1, 64)), dim3(64), 0, (hipStream_t)stream, *a, rb);
+  ::vog::launch(pred_kernel, dim3(ceil_div(n1, 64)), dim3(64), 0, (hipStream_t)stream, *a, rb);
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -9,7 +9,9 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <stdlib.h>
 #include "common.h"
+#include "aql.h"
 
 namespace vog {
 
@@ -633,6 +635,23 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
     steps.push_back({"pred_head", [=](hipStream_t st) { return vog_pred_head(&pr, st); }});
   }
+  // VOG_SKIP_STEPS=name,name,... (perf experiments only; results are WRONG): drop steps whose
+  // name starts with one of the entries, to measure their marginal cost in the throughput regime
+  if (const char* skip = getenv("VOG_SKIP_STEPS")) {
+    std::vector<std::string> pre;
+    std::string cur;
+    for (const char* q = skip;; ++q) {
+      if (*q == ',' || *q == 0) { if (!cur.empty()) pre.push_back(cur); cur.clear(); if (!*q) break; }
+      else cur.push_back(*q);
+    }
+    std::vector<Step> kept;
+    for (auto& s : steps) {
+      bool drop = false;
+      for (auto& pfx : pre) drop |= s.name.rfind(pfx, 0) == 0;
+      if (!drop) kept.push_back(s);
+    }
+    steps.swap(kept);
+  }
   return 0;
 }
 
@@ -936,6 +955,96 @@ extern "C" int vog_graph_destroy(vog_graph* g) {
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
   return 0;
+}
+
+// ---- AQL programs (aql.hip): the same launch sequence as vog_forward, recorded instead of launched
+struct vog_aql_program {
+  vog::AqlProgram* p = nullptr;
+};
+
+namespace vog {
+struct ChainRecorder : LaunchRecorder {
+  std::vector<LaunchRecord>* dst = nullptr;
+  void add(const LaunchRecord& r) override { dst->push_back(r); }
+};
+}  // namespace vog
+
+extern "C" int vog_aql_open(int n_queues) { return vog::aql_open(n_queues); }
+
+extern "C" int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
+                                      int split_chains, vog_aql_program** out) {
+  VOG_CHECK_ARG(c && b && ws && out);
+  Plan plan;
+  std::vector<Step> steps;
+  VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
+  // three chains: language (branch 1) and vision (branch 0) before the join marker are
+  // independent of each other; everything after the join is one chain
+  std::vector<LaunchRecord> lang, vis, tail;
+  vog::ChainRecorder rec;
+  bool joined = false;
+  int rc = 0;
+  vog::g_recorder = &rec;
+  for (auto& s : steps) {
+    if (s.branch < 0) { joined = true; continue; }
+    rec.dst = joined ? &tail : (s.branch == 1 ? &lang : &vis);
+    rc = s.fn(vog::recorder_stream());
+    if (rc != 0) break;
+  }
+  vog::g_recorder = nullptr;
+  if (rc != 0) return rc;
+  std::vector<std::vector<LaunchRecord>> rows;
+  if (split_chains) {
+    const size_t n = lang.size() > vis.size() ? lang.size() : vis.size();
+    for (size_t i = 0; i < n; ++i) {
+      std::vector<LaunchRecord> row;
+      if (i < vis.size()) row.push_back(vis[i]);
+      if (i < lang.size()) row.push_back(lang[i]);
+      rows.push_back(row);
+    }
+  } else {
+    for (auto& r : lang) rows.push_back({r});
+    for (auto& r : vis) rows.push_back({r});
+  }
+  if (tail.empty()) {
+    // the completion signal rides on the last packet: it must be alone in its row
+    if (!rows.empty() && rows.back().size() > 1) {
+      LaunchRecord last = rows.back().back();
+      rows.back().pop_back();
+      rows.push_back({last});
+    }
+  }
+  for (auto& r : tail) rows.push_back({r});
+  vog_aql_program* pr = new vog_aql_program();
+  rc = vog::aql_program_build(rows, &pr->p);
+  if (rc != 0) { delete pr; return rc; }
+  *out = pr;
+  return 0;
+}
+
+extern "C" int vog_aql_program_info(const vog_aql_program* p, int* packets, int* rows) {
+  VOG_CHECK_ARG(p && p->p);
+  if (packets) *packets = vog::aql_program_packets(p->p);
+  if (rows) *rows = vog::aql_program_rows(p->p);
+  return 0;
+}
+
+extern "C" int vog_aql_submit(vog_aql_program* const* progs, int n, int queue) {
+  VOG_CHECK_ARG(progs && n >= 1 && n <= 64);
+  vog::AqlProgram* ps[64];
+  for (int i = 0; i < n; ++i) { VOG_CHECK_ARG(progs[i] && progs[i]->p); ps[i] = progs[i]->p; }
+  return vog::aql_submit(ps, n, queue);
+}
+
+extern "C" int vog_aql_wait(vog_aql_program* p, uint64_t timeout_us) {
+  VOG_CHECK_ARG(p && p->p);
+  return vog::aql_wait(p->p, timeout_us);
+}
+
+extern "C" int vog_aql_program_destroy(vog_aql_program* p) {
+  if (!p) return 0;
+  const int rc = vog::aql_program_destroy(p->p);
+  delete p;
+  return rc;
 }
 
 extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,

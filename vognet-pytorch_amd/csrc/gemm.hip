@@ -539,13 +539,14 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
 // SK_CH = k-steps (of 32) per register chunk. The W panel is the HBM-bound stream of this
 // kernel: with K = 2048 a wave owns 16 k-steps, and all 16 of its weight fragments are
 // requested before anything else (one round trip instead of two).
-template <typename T16, bool A_F32, int SK_CH>
+template <typename T16, bool A_F32, int SK_CH, int NT>
 __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
-  __shared__ float red[4][4][64][4];          // [wave][mtile][lane][reg]
+  // NT 16-column tiles per workgroup: every A fragment a wave loads feeds NT MFMAs, so the
+  // L2 traffic for A (re-read by every workgroup) drops by NT; used when there are enough
+  // column tiles to still fill the chip.
+  __shared__ float red[4][NT][4][64][4];      // [wave][ntile][mtile][lane][reg]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int n0 = blockIdx.x * 16;
-  const int n = n0 + (lane & 15);
-  const bool n_ok = n < p.N;
+  const int ct0 = blockIdx.x * NT;            // first 16-column tile
   const int kg = (lane >> 4) * 8;
   const int mt_all = (p.M + 15) / 16;         // <= 4
   // grid.y > 1: one 16-row tile of A per workgroup (few output columns: parallelism
@@ -553,9 +554,11 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
   const int mt_lo = gridDim.y > 1 ? blockIdx.y : 0;
   const int mt_n = gridDim.y > 1 ? mt_lo + 1 : mt_all;
   const int ksteps = p.K / 32;
-  f32x4 acc[4];
+  f32x4 acc[NT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int64_t a_off[4]; bool a_ok[4];
 #pragma unroll
@@ -565,22 +568,30 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
     const int64_t src = a_ok[mt] ? (p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m) : 0;
     a_off[mt] = src * p.lda;
   }
-  const int64_t w_off = (int64_t)(n_ok ? n : 0) * p.ldw;
+  int64_t w_off[NT]; bool n_ok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = (ct0 + t) * 16 + (lane & 15);
+    n_ok[t] = n < p.N;
+    w_off[t] = (int64_t)(n_ok[t] ? n : 0) * p.ldw;
+  }
 
   // wave `wid` owns k-steps wid, wid+4, ... ; processed SK_CH at a time
   for (int base = wid; base < ksteps; base += 4 * SK_CH) {
-    u16x8 fw[SK_CH];
+    u16x8 fw[NT][SK_CH];
 #pragma unroll
-    for (int c = 0; c < SK_CH; ++c) {
-      const int ks = base + c * 4;
-      if (p.w_frag) {   // one contiguous KiB per (column tile, k-step)
-        u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        fw[c] = ks < ksteps ? *reinterpret_cast<const u16x8*>(
-                                  p.w + (((int64_t)blockIdx.x * ksteps + ks) * 64 + lane) * 8) : z;
-      } else {
-        fw[c] = load_a_chunk<T16, false>(p.w, w_off, ks * 32 + kg, n_ok && ks < ksteps);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int c = 0; c < SK_CH; ++c) {
+        const int ks = base + c * 4;
+        if (p.w_frag) {   // one contiguous KiB per (column tile, k-step)
+          u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          fw[t][c] = (ks < ksteps && n_ok[t]) ? *reinterpret_cast<const u16x8*>(
+                                    p.w + (((int64_t)(ct0 + t) * ksteps + ks) * 64 + lane) * 8) : z;
+        } else {
+          fw[t][c] = load_a_chunk<T16, false>(p.w, w_off[t], ks * 32 + kg, n_ok[t] && ks < ksteps);
+        }
       }
-    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (mt >= mt_lo && mt < mt_n) {
@@ -597,24 +608,30 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
           }
         }
 #pragma unroll
-        for (int c = 0; c < SK_CH; ++c) acc[mt] = mfma16<T16>(fa[c], fw[c], acc[mt]);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int c = 0; c < SK_CH; ++c) acc[t][mt] = mfma16<T16>(fa[c], fw[t][c], acc[t][mt]);
       }
     }
   }
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wid][mt][lane][r] = acc[mt][r];
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wid][t][mt][lane][r] = acc[t][mt][r];
   __syncthreads();
   // wave w finishes m-tile w
   const int mt = wid;
   if (mt >= mt_lo && mt < mt_n) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = red[0][mt][lane][r] + red[1][mt][lane][r] + red[2][mt][lane][r] + red[3][mt][lane][r];
-      const int row = mt * 16 + (lane >> 4) * 4 + r;
-      epilogue_store<T16>(p, row, n, v);
-    }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = red[0][t][mt][lane][r] + red[1][t][mt][lane][r] + red[2][t][mt][lane][r] + red[3][t][mt][lane][r];
+        const int row = mt * 16 + (lane >> 4) * 4 + r;
+        epilogue_store<T16>(p, row, (ct0 + t) * 16 + (lane & 15), v);
+      }
   }
 }
 
@@ -634,7 +651,7 @@ static int launch_pipe_cfg(const GemmParams& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN), p.splitk > 1 ? p.splitk : 1);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  ::vog::launch(kern, grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -681,10 +698,10 @@ static int launch_tiled(const GemmParams& p, hipStream_t st) {
   const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   if (p.M > 64 && t128 >= 192) {
     dim3 grid(ceil_div(p.M, 128) * ceil_div(p.N, 128));
-    hipLaunchKernelGGL((gemm_tiled<T16, 128, 128, A_F32, EPI>), grid, dim3(256), 0, st, p);
+    ::vog::launch((gemm_tiled<T16, 128, 128, A_F32, EPI>), grid, dim3(256), 0, st, p);
   } else {
     dim3 grid(ceil_div(p.M, 64) * ceil_div(p.N, 64));
-    hipLaunchKernelGGL((gemm_tiled<T16, 64, 64, A_F32, EPI>), grid, dim3(256), 0, st, p);
+    ::vog::launch((gemm_tiled<T16, 64, 64, A_F32, EPI>), grid, dim3(256), 0, st, p);
   }
   VOG_LAUNCH_CHECK();
   return 0;
@@ -720,14 +737,19 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
     VOG_FAIL(-1, "w_frag weights are only valid for the M <= 64 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);
   if (p.M <= 64 && (p.K % 32) == 0) {
     const int ncol = ceil_div(p.N, 16);
-    dim3 grid(ncol, ncol < 128 ? ceil_div(p.M, 16) : 1);
-    const bool deep = false;   // 16-deep weight prefetch measured SLOWER (26 vs 18.6 us at M=48,N=8192,K=2048: 230 VGPRs)
-    if (g->a_is_f32) {
-      if (deep) hipLaunchKernelGGL((gemm_skinny<T16, true, 16>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_skinny<T16, true, 8>), grid, dim3(256), 0, st, p);
+    // (a 16-deep weight prefetch measured SLOWER: 26 vs 18.6 us at M=48,N=8192,K=2048, 230 VGPRs)
+    static const int nt_env = getenv("VOG_SKINNY_NT") ? atoi(getenv("VOG_SKINNY_NT")) : 0;
+    // NT = 2 halves the L2 re-reads of A but also the workgroup count: measured SLOWER at
+    // M=48,N=8192,K=2048 (12.7 vs 11.1 us) and much slower at small N -> opt-in for experiments
+    const int nt = nt_env == 2 ? 2 : 1;
+    if (nt == 2) {
+      dim3 grid(ceil_div(ncol, 2), 1);
+      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 2>), grid, dim3(256), 0, st, p);
+      else ::vog::launch((gemm_skinny<T16, false, 8, 2>), grid, dim3(256), 0, st, p);
     } else {
-      if (deep) hipLaunchKernelGGL((gemm_skinny<T16, false, 16>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_skinny<T16, false, 8>), grid, dim3(256), 0, st, p);
+      dim3 grid(ncol, ncol < 128 ? ceil_div(p.M, 16) : 1);
+      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), 0, st, p);
+      else ::vog::launch((gemm_skinny<T16, false, 8, 1>), grid, dim3(256), 0, st, p);
     }
     VOG_LAUNCH_CHECK();
     return 0;

@@ -24,6 +24,7 @@
 // dependent load: the input projections arrive already in (direction, step)
 // order (the GEMM scatters its rows by the schedule of vog_lstm_schedule), and
 // W_hh is stored in MFMA-fragment order so each wave load is one contiguous KiB.
+#include <stdlib.h>
 #include "common.h"
 
 namespace vog {
@@ -31,7 +32,7 @@ namespace vog {
 struct LstmParams {
   const float* gxs; const unsigned short* whh; const unsigned short* h_in; unsigned short* h_out;
   float* c; unsigned short* out16; const int64_t* lens;
-  int Bn, T, R, step; int out_frag, final_row0;
+  int Bn, T, R, step; int out_frag, final_row0; int debug;
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -45,10 +46,19 @@ __device__ __forceinline__ float tanh_(float x) {
 
 constexpr int LS_CH = 8;      // k-steps per wave kept in registers per chunk
 
+#ifdef VOG_TS_DEBUG   // scratch/ts_lstm.hip: per-wave wall-clock stamps (100 MHz) to split launch gap / in-kernel latency
+__device__ unsigned long long g_ts[64][2048][4];
+__device__ int g_ts_launch;
+#define VOG_TS(slot) do { if (lane == 0) g_ts[p.step][(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid][slot] = wall_clock64(); } while (0)
+#else
+#define VOG_TS(slot) do { } while (0)
+#endif
+
 template <typename T16>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
   __shared__ float red[4][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  VOG_TS(0);
   const int dir = blockIdx.y;
   const int tile = blockIdx.x;
   const int u0 = tile * 4;
@@ -56,7 +66,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
   const int kg = (lane >> 4) * 8;
   const int ksteps = R / 32;
   // fragment-ordered weights: [dir][tile][kstep][lane][8] -> every load is one contiguous KiB
-  const unsigned short* wp = p.whh + (((int64_t)dir * (R / 4) + tile) * ksteps) * 512 + lane * 8;
+  // debug & 1 (perf experiments only): every workgroup reads tile 0's weights
+  const unsigned short* wp = p.whh + (((int64_t)dir * (R / 4) + ((p.debug & 1) ? 0 : tile)) * ksteps) * 512 + lane * 8;
   const int nbt = (p.Bn + 15) / 16;
   const int unit = u0 + (lane >> 4);
 
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
 #pragma unroll
       for (int c = 0; c < LS_CH; ++c) acc = mfma16<T16>(fw[c], fh[c], acc);
     }
+    VOG_TS(1);
     __syncthreads();                              // red[] free (previous batch tile consumed)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wid][lane][r] = acc[r];
@@ -119,6 +131,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
         p.h_out[st] = h_prev;
       }
     }
+    VOG_TS(2);
   }
 }
 
@@ -258,9 +271,11 @@ int lstm_step_run(const vog_lstm_step_args* a, hipStream_t st) {
   VOG_CHECK_ARG(a->h_in != a->h_out);
   LstmParams p{a->gx, (const unsigned short*)a->whh, (const unsigned short*)a->h_in,
                (unsigned short*)a->h_out, a->c, (unsigned short*)a->out16, a->lens,
-               a->Bn, a->T, a->R, a->step, a->out_frag, a->final_row0};
+               a->Bn, a->T, a->R, a->step, a->out_frag, a->final_row0, 0};
+  static const int dbg = getenv("VOG_LSTM_DEBUG") ? atoi(getenv("VOG_LSTM_DEBUG")) : 0;
+  p.debug = dbg;
   dim3 grid(ceil_div(a->R, 4), 2);
-  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((lstm_step_kernel<T16>), grid, dim3(256), 0, st, p));
+  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((lstm_step_kernel<T16>), grid, dim3(256), 0, st, p));
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -285,7 +300,7 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
   dim3 grid(a->R / 32, 2);
   hipStream_t st = (hipStream_t)stream;
 #define VOG_LAUNCH_LAYER(KS)                                                                     \
-  VOG_DISPATCH_DTYPE(a->dtype, hipLaunchKernelGGL((vog::lstm_layer_kernel<T16, KS>), grid, dim3(256), 0, st, p))
+  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vog::lstm_layer_kernel<T16, KS>), grid, dim3(256), 0, st, p))
   switch (a->R / 32) {
     case 1: VOG_LAUNCH_LAYER(1); break;
     case 2: VOG_LAUNCH_LAYER(2); break;
@@ -299,7 +314,7 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
 
 extern "C" int vog_lstm_schedule(const int64_t* lens, int32_t* rows, int Bn, int T, void* stream) {
   VOG_CHECK_ARG(lens && rows && Bn > 0 && T > 0);
-  hipLaunchKernelGGL(vog::lstm_schedule_kernel, dim3(vog::ceil_div(Bn * T, 128)), dim3(128), 0,
+  ::vog::launch(vog::lstm_schedule_kernel, dim3(vog::ceil_div(Bn * T, 128)), dim3(128), 0,
                      (hipStream_t)stream, lens, rows, Bn, T);
   VOG_LAUNCH_CHECK();
   return 0;

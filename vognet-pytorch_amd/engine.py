@@ -195,6 +195,17 @@ class VogEngine:
         L.check(self.lib.vog_ctx_set_int(self.ctx, b"graph_dag", int(dag)), "vog_ctx_set_int")
         return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph)
 
+    def aql_open(self, n_queues: int = 1) -> None:
+        """Create the library's own hardware queues on this device (AQL submission path)."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.vog_aql_open(int(n_queues)), "vog_aql_open")
+
+    def aql_submit(self, slots, queue: int = 0) -> None:
+        """Enqueue the AQL programs of `slots` row-interleaved on one queue. NOT stream ordered:
+        the slots' inputs must already be complete; collect results with slot.wait()."""
+        arr = (C.c_void_p * len(slots))(*[s.aql for s in slots])
+        L.check(self.lib.vog_aql_submit(arr, len(slots), int(queue)), "vog_aql_submit")
+
     def set_option(self, name: str, value: int) -> None:
         """Integer options of the context: 'graph_dag', 'lstm_persistent' (include/vog_hip.h)."""
         L.check(self.lib.vog_ctx_set_int(self.ctx, name.encode(), int(value)), f"vog_ctx_set_int({name})")
@@ -251,6 +262,7 @@ class Slot:
             L.check(eng.lib.vog_workspace_init(eng.ctx, self.B, self.ncmp, self.T, self.ws.data_ptr(),
                                                self.ws.numel(), L.stream_ptr()), "vog_workspace_init")
             self.graph = None
+            self.aql = None
             if graph:
                 torch.cuda.synchronize()
                 cap = torch.cuda.Stream(device=eng.device)
@@ -260,6 +272,28 @@ class Slot:
                         "vog_graph_capture")
                 self.graph = g
                 torch.cuda.synchronize()
+
+    # ---- AQL path (include/vog_hip.h "AQL programs") ------------------------------------------
+    def build_aql(self, split_chains: bool = True) -> "Slot":
+        """Record this slot's forward as an AQL program (pre-built dispatch packets)."""
+        if getattr(self, "aql", None) is not None:
+            return self
+        with torch.cuda.device(self.eng.device):
+            torch.cuda.synchronize()
+            p = C.c_void_p()
+            L.check(self.eng.lib.vog_aql_program_create(self.eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
+                                                        self.ws.numel(), int(split_chains), C.byref(p)),
+                    "vog_aql_program_create")
+            self.aql = p
+            npk, nrow = C.c_int32(), C.c_int32()
+            L.check(self.eng.lib.vog_aql_program_info(p, C.byref(npk), C.byref(nrow)), "vog_aql_program_info")
+            self.aql_packets, self.aql_rows = int(npk.value), int(nrow.value)
+        return self
+
+    def wait(self, timeout_us: int = 10_000_000):
+        """Block until the slot's AQL program has completed; returns the output dict."""
+        L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
+        return self.out
 
     def update_inputs(self, inp):
         """Copy a new batch (same shapes, same T) into the slot's buffers."""
@@ -279,6 +313,8 @@ class Slot:
 
     def __del__(self):
         try:
+            if getattr(self, "aql", None) is not None:
+                self.eng.lib.vog_aql_program_destroy(self.aql)
             if self.graph is not None:
                 self.eng.lib.vog_graph_destroy(self.graph)
         except Exception:

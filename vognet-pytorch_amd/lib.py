@@ -178,6 +178,12 @@ SYMBOLS = {
     "vog_ctx_set_int": (c_i32, [c_vp, C.c_char_p, c_i32]),
     "vog_graph_launch": (c_i32, [c_vp, c_vp]),
     "vog_graph_destroy": (c_i32, [c_vp]),
+    "vog_aql_open": (c_i32, [c_i32]),
+    "vog_aql_program_create": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_i32, C.POINTER(c_vp)]),
+    "vog_aql_program_info": (c_i32, [c_vp, C.POINTER(c_i32), C.POINTER(c_i32)]),
+    "vog_aql_submit": (c_i32, [C.POINTER(c_vp), c_i32, c_i32]),
+    "vog_aql_wait": (c_i32, [c_vp, C.c_uint64]),
+    "vog_aql_program_destroy": (c_i32, [c_vp]),
     "vog_time_kernel": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.c_char_p, c_i32, c_vp, C.POINTER(c_f32)]),
 }
 
