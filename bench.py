@@ -47,6 +47,7 @@ WORKLOADS = {
 }
 VOCAB = 5000
 PEAK_MFMA_TFLOPS = 2500.0       # dense bf16/f16, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0           # HBM3E peak (same table; ~6300 GB/s is what streaming kernels achieve)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -99,6 +100,31 @@ def kernel_flops(w, T):
                                                      "lstm_outproj")}
     total = sum(dense.values()) + lstm + f["lstm_outproj"]
     return f, total
+
+
+def lstm_step_bytes(w, T):
+    """Algorithmic HBM bytes of ONE recurrent step launch (both directions of one layer):
+    W_hh is streamed once per step (2 dirs x 4R x R 16-bit: it cannot stay on chip between
+    dependent launches), plus the step's slice of the input-projection gates, the fp32 cell
+    state (read + write) and the 16-bit hidden state in / out."""
+    R = 1024
+    ncmp = 1 if w["conc"] == "svsq" else 4
+    Bn = w["B"] * (ncmp if w["conc"] in ("sep", "svsq") else 1)
+    whh = 2 * 4 * R * R * 2
+    gates = 2 * Bn * 4 * R * 4
+    state = 2 * Bn * R * (4 + 4 + 2 + 2 + 2)
+    return whh + gates + state
+
+
+def pmc_traffic(workload):
+    """HBM traffic measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
+    correction applied), committed under profiles/ by scratch/run_round_profiles.sh."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
 
 
 def cpu_baseline(w, cfg, sd, batch, budget_s=24.0):
@@ -294,11 +320,34 @@ def main():
             break
         except Exception:
             pass
-    dom = max((k for k in flops if ktimes[k] and flops[k] > 0), key=lambda k: ktimes[k])
-    ach = flops[dom] / (ktimes[dom] * 1e-6) / 1e12
-    res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
-                       "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None,
-                       "usec_per_launch": ktimes[dom], "flops_per_launch": flops[dom]}
+    # dominant kernel = largest share of a forward's kernel time (launches x duration). At the
+    # gt5 shapes that is the recurrent step (2 layers x T launches, HBM bound: W_hh streams once
+    # per step); at p100 it is an MFMA GEMM.
+    pmc = pmc_traffic(args.workload) or {}
+    mfma_dom = max((k for k in flops if ktimes[k] and flops[k] > 0), key=lambda k: ktimes[k])
+    ach = flops[mfma_dom] / (ktimes[mfma_dom] * 1e-6) / 1e12
+    roof_mfma = {"bound": "mfma", "kernel": mfma_dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
+                 "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
+                 "traffic": (pmc.get("kernels", {}).get(mfma_dom) or {}).get("bytes_per_launch"),
+                 "usec_per_launch": ktimes[mfma_dom], "flops_per_launch": flops[mfma_dom],
+                 "launches_per_forward": 1}
+    res["roofline"] = roof_mfma
+    if lstm_us and lstm_us[0] == "lstm_step" and 2 * T * lstm_us[1] > ktimes[mfma_dom]:
+        nbytes = lstm_step_bytes(w, T)
+        ach_b = nbytes / (lstm_us[1] * 1e-6) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "lstm_step", "achieved": ach_b, "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
+                           "traffic": (pmc.get("kernels", {}).get("lstm_step") or {}).get("bytes_per_launch"),
+                           "usec_per_launch": lstm_us[1], "bytes_per_launch": nbytes,
+                           "launches_per_forward": 2 * T,
+                           "share_of_forward_kernel_time": 2 * T * lstm_us[1] / (
+                               2 * T * lstm_us[1] + sum(v for v in ktimes.values() if v))}
+        res["roofline_mfma"] = roof_mfma
+    if pmc.get("bytes_per_forward"):
+        # whole-forward view: every kernel's measured HBM-side bytes / the measured step time
+        gbs = pmc["bytes_per_forward"] / (dt / args.steps) / 1e9
+        res["forward_hbm"] = {"bytes_per_forward_pmc": pmc["bytes_per_forward"], "achieved": gbs, "unit": "GB/s",
+                              "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS, "source": pmc.get("source")}
     res["kernels_usec"] = {k: (round(v, 2) if v else None) for k, v in ktimes.items()}
     if lstm_us:
         res["kernels_usec"][lstm_us[0]] = round(lstm_us[1], 2)

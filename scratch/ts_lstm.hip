@@ -5,7 +5,7 @@
 #include <vector>
 namespace vog { thread_local LaunchRecorder* g_recorder = nullptr; void set_error(const char*, ...) {} }
 int main() {
-  const int Bn = 20, T = 12, R = 1024;
+  const int Bn = 4, T = 12, R = 1024;
   float *gx, *c; unsigned short *whh, *hA, *hB, *out16; int64_t* lens;
   hipMalloc(&gx, (size_t)2 * T * Bn * 4 * R * 4); hipMemset(gx, 0, (size_t)2 * T * Bn * 4 * R * 4);
   hipMalloc(&c, 32 * 2 * R * 4); hipMemset(c, 0, 32 * 2 * R * 4);
@@ -26,7 +26,9 @@ int main() {
   hipMemcpyFromSymbol(ts, HIP_SYMBOL(vog::g_ts), sizeof(ts));
   unsigned long long prev_end = 0;
   for (int s = 0; s < T; ++s) {
-    unsigned long long s_min = ~0ull, s_max = 0, m_max = 0, e_min = ~0ull, e_max = 0; double life = 0;
+    unsigned long long s_min = ~0ull, s_max = 0, m_max = 0, e_min = ~0ull, e_max = 0; double life = 0, ld = 0, mm = 0;
+    for (int w = 0; w < 2048; ++w) { ld += (double)(ts[s][w][3] - ts[s][w][0]); mm += (double)(ts[s][w][1] - ts[s][w][3]); }
+    printf("   mean per wave: entry -> operands loaded %5.2f us, MFMA part %5.2f us\n", ld / 2048 / 100.0, mm / 2048 / 100.0);
     for (int w = 0; w < 2048; ++w) {
       s_min = std::min(s_min, ts[s][w][0]); s_max = std::max(s_max, ts[s][w][0]); m_max = std::max(m_max, ts[s][w][1]);
       if (w % 4 == 0) { e_min = std::min(e_min, ts[s][w][2]); e_max = std::max(e_max, ts[s][w][2]); life += (double)(ts[s][w][2] - ts[s][w][0]); }

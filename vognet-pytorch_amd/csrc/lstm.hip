@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
         fw[c] = (ks < ksteps) ? *reinterpret_cast<const u16x8*>(wp + (int64_t)ks * 512) : z;
         fh[c] = (ks < ksteps) ? *reinterpret_cast<const u16x8*>(hp + ks * 32 + kg) : z;
       }
+#ifdef VOG_TS_DEBUG
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      VOG_TS(3);
+#endif
 #pragma unroll
       for (int c = 0; c < LS_CH; ++c) acc = mfma16<T16>(fw[c], fh[c], acc);
     }
