@@ -177,6 +177,13 @@ def main():
     ap.add_argument("--queues", type=int, default=4, help="aql: hardware queues")
     ap.add_argument("--interleave", type=int, default=1,
                     help="aql: forwards submitted together, row-interleaved behind shared barrier packets")
+    ap.add_argument("--cobatch", type=int, default=1,
+                    help="G > 1: the language encoder (BiLSTM) of G in-flight batches runs as one pass "
+                         "(W_hh streamed once per recurrent step for all of them); every batch keeps its own "
+                         "inputs/outputs and its stand-alone results (tests/test_gpu_forward.py)")
+    ap.add_argument("--no-cobatch-extra", action="store_true",
+                    help="skip the second timed run that reports the co-batched language encoder (G=4) "
+                         "beside the strict per-batch figure")
     ap.add_argument("--no-split", action="store_true", help="aql: one kernel per row (no lang/vis row sharing)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dag", action="store_true", help="capture the language chain as a parallel graph branch")
@@ -205,79 +212,117 @@ def main():
     eng.load_state_dict(sd)
     cfg_id = int(args.workload[3:])
     aql = args.mode == "aql"
-    Q, K, DEPTH = max(1, args.queues), max(1, args.interleave), 2
-    nstreams = Q * K * DEPTH if aql else max(1, args.streams)
-    slots, streams, batches = [], [], []
-    for s in range(nstreams):
-        b = synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=VOCAB,
-                             seed=1000 * cfg_id + rank * 16 + s)
-        batches.append(b)
-        slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
-                                   graph=(not args.no_graph) and not aql, dag=args.dag))
-        streams.append(torch.cuda.Stream(device=dev))
-    if aql:
-        eng.aql_open(Q)
-        for sl in slots:
-            sl.build_aql(split_chains=not args.no_split)
-    T = slots[0].T
-    gathered = [torch.empty((world * w["B"],) + tuple(slots[0].out["pred_rec"].shape[1:]),
-                            dtype=torch.float32, device=dev) for _ in range(nstreams)]
 
-    def step(i):
-        s = i % nstreams
-        out = slots[s].launch(streams[s])
-        if world > 1:
-            with torch.cuda.stream(streams[s]):
-                dist.all_gather_into_tensor(gathered[s], out["pred_rec"])
+    def measure(G, steps, warmup):
+        """K timed steps (one step = one batch of the workload) after W warm-up steps with G
+        batches per language-encoder pass. Returns (seconds, slots, batches, in-flight count)."""
+        Q, K, DEPTH = max(1, args.queues), max(1, args.interleave), 2
+        if G > 1:
+            K = 1
+        nunits = Q * K * DEPTH if aql else max(1, args.streams)      # units in flight (slot or group)
+        nstreams = nunits * G                                         # batches in flight
+        slots, streams, batches, units = [], [], [], []
+        for s in range(nstreams):
+            b = synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=VOCAB,
+                                 seed=1000 * cfg_id + rank * 64 + s)
+            batches.append(b)
+            streams.append(torch.cuda.Stream(device=dev))
+        if G == 1:
+            for b in batches:
+                slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
+                                           graph=(not args.no_graph) and not aql, dag=args.dag))
+            units = slots
+        else:
+            assert steps % G == 0 and warmup % G == 0, "--steps / --warmup must be multiples of the co-batch size"
+            for u in range(nunits):
+                grp = eng.make_group([{k: torch.from_numpy(v) for k, v in b.items()}
+                                      for b in batches[u * G:(u + 1) * G]], graph=(not args.no_graph) and not aql)
+                units.append(grp)
+                slots.extend(grp.slots)
+        if aql:
+            eng.aql_open(Q)
+            for un in units:
+                un.build_aql(split_chains=not args.no_split) if G == 1 else un.build_aql()
+        gathered = [torch.empty((world * w["B"],) + tuple(slots[0].out["pred_rec"].shape[1:]),
+                                dtype=torch.float32, device=dev) for _ in range(nstreams)]
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # aql mode: groups of K slots; group g lives on queue g % Q; a group is re-submitted only
-    # after its previous submission completed (DEPTH groups per queue keep the queue fed).
-    groups = [slots[g * K:(g + 1) * K] for g in range(Q * DEPTH)] if aql else []
-    inflight = [0] * len(groups)
-
-    def wait_group(g):
-        for j, sl in enumerate(groups[g][:inflight[g]]):
-            out = sl.wait()
+        def step(i):                       # graph mode: one unit (slot, or group of G batches) per call
+            u = i % nunits
+            outs = units[u].launch(streams[u])
             if world > 1:
-                s = g * K + j
-                with torch.cuda.stream(streams[s]):
-                    dist.all_gather_into_tensor(gathered[s], out["pred_rec"])
-        inflight[g] = 0
+                with torch.cuda.stream(streams[u]):
+                    for j, out in enumerate(outs if G > 1 else [outs]):
+                        dist.all_gather_into_tensor(gathered[u * G + j], out["pred_rec"])
 
-    def run(nsteps):
-        if not aql:
-            for i in range(nsteps):
-                step(i)
-            return
-        done, g = 0, 0
-        while done < nsteps:
-            n = min(K, nsteps - done)
-            if inflight[g]:
-                wait_group(g)
-            eng.aql_submit(groups[g][:n], g % Q)
-            inflight[g] = n
-            done += n
-            g = (g + 1) % len(groups)
-        for g in range(len(groups)):
-            if inflight[g]:
-                wait_group(g)
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # aql mode: groups of K units; group g lives on queue g % Q; a group is re-submitted only
+        # after its previous submission completed (DEPTH groups per queue keep the queue fed).
+        groups = [units[g * K:(g + 1) * K] for g in range(Q * DEPTH)] if aql else []
+        inflight = [0] * len(groups)
+
+        def wait_group(g):
+            for j, un in enumerate(groups[g][:inflight[g]]):
+                outs = un.wait()
+                if world > 1:
+                    u = g * K + j
+                    with torch.cuda.stream(streams[u]):
+                        for jj, out in enumerate(outs if G > 1 else [outs]):
+                            dist.all_gather_into_tensor(gathered[u * G + jj], out["pred_rec"])
+            inflight[g] = 0
+
+        def run(nsteps):
+            if not aql:
+                for i in range(nsteps // G):
+                    step(i)
+                return
+            done, g = 0, 0
+            while done < nsteps:
+                n = min(K, (nsteps - done) // G)
+                if inflight[g]:
+                    wait_group(g)
+                eng.aql_submit(groups[g][:n], g % Q)
+                inflight[g] = n
+                done += n * G
+                g = (g + 1) % len(groups)
+            for g in range(len(groups)):
+                if inflight[g]:
+                    wait_group(g)
+
+        run(warmup)
+        fence()
+        t0 = time.perf_counter()
+        run(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, slots, batches, nstreams
+
+    G = max(1, args.cobatch)
+    dt, slots, batches, nstreams = measure(G, args.steps, args.warmup)
+    T = slots[0].T
+    Q, K = max(1, args.queues), (1 if G > 1 else max(1, args.interleave))
+    # second, separately timed run of the same K steps: the language encoder of 4 in-flight batches as
+    # one pass (reported beside `value`, never instead of it: `value` is the strict per-batch path)
+    extra = None
+    if G == 1 and not args.no_cobatch_extra and not args.throughput_only and not args.no_graph \
+            and args.steps % 4 == 0 and args.warmup % 4 == 0:
+        dt4, slots4, _, n4 = measure(4, args.steps, args.warmup)
+        assert np.isfinite(float(slots4[0].out["mdl_outs_eval"].sum().item()))
+        extra = {"value": world * args.steps * w["B"] / dt4, "unit": "queries/s", "ms_per_step": dt4 / args.steps * 1e3,
+                 "batches_in_flight": n4, "steps": args.steps, "warmup": args.warmup,
+                 "what": "same K steps, same per-batch inputs/outputs; the BiLSTM language encoder of 4 in-flight "
+                         "batches runs as one pass (W_hh streamed once per recurrent step for the 16 sentences "
+                         "instead of once per batch), transformers/heads per batch as before; every batch's "
+                         "outputs match its stand-alone forward (tests/test_gpu_forward.py::test_group_*)"}
+        del slots4
     if args.throughput_only:
         if rank == 0:
             print(f"{world * args.steps * w['B'] / dt:.1f} {dt / args.steps * 1e6:.2f}")
@@ -298,13 +343,15 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": w["tx"], "data": "synthetic",
         "config": {"workload": w["desc"], "global_batch": world * w["B"], "batch_per_gpu": w["B"],
-                   "sentence_len": T, "batches_in_flight": nstreams,
+                   "sentence_len": T, "batches_in_flight": nstreams, "lang_cobatch": G,
                    "submission": (f"AQL packets, {Q} queues x {K} row-interleaved forwards"
                                   + ("" if args.no_split else ", lang/vis chains share rows")) if aql
                    else f"hipGraph on {nstreams} HIP streams",
                    "weights": "seeded default-init-like, vocab 5000",
                    "parallelism": f"dp{world} (replicated weights, one RCCL all-gather of predictions per step)"},
     }
+    if extra:
+        res["lang_cobatch4"] = extra
     # ---- roofline of the dominant kernel: HIP-event timing inside libvog_hip on this stream
     flops, total_flops = kernel_flops(w, T)
     ktimes = {}

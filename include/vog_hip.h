@@ -333,6 +333,12 @@ typedef struct vog_batch {
   float* mdl_outs; float* mdl_outs_eval;           /* [B,nc_v,nsrl,NP] */
   float* vidf_outs; float* fin_scores_loss; float* fin_scores;  /* sep only */
   void* pred_rec;                                  /* [B] packed records or NULL */
+  /* Optional: argument vectors computed elsewhere (vog_lang_forward over a GROUP of batches).
+   * shared_lang != NULL: this batch's rows [B*nvl*nsrl, lang_enc] of the group encoder's output;
+   * the language chain is skipped and the four word-level inputs above may be NULL.
+   * shared_final_hidden: its rows [B*nvl, lang_enc] of the final hidden projection (sep only). */
+  const float* shared_lang;
+  const float* shared_final_hidden;
 } vog_batch;
 
 int64_t vog_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T);
@@ -359,6 +365,38 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
+
+/* ---- language encoder over a group of batches ------------------------------------------------
+ * The BiLSTM re-streams W_hh (16.8 MB per layer) in every one of its 2T dependent step launches:
+ * at bs = 4 that is more than half of a forward's HBM traffic, for 4 of the 16 rows of the MFMA
+ * tile. vog_lang_forward runs the language chain (mdl_vog.py:250-283 + :97-140) once for the
+ * concatenated sentences of several in-flight batches (`lb`: B = sum of the members' B, T = max
+ * of their T; the five word-level arrays are the members' arrays back to back, which is how
+ * VogEngine.make_group allocates them). Rows never interact (the recurrence, the projections and
+ * the argument gather are row-wise), so each member's argument vectors are what its own forward
+ * computes up to fp32 summation order. Members then run vog_forward / graphs / AQL programs with
+ * vog_batch.shared_lang pointing at their rows of vog_lang_outputs(). */
+typedef struct vog_aql_program vog_aql_program;
+int64_t vog_lang_workspace_bytes(const vog_ctx* c, int B_total, int ncmp, int T);
+int vog_lang_workspace_init(const vog_ctx* c, int B_total, int ncmp, int T, void* lang_ws, size_t bytes, void* stream);
+/* lb: only B, ncmp, T and the five srl_* word-level pointers are read */
+int vog_lang_forward(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t bytes, void* stream);
+/* device pointers inside lang_ws: argument vectors [B_total*nvl*nsrl, lang_enc] and the final
+ * hidden projection [B_total*nvl, lang_enc] */
+int vog_lang_outputs(const vog_ctx* c, int B_total, int ncmp, int T, void* lang_ws, float** lang,
+                     float** final_hidden);
+/* One hipGraph / one AQL program for a whole group: the group's language chain, then every
+ * member's remaining forward (members[i].shared_lang must already point into lang_ws).
+ * AQL rows: language rows first, then row r of every member behind one barrier packet. */
+int vog_group_forward(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t lang_bytes,
+                      const vog_batch* const* members, void* const* workspaces, const size_t* ws_bytes,
+                      int n_members, void* stream);
+int vog_group_graph_capture(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t lang_bytes,
+                            const vog_batch* const* members, void* const* workspaces,
+                            const size_t* ws_bytes, int n_members, void* stream, vog_graph** out);
+int vog_group_aql_program_create(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t lang_bytes,
+                                 const vog_batch* const* members, void* const* workspaces,
+                                 const size_t* ws_bytes, int n_members, vog_aql_program** out);
 
 /* ---- AQL programs: the forward as pre-built dispatch packets on user-mode queues ---------------
  * The steady-state path of the validation loop (replaces `for batch in dl: mdl(batch)` of

@@ -231,3 +231,70 @@ def test_aql_golden_parity():
     pred = eng.unpack_pred(slot.out["pred_rec"], ncmp)
     g = np.load(cases.golden_path(name))
     _check_against(name, slot.out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+# ---- language encoder shared by a group of in-flight batches ---------------------------------
+def _group_members(name, n):
+    """n batches of the case's shape with different data seeds (member 0 = the golden case)."""
+    out = []
+    for k in range(n):
+        key = name if k == 0 else f"{name}#m{k}"
+        if k:
+            c = dict(cases.CASES[name])
+            c["dseed"] = c["dseed"] + 101 * k
+            cases.CASES[key] = c
+        try:
+            out.append(cases.build(key))
+        finally:
+            if k:
+                del cases.CASES[key]
+    return out
+
+
+@pytest.mark.parametrize("name,n", [("full/cfg2_vog_spat_gt5_bs4", 4), ("full/cfg2_ragged", 4),
+                                    ("full/vog_sep_gt5_bs4_ragged", 2), ("full/cfg3_vog_temp_gt5_bs8", 2),
+                                    ("full/cfg1_igrnd_spat_gt5_bs2", 3), ("small/vog_spat", 4),
+                                    ("small/vgrnd_sep", 2)])
+@pytest.mark.parametrize("mode", ["eager", "graph", "aql"])
+def test_group_language_encoder_matches_standalone_forwards(name, n, mode):
+    """Every member of a group (one shared BiLSTM pass for all members' sentences) must get the
+    outputs of its own stand-alone forward: rows never interact, only the fp32 summation order of
+    the input-projection GEMMs differs (M = sum of rows picks another tile shape)."""
+    from tests.gpu_util import engine_mod, comm_for
+    members = _group_members(name, n)
+    cfg, sd, _, c = members[0]
+    eng = engine_mod.VogEngine(cfg, comm_for(c))
+    eng.load_state_dict(sd)
+    devs = [{k: torch.from_numpy(v).cuda() for k, v in m[2].items()} for m in members]
+    refs = []
+    for dv in devs:
+        o = eng.forward(dv)
+        refs.append({k: v.clone() for k, v in o.items() if isinstance(v, torch.Tensor)})
+    torch.cuda.synchronize()
+    grp = eng.make_group(devs, graph=(mode == "graph"))
+    for rep in range(2):                      # replay: state is re-zeroed inside the program
+        for s in grp.slots:
+            s.out["mdl_outs"].fill_(float("nan"))
+        torch.cuda.synchronize()
+        if mode == "aql":
+            eng.aql_open(1)
+            grp.build_aql()
+            eng.aql_submit([grp], 0)
+            outs = grp.wait(timeout_us=5_000_000)
+        else:
+            outs = grp.launch()
+            torch.cuda.synchronize()
+        ncmp = members[0][2]["new_srl_idxs"].shape[1]
+        for m, (ref, out) in enumerate(zip(refs, outs)):
+            # a 1-ulp fp32 difference in a gate can flip the 16-bit rounding of h; downstream that is
+            # the same size of perturbation as the 16-bit plan itself (budget: tests/test_quant_budget.py),
+            # so the bound is a fraction of the golden tolerances, not bit equality
+            e = (ref["mdl_outs"] - out["mdl_outs"]).abs().max().item()
+            assert e <= 1.5e-3, (name, mode, m, e)
+            pa, pb = eng.unpack_pred(ref["pred_rec"], ncmp), eng.unpack_pred(out["pred_rec"], ncmp)
+            assert (pa["scores"] - pb["scores"]).abs().max().item() <= 4e-4, (name, mode, m)
+    # member 0 is the golden case: the reference-parity bound holds for the grouped path too
+    g = np.load(cases.golden_path(name))
+    pred = eng.unpack_pred(outs[0]["pred_rec"], ncmp)
+    tol = (1e-3, 6e-3) if name.startswith("full/") else (2e-3, 1.2e-2)
+    _check_against(name, outs[0], pred, g, None, tol_rel=tol[0], tol_logit=tol[1])

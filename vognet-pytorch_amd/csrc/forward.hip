@@ -75,6 +75,7 @@ struct vog_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
   float* emb = nullptr;
+  unsigned short* emb16 = nullptr;                      // 16-bit copy: A operand when the LSTM input GEMM has M > 64
   std::vector<unsigned short*> wih;                     // [layer] [8R, in]
   std::vector<unsigned short*> wih_f;                   // same, fragment order (M <= 64 kernel)
   unsigned short* w_outproj_f = nullptr;
@@ -260,7 +261,7 @@ struct Plan {
   }
 };
 
-static Plan make_plan(const vog_ctx* c, const Geo& g) {
+static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   const vog_model_desc& d = c->d;
   Plan p;
   const int nl = d.rnn_layers;
@@ -283,6 +284,8 @@ static Plan make_plan(const vog_ctx* c, const Geo& g) {
   p.add("gx", (int64_t)g.Bn * g.T * 8 * g.R * 4);
   p.add("full", (int64_t)(g.Bn * g.T + g.Bn16) * g.L * 4);
   p.add("lang", (int64_t)g.Bn * d.nsrl * g.L * 4);
+  p.add("outproj_slabs", (int64_t)8 * (g.Bn * g.T + g.Bn) * g.L * 4);
+  if (lang_only) return p;
   p.add("prop16", g.rows_obj * d.prop_dim * 2);
   p.add("seg16", (int64_t)g.n_vid * g.Fv * d.seg_dim * 2);
   p.add("enc_slabs", (int64_t)16 * (g.rows_obj * d.prop_enc + (int64_t)g.n_vid * g.Fv * d.seg_enc) * 4);
@@ -415,18 +418,25 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
   *out16 = cur16;
 }
 
+// lang_only: just the language chain of `b` (group encoder, vog_lang_forward): only the language
+// inputs of `b` are read and the workspace is the language-only plan.
+// b->shared_lang != NULL: the language chain is NOT run; argument vectors (and the final hidden
+// states for the sep head) come from a group encoder's workspace.
 static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t ws_bytes,
-                       Plan& plan, std::vector<Step>& steps) {
+                       Plan& plan, std::vector<Step>& steps, bool lang_only = false) {
   const vog_model_desc& d = c->d;
   VOG_CHECK_ARG(c->finalized);
   VOG_CHECK_ARG(b && b->B > 0 && b->ncmp > 0 && b->T > 0 && b->T <= d.seq_len);
-  VOG_CHECK_ARG(b->srl_arg_words_ind && b->srl_arg_word_mask && b->srl_arg_word_mask_len &&
-                b->srl_arg_words_capture && b->srl_arg_inds_msk && b->num_cmp_msk &&
-                b->pad_region_feature && b->seg_feature_for_frms && b->pad_proposals);
-  VOG_CHECK_ARG(b->mdl_outs && b->mdl_outs_eval);
+  const bool shared = !lang_only && b->shared_lang != nullptr;
+  VOG_CHECK_ARG(b->srl_arg_inds_msk != nullptr);
+  VOG_CHECK_ARG(shared || (b->srl_arg_words_ind && b->srl_arg_word_mask && b->srl_arg_word_mask_len &&
+                           b->srl_arg_words_capture));
+  VOG_CHECK_ARG(lang_only || (b->num_cmp_msk && b->pad_region_feature && b->seg_feature_for_frms &&
+                              b->pad_proposals && b->mdl_outs && b->mdl_outs_eval));
   const Geo g = make_geo(d, b->B, b->ncmp, b->T);
-  VOG_CHECK_ARG(!g.sep || (b->verb_ind_in_srl && b->vidf_outs && b->fin_scores && b->fin_scores_loss));
-  plan = make_plan(c, g);
+  VOG_CHECK_ARG(lang_only || !g.sep || (b->verb_ind_in_srl && b->vidf_outs && b->fin_scores && b->fin_scores_loss));
+  VOG_CHECK_ARG(!shared || !g.sep || b->shared_final_hidden);
+  plan = make_plan(c, g, lang_only);
   if ((int64_t)ws_bytes < plan.total) VOG_FAIL(-2, "workspace too small: %zu < %lld", ws_bytes, (long long)plan.total);
   WS ws{(char*)wsp, &plan};
   const vog_dtype et = (vog_dtype)d.enc_dtype;
@@ -435,7 +445,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // ---- language path (a14-a16): branch 1
   const size_t lang_begin = steps.size();
   const bool structured = has_mul(d) && (g.d_obj % 64) == 0 && (g.L % 32) == 0 && g.rows_obj > 64;
-  {
+  float* const lang_vec = shared ? const_cast<float*>(b->shared_lang) : ws.at<float>("lang");
+  if (!shared) {
     char* z = ws.base + plan.zero_off;
     const int64_t zb = plan.zero_bytes;
     int32_t* tok = ws.at<int32_t>("tok");
@@ -453,7 +464,11 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       // LSTM outputs feed M <= 64 GEMMs (next layer's input projection, final projection): then the
       // step kernel writes them in A-fragment order and those GEMMs load contiguous fragments
       const bool ofrag = (Bn * T + Bn) <= 64 && !(c->lstm_persistent && vog_bilstm_layer_supported(Bn, R));
-      if (l == 0) { ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E; }
+      if (l == 0) {
+        ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E;
+        // M > 64 runs on the LDS-DMA kernel, which cannot convert in flight: same values, pre-rounded
+        if (Bn * T > 64 && c->emb16 && (g.E % 64) == 0) { ga.a = c->emb16; ga.a_is_f32 = 0; }
+      }
       else {
         ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R;
         ga.a_frag = ofrag ? 1 : 0;
@@ -495,16 +510,31 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     po.rep = 1; po.dtype = et;
     if (po.M <= 64 && c->w_outproj_f) { po.w = c->w_outproj_f; po.w_frag = 1; }
     po.a_frag = ((Bn * T + Bn) <= 64 && !(c->lstm_persistent && vog_bilstm_layer_supported(Bn, R))) ? 1 : 0;
-    steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
+    if (po.M > 64 && (po.K % 512) == 0 && (g.L % 4) == 0) {
+      // few output tiles (L = 256 columns), long K: split K over 8 slabs, bias + ReLU in the finish
+      float* full32 = po.c32;
+      vog_gemm_args ps = po; ps.bias = nullptr; ps.relu = 0; ps.c32 = ws.at<float>("outproj_slabs"); ps.splitk = 8;
+      ps.w_frag = 0; ps.a_frag = 0; ps.w = c->w_outproj; ps.ldw = 2 * R;
+      steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&ps, st); }});
+      vog_splitk_prob f0{};
+      f0.slabs = ps.c32; f0.splits = 8; f0.M = po.M; f0.N = g.L; f0.bias = c->b_outproj; f0.relu = 1; f0.rep = 1;
+      f0.c32 = full32; f0.ldc = g.L;
+      steps.push_back({"lstm_outproj_finish", [=](hipStream_t st) { return vog_splitk_finish(&f0, nullptr, st); }});
+    } else {
+      steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
+    }
     const float* full = po.c32;
-    float* lang = ws.at<float>("lang");
+    float* lang = lang_vec;
     const int64_t *cap = b->srl_arg_words_capture, *im = b->srl_arg_inds_msk;
     const float *wa = c->w_arg, *ba = c->b_arg;
     const int L = g.L;
     steps.push_back({"argvec", [=](hipStream_t st) {
       return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
-    if (structured) {
+  }
+  if (structured && !lang_only) {
+    {
       // language half of mul_tx's layer-0 QKV: depends on `lang` only, so it rides on this branch
+      float* lang = lang_vec;
       const TxWeights& tw = c->mul;
       const TxLayer& L0 = tw.layers[0];
       const int ncol = 3 * tw.H * tw.dp;
@@ -517,6 +547,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     }
   }
   for (size_t i = lang_begin; i < steps.size(); ++i) steps[i].branch = 1;
+  if (lang_only) return 0;
   // ---- visual encoders (a12, a13)
   float* ps32 = ws.at<float>("prop_seg");
   void* ps16 = ws.at<void>("prop_seg16");
@@ -587,7 +618,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
              g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16);
   // ---- vis || lang tokens in mul_tx order (a10, a11)
   vog_vislang_args va{};
-  va.vis = vis32; va.lang = ws.at<float>("lang"); va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
+  va.vis = vis32; va.lang = lang_vec; va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
   va.n_vid = g.n_vid; va.nfrm = g.nfrm; va.nppf = g.nppf; va.nsrl = d.nsrl; va.dv = g.d_obj; va.dl = g.L;
   va.lang_per_vid = g.nvl > 1 ? 1 : 0; va.nc_v = g.nc_v; va.dtype = (vog_dtype)(has_mul(d) ? d.tx_dtype : d.enc_dtype);
   // mul_tx consumes the token structure directly (layer-0 QKV and its residual), so the
@@ -620,7 +651,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   }
   if (g.sep) {
     vog_predcmp_args pa{};
-    pa.final_hidden = ws.at<float>("full") + (int64_t)g.Bn * g.T * g.L;
+    pa.final_hidden = shared ? b->shared_final_hidden : ws.at<float>("full") + (int64_t)g.Bn * g.T * g.L;
     pa.prop_seg = ps32; pa.w0 = c->w_sv0; pa.b0 = c->b_sv0; pa.w2 = c->w_sv2; pa.b2 = c->b_sv2;
     pa.outs = b->mdl_outs; pa.arg_msk = b->srl_arg_inds_msk; pa.cmp_msk = b->num_cmp_msk;
     pa.verb_ind = b->verb_ind_in_srl; pa.vidf_outs = b->vidf_outs; pa.fin_scores_loss = b->fin_scores_loss;
@@ -759,6 +790,7 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
   const vog_model_desc& d = c->d;
   const int R = d.rnn_size, et = d.enc_dtype;
   VOG_TRY(up32(c, "lstm_encoder.embed_tokens.weight", &c->emb));
+  VOG_TRY(up16(c, "lstm_encoder.embed_tokens.weight", d.enc_dtype, &c->emb16));
   for (int l = 0; l < d.rnn_layers; ++l) {
     const int in = l == 0 ? d.emb_dim : 2 * R;
     std::vector<unsigned short> wih((size_t)8 * R * in), whh((size_t)8 * R * R);
@@ -867,6 +899,78 @@ extern "C" int vog_workspace_stage(const vog_ctx* c, int B, int ncmp, int T, con
   return 0;
 }
 
+// ---- group language encoder -------------------------------------------------------------------
+extern "C" int64_t vog_lang_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T) {
+  if (!c || !c->finalized || B <= 0 || ncmp <= 0 || T <= 0) return -1;
+  return make_plan(c, make_geo(c->d, B, ncmp, T), true).total;
+}
+
+extern "C" int vog_lang_workspace_init(const vog_ctx* c, int B, int ncmp, int T, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  VOG_CHECK_ARG(c && ws);
+  const int64_t need = vog_lang_workspace_bytes(c, B, ncmp, T);
+  if (need < 0 || (int64_t)ws_bytes < need) VOG_FAIL(-2, "language workspace too small");
+  VOG_HIP(hipMemsetAsync(ws, 0, (size_t)need, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int vog_lang_outputs(const vog_ctx* c, int B, int ncmp, int T, void* ws, float** lang,
+                                float** final_hidden) {
+  VOG_CHECK_ARG(c && c->finalized && ws && B > 0 && ncmp > 0 && T > 0);
+  const Geo g = make_geo(c->d, B, ncmp, T);
+  Plan p = make_plan(c, g, true);
+  WS w{(char*)ws, &p};
+  if (lang) *lang = w.at<float>("lang");
+  if (final_hidden) *final_hidden = w.at<float>("full") + (int64_t)g.Bn * g.T * g.L;
+  return 0;
+}
+
+extern "C" int vog_lang_forward(vog_ctx* c, const vog_batch* lb, void* ws, size_t ws_bytes, void* stream) {
+  VOG_CHECK_ARG(c && lb && ws);
+  Plan plan;
+  std::vector<Step> steps;
+  VOG_TRY(build_steps(c, lb, ws, ws_bytes, plan, steps, true));
+  for (auto& s : steps) VOG_TRY(s.fn((hipStream_t)stream));
+  return 0;
+}
+
+namespace vog {
+// steps of a whole group: [language chain] + members' forwards; member_of[i] = -1 for language steps
+static int build_group(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes, const vog_batch* const* members,
+                       void* const* wss, const size_t* wbytes, int n, std::vector<Step>& steps,
+                       std::vector<int>& member_of) {
+  VOG_CHECK_ARG(c && lb && lws && members && wss && wbytes && n >= 1 && n <= 16);
+  Plan lp;
+  VOG_TRY(build_steps(c, lb, lws, lbytes, lp, steps, true));
+  member_of.assign(steps.size(), -1);
+  int b_sum = 0;
+  for (int m = 0; m < n; ++m) {
+    VOG_CHECK_ARG(members[m] && wss[m] && members[m]->shared_lang && members[m]->ncmp == lb->ncmp);
+    b_sum += members[m]->B;
+    Plan mp;
+    std::vector<Step> ms;
+    VOG_TRY(build_steps(c, members[m], wss[m], wbytes[m], mp, ms));
+    for (auto& s : ms) {
+      if (s.branch < 0) continue;
+      steps.push_back(s);
+      member_of.push_back(m);
+    }
+  }
+  if (b_sum != lb->B) VOG_FAIL(-1, "group: members hold %d queries, the language batch %d", b_sum, lb->B);
+  return 0;
+}
+}  // namespace vog
+
+extern "C" int vog_group_forward(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes,
+                                 const vog_batch* const* members, void* const* wss, const size_t* wbytes,
+                                 int n, void* stream) {
+  std::vector<Step> steps;
+  std::vector<int> mo;
+  VOG_TRY(vog::build_group(c, lb, lws, lbytes, members, wss, wbytes, n, steps, mo));
+  for (auto& s : steps) VOG_TRY(s.fn((hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int vog_forward(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, void* stream) {
   VOG_CHECK_ARG(c && b && ws);
   Plan plan;
@@ -924,6 +1028,29 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
     if (fe == hipSuccess) fe = hipStreamWaitEvent(st, c->ev_join, 0);
     if (fe != hipSuccess) rc = -(int)fe - 1000;
   }
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) VOG_FAIL(-(int)e - 1000, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  vog_graph* vg = new vog_graph();
+  vg->graph = g;
+  e = hipGraphInstantiate(&vg->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); delete vg; VOG_FAIL(-(int)e - 1000, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  *out = vg;
+  return 0;
+}
+
+extern "C" int vog_group_graph_capture(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes,
+                                       const vog_batch* const* members, void* const* wss,
+                                       const size_t* wbytes, int n, void* stream, vog_graph** out) {
+  VOG_CHECK_ARG(out && stream);
+  std::vector<Step> steps;
+  std::vector<int> mo;
+  VOG_TRY(vog::build_group(c, lb, lws, lbytes, members, wss, wbytes, n, steps, mo));
+  hipStream_t st = (hipStream_t)stream;
+  VOG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (auto& s : steps) { rc = s.fn(st); if (rc != 0) break; }
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(st, &g);
   if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -1014,6 +1141,47 @@ extern "C" int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* ws, 
     }
   }
   for (auto& r : tail) rows.push_back({r});
+  vog_aql_program* pr = new vog_aql_program();
+  rc = vog::aql_program_build(rows, &pr->p);
+  if (rc != 0) { delete pr; return rc; }
+  *out = pr;
+  return 0;
+}
+
+extern "C" int vog_group_aql_program_create(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes,
+                                            const vog_batch* const* members, void* const* wss,
+                                            const size_t* wbytes, int n, vog_aql_program** out) {
+  VOG_CHECK_ARG(out);
+  std::vector<Step> steps;
+  std::vector<int> mo;
+  VOG_TRY(vog::build_group(c, lb, lws, lbytes, members, wss, wbytes, n, steps, mo));
+  // language rows one kernel each; then row r = r-th kernel of every member (independent of each other)
+  std::vector<LaunchRecord> lang;
+  std::vector<std::vector<LaunchRecord>> chains(n);
+  vog::ChainRecorder rec;
+  int rc = 0;
+  vog::g_recorder = &rec;
+  for (size_t i = 0; i < steps.size() && rc == 0; ++i) {
+    rec.dst = mo[i] < 0 ? &lang : &chains[mo[i]];
+    rc = steps[i].fn(vog::recorder_stream());
+  }
+  vog::g_recorder = nullptr;
+  if (rc != 0) return rc;
+  std::vector<std::vector<LaunchRecord>> rows;
+  for (auto& r : lang) rows.push_back({r});
+  size_t longest = 0;
+  for (auto& ch : chains) longest = ch.size() > longest ? ch.size() : longest;
+  for (size_t r = 0; r < longest; ++r) {
+    std::vector<LaunchRecord> row;
+    for (auto& ch : chains) if (r < ch.size()) row.push_back(ch[r]);
+    rows.push_back(row);
+  }
+  // one completion signal rides on the very last packet: close with a single-kernel row
+  if (rows.back().size() > 1) {
+    std::vector<LaunchRecord> last = rows.back();
+    rows.pop_back();
+    for (auto& r : last) rows.push_back({r});
+  }
   vog_aql_program* pr = new vog_aql_program();
   rc = vog::aql_program_build(rows, &pr->p);
   if (rc != 0) { delete pr; return rc; }

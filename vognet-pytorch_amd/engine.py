@@ -206,6 +206,13 @@ class VogEngine:
         arr = (C.c_void_p * len(slots))(*[s.aql for s in slots])
         L.check(self.lib.vog_aql_submit(arr, len(slots), int(queue)), "vog_aql_submit")
 
+    def make_group(self, inps, with_pred: bool = True, graph: bool = True) -> "Group":
+        """Several batches whose LANGUAGE encoder runs once for all of them (W_hh is streamed once
+        per recurrent step instead of once per batch per step; include/vog_hip.h, "language
+        encoder over a group"). Every member keeps its own inputs, outputs and workspace, and its
+        outputs equal its stand-alone forward up to fp32 summation order."""
+        return Group(self, inps, with_pred, graph)
+
     def set_option(self, name: str, value: int) -> None:
         """Integer options of the context: 'graph_dag', 'lstm_persistent' (include/vog_hip.h)."""
         L.check(self.lib.vog_ctx_set_int(self.ctx, name.encode(), int(value)), f"vog_ctx_set_int({name})")
@@ -314,6 +321,108 @@ class Slot:
     def __del__(self):
         try:
             if getattr(self, "aql", None) is not None:
+                self.eng.lib.vog_aql_program_destroy(self.aql)
+            if self.graph is not None:
+                self.eng.lib.vog_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+LANG_KEYS = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", "srl_arg_words_capture",
+             "srl_arg_inds_msk")
+
+
+class Group:
+    """G batch slots + one shared language-encoder workspace + one graph / AQL program for all."""
+
+    def __init__(self, eng: VogEngine, inps, with_pred=True, graph=True):
+        assert len(inps) >= 1
+        self.eng = eng
+        dev = eng.device
+        d = eng.desc
+
+        def dev_t(v):
+            return (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))).to(dev)
+
+        # the members' word-level arrays live back to back: the group encoder reads them as ONE batch
+        self.lang_in = {k: torch.cat([dev_t(i[k]) for i in inps], dim=0).contiguous() for k in LANG_KEYS}
+        sizes = [int(dev_t(i["srl_arg_words_ind"]).shape[0]) for i in inps]
+        assert len(set(sizes)) == 1, "group members must have the same batch size"
+        B = sizes[0]
+        self.slots = []
+        with torch.cuda.device(dev):
+            T_max = int(self.lang_in["srl_arg_word_mask_len"].max().item())
+            for m, inp in enumerate(inps):
+                mi = {k: dev_t(v) for k, v in inp.items() if k not in LANG_KEYS}
+                for k in LANG_KEYS:
+                    mi[k] = self.lang_in[k][m * B:(m + 1) * B]
+                self.slots.append(Slot(eng, mi, T_max, with_pred, graph=False))
+            s0 = self.slots[0]
+            self.B_total, self.ncmp, self.T = B * len(inps), s0.ncmp, T_max
+            n = eng.lib.vog_lang_workspace_bytes(eng.ctx, self.B_total, self.ncmp, self.T)
+            self.lang_ws = torch.empty(int(n), dtype=torch.uint8, device=dev)
+            L.check(eng.lib.vog_lang_workspace_init(eng.ctx, self.B_total, self.ncmp, self.T,
+                                                    self.lang_ws.data_ptr(), self.lang_ws.numel(), L.stream_ptr()),
+                    "vog_lang_workspace_init")
+            self.lb = L.Batch()
+            self.lb.B, self.lb.ncmp, self.lb.T = self.B_total, self.ncmp, self.T
+            for k in LANG_KEYS:
+                setattr(self.lb, k, L.ptr(self.lang_in[k]))
+            lang, fh = C.c_void_p(), C.c_void_p()
+            L.check(eng.lib.vog_lang_outputs(eng.ctx, self.B_total, self.ncmp, self.T, self.lang_ws.data_ptr(),
+                                             C.byref(lang), C.byref(fh)), "vog_lang_outputs")
+            nvl = self.ncmp if eng.sep else 1
+            for m, sl in enumerate(self.slots):
+                sl.batch.shared_lang = lang.value + m * B * nvl * d.nsrl * d.lang_enc * 4
+                sl.batch.shared_final_hidden = fh.value + m * B * nvl * d.lang_enc * 4
+            G = len(self.slots)
+            self._members = (C.POINTER(L.Batch) * G)(*[C.pointer(sl.batch) for sl in self.slots])
+            self._wss = (C.c_void_p * G)(*[sl.ws.data_ptr() for sl in self.slots])
+            self._wsb = (C.c_size_t * G)(*[sl.ws.numel() for sl in self.slots])
+            self.graph = None
+            self.aql = None
+            torch.cuda.synchronize()
+            if graph:
+                cap = torch.cuda.Stream(device=dev)
+                g = C.c_void_p()
+                L.check(eng.lib.vog_group_graph_capture(eng.ctx, C.byref(self.lb), self.lang_ws.data_ptr(),
+                                                        self.lang_ws.numel(), self._members, self._wss, self._wsb,
+                                                        G, cap.cuda_stream, C.byref(g)), "vog_group_graph_capture")
+                self.graph = g
+                torch.cuda.synchronize()
+
+    @property
+    def out(self):
+        return [s.out for s in self.slots]
+
+    def launch(self, stream: Optional[torch.cuda.Stream] = None):
+        sp = L.stream_ptr(stream)
+        if self.graph is not None:
+            L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
+        else:
+            L.check(self.eng.lib.vog_group_forward(self.eng.ctx, C.byref(self.lb), self.lang_ws.data_ptr(),
+                                                   self.lang_ws.numel(), self._members, self._wss, self._wsb,
+                                                   len(self.slots), sp), "vog_group_forward")
+        return self.out
+
+    def build_aql(self) -> "Group":
+        if self.aql is None:
+            with torch.cuda.device(self.eng.device):
+                torch.cuda.synchronize()
+                p = C.c_void_p()
+                L.check(self.eng.lib.vog_group_aql_program_create(
+                    self.eng.ctx, C.byref(self.lb), self.lang_ws.data_ptr(), self.lang_ws.numel(), self._members,
+                    self._wss, self._wsb, len(self.slots), C.byref(p)), "vog_group_aql_program_create")
+                self.aql = p
+        return self
+
+    def wait(self, timeout_us: int = 10_000_000):
+        L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
+        return self.out
+
+    def __del__(self):
+        try:
+            if self.aql is not None:
                 self.eng.lib.vog_aql_program_destroy(self.aql)
             if self.graph is not None:
                 self.eng.lib.vog_graph_destroy(self.graph)

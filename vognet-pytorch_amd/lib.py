@@ -133,7 +133,8 @@ class Batch(C.Structure):
                 ("srl_arg_inds_msk", c_vp), ("num_cmp_msk", c_vp), ("verb_ind_in_srl", c_vp),
                 ("pad_region_feature", c_vp), ("seg_feature_for_frms", c_vp), ("pad_proposals", c_vp),
                 ("mdl_outs", c_vp), ("mdl_outs_eval", c_vp), ("vidf_outs", c_vp),
-                ("fin_scores_loss", c_vp), ("fin_scores", c_vp), ("pred_rec", c_vp)]
+                ("fin_scores_loss", c_vp), ("fin_scores", c_vp), ("pred_rec", c_vp),
+                ("shared_lang", c_vp), ("shared_final_hidden", c_vp)]
 
 
 # every symbol include/vog_hip.h declares: name -> (restype, argtypes)
@@ -178,6 +179,17 @@ SYMBOLS = {
     "vog_ctx_set_int": (c_i32, [c_vp, C.c_char_p, c_i32]),
     "vog_graph_launch": (c_i32, [c_vp, c_vp]),
     "vog_graph_destroy": (c_i32, [c_vp]),
+    "vog_lang_workspace_bytes": (c_i64, [c_vp, c_i32, c_i32, c_i32]),
+    "vog_lang_workspace_init": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, C.c_size_t, c_vp]),
+    "vog_lang_forward": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp]),
+    "vog_lang_outputs": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp), C.POINTER(c_vp)]),
+    "vog_group_forward": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.POINTER(C.POINTER(Batch)),
+                                  C.POINTER(c_vp), C.POINTER(C.c_size_t), c_i32, c_vp]),
+    "vog_group_graph_capture": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.POINTER(C.POINTER(Batch)),
+                                        C.POINTER(c_vp), C.POINTER(C.c_size_t), c_i32, c_vp, C.POINTER(c_vp)]),
+    "vog_group_aql_program_create": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t,
+                                             C.POINTER(C.POINTER(Batch)), C.POINTER(c_vp),
+                                             C.POINTER(C.c_size_t), c_i32, C.POINTER(c_vp)]),
     "vog_aql_open": (c_i32, [c_i32]),
     "vog_aql_program_create": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_i32, C.POINTER(c_vp)]),
     "vog_aql_program_info": (c_i32, [c_vp, C.POINTER(c_i32), C.POINTER(c_i32)]),
