@@ -231,6 +231,7 @@ int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
 typedef struct vog_lstm_layer_args {
   const float* gxs; const void* whh; void* hx; uint32_t* sync; void* out16;
   const int64_t* lens; int Bn, T, R; vog_dtype dtype;
+  int out_frag;   /* 1: out16 in the A-fragment order of vog_gemm_args.a_frag (as vog_bilstm_step) */
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);
 int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream);

@@ -70,7 +70,7 @@ struct vog_ctx {
   std::vector<void*> allocs;
   bool finalized = false;
   int graph_dag = 0;                    // capture the language chain as a parallel branch
-  int lstm_persistent = 0;              // one launch per BiLSTM layer (opt-in: measured slower, see vog_hip.h)
+  int lstm_persistent = 0;              // one launch per BiLSTM layer (W_hh resident on chip; see vog_hip.h)
   hipStream_t side = nullptr;           // language branch during graph capture
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
@@ -276,7 +276,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_hA2_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);   // ping buffer when out16 is fragment-ordered
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
     p.add("lstm_hx_" + std::to_string(l), (int64_t)2 * 2 * 16 * g.R * 2);
-    p.add("lstm_sync_" + std::to_string(l), 64);
+    p.add("lstm_sync_" + std::to_string(l), 1024);   // [0..3] status words, [4 + dir*64 + g] arrival flags
   }
   p.zero_bytes = p.total - p.zero_off;
   p.add("tok", (int64_t)g.Bn * g.T * 4);
@@ -463,7 +463,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       vog_gemm_args ga{}; ga.c16_dtype = -1;
       // LSTM outputs feed M <= 64 GEMMs (next layer's input projection, final projection): then the
       // step kernel writes them in A-fragment order and those GEMMs load contiguous fragments
-      const bool ofrag = (Bn * T + Bn) <= 64 && !(c->lstm_persistent && vog_bilstm_layer_supported(Bn, R));
+      const bool ofrag = (Bn * T + Bn) <= 64;
       if (l == 0) {
         ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E;
         // M > 64 runs on the LDS-DMA kernel, which cannot convert in flight: same values, pre-rounded
@@ -489,7 +489,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         pa.gxs = gx; pa.whh = c->whh[l]; pa.hx = ws.at<void>("lstm_hx_" + std::to_string(l));
         pa.sync = ws.at<uint32_t>("lstm_sync_" + std::to_string(l));
         pa.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
-        pa.lens = b->srl_arg_word_mask_len; pa.Bn = Bn; pa.T = T; pa.R = R; pa.dtype = et;
+        pa.lens = b->srl_arg_word_mask_len; pa.Bn = Bn; pa.T = T; pa.R = R; pa.dtype = et; pa.out_frag = ofrag ? 1 : 0;
         steps.push_back({"lstm_layer", [=](hipStream_t st) { return vog_bilstm_layer(&pa, st); }});
         continue;
       }
@@ -509,7 +509,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     po.c32 = ws.at<float>("full"); po.ldc = g.L; po.M = Bn * T + Bn; po.N = g.L; po.K = 2 * R;
     po.rep = 1; po.dtype = et;
     if (po.M <= 64 && c->w_outproj_f) { po.w = c->w_outproj_f; po.w_frag = 1; }
-    po.a_frag = ((Bn * T + Bn) <= 64 && !(c->lstm_persistent && vog_bilstm_layer_supported(Bn, R))) ? 1 : 0;
+    po.a_frag = (Bn * T + Bn) <= 64 ? 1 : 0;
     if (po.M > 64 && (po.K % 512) == 0 && (g.L % 4) == 0) {
       // few output tiles (L = 256 columns), long K: split K over 8 slabs, bias + ReLU in the finish
       float* full32 = po.c32;
@@ -703,6 +703,8 @@ extern "C" int vog_ctx_create(const vog_model_desc* d, vog_ctx** out) {
   VOG_CHECK_ARG(d->nsrl > 0 && d->seq_len > 0 && d->nfrm0 > 0 && d->nppf0 > 0 && d->rnn_layers > 0);
   vog_ctx* c = new vog_ctx();
   c->d = *d;
+  // VOG_LSTM_PERSISTENT=0/1 presets the option (test sweeps); vog_ctx_set_int overrides it
+  if (const char* e = getenv("VOG_LSTM_PERSISTENT")) c->lstm_persistent = atoi(e) ? 1 : 0;
   const int R = d->rnn_size, E = d->emb_dim, L = d->lang_enc;
   add_w(c, "lstm_encoder.embed_tokens.weight", (int64_t)(d->vocab_size + 1) * E);
   for (int l = 0; l < d->rnn_layers; ++l)

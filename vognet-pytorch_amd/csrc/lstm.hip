@@ -144,13 +144,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
 // ----------------------------------------------------------------------------
 struct LstmLayerParams {
   const float* gxs; const unsigned short* whh; unsigned long long* hx; unsigned int* sync;
-  unsigned short* out16; const int64_t* lens; int Bn, T, R;
+  unsigned short* out16; const int64_t* lens; int Bn, T, R; int out_frag;
 };
 
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 template <typename T16, int KSTEPS>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
+  constexpr int RW = KSTEPS * 32, HS_LD = RW + 8;          // +8 halfwords: rows land on different banks
+  __shared__ __attribute__((aligned(16))) unsigned short hs[16 * HS_LD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.y, G = gridDim.x;
@@ -174,7 +176,15 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
   const int64_t hx_par = (int64_t)2 * 16 * R / 4;
   bool dead = false;
 
+#ifdef VOG_TS_DEBUG
+#define VOG_TSL(slot) do { if (tid == 0 && blockIdx.x == 3) g_ts[s][dir][slot & 3] = wall_clock64(); } while (0)
+#define VOG_TSL2(slot) do { if (tid == 0 && blockIdx.x == 3) g_ts[s][2 + dir][slot & 3] = wall_clock64(); } while (0)
+#else
+#define VOG_TSL(slot) do { } while (0)
+#define VOG_TSL2(slot) do { } while (0)
+#endif
   for (int s = 0; s < p.T; ++s) {
+    VOG_TSL(0);
     // input projections of this step (address-independent of everything else)
     float gin[2][4];
 #pragma unroll
@@ -183,27 +193,31 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
       for (int r = 0; r < 4; ++r)
         gin[t][r] = valid_b ? p.gxs[(((int64_t)dir * p.T + s) * p.Bn + b) * 4 * R + (int64_t)r * R + (tile0 + t) * 4 + ul]
                             : 0.f;
-    // h_{s-1} of ALL units: written by the other workgroups with write-through atomics,
-    // read here with L1-bypassing atomics (agent scope on both sides: no fences needed)
-    const unsigned long long* hp = p.hx + (s & 1) * hx_par + hx_dir + (int64_t)b * R / 4;
+    // h_{s-1} of ALL units: written by the other workgroups with write-through atomics, read
+    // with L1-bypassing atomics (agent scope on both sides: no fences needed). The four waves need
+    // the same Bn x R vector: the workgroup fetches it ONCE, 8 bytes per thread per sentence, into
+    // LDS (measured: per-lane fragment loads, 64 dependent-ish 8-byte atomics per lane, were 7.4 of
+    // a 9.6 us step) and every wave reads its MFMA B fragments from there.
+    {
+      const unsigned long long* hsrc = p.hx + (s & 1) * hx_par + hx_dir;
+      for (int row = 0; row < p.Bn; ++row)
+        for (int cc = tid; cc < RW / 4; cc += 256) {
+          const unsigned long long v = __hip_atomic_load(hsrc + (int64_t)row * (R / 4) + cc, VOG_RLX_AGENT);
+          *reinterpret_cast<unsigned long long*>(&hs[row * HS_LD + cc * 4]) = v;
+        }
+    }
+    __syncthreads();
     f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      unsigned long long lo = 0, hi = 0;
-      if (valid_b) {
-        lo = __hip_atomic_load(hp + (ks * 32 + kg) / 4, VOG_RLX_AGENT);
-        hi = __hip_atomic_load(hp + (ks * 32 + kg) / 4 + 1, VOG_RLX_AGENT);
-      }
-      u16x8 fh;
-      fh[0] = (unsigned short)lo; fh[1] = (unsigned short)(lo >> 16); fh[2] = (unsigned short)(lo >> 32);
-      fh[3] = (unsigned short)(lo >> 48);
-      fh[4] = (unsigned short)hi; fh[5] = (unsigned short)(hi >> 16); fh[6] = (unsigned short)(hi >> 32);
-      fh[7] = (unsigned short)(hi >> 48);
+      u16x8 fh = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid_b) fh = *reinterpret_cast<const u16x8*>(&hs[b * HS_LD + ks * 32 + kg]);
       acc[0] = mfma16<T16>(wf[0][ks], fh, acc[0]);
       acc[1] = mfma16<T16>(wf[1][ks], fh, acc[1]);
     }
+    VOG_TSL(1);
     const bool active = s < len;
     const int pos = dir == 0 ? s : len - 1 - s;
 #pragma unroll
@@ -216,7 +230,8 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
         const float hn = sigm(go) * tanh_(c[t]);
         const unsigned short h16 = to16<T16>(hn);
         h_own[t] = from16<T16>(h16);
-        p.out16[((int64_t)b * p.T + pos) * 2 * R + (int64_t)dir * R + unit] = h16;
+        if (p.out_frag) p.out16[frag_a(b * p.T + pos, dir * R + unit, 2 * R)] = h16;
+        else p.out16[((int64_t)b * p.T + pos) * 2 * R + (int64_t)dir * R + unit] = h16;
       }
       // publish h_s of this tile: 4 units of one sentence = one 8-byte write-through store
       const unsigned int x0 = to16<T16>(h_own[t]);
@@ -229,31 +244,42 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
       }
     }
     if (s + 1 == p.T) break;                             // nothing reads h_T through hx
-    // arrive (all stores of this workgroup acknowledged first), then wait for the other G-1
+    // arrive: one flag per producer workgroup (no read-modify-write on a shared counter), raised
+    // after all of this workgroup's write-through stores are acknowledged; wave 0 polls the G
+    // flags of its direction in parallel, one lane per producer
+    VOG_TSL(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VOG_TSL(3);
     __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(p.sync + dir, 1u, VOG_RLX_AGENT);
-      const unsigned int want = (unsigned int)G * (unsigned int)(s + 1);
-      if (!dead) {
-        unsigned int spins = 0;
-        while (__hip_atomic_load(p.sync + dir, VOG_RLX_AGENT) < want) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 21)) {                    // ~1 s: give up, flag, drain
-            __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
-            break;
-          }
+    VOG_TSL2(0);
+    unsigned int* flags = p.sync + 4 + dir * 64;
+    if (tid == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned int)(s + 1), VOG_RLX_AGENT);
+    if (wid == 0 && !dead) {
+      unsigned int spins = 0;
+      for (;;) {
+        const unsigned int v = lane < G ? __hip_atomic_load(flags + lane, VOG_RLX_AGENT) : 0xffffffffu;
+        if (__all(v >= (unsigned int)(s + 1))) break;
+        if (++spins > (1u << 21)) {                        // ~1 s: give up, flag, drain
+          if (lane == 0) __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
+          break;
         }
       }
     }
     __syncthreads();
+    VOG_TSL2(1);
     if (!dead && __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0) dead = true;   // uniform enough: only skips waits
   }
-  // final hidden state rows (h of the last ACTIVE step of every sentence)
+  // final hidden state rows (h of the last ACTIVE step of every sentence). A stalled hand-off
+  // (a producer workgroup never became resident: more of these kernels in flight than the chip
+  // holds, see vog_hip.h) must not pass for a result: poison the rows with NaN.
   if (valid_b) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-      p.out16[((int64_t)p.Bn * p.T + b) * 2 * R + (int64_t)dir * R + (tile0 + t) * 4 + ul] = to16<T16>(h_own[t]);
+    for (int t = 0; t < 2; ++t) {
+      const int unit = (tile0 + t) * 4 + ul;
+      const unsigned short v = dead ? (unsigned short)0x7fff : to16<T16>(h_own[t]);
+      if (p.out_frag) p.out16[frag_a(p.Bn * p.T + b, dir * R + unit, 2 * R)] = v;
+      else p.out16[((int64_t)p.Bn * p.T + b) * 2 * R + (int64_t)dir * R + unit] = v;
+    }
   }
 }
 
@@ -292,7 +318,7 @@ extern "C" int vog_bilstm_step(const vog_lstm_step_args* a, void* stream) {
 
 extern "C" int vog_bilstm_layer_supported(int Bn, int R) {
   const int ks = R / 32;
-  return Bn >= 1 && Bn <= 16 && R % 32 == 0 && (ks == 1 || ks == 2 || ks == 4 || ks == 32);
+  return Bn >= 1 && Bn <= 16 && R % 32 == 0 && R / 32 <= 64 && (ks == 1 || ks == 2 || ks == 4 || ks == 32);
 }
 
 extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
@@ -300,7 +326,7 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
   if (!vog_bilstm_layer_supported(a->Bn, a->R))
     VOG_FAIL(-1, "persistent BiLSTM layer: unsupported Bn=%d R=%d (use vog_bilstm_step)", a->Bn, a->R);
   vog::LstmLayerParams p{a->gxs, (const unsigned short*)a->whh, (unsigned long long*)a->hx, a->sync,
-                         (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R};
+                         (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R, a->out_frag};
   dim3 grid(a->R / 32, 2);
   hipStream_t st = (hipStream_t)stream;
 #define VOG_LAUNCH_LAYER(KS)                                                                     \

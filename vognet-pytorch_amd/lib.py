@@ -81,7 +81,7 @@ class LstmStepArgs(C.Structure):
 
 class LstmLayerArgs(C.Structure):
     _fields_ = [("gxs", c_vp), ("whh", c_vp), ("hx", c_vp), ("sync", c_vp), ("out16", c_vp),
-                ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32)]
+                ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32), ("out_frag", c_i32)]
 
 
 class VislangArgs(C.Structure):
