@@ -275,7 +275,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_hB_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);
     p.add("lstm_hA2_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);   // ping buffer when out16 is fragment-ordered
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
-    p.add("lstm_hx_" + std::to_string(l), (int64_t)2 * 2 * 16 * g.R * 2);
+    p.add("lstm_hx_" + std::to_string(l), (int64_t)2 * 2 * 16 * (g.R / 2) * 8);   // tagged hand-off words
     p.add("lstm_sync_" + std::to_string(l), 1024);   // [0..3] status words, [4 + dir*64 + g] arrival flags
   }
   p.zero_bytes = p.total - p.zero_off;
@@ -1227,18 +1227,28 @@ extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t 
   for (auto& x : steps) if (x.name == kernel && x.branch >= 0) { s = &x; break; }
   if (!s) VOG_FAIL(-4, "no kernel step '%s'", kernel);
   hipStream_t st = (hipStream_t)stream;
+  // the persistent layer kernel consumes per-forward state (hand-off tags zeroed by lang_prep):
+  // time (lang_prep + layer) pairs and subtract lang_prep timed alone the same way
+  const Step* reset = nullptr;
+  if (s->name == "lstm_layer")
+    for (auto& x : steps) if (x.name == "lang_prep") { reset = &x; break; }
   hipEvent_t e0, e1;
   VOG_HIP(hipEventCreate(&e0));
   VOG_HIP(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) VOG_TRY(s->fn(st));
-  VOG_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) VOG_TRY(s->fn(st));
-  VOG_HIP(hipEventRecord(e1, st));
-  VOG_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  VOG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  auto timed = [&](const Step* a, const Step* b2, float* out_ms) -> int {
+    for (int i = 0; i < 3; ++i) { if (a) VOG_TRY(a->fn(st)); if (b2) VOG_TRY(b2->fn(st)); }
+    VOG_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) { if (a) VOG_TRY(a->fn(st)); if (b2) VOG_TRY(b2->fn(st)); }
+    VOG_HIP(hipEventRecord(e1, st));
+    VOG_HIP(hipEventSynchronize(e1));
+    VOG_HIP(hipEventElapsedTime(out_ms, e0, e1));
+    return 0;
+  };
+  float ms = 0.f, ms_reset = 0.f;
+  VOG_TRY(timed(reset, s, &ms));
+  if (reset) VOG_TRY(timed(reset, nullptr, &ms_reset));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  *usec = ms * 1000.0f / (float)iters;
+  *usec = (ms - ms_reset) * 1000.0f / (float)iters;
   return 0;
 }

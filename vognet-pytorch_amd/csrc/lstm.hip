@@ -172,8 +172,11 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
           p.whh + ((((int64_t)dir * (R / 4) + tile0 + t) * KSTEPS + ks) * 64 + lane) * 8);
 
   float c[2] = {0.f, 0.f}, h_own[2] = {0.f, 0.f};
-  const int64_t hx_dir = (int64_t)dir * 16 * R / 4;        // u64 units; [parity][dir][16][R]
-  const int64_t hx_par = (int64_t)2 * 16 * R / 4;
+  // hand-off buffer, u64 words: [parity][dir][16 sentences][R/2]; a word = two 16-bit h values +
+  // the 32-bit number of the step that produced them. The tag makes every word self-validating:
+  // a consumer needs no arrival flag and no acknowledgement wait, just one (re-tried) load.
+  const int64_t hx_dir = (int64_t)dir * 16 * (R / 2);
+  const int64_t hx_par = (int64_t)2 * 16 * (R / 2);
   bool dead = false;
 
 #ifdef VOG_TS_DEBUG
@@ -200,13 +203,45 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
     // a 9.6 us step) and every wave reads its MFMA B fragments from there.
     {
       const unsigned long long* hsrc = p.hx + (s & 1) * hx_par + hx_dir;
-      for (int row = 0; row < p.Bn; ++row)
-        for (int cc = tid; cc < RW / 4; cc += 256) {
-          const unsigned long long v = __hip_atomic_load(hsrc + (int64_t)row * (R / 4) + cc, VOG_RLX_AGENT);
-          *reinterpret_cast<unsigned long long*>(&hs[row * HS_LD + cc * 4]) = v;
+      const int items = p.Bn * (RW / 2);                   // words to fetch: sentence-major
+      for (int base = tid; base < items; base += 256 * 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int it = base + j * 256;
+          v[j] = it < items ? __hip_atomic_load(hsrc + (int64_t)(it / (RW / 2)) * (R / 2) + it % (RW / 2), VOG_RLX_AGENT)
+                            : ((unsigned long long)(unsigned)s << 32);
         }
+        // re-fetch, as ONE batch per round, the words whose producer had not stored yet (a
+        // word-at-a-time retry chain cost up to 8 sequential fabric round trips per step)
+        unsigned int spins = 0;
+        for (;;) {
+          bool stale = false;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            stale |= (base + j * 256 < items) && (unsigned int)(v[j] >> 32) != (unsigned int)s;
+          if (!stale || dead) break;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int it = base + j * 256;
+            if (it < items && (unsigned int)(v[j] >> 32) != (unsigned int)s)
+              v[j] = __hip_atomic_load(hsrc + (int64_t)(it / (RW / 2)) * (R / 2) + it % (RW / 2), VOG_RLX_AGENT);
+          }
+          if ((++spins & 255u) == 0 &&
+              (spins > (1u << 20) || __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0)) {   // ~1 s: give up
+            __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
+            dead = true;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int it = base + j * 256;
+          if (it < items)
+            *reinterpret_cast<unsigned int*>(&hs[(it / (RW / 2)) * HS_LD + (it % (RW / 2)) * 2]) = (unsigned int)v[j];
+        }
+      }
     }
-    __syncthreads();
+    dead = __syncthreads_or(dead ? 1 : 0) != 0;
     f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -237,37 +272,16 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmLayerParams p) {
       const unsigned int x0 = to16<T16>(h_own[t]);
       const unsigned int x1 = __shfl(x0, b + 16), x2 = __shfl(x0, b + 32), x3 = __shfl(x0, b + 48);
       if (lane < 16 && valid_b) {
-        const unsigned long long v = (unsigned long long)x0 | ((unsigned long long)x1 << 16) |
-                                     ((unsigned long long)x2 << 32) | ((unsigned long long)x3 << 48);
-        __hip_atomic_store(p.hx + ((s + 1) & 1) * hx_par + hx_dir + ((int64_t)b * R + (tile0 + t) * 4) / 4, v,
-                           VOG_RLX_AGENT);
+        const unsigned long long tag = (unsigned long long)(unsigned int)(s + 1) << 32;
+        unsigned long long* dst = p.hx + ((s + 1) & 1) * hx_par + hx_dir + (int64_t)b * (R / 2) + (tile0 + t) * 2;
+        __hip_atomic_store(dst, tag | x0 | ((unsigned long long)x1 << 16), VOG_RLX_AGENT);
+        __hip_atomic_store(dst + 1, tag | x2 | ((unsigned long long)x3 << 16), VOG_RLX_AGENT);
       }
     }
     if (s + 1 == p.T) break;                             // nothing reads h_T through hx
-    // arrive: one flag per producer workgroup (no read-modify-write on a shared counter), raised
-    // after all of this workgroup's write-through stores are acknowledged; wave 0 polls the G
-    // flags of its direction in parallel, one lane per producer
     VOG_TSL(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    VOG_TSL(3);
-    __syncthreads();
-    VOG_TSL2(0);
-    unsigned int* flags = p.sync + 4 + dir * 64;
-    if (tid == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned int)(s + 1), VOG_RLX_AGENT);
-    if (wid == 0 && !dead) {
-      unsigned int spins = 0;
-      for (;;) {
-        const unsigned int v = lane < G ? __hip_atomic_load(flags + lane, VOG_RLX_AGENT) : 0xffffffffu;
-        if (__all(v >= (unsigned int)(s + 1))) break;
-        if (++spins > (1u << 21)) {                        // ~1 s: give up, flag, drain
-          if (lane == 0) __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
+    __syncthreads();                                     // hs is rewritten at the top of the next step
     VOG_TSL2(1);
-    if (!dead && __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0) dead = true;   // uniform enough: only skips waits
   }
   // final hidden state rows (h of the last ACTIVE step of every sentence). A stalled hand-off
   // (a producer workgroup never became resident: more of these kernels in flight than the chip
