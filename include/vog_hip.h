@@ -187,7 +187,11 @@ int vog_lstm_schedule(const int64_t* lens, int32_t* rows, int Bn, int T, void* s
  * packed-sequence schedule. */
 int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
                   const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
-                  int seq_len, int vocab_size, void* stream);
+                  int seq_len, int vocab_size,
+                  /* optional (a0_frag != NULL): also gather the tokens' 16-bit embedding rows
+                   * [vocab+1, emb_dim] into a0_frag in the A-fragment order of vog_gemm_args.a_frag
+                   * (rows beyond Bn*T of the last 16-row tile must already be zero) */
+                  const void* emb16, void* a0_frag, int emb_dim, void* stream);
 
 /* Fused prologue of the visual path (one launch instead of vog_cast_f32_to_t16 + up to two
  * vog_box_u): u0/u1 = bias precursors for obj_tx / mul_tx (either w_pe may be NULL). */

@@ -436,10 +436,25 @@ __global__ __launch_bounds__(256) void lang_prep_kernel(uint4* __restrict__ zero
                                                         const int64_t* __restrict__ mask,
                                                         const int64_t* __restrict__ lens,
                                                         int32_t* __restrict__ tok, int32_t* __restrict__ rows,
-                                                        int Bn, int T, int nsrl, int seq_len, int vocab) {
+                                                        int Bn, int T, int nsrl, int seq_len, int vocab,
+                                                        const unsigned short* __restrict__ emb16,
+                                                        unsigned short* __restrict__ a0, int E) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = gid; i < zero16; i += stride) zero[i] = make_uint4(0, 0, 0, 0);
+  if (a0) {
+    // embedding rows of the Bn*T tokens, 16 bit, in the A-fragment order of the M <= 64 GEMM:
+    // one 16-byte chunk (8 consecutive k of one token) per thread
+    const int cpr = E / 8;
+    for (int64_t j = gid; j < (int64_t)Bn * T * cpr; j += stride) {
+      const int i = (int)(j / cpr), ch = (int)(j % cpr), b = i / T, t = i % T;
+      const int64_t m = mask[(int64_t)b * seq_len + t];
+      int64_t v = vocab;
+      if (m >= 0 && m < (int64_t)nsrl * seq_len) v = words[(int64_t)b * nsrl * seq_len + m];
+      *reinterpret_cast<uint4*>(a0 + frag_a(i, ch * 8, E)) =
+          *reinterpret_cast<const uint4*>(emb16 + v * E + ch * 8);
+    }
+  }
   if (gid < (int64_t)Bn * T) {
     const int i = (int)gid, b = i / T, t = i % T;
     const int64_t m = mask[(int64_t)b * seq_len + t];
@@ -510,16 +525,21 @@ extern "C" int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, co
 
 extern "C" int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
                              const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
-                             int seq_len, int vocab_size, void* stream) {
+                             int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
+                             void* stream) {
   VOG_CHECK_ARG(words_ind && word_mask && lens && tok && rows && Bn > 0 && T > 0 && T <= seq_len);
+  VOG_CHECK_ARG(!a0_frag || (emb16 && emb_dim > 0 && (emb_dim % 32) == 0));
   VOG_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && (zero_bytes == 0 || zero));
   const int64_t z16 = zero_bytes / 16;
   int64_t blocks = (z16 + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  const int64_t need = ((int64_t)Bn * T + 255) / 256;
+  int64_t need = ((int64_t)Bn * T + 255) / 256;
+  if (a0_frag) { const int64_t n2 = ((int64_t)Bn * T * (emb_dim / 8) + 255) / 256; need = n2 > need ? n2 : need; }
+  if (need > 1024) need = 1024;
   if (blocks < need) blocks = need;
   ::vog::launch(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size);
+                     (uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size,
+                     (const unsigned short*)emb16, (unsigned short*)a0_frag, emb_dim);
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -279,6 +279,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_sync_" + std::to_string(l), 1024);   // [0..3] status words, [4 + dir*64 + g] arrival flags
   }
   p.zero_bytes = p.total - p.zero_off;
+  p.add("emb_a0", round_up64(g.Bn * g.T, 16) * g.E * 2);   // layer-0 A operand in fragment order (M <= 64)
   p.add("tok", (int64_t)g.Bn * g.T * 4);
   p.add("lstm_rows", (int64_t)2 * g.Bn * g.T * 4);
   p.add("gx", (int64_t)g.Bn * g.T * 8 * g.R * 4);
@@ -456,8 +457,12 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     int32_t* lrows = ws.at<int32_t>("lstm_rows");
     {
       const int64_t* lens = b->srl_arg_word_mask_len;
+      const bool a0f = Bn * T <= 64 && c->emb16 && (g.E % 32) == 0;
+      const void* e16 = c->emb16;
+      void* a0 = a0f ? ws.at<void>("emb_a0") : nullptr;
+      const int E = g.E;
       steps.push_back({"lang_prep", [=](hipStream_t st) {
-        return vog_lang_prep(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, st); }});
+        return vog_lang_prep(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, st); }});
     }
     for (int l = 0; l < d.rnn_layers; ++l) {
       vog_gemm_args ga{}; ga.c16_dtype = -1;
@@ -468,6 +473,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E;
         // M > 64 runs on the LDS-DMA kernel, which cannot convert in flight: same values, pre-rounded
         if (Bn * T > 64 && c->emb16 && (g.E % 64) == 0) { ga.a = c->emb16; ga.a_is_f32 = 0; }
+        // M <= 64: lang_prep already gathered the rows, 16 bit, in fragment order
+        if (Bn * T <= 64 && c->emb16 && (g.E % 32) == 0) {
+          ga.a = ws.at<void>("emb_a0"); ga.a_is_f32 = 0; ga.a_rows = nullptr; ga.a_frag = 1;
+        }
       }
       else {
         ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R;
