@@ -379,7 +379,7 @@ def main():
     # dominant kernel = largest share of a forward's kernel time (launches x duration). At the
     # gt5 shapes that is the recurrent step (2 layers x T launches, HBM bound: W_hh streams once
     # per step); at p100 it is an MFMA GEMM.
-    pmc = pmc_traffic(args.workload) or {}
+    pmc = pmc_traffic(args.workload + ("" if persistent else "_lstm_steps")) or {}
     mfma_dom = max((k for k in flops if ktimes[k] and flops[k] > 0), key=lambda k: ktimes[k])
     ach = flops[mfma_dom] / (ktimes[mfma_dom] * 1e-6) / 1e12
     roof_mfma = {"bound": "mfma", "kernel": mfma_dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
@@ -393,14 +393,16 @@ def main():
         nbytes = lstm_step_bytes(w, T) + (T - 1) * (lstm_step_bytes(w, T) - 2 * 4 * 1024 * 1024 * 2)
         ach_b = nbytes / (lstm_us[1] * 1e-6) / 1e9
         res["roofline"] = {"bound": "hbm", "kernel": "lstm_layer", "achieved": ach_b, "peak": PEAK_HBM_GBS,
-                           "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
+                           "traffic": (pmc.get("kernels", {}).get("lstm_layer") or {}).get("bytes_per_launch"),
                            "usec_per_launch": lstm_us[1], "bytes_per_launch": nbytes, "launches_per_forward": 2,
                            "share_of_forward_kernel_time": 2 * lstm_us[1] / (
                                2 * lstm_us[1] + sum(v for v in ktimes.values() if v)),
                            "note": "latency bound by design, not bandwidth bound: T dependent steps per launch, each "
-                                   "two fabric round trips (arrival flags, then the new h of all workgroups) + 64 "
-                                   "MFMAs + gates, ~5.4 us per step (scratch/ts_layer.hip); it replaces 2T step "
-                                   "launches that ran at 43 % of the HBM peak but moved T x 16.8 MB of W_hh per layer"}
+                                   "one fabric round trip (self-validating tagged h words of all workgroups) + LDS + "
+                                   "64 MFMAs + gates, ~3.7 us per step (scratch/ts_layer.hip); W_hh is read once and "
+                                   "stays in registers. It replaces 2T step launches that ran at 43 % of the HBM "
+                                   "peak but moved T x 16.8 MB of W_hh per layer (--lstm-steps)"}
         res["roofline_mfma"] = roof_mfma
     elif lstm_us and lstm_us[0] == "lstm_step" and 2 * T * lstm_us[1] > ktimes[mfma_dom]:
         nbytes = lstm_step_bytes(w, T)
@@ -413,7 +415,8 @@ def main():
                            "share_of_forward_kernel_time": 2 * T * lstm_us[1] / (
                                2 * T * lstm_us[1] + sum(v for v in ktimes.values() if v))}
         res["roofline_mfma"] = roof_mfma
-    if pmc.get("bytes_per_forward") and not persistent:
+    pmc = pmc_traffic(args.workload + ("" if persistent else "_lstm_steps")) or {}
+    if pmc.get("bytes_per_forward"):
         # whole-forward view: every kernel's measured HBM-side bytes / the measured step time
         gbs = pmc["bytes_per_forward"] / (dt / args.steps) / 1e9
         res["forward_hbm"] = {"bytes_per_forward_pmc": pmc["bytes_per_forward"], "achieved": gbs, "unit": "GB/s",

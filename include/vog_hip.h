@@ -220,18 +220,20 @@ typedef struct vog_lstm_step_args {
 } vog_lstm_step_args;
 int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
 /* ALL T steps of one BiLSTM layer in ONE launch (persistent workgroups): 2 x R/32
- * workgroups, each keeps its 128 rows of W_hh in registers for the whole sequence; the
- * hidden state is exchanged between steps through `hx` with 8-byte agent-scope
- * (write-through / L1-bypassing) atomics and a per-direction arrival counter in `sync`.
- * Alternative to T launches of vog_bilstm_step. MEASURED SLOWER on MI355X and therefore
- * opt-in (vog_ctx_set_int "lstm_persistent"): a software all-to-all step barrier (write-
- * through store -> counter -> poll -> L1-bypassing reload) costs ~9.8 us per step against
- * ~5.1 us for a dependent graph node (cfg 2: 117 us vs 61 us per layer). Kept because it is
- * parity-tested and is the right shape once the exchange is cheaper (fewer, fatter
- * workgroups per XCD). Requires Bn <= 16 and R/32 in {1,2,4,32}
- * (vog_bilstm_layer_supported); hx ([2][2][16][R] t16) and sync (16 x u32) must be zero at
- * launch; every wait is bounded (on timeout sync[2] is set and the kernel drains).
- * Launch at most 4 instances concurrently (64 workgroups x 1 per CU each). */
+ * workgroups of 4 waves, every wave keeps its 32 rows of W_hh in registers for the whole
+ * sequence (W_hh is read once per layer instead of once per step). Between steps the hidden
+ * state goes through `hx` as SELF-VALIDATING 8-byte words (two 16-bit h values + the 32-bit
+ * number of the producing step), stored with write-through agent-scope atomics and fetched
+ * (L1-bypassing) once per workgroup into LDS; stale words are re-fetched as a batch. No flags,
+ * no fences: one fabric round trip per step. Measured on MI355X (cfg 2, Bn = 4, R = 1024):
+ * 3.7 us per step, 45.9 us per layer, against 12 x 4.95 us for vog_bilstm_step launches that
+ * each re-stream 16.8 MB of W_hh; single-batch latency 336 vs 365 us, 27.0k vs 21.6k queries/s
+ * with 4 batches in flight. Requires Bn <= 16 and R/32 in {1,2,4,32} (vog_bilstm_layer_supported);
+ * hx ([2 parities][2 dirs][16][R/2] u64) and sync (256 x u32) must be zero at launch (vog_lang_prep
+ * does it); every wait is bounded (~1 s): on timeout sync[2] is set, the kernel drains and writes
+ * NaN into the final-state rows so that a stalled run cannot pass for a result.
+ * CO-RESIDENCY: all 2 x R/32 workgroups (one per CU) must be resident at once; launch at most 4
+ * instances concurrently on a 256-CU part (HIP's 4 hardware queues guarantee that for streams). */
 typedef struct vog_lstm_layer_args {
   const float* gxs; const void* whh; void* hx; uint32_t* sync; void* out16;
   const int64_t* lens; int Bn, T, R; vog_dtype dtype;
@@ -365,9 +367,10 @@ int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
 int vog_graph_launch(vog_graph* g, void* stream);
 /* Integer options of a context. "graph_dag" (default 0): capture the language chain as a
  * parallel branch of the graph (forked beside the encoders + obj_tx, joined before mul_tx).
- * "lstm_persistent" (default 0): use vog_bilstm_layer instead of T step launches.
- * Measured on MI355X: lower single-batch latency (381 -> 332 us at cfg 2) but lower
- * throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in. */
+ * Measured on MI355X: lower single-batch latency (381 -> 332 us at cfg 2, step-launch LSTM) but
+ * lower throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in.
+ * "lstm_persistent" (default 0; bench.py and the serving loop turn it on): use vog_bilstm_layer
+ * instead of T step launches where vog_bilstm_layer_supported; see its co-residency note. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 

@@ -25,6 +25,7 @@ f, w = load(fetch_csv), load(write_csv)
 # step name <- (kernel, grid) at the cfg2 shapes (bench.py --workload cfg2)
 STEP = {
     ("lstm_step_kernel<F16>", 131072): ("lstm_step", 24),
+    ("lstm_layer_kernel<F16, 32>", 16384): ("lstm_layer", 2),
     ("gemm_pipe<BF16, 64, 64, 2, 0>", 193536): ("mul_wo", 1),      # also mul_ffn2 (same grid): averaged
     ("gemm_skinny<F16, false, 8, 1>", 131072): ("lstm_ih1", 1),
     ("gemm_skinny<F16, true, 8, 1>", 131072): ("lstm_ih0", 1),
