@@ -36,9 +36,10 @@ REL = {"mdl.obj_tx.use_rel": True, "mdl.mul_tx.use_rel": True}
 
 
 def _case(over, B, nppf0=5, vocab=5000, ragged=False, wseed=1, dseed=3,
-          perturb_ln=False, ncmp=4):
+          perturb_ln=False, ncmp=4, arg_lens=None, cmp_msk=None):
     return dict(over=over, B=B, nppf0=nppf0, vocab=vocab, ragged=ragged,
-                wseed=wseed, dseed=dseed, perturb_ln=perturb_ln, ncmp=ncmp)
+                wseed=wseed, dseed=dseed, perturb_ln=perturb_ln, ncmp=ncmp,
+                arg_lens=arg_lens, cmp_msk=cmp_msk)
 
 
 CASES: Dict[str, dict] = {}
@@ -94,6 +95,22 @@ CASES["small/vog_sep_r64"] = _case(
     B=2, vocab=50, ragged=True, perturb_ln=True, dseed=32)
 
 
+# ---- edge cases: single query, one-word sentences (T = 1), sentences at the maximum length
+# (T = seq_len = 20), one-argument queries next to five-argument ones, masked-out videos
+_SM = {"mdl.name": "vog", **REL, **SMALL_DIMS}
+CASES["small/edge_spat_b1"] = _case({**_SM, "ds.conc_type": "spat"}, B=1, vocab=50, ragged=True,
+                                    perturb_ln=True, dseed=41)
+CASES["small/edge_temp_len1"] = _case({**_SM, "ds.conc_type": "temp"}, B=2, vocab=50, perturb_ln=True,
+                                      dseed=42, arg_lens=[[1, 0, 0, 0, 0]])
+CASES["small/edge_sep_maxlen"] = _case({**_SM, "ds.conc_type": "sep"}, B=2, vocab=50, perturb_ln=True,
+                                       dseed=43, arg_lens=[[4, 4, 4, 4, 4], [20, 0, 0, 0, 0]])
+CASES["small/edge_spat_mixed_args"] = _case({**_SM, "ds.conc_type": "spat"}, B=3, vocab=50, perturb_ln=True,
+                                            dseed=44, arg_lens=[[1, 0, 0, 0, 0], [2, 3, 1, 5, 4], [7, 1, 0, 0, 0]],
+                                            cmp_msk=[[1, 1, 1, 1], [1, 0, 0, 0], [1, 1, 0, 1]])
+CASES["small/edge_temp_cmpmsk"] = _case({**_SM, "ds.conc_type": "temp"}, B=2, vocab=50, ragged=True,
+                                        perturb_ln=True, dseed=45, cmp_msk=[[1, 1, 0, 0], [1, 1, 1, 0]])
+
+
 def build(name: str):
     """-> (cfg, state_dict(np), batch(np), case)."""
     c = CASES[name]
@@ -102,12 +119,14 @@ def build(name: str):
     sd = _synth.init_state_dict(cfg, c["vocab"], seed=c["wseed"],
                                 perturb_ln=c["perturb_ln"])
     msk = None
-    if name.endswith("cmpmsk"):
+    if c.get("cmp_msk") is not None:
+        msk = np.array(c["cmp_msk"], np.int64)
+    elif name.endswith("cmpmsk"):
         msk = np.array([[1, 1, 1, 1], [1, 1, 0, 0], [1, 0, 1, 1]], np.int64)
     batch = _synth.make_batch(
         cfg.ds.conc_type, c["B"], c["nppf0"], ncmp=c["ncmp"], vocab_size=c["vocab"],
         prop_dim=cfg.mdl.prop_feat_dim, seg_dim=cfg.mdl.seg_feat_dim,
-        seed=c["dseed"], ragged=c["ragged"], num_cmp_msk=msk)
+        seed=c["dseed"], ragged=c["ragged"], num_cmp_msk=msk, arg_lens=c.get("arg_lens"))
     return cfg, sd, batch, c
 
 

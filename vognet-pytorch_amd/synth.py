@@ -76,7 +76,8 @@ def ragged_arg_lens(rng, lo: int = 6, hi: int = 18) -> List[int]:
 def make_batch(conc_type: str, B: int, nppf0: int, *, ncmp: int = 4,
                vocab_size: int = 5000, prop_dim: int = 2048,
                seg_dim: int = 3072, seed: int = 0, ragged: bool = False,
-               num_cmp_msk: Optional[np.ndarray] = None
+               num_cmp_msk: Optional[np.ndarray] = None,
+               arg_lens: Optional[Sequence[Sequence[int]]] = None
                ) -> Dict[str, np.ndarray]:
     """One synthetic batch (numpy, fp32/int64) of SURVEY.md section 8(d)."""
     assert conc_type in ("spat", "temp", "sep", "svsq")
@@ -93,7 +94,10 @@ def make_batch(conc_type: str, B: int, nppf0: int, *, ncmp: int = 4,
     I = np.zeros((B, nv, NSRL), np.int64)
     V = np.zeros((B, ncmp), np.int64)
     for b in range(B):
-        lens = ragged_arg_lens(rng) if ragged else list(DEFAULT_ARG_LENS)
+        if arg_lens is not None:          # explicit per-query argument lengths (edge cases)
+            lens = list(arg_lens[b % len(arg_lens)])
+        else:
+            lens = ragged_arg_lens(rng) if ragged else list(DEFAULT_ARG_LENS)
         w, m, l, c, i = _lang_one(rng, vocab_size, lens)
         W[b, :], M[b, :], L[b, :], C[b, :], I[b, :] = w, m, l, c, i
         nreal = int(i.sum())
