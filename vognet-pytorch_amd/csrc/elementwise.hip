@@ -27,31 +27,43 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float* xr = x + (int64_t)row * d;
-  float v[16];
+  // d % 4 == 0 (checked by the launcher): 16 bytes per lane per access, a wave covers 1 KiB of the row
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * d);
+  const int nq = d >> 2;
+  float4 v[4];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int c = lane + i * 64;
-    v[i] = c < d ? xr[c] : 0.f;
-    s += v[i];
+    v[i] = c < nq ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int c = lane + i * 64;
-    const float t = c < d ? v[i] - mean : 0.f;
-    q += t * t;
+    if (c < nq) {
+      const float t0 = v[i].x - mean, t1 = v[i].y - mean, t2 = v[i].z - mean, t3 = v[i].w - mean;
+      q += (t0 * t0 + t1 * t1) + (t2 * t2 + t3 * t3);
+    }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int c = lane + i * 64;
-    if (c < d) {
-      const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
-      if (y32) y32[(int64_t)row * d + c] = o;
-      if (y16) y16[(int64_t)row * d + c] = to16<T16>(o);
+    if (c < nq) {
+      const float4 g = g4[c], bb = b4[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + bb.x; o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * g.z + bb.z; o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+      if (y32) reinterpret_cast<float4*>(y32 + (int64_t)row * d)[c] = o;
+      if (y16) {
+        const u16x4 h = {to16<T16>(o.x), to16<T16>(o.y), to16<T16>(o.z), to16<T16>(o.w)};
+        reinterpret_cast<u16x4*>(y16 + (int64_t)row * d)[c] = h;
+      }
     }
   }
 }
@@ -505,7 +517,7 @@ using namespace vog;
 extern "C" int vog_residual_layernorm(const float* x, const float* gamma, const float* beta,
                                       float* y32, void* y16, int rows, int d, vog_dtype dtype,
                                       void* stream) {
-  VOG_CHECK_ARG(x && gamma && beta && (y32 || y16) && rows > 0 && d > 0 && d <= 1024);
+  VOG_CHECK_ARG(x && gamma && beta && (y32 || y16) && rows > 0 && d > 0 && d <= 1024 && (d % 4) == 0);
   VOG_DISPATCH_DTYPE(dtype, ::vog::launch((layernorm_kernel<T16>), dim3(ceil_div(rows, 4)),
                      dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32, (unsigned short*)y16, rows, d));
   VOG_LAUNCH_CHECK();
