@@ -56,3 +56,52 @@ def test_single_process_passthrough():
     x = torch.randn(4, 1700)
     assert D.all_gather_records(x) is x
     assert D.shard_range(8, 1, 2) == (4, 8)
+
+
+def _worker_async(rank, world, port, q):
+    """The exchange pattern of bench.py's N > 1 loop: several slots in flight, one asynchronous
+    all-gather of a slot's records per step, settled (work.wait()) only before the slot is reused."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nslots, B, W = 4, 4, 1700
+    recs = [torch.zeros(B, W) for _ in range(nslots)]
+    gathered = [torch.zeros(world * B, W) for _ in range(nslots)]
+    pending = [None] * nslots
+    seen = []
+    for step in range(10):
+        u = step % nslots
+        if pending[u] is not None:
+            pending[u].wait()
+            seen.append(gathered[u][:, 0].clone())
+            pending[u] = None
+        recs[u].fill_(float(100 * step + rank))            # "forward" of this step writes the records
+        pending[u] = dist.all_gather_into_tensor(gathered[u], recs[u], async_op=True)
+    for u in range(nslots):
+        if pending[u] is not None:
+            pending[u].wait()
+            seen.append(gathered[u][:, 0].clone())
+    if rank == 0:
+        q.put([s.tolist() for s in seen])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_gather_settled_before_slot_reuse_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_async, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(seen) == 10
+    steps = sorted(int(s[0]) // 100 for s in seen)
+    assert steps == list(range(10))
+    for s in seen:                       # rank-major: rank 0's rows then rank 1's, same step
+        st = int(s[0]) // 100
+        assert s == [float(100 * st)] * 4 + [float(100 * st + 1)] * 4

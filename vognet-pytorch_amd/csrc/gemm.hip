@@ -669,6 +669,7 @@ static int launch_pipe(const GemmParams& p, hipStream_t st) {
     case 4: return launch_pipe_cfg<T16, 128, 64, 2, EPI>(p, st);
     case 5: return launch_pipe_cfg<T16, 64, 64, 2, EPI>(p, st);
     case 6: return launch_pipe_cfg<T16, 64, 128, 3, EPI>(p, st);
+    case 7: return launch_pipe_cfg<T16, 64, 64, 3, EPI>(p, st);
     default: break;
   }
   // Measured on MI355X (scratch/mb_gemm.py, M = 800..8192): occupancy beats pipeline

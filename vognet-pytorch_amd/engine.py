@@ -123,8 +123,10 @@ class VogEngine:
         return B, ncmp, nc_v, NP
 
     def make_batch(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
-                   with_pred: bool = True):
-        """Validate a batch dict, allocate outputs, fill the C struct."""
+                   with_pred: bool = True, pred_rec: Optional[torch.Tensor] = None):
+        """Validate a batch dict, allocate outputs, fill the C struct. `pred_rec`: caller-owned
+        storage for the packed prediction records ([B, record_words] fp32, contiguous), e.g. a
+        slice of one buffer shared by the slots in flight so that ONE all-gather exchanges them."""
         d = self.desc
         B, ncmp, nc_v, NP = self._geometry(inp)
         for k in NSRL_KEYS_I64:
@@ -155,7 +157,12 @@ class VogEngine:
         rec = None
         if with_pred:
             rb = int(self.lib.vog_pred_record_bytes(ncmp, d.nsrl, d.nfrm0))
-            rec = torch.empty(B, rb // 4, dtype=torch.float32, device=dev)
+            if pred_rec is not None:
+                assert pred_rec.is_cuda and pred_rec.dtype == torch.float32 and pred_rec.is_contiguous() \
+                    and tuple(pred_rec.shape) == (B, rb // 4), "pred_rec storage has the wrong shape"
+                rec = pred_rec
+            else:
+                rec = torch.empty(B, rb // 4, dtype=torch.float32, device=dev)
             out["pred_rec"] = rec
         b = L.Batch()
         b.B, b.ncmp, b.T = B, ncmp, T
@@ -189,11 +196,12 @@ class VogEngine:
 
     # ---- persistent slots (graph replay; what bench.py and the evaluator use) ----
     def make_slot(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
-                  with_pred: bool = True, graph: Optional[bool] = None, dag: bool = False) -> "Slot":
+                  with_pred: bool = True, graph: Optional[bool] = None, dag: bool = False,
+                  pred_rec: Optional[torch.Tensor] = None) -> "Slot":
         """dag=True captures the language chain as a parallel graph branch (lower latency of a
         single batch, lower throughput with several slots in flight)."""
         L.check(self.lib.vog_ctx_set_int(self.ctx, b"graph_dag", int(dag)), "vog_ctx_set_int")
-        return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph)
+        return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph, pred_rec)
 
     def aql_open(self, n_queues: int = 1) -> None:
         """Create the library's own hardware queues on this device (AQL submission path)."""
@@ -206,12 +214,16 @@ class VogEngine:
         arr = (C.c_void_p * len(slots))(*[s.aql for s in slots])
         L.check(self.lib.vog_aql_submit(arr, len(slots), int(queue)), "vog_aql_submit")
 
-    def make_group(self, inps, with_pred: bool = True, graph: bool = True) -> "Group":
+    def record_words(self, ncmp: int) -> int:
+        """fp32 words of one packed prediction record (boxes || scores || pred_cmp)."""
+        return int(self.lib.vog_pred_record_bytes(ncmp, self.desc.nsrl, self.desc.nfrm0)) // 4
+
+    def make_group(self, inps, with_pred: bool = True, graph: bool = True, pred_rec=None) -> "Group":
         """Several batches whose LANGUAGE encoder runs once for all of them (W_hh is streamed once
         per recurrent step instead of once per batch per step; include/vog_hip.h, "language
         encoder over a group"). Every member keeps its own inputs, outputs and workspace, and its
         outputs equal its stand-alone forward up to fp32 summation order."""
-        return Group(self, inps, with_pred, graph)
+        return Group(self, inps, with_pred, graph, pred_rec)
 
     def set_option(self, name: str, value: int) -> None:
         """Integer options of the context: 'graph_dag', 'lstm_persistent' (include/vog_hip.h)."""
@@ -257,13 +269,13 @@ class Slot:
     Inputs live at fixed addresses (H2D copies land here directly), so one
     forward is a single hipGraphLaunch of ~50 kernel nodes."""
 
-    def __init__(self, eng: VogEngine, inp, T, with_pred, graph):
+    def __init__(self, eng: VogEngine, inp, T, with_pred, graph, pred_rec=None):
         self.eng = eng
         self.inp = {k: (v.to(eng.device).contiguous() if isinstance(v, torch.Tensor)
                         else torch.from_numpy(np.ascontiguousarray(v)).to(eng.device))
                     for k, v in inp.items()}
         with torch.cuda.device(eng.device):
-            self.batch, self.out, (self.B, self.ncmp, self.T) = eng.make_batch(self.inp, T, with_pred)
+            self.batch, self.out, (self.B, self.ncmp, self.T) = eng.make_batch(self.inp, T, with_pred, pred_rec)
             n = eng.lib.vog_workspace_bytes(eng.ctx, self.B, self.ncmp, self.T)
             self.ws = torch.empty(int(n), dtype=torch.uint8, device=eng.device)
             L.check(eng.lib.vog_workspace_init(eng.ctx, self.B, self.ncmp, self.T, self.ws.data_ptr(),
@@ -335,7 +347,8 @@ LANG_KEYS = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", 
 class Group:
     """G batch slots + one shared language-encoder workspace + one graph / AQL program for all."""
 
-    def __init__(self, eng: VogEngine, inps, with_pred=True, graph=True):
+    def __init__(self, eng: VogEngine, inps, with_pred=True, graph=True, pred_rec=None):
+        # pred_rec: optional [len(inps) * B, record_words] buffer; member m writes rows [m*B, (m+1)*B)
         assert len(inps) >= 1
         self.eng = eng
         dev = eng.device
@@ -356,7 +369,8 @@ class Group:
                 mi = {k: dev_t(v) for k, v in inp.items() if k not in LANG_KEYS}
                 for k in LANG_KEYS:
                     mi[k] = self.lang_in[k][m * B:(m + 1) * B]
-                self.slots.append(Slot(eng, mi, T_max, with_pred, graph=False))
+                self.slots.append(Slot(eng, mi, T_max, with_pred, False,
+                                       None if pred_rec is None else pred_rec[m * B:(m + 1) * B]))
             s0 = self.slots[0]
             self.B_total, self.ncmp, self.T = B * len(inps), s0.ncmp, T_max
             n = eng.lib.vog_lang_workspace_bytes(eng.ctx, self.B_total, self.ncmp, self.T)
