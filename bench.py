@@ -218,7 +218,7 @@ def main():
     eng.load_state_dict(sd)
     # the persistent layer kernel needs all its 64 workgroups co-resident: safe up to 4 of them in
     # flight (4 hardware queues x 64 workgroups = 256 CUs); a stalled hand-off poisons the output with NaN
-    persistent = not args.lstm_steps and (max(1, args.queues) if args.mode == "aql" else max(1, args.streams)) <= 4
+    persistent = not args.lstm_steps and (args.mode != "aql" or max(1, args.queues) <= 4)
     eng.set_option("lstm_persistent", int(persistent))
     cfg_id = int(args.workload[3:])
     aql = args.mode == "aql"

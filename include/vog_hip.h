@@ -369,8 +369,10 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * parallel branch of the graph (forked beside the encoders + obj_tx, joined before mul_tx).
  * Measured on MI355X: lower single-batch latency (381 -> 332 us at cfg 2, step-launch LSTM) but
  * lower throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in.
- * "lstm_persistent" (default 0; bench.py and the serving loop turn it on): use vog_bilstm_layer
- * instead of T step launches where vog_bilstm_layer_supported; see its co-residency note. */
+ * "lstm_persistent" (default 1; env VOG_LSTM_PERSISTENT presets it): use vog_bilstm_layer instead
+ * of T step launches where vog_bilstm_layer_supported. Its co-residency limit (4 instances) is met
+ * automatically on HIP streams (4 hardware queues execute at most 4 kernels at once); set it to 0
+ * when submitting through more than 4 AQL queues or with GPU_MAX_HW_QUEUES > 4. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 

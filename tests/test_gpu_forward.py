@@ -100,7 +100,8 @@ def test_forward_persistent_lstm_layer(name):
     """The opt-in one-launch-per-layer LSTM (cross-workgroup hand-off through agent-scope
     atomics; 64 / 4 / 2 workgroups per direction here) must agree with the T-launch path."""
     eng, cfg, sd, batch, c, dev = build_engine(name)
-    a = eng.forward(dev)
+    eng.set_option("lstm_persistent", 0)
+    a = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in eng.forward(dev).items()}
     eng.set_option("lstm_persistent", 1)
     b = eng.forward(dev)
     torch.cuda.synchronize()
@@ -109,6 +110,22 @@ def test_forward_persistent_lstm_layer(name):
     ncmp = batch["new_srl_idxs"].shape[1]
     pa, pb = eng.unpack_pred(a["pred_rec"], ncmp), eng.unpack_pred(b["pred_rec"], ncmp)
     assert (pa["scores"] - pb["scores"]).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("name", FULL + ["small/vog_spat", "small/vgrnd_sep", "small/edge_temp_len1",
+                                         "small/edge_sep_maxlen"])
+def test_forward_step_launch_lstm_vs_reference_golden(name):
+    """The step-launch BiLSTM (lstm_persistent = 0: lowest latency fallback, any number in flight)
+    against the same reference goldens as the default persistent layer kernel."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("lstm_persistent", 0)
+    out = eng.forward(dev)
+    torch.cuda.synchronize()
+    ncmp = batch["new_srl_idxs"].shape[1]
+    pred = eng.unpack_pred(out["pred_rec"], ncmp)
+    g = np.load(cases.golden_path(name))
+    tol = (1e-3, 6e-3) if name.startswith("full/") else (2e-3, 1.2e-2)
+    _check_against(name, out, pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
 
 
 def test_forward_f16_transformers():

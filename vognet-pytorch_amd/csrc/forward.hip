@@ -70,7 +70,7 @@ struct vog_ctx {
   std::vector<void*> allocs;
   bool finalized = false;
   int graph_dag = 0;                    // capture the language chain as a parallel branch
-  int lstm_persistent = 0;              // one launch per BiLSTM layer (W_hh resident on chip; see vog_hip.h)
+  int lstm_persistent = 1;              // one launch per BiLSTM layer where supported (W_hh resident on chip; vog_hip.h)
   hipStream_t side = nullptr;           // language branch during graph capture
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
