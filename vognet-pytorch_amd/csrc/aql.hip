@@ -136,9 +136,13 @@ static std::string lib_dir() {
 }
 
 static int runtime_init(AqlRuntime& rt) {
-  if (rt.ready) return 0;
   int dev = 0;
   VOG_HIP(hipGetDevice(&dev));
+  if (rt.ready) {
+    // one process drives one GPU (torchrun: one rank per device); the queues belong to that device
+    if (dev != rt.device) VOG_FAIL(-2001, "AQL path: opened on HIP device %d, current device is %d", rt.device, dev);
+    return 0;
+  }
   char bus[64] = "";
   VOG_HIP(hipDeviceGetPCIBusId(bus, sizeof(bus), dev));
   unsigned dom = 0, b = 0, d = 0, f = 0;
@@ -349,7 +353,7 @@ int aql_submit(AqlProgram* const* progs, int n, int queue) {
   const hsa_signal_t none{0};
   // VOG_AQL_FENCE (perf experiments only, results may be WRONG): fence scope between the kernels
   // of a forward: 0 = none, 1 = agent (default), 2 = system; +10: acquire only, +20: release only
-  static const int fence_env = getenv("VOG_AQL_FENCE") ? atoi(getenv("VOG_AQL_FENCE")) : 1;
+  static const int fence_env = perf_env("VOG_AQL_FENCE") ? atoi(perf_env("VOG_AQL_FENCE")) : 1;
   const int mid_acq = (fence_env / 10 == 2) ? HSA_FENCE_SCOPE_NONE : (fence_env % 10);
   const int mid_rel = (fence_env / 10 == 1) ? HSA_FENCE_SCOPE_NONE : (fence_env % 10);
   for (size_t r = 0; r < max_rows; ++r) {

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
 template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   static int force_general = -2;      // VOG_ATTN_GENERAL=1: perf experiments only
-  if (force_general == -2) { const char* e = getenv("VOG_ATTN_GENERAL"); force_general = e ? atoi(e) : 0; }
+  if (force_general == -2) { const char* e = perf_env("VOG_ATTN_GENERAL"); force_general = e ? atoi(e) : 0; }
   if (p.N <= 128 && !force_general) {
     constexpr int HB = (NDB + 1) / 2;
     const size_t lds = ((size_t)4 * HB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/vog_hip.h"
 
@@ -139,6 +140,15 @@ inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hi
     return;
   }
   hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<KArgs>(args)...);
+}
+
+// Perf-experiment knobs (tile forcing, ablations that produce WRONG results, fence scopes) are read
+// from the environment only when VOG_PERF_EXPERIMENTS=1 is also set, so that a stray variable can
+// never change what the product path computes.
+static inline const char* perf_env(const char* name) {
+  const char* on = getenv("VOG_PERF_EXPERIMENTS");
+  if (!on || on[0] != '1') return nullptr;
+  return getenv(name);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -682,7 +682,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   }
   // VOG_SKIP_STEPS=name,name,... (perf experiments only; results are WRONG): drop steps whose
   // name starts with one of the entries, to measure their marginal cost in the throughput regime
-  if (const char* skip = getenv("VOG_SKIP_STEPS")) {
+  if (const char* skip = perf_env("VOG_SKIP_STEPS")) {
     std::vector<std::string> pre;
     std::string cur;
     for (const char* q = skip;; ++q) {

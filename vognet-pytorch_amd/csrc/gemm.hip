@@ -25,7 +25,7 @@ static bool pipe_ok(const GemmParams& p, bool a_f32);
 // VOG_GEMM_DEBUG (ablation, perf experiments only): 1 = no DMA, 2 = no MFMA, 4 = no epilogue
 static int gemm_debug_flags() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("VOG_GEMM_DEBUG"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = perf_env("VOG_GEMM_DEBUG"); v = e ? atoi(e) : 0; }
   return v;
 }
 
@@ -660,7 +660,7 @@ template <typename T16, int EPI>
 static int launch_pipe(const GemmParams& p, hipStream_t st) {
   // VOG_GEMM_TILE (perf experiments only) forces a tile configuration
   static int force = -2;
-  if (force == -2) { const char* e = getenv("VOG_GEMM_TILE"); force = e ? atoi(e) : -1; }
+  if (force == -2) { const char* e = perf_env("VOG_GEMM_TILE"); force = e ? atoi(e) : -1; }
   switch (force) {
     case 0: return launch_pipe_cfg<T16, 128, 128, 3, EPI>(p, st);
     case 1: return launch_pipe_cfg<T16, 128, 64, 3, EPI>(p, st);
@@ -739,7 +739,7 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   if (p.M <= 64 && (p.K % 32) == 0) {
     const int ncol = ceil_div(p.N, 16);
     // (a 16-deep weight prefetch measured SLOWER: 26 vs 18.6 us at M=48,N=8192,K=2048, 230 VGPRs)
-    static const int nt_env = getenv("VOG_SKINNY_NT") ? atoi(getenv("VOG_SKINNY_NT")) : 0;
+    static const int nt_env = perf_env("VOG_SKINNY_NT") ? atoi(perf_env("VOG_SKINNY_NT")) : 0;
     // NT = 2 halves the L2 re-reads of A but also the workgroup count: measured SLOWER at
     // M=48,N=8192,K=2048 (12.7 vs 11.1 us) and much slower at small N -> opt-in for experiments
     const int nt = nt_env == 2 ? 2 : 1;

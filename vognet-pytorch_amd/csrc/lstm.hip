@@ -316,7 +316,7 @@ int lstm_step_run(const vog_lstm_step_args* a, hipStream_t st) {
   LstmParams p{a->gx, (const unsigned short*)a->whh, (const unsigned short*)a->h_in,
                (unsigned short*)a->h_out, a->c, (unsigned short*)a->out16, a->lens,
                a->Bn, a->T, a->R, a->step, a->out_frag, a->final_row0, 0};
-  static const int dbg = getenv("VOG_LSTM_DEBUG") ? atoi(getenv("VOG_LSTM_DEBUG")) : 0;
+  static const int dbg = perf_env("VOG_LSTM_DEBUG") ? atoi(perf_env("VOG_LSTM_DEBUG")) : 0;
   p.debug = dbg;
   dim3 grid(ceil_div(a->R, 4), 2);
   VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((lstm_step_kernel<T16>), grid, dim3(256), 0, st, p));
