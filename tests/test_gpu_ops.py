@@ -201,7 +201,10 @@ def _attn_ref(q, k, v, u, peb, n_box, inv_scale, use_rel):
 @pytest.mark.parametrize("S,N,H,dh,dp,nsrl,use_rel", [
     (40, 100, 3, 256, 256, 5, 1), (4, 200, 3, 171, 192, 1, 1), (6, 25, 3, 256, 256, 5, 1),
     (3, 140, 3, 11, 32, 1, 1), (2, 700, 2, 64, 64, 1, 0), (5, 50, 3, 100, 128, 2, 1),
-    (2, 33, 1, 16, 32, 1, 1)])
+    (2, 33, 1, 16, 32, 1, 1),
+    # long sequences -> shared-tile kernel (K/V blocks through LDS-DMA, 128 queries per workgroup)
+    (2, 1000, 3, 128, 128, 5, 1), (1, 2011, 3, 171, 192, 1, 1), (3, 520, 2, 100, 128, 2, 1),
+    (9, 640, 1, 32, 32, 1, 1)])
 def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
     lib = _lib()
     torch.manual_seed(S * 1000 + N)

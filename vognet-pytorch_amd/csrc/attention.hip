@@ -374,6 +374,153 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
   }
 }
 
+// ----------------------------------------------------------------------------
+// Shared-tile variant for long sequences (p100: N = 2000 / 4000). The kernels above give every
+// 32-query block its own pass over K and V (fine up to a few hundred tokens: everything is
+// L2-resident and parallelism matters more); at N = 2000 that is 1 MiB of K/V per 32 queries and the
+// kernel becomes L2-bandwidth bound (measured: 345 TFLOP/s = 14 % of the MFMA peak). Here a workgroup
+// owns 128 queries (one 32-query block per wave, Q fragments in registers for the whole pass) and the
+// 4 waves walk the key blocks TOGETHER: each 32-key block of K and V^T fragments is brought into LDS
+// once per workgroup by LDS-DMA (the fragment order is lane-linear, i.e. exactly what
+// global_load_lds writes), double buffered, one barrier per block; every wave reads its MFMA A
+// operands from LDS (conflict-free 16-byte lane-linear reads). No merge at the end: a wave owns
+// its queries' whole softmax row. K/V traffic per query drops 4x, Q is read once.
+// ----------------------------------------------------------------------------
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  constexpr int NF = KS + 2 * NDB;                   // KiB fragments per key block (K then V^T)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char tsm[];
+  unsigned char* kv = tsm;                           // [2][NF][1024]
+  float* us = reinterpret_cast<float*>(tsm + 2 * NF * 1024);   // [npad] bias precursor of every key
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int nkb = (p.N + 31) >> 5;
+  const int nqg = (p.N + 127) >> 7;                  // 128-query groups per (sequence, head)
+  const int npair = p.S * p.H;
+  int pair, qg;
+  {   // XCD-aware: the query groups of one (sequence, head) stay on one XCD (its K/V in one L2)
+    const int b = blockIdx.x;
+    const int full = (npair / 8) * 8;
+    const int grp = b / (8 * nqg);
+    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qg = (b >> 3) % nqg; }
+    else { const int r = b - full * nqg; pair = full + r / nqg; qg = r % nqg; }
+  }
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qb = qg * 4 + wid;                       // this wave's 32-query block
+  const bool wave_ok = qb < nkb;                     // a wave past the end still helps with the DMA
+  const int qi = qb * 32 + ql;
+  const bool q_ok = qi < p.N;
+  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
+  const unsigned short* Kg = p.k + base;
+  const unsigned short* Vg = p.vt + base;
+
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
+    peb = p.pe_b[h];
+    for (int key = tid; key < p.npad; key += 256)
+      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
+  }
+  // Q fragments of this wave's block: registers for the whole pass
+  u16x8 qf[KS];
+  {
+    const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)(wave_ok ? qb : 0) * KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
+  }
+  // fragment f of key block kb: f < KS -> K fragment, else V^T fragment f - KS
+  auto issue = [&](int kb, int buf) {
+    for (int f = wid; f < NF; f += 4) {
+      const unsigned short* src = f < KS ? Kg + ((int64_t)kb * KS + f) * 512
+                                         : Vg + ((int64_t)kb * NDB * 2 + (f - KS)) * 512;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + lane * 8),
+          (__attribute__((address_space(3))) void*)(kv + (buf * NF + f) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  issue(0, 0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of block kb has landed
+    __syncthreads();                                      // ... everybody's; and block kb-1 is consumed
+    if (kb + 1 < nkb) issue(kb + 1, (kb + 1) & 1);
+    if (!wave_ok) continue;
+    const unsigned char* blk = kv + ((kb & 1) * NF) * 1024 + lane * 16;
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      s0 = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + ks * 1024), qf[ks], s0);
+      if (ks + 1 < KS) s1 = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + (ks + 1) * 1024), qf[ks + 1], s1);
+    }
+    f32x16 sacc;
+    float mloc = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + c32_row(r, lane);
+      float x = s0[r] + s1[r];
+      if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
+      x *= p.inv_scale;
+      x = key < p.N ? x : -1e30f;
+      sacc[r] = x;
+      mloc = fmaxf(mloc, x);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(sacc[r] - m_new);
+      sacc[r] = e;
+      lsum += e;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+    if (kb > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    u16x8 pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        o[db] = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + (KS + db * 2 + ks) * 1024), pf[ks], o[db]);
+  }
+  if (wave_ok && q_ok) {
+    const float inv_l = 1.0f / l_run;
+    unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[db][g * 4 + e] * inv_l);
+        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
+      }
+  }
+}
+
 template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   static int force_general = -2;      // VOG_ATTN_GENERAL=1: perf experiments only
@@ -389,6 +536,25 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
       attr_sb = true;
     }
     dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
+    ::vog::launch(kern, grid, dim3(256), lds, st, p);
+    VOG_LAUNCH_CHECK();
+    return 0;
+  }
+  // long sequences: enough 128-query groups to fill the chip -> shared K/V tiles through LDS
+  static int tile_min = -2;           // VOG_ATTN_TILE_MIN (perf experiments): N threshold, 0 = never
+  if (tile_min == -2) { const char* e = perf_env("VOG_ATTN_TILE_MIN"); tile_min = e ? atoi(e) : 512; }
+  if (tile_min > 0 && p.N >= tile_min && !force_general) {
+    constexpr int NF = (NDB * 32) / 16 + 2 * NDB;
+    const size_t lds = (size_t)2 * NF * 1024 + (size_t)p.npad * sizeof(float);
+    if (lds > 150 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the LDS budget", p.N);
+    auto kern = attn_tile_kernel<T16, NDB>;
+    static bool attr_tile = false;
+    if (!attr_tile && lds > 48 * 1024) {
+      VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_tile = true;
+    }
+    dim3 grid(ceil_div(p.N, 128) * p.H * p.S);
     ::vog::launch(kern, grid, dim3(256), lds, st, p);
     VOG_LAUNCH_CHECK();
     return 0;
