@@ -448,6 +448,10 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+  // (a 3-buffer software pipeline that issues S^T of block kb+1 before the softmax of block kb was
+  // measured equal: mul 1151 vs 1166 us, obj 497 vs 474 us at p100 - kept simple)
 
   issue(0, 0);
   for (int kb = 0; kb < nkb; ++kb) {
@@ -464,25 +468,38 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
       s0 = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + ks * 1024), qf[ks], s0);
       if (ks + 1 < KS) s1 = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + (ks + 1) * 1024), qf[ks + 1], s1);
     }
+    // softmax in the log2 domain: x2 = (s + bias) * (inv_scale * log2 e), p = 2^(x2 - m2). The row
+    // of register r is (r&3) + 8*(r>>2) + 4*hi: the 4 bias precursors of a register quad are one
+    // 16-byte LDS read; keys >= N exist only in the last block (uniform branch).
     f32x16 sacc;
     float mloc = -1e30f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + c32_row(r, lane);
-      float x = s0[r] + s1[r];
-      if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
-      x *= p.inv_scale;
-      x = key < p.N ? x : -1e30f;
-      sacc[r] = x;
-      mloc = fmaxf(mloc, x);
+    for (int g = 0; g < 4; ++g) {
+      float4 ub = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.use_rel) ub = *reinterpret_cast<const float4*>(&us[kb * 32 + 8 * g + 4 * hi]);
+      const float ubv[4] = {ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = g * 4 + e;
+        float x = s0[r] + s1[r];
+        if (p.use_rel) x += fmaxf(uqp - ubv[e], 0.f);
+        sacc[r] = x * c2;
+      }
     }
+    if (kb == nkb - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + c32_row(r, lane) >= p.N) sacc[r] = -1e30f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float lsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(sacc[r] - m_new);
+      const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
       sacc[r] = e;
       lsum += e;
     }
