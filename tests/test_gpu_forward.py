@@ -316,3 +316,38 @@ def test_group_language_encoder_matches_standalone_forwards(name, n, mode):
     pred = eng.unpack_pred(outs[0]["pred_rec"], ncmp)
     tol = (1e-3, 6e-3) if name.startswith("full/") else (2e-3, 1.2e-2)
     _check_against(name, outs[0], pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
+
+
+def test_persistent_lstm_handoff_is_deterministic_under_load():
+    """Four graphs in flight for 3000 launches: every output stays bit-identical to the slot's
+    first result. The persistent BiLSTM hands h between 64 workgroups through self-validating
+    words; a stale, torn or timed-out hand-off would show up here as a difference or a NaN
+    (scratch/stress_lstm.py is the long version: 76k forwards without a mismatch)."""
+    name = "full/cfg2_ragged"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    from tests.gpu_util import cases as _cases
+    slots, streams = [], []
+    for s in range(4):
+        key = f"{name}#stress{s}"
+        cc = dict(_cases.CASES[name])
+        cc["dseed"] = cc["dseed"] + 17 * s
+        _cases.CASES[key] = cc
+        try:
+            _, _, b, _ = _cases.build(key)
+        finally:
+            del _cases.CASES[key]
+        slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()}, graph=True))
+        streams.append(torch.cuda.Stream())
+    for sl, st in zip(slots, streams):
+        sl.launch(st)
+    torch.cuda.synchronize()
+    refs = [{k: v.clone() for k, v in sl.out.items() if isinstance(v, torch.Tensor)} for sl in slots]
+    for r in refs:
+        assert torch.isfinite(r["mdl_outs"]).all()
+    for i in range(3000):
+        slots[i % 4].launch(streams[i % 4])
+        if (i + 1) % 500 == 0:
+            torch.cuda.synchronize()
+            for sl, ref in zip(slots, refs):
+                for k in ref:
+                    assert torch.equal(sl.out[k], ref[k]), (i, k)
