@@ -436,23 +436,29 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
         // structured layer 0: row m = visual row (v, f, p'); token(arg) = arg*nppf + p'
         const int ldp = 3 * hd;
         if (which < 2) {
+          // one lane = 8 consecutive head columns of one visual row = ONE 16-byte fragment chunk per
+          // argument (vs two 8-byte halves from adjacent lanes: same 13.9 us at cfg 2 - the epilogue's
+          // 8.5 us are the 18 MB of fan-out writes themselves, not their granularity)
           unsigned short* base = which == 0 ? p.q : p.k;
-          const int c = lane & 7, rsub = lane >> 3;
+          const int c = lane & 3, rsub = lane >> 2;
 #pragma unroll 2
-          for (int ps = 0; ps < WTM / 8; ++ps) {
-            const int rl = ps * 8 + rsub;
+          for (int ps = 0; ps < WTM / 16; ++ps) {
+            const int rl = ps * 16 + rsub;
             const int m = mw + rl;
             if (m >= p.M) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
+            const float4 v0 = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c]);
+            const float4 v1 = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c + 4]);
             const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
             const int vid = sq / p.st_nfrm;
             const int lv = p.st_lpv ? vid : vid / p.st_ncv;
-            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + 4 * c;
+            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + 8 * c;
             unsigned short* dst = base + ((int64_t)sq * p.H + h) * p.npad * p.dp;
             for (int ar = 0; ar < p.st_nsrl; ++ar) {
-              const float4 l = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp);
-              const u16x4 o = {to16<T16>(v.x + l.x), to16<T16>(v.y + l.y), to16<T16>(v.z + l.z), to16<T16>(v.w + l.w)};
-              *reinterpret_cast<u16x4*>(dst + frag_qk(ar * p.st_nppf + pp, dd0 + 4 * c, p.dp)) = o;
+              const float4 l0 = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp);
+              const float4 l1 = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp + 4);
+              const u16x8 o = {to16<T16>(v0.x + l0.x), to16<T16>(v0.y + l0.y), to16<T16>(v0.z + l0.z), to16<T16>(v0.w + l0.w),
+                               to16<T16>(v1.x + l1.x), to16<T16>(v1.y + l1.y), to16<T16>(v1.z + l1.z), to16<T16>(v1.w + l1.w)};
+              *reinterpret_cast<u16x8*>(dst + frag_qk(ar * p.st_nppf + pp, dd0 + 8 * c, p.dp)) = o;
             }
           }
         } else if ((p.st_nppf & 3) == 0) {
