@@ -118,6 +118,10 @@ typedef struct vog_qkv_args {
    * S = n_vid*nfrm sequences of N = nsrl*nppf tokens, no [tokens, d] matrix and no fp32
    * intermediate in HBM (see vog_qkv_combine for the unfused form). */
   const float* pl; int nsrl, nppf, nfrm, lang_per_vid, nc_v;
+  /* kv_visual_only = 1 (with pl): q is fanned out as above, but k and vt are written for the nppf
+   * VISUAL tokens of every sequence only ([S,H,npad_kv*dp], no language part): the operands of
+   * vog_rel_attention_struct_fwd. */
+  int kv_visual_only, npad_kv;
 } vog_qkv_args;
 int vog_qkv_proj(const vog_qkv_args* a, void* stream);
 
@@ -151,6 +155,24 @@ typedef struct vog_attn_args {
   float inv_scale; vog_dtype dtype;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
+
+/* Attention of mul_tx layer 0 through the token structure (exact): token (arg a, proposal p) =
+ * [vis[p] || lang[a]], so k = Kv[p] + Kl[a], v = Vv[p] + Vl[a] and the bias depends on (p, p') only.
+ * The logit of key (a', p') is X[p'] + Y[a'] with X = q.Kv[p'] + bias, Y = q.Kl[a']: the softmax over
+ * the nsrl*nppf keys FACTORISES into softmax_p'(X) x softmax_a'(Y), and the output is
+ *     softmax_p'(X) . Vv  +  softmax_a'(Y) . Vl
+ * - nppf + nsrl keys per query instead of nsrl*nppf (25 instead of 100 at gt5, 405 instead of 2000
+ * at p100), and no fanned-out K / V in HBM. q: [S,H,npad_q*dp] fragment order, N_q = nsrl*nppf
+ * tokens (token = a*nppf + p); kv, vv: [S,H,npad_kv*dp] fragment order, nppf tokens; pl: the
+ * language projection [n_lang*nsrl, 3*H*dp] fp32 of vog_qkv_args (K block at column H*dp, V block at
+ * 2*H*dp); u / pe_b / seq_per_vid / NP as in vog_attn_args with n_box = nppf. out16: [S*N_q, H*dp]. */
+typedef struct vog_attn_struct_args {
+  const void* q; const void* kv; const void* vv; const float* pl; void* out16;
+  const float* u; const float* pe_b;
+  int S, H, dp, nsrl, nppf, npad_q, npad_kv, nfrm, lang_per_vid, nc_v;
+  int use_rel, seq_per_vid, NP; float inv_scale; vog_dtype dtype;
+} vog_attn_struct_args;
+int vog_rel_attention_struct_fwd(const vog_attn_struct_args* a, void* stream);
 
 /* y = LayerNorm(x) * gamma + beta, eps 1e-5 (ResidualBlock.forward
  * transformer_code.py:30-31; the residual add is fused into the producing

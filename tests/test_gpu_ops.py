@@ -447,3 +447,63 @@ def test_pred_head_exact(conc):
         assert (idx == 0).all()
     else:
         assert torch.equal(idx, ref["indexs"])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("S,nfrm,nsrl,nppf,H,dh,dp,use_rel,lpv", [
+    (8, 4, 5, 20, 3, 128, 128, 1, 0), (6, 3, 5, 7, 3, 16, 32, 1, 1), (4, 2, 5, 100, 2, 100, 128, 1, 0),
+    (4, 4, 3, 40, 1, 64, 64, 0, 0), (2, 1, 5, 400, 2, 128, 128, 1, 0)])
+def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype):
+    """Separable mul_tx layer-0 attention: token (a, p) has k = Kv[p] + Kl[a], v = Vv[p] + Vl[a]; the
+    softmax over all nsrl*nppf keys must equal softmax_p'(.)Vv + softmax_a'(.)Vl."""
+    lib = _lib()
+    torch.manual_seed(S * 100 + nppf)
+    td = t16(dtype)
+    n_vid = S // nfrm
+    n_lang = n_vid if lpv else 1            # nc_v = n_vid: every video shares language row 0 when lpv = 0
+    nc_v = 1 if lpv else n_vid
+    Nq = nsrl * nppf
+    npad_q, npad_kv = (Nq + 31) // 32 * 32, (nppf + 31) // 32 * 32
+    hd = H * dp
+    qv = torch.zeros(S, H, nppf, dp, device="cuda"); kvv = torch.zeros_like(qv); vvv = torch.zeros_like(qv)
+    qv[..., :dh] = torch.randn(S, H, nppf, dh, device="cuda")
+    kvv[..., :dh] = torch.randn(S, H, nppf, dh, device="cuda")
+    vvv[..., :dh] = torch.randn(S, H, nppf, dh, device="cuda")
+    pl = torch.zeros(n_lang * nsrl, 3, H, dp, device="cuda")
+    pl[..., :dh] = torch.randn(n_lang * nsrl, 3, H, dh, device="cuda")
+    lrow = torch.tensor([(s // nfrm) if lpv else (s // nfrm) // nc_v for s in range(S)], device="cuda")
+    pls = pl.view(n_lang, nsrl, 3, H, dp)[lrow]                     # [S, nsrl, 3, H, dp]
+    ql, kl, vl = (pls[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # [S, H, nsrl, dp]
+    # what the structured QKV epilogue stores: q fanned out (one rounding of the sum), k / v visual only
+    q_tok = (qv.unsqueeze(2) + ql.unsqueeze(3)).reshape(S, H, Nq, dp).to(td)
+    kv16, vv16 = kvv.to(td), vvv.to(td)
+    u_box = torch.randn(n_vid, nfrm * nppf, H, device="cuda") * 2
+    peb = torch.randn(H, device="cuda")
+    out = torch.full((S * Nq, hd), float("nan"), device="cuda").to(td)
+    inv_scale = 1.0 / math.sqrt(H * dh)
+    a = L.AttnStructArgs()
+    qf, kf, vf = to_frag(q_tok, "qk"), to_frag(kv16, "qk"), to_frag(vv16, "v")
+    plc = pl.reshape(n_lang * nsrl, 3 * hd).contiguous()
+    a.q, a.kv, a.vv, a.pl, a.out16 = L.ptr(qf), L.ptr(kf), L.ptr(vf), L.ptr(plc), L.ptr(out)
+    a.u, a.pe_b = L.ptr(u_box), L.ptr(peb)
+    a.S, a.H, a.dp, a.nsrl, a.nppf, a.npad_q, a.npad_kv = S, H, dp, nsrl, nppf, npad_q, npad_kv
+    a.nfrm, a.lang_per_vid, a.nc_v = nfrm, lpv, nc_v
+    a.use_rel, a.seq_per_vid, a.NP, a.inv_scale, a.dtype = use_rel, nfrm, nfrm * nppf, inv_scale, DT[dtype]
+    L.check(lib.vog_rel_attention_struct_fwd(C.byref(a), _sp()), "struct attention")
+    torch.cuda.synchronize()
+    # full reference over all (a', p') keys with the operands the kernel sees (16-bit rounded parts)
+    klr, vlr = kl.to(td).float(), vl.to(td).float()
+    k_tok = (kv16.float().unsqueeze(2) + klr.unsqueeze(3)).reshape(S, H, Nq, dp)
+    v_tok = (vv16.float().unsqueeze(2) + vlr.unsqueeze(3)).reshape(S, H, Nq, dp)
+    logits = q_tok.float() @ k_tok.transpose(-1, -2)
+    if use_rel:
+        ub = u_box.view(n_vid, nfrm, nppf, H)[torch.arange(S, device="cuda") // nfrm,
+                                              torch.arange(S, device="cuda") % nfrm]        # [S, nppf, H]
+        ut = ub.repeat(1, nsrl, 1).permute(0, 2, 1)                                         # [S, H, Nq]
+        logits = logits + torch.relu(ut.unsqueeze(-1) - ut.unsqueeze(-2) + peb.view(1, -1, 1, 1))
+    ref = torch.softmax(logits * inv_scale, dim=-1) @ v_tok
+    got = out.float().view(S, Nq, H, dp).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    tol = (3e-2 if dtype == "bf16" else 5e-3) * max(1.0, ref.abs().max().item())
+    assert err <= tol, (err, tol)

@@ -538,6 +538,270 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
   }
 }
 
+// ----------------------------------------------------------------------------
+// Separable attention of mul_tx layer 0 (include/vog_hip.h, vog_attn_struct_args). Token (a, p) has
+// k = Kv[p] + Kl[a], v = Vv[p] + Vl[a] and a bias that depends on (p, p') only, so the softmax over
+// the nsrl*nppf keys is the product of a softmax over the nppf visual keys and one over the nsrl
+// language keys, and   out = softmax_p'(q.Kv + bias).Vv + softmax_a'(q.Kl).Vl   (exact).
+// One wave = one 32-query block, nothing shared between waves: the visual part is the flash loop of
+// the kernels above over ceil(nppf/32) key blocks (ONE at gt5), the language part one masked block
+// whose K / V fragments are assembled from the fp32 language projection (5 rows) in registers. The
+// language probabilities are normalised BEFORE their P.V product so that it accumulates into the
+// (already normalised) visual output registers.
+// ----------------------------------------------------------------------------
+struct AttnStructParams {
+  const unsigned short* q; const unsigned short* kv; const unsigned short* vv; const float* pl;
+  unsigned short* out; const float* u; const float* pe_b;
+  int S, H, dp, nsrl, nppf, npad_q, npad_kv, nfrm, lpv, ncv, use_rel, seq_per_vid, NP;
+  float inv_scale;
+};
+
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(AttnStructParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  extern __shared__ __attribute__((aligned(16))) float ssm[];
+  float* us = ssm;                                   // [npad_kv] bias precursor of the visual keys
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int Nq = p.nsrl * p.nppf;
+  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
+  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qb = qg * 4 + wid;
+  const bool wave_ok = qb < nqb;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = wave_ok && qi < Nq;
+  const int nkb = p.npad_kv >> 5;
+  const int hd = p.H * DP, ldp = 3 * hd;
+  const int vid = s / p.nfrm;
+  const int lv = p.lpv ? vid : vid / p.ncv;
+  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
+
+  // every load of this wave is requested up front (Q, the first visual key block, the language K
+  // and V fragments, the bias precursors): the kernel is one memory round trip deep
+  const int qbs = wave_ok ? qb : 0;
+  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) +
+                    (int64_t)qbs * KS * 64 + lane;
+  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
+  u16x8 qf[KS], kf0[KS], vf0[NDB * 2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) { qf[ks] = Qf[ks * 64]; kf0[ks] = Kf[ks * 64]; }
+#pragma unroll
+  for (int i = 0; i < NDB * 2; ++i) vf0[i] = Vf[i * 64];
+  // language K fragments: lane = key a (rows >= nsrl are zero), 8 consecutive head columns
+  u16x8 klf[KS];
+  {
+    const bool a_ok = ql < p.nsrl;
+    const float* kr = plr + hd + (int64_t)ql * ldp + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
+      klf[ks] = u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
+                      to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
+    }
+  }
+  // language V fragments of k-step 0 (keys 0..15; nsrl > 16 adds k-step 1 below): lane = (hi, head
+  // column), register j = key 8*(j>>2) + 4*hi + (j&3)
+  u16x8 vlf[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    const float* vr = plr + 2 * hd + db * 32 + ql;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = 8 * (j >> 2) + 4 * hi + (j & 3);
+      vlf[db][j] = key < p.nsrl ? to16<T16>(vr[(int64_t)key * ldp]) : (unsigned short)0;
+    }
+  }
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
+    peb = p.pe_b[h];
+    for (int key = tid; key < p.npad_kv; key += 256)
+      us[key] = key < p.nppf ? p.u[(u_base + key) * p.H + h] : 0.f;
+    if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
+  }
+  __syncthreads();
+  if (!wave_ok) return;
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  // ---- visual keys: flash loop (one block at gt5)
+  for (int kb = 0; kb < nkb; ++kb) {
+    u16x8 kf[KS], vf[NDB * 2];
+    if (kb == 0) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = kf0[ks];
+#pragma unroll
+      for (int i = 0; i < NDB * 2; ++i) vf[i] = vf0[i];
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
+#pragma unroll
+      for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
+    }
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      s0 = mfma32<T16>(kf[ks], qf[ks], s0);
+      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+    }
+    f32x16 sacc;
+    float mloc = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + c32_row(r, lane);
+      float x = s0[r] + s1[r];
+      if (p.use_rel) x += fmaxf(uqp - us[key], 0.f);
+      x = key < p.nppf ? x * c2 : -1e30f;
+      sacc[r] = x;
+      mloc = fmaxf(mloc, x);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+      sacc[r] = e;
+      lsum += e;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+    if (kb > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    u16x8 pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) o[db] = mfma32<T16>(vf[db * 2 + ks], pf[ks], o[db]);
+  }
+  {
+    const float inv_l = 1.0f / l_run;                // normalise the visual part in place
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= inv_l;
+  }
+  // ---- language keys: one masked block, its own softmax
+  {
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      s0 = mfma32<T16>(klf[ks], qf[ks], s0);
+      if (ks + 1 < KS) s1 = mfma32<T16>(klf[ks + 1], qf[ks + 1], s1);
+    }
+    f32x16 sacc;
+    float m2 = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = c32_row(r, lane);
+      const float x = key < p.nsrl ? (s0[r] + s1[r]) * c2 : -1e30f;
+      sacc[r] = x;
+      m2 = fmaxf(m2, x);
+    }
+    m2 = fmaxf(m2, __shfl_xor(m2, 32));
+    float l2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sacc[r] - m2);
+      sacc[r] = e;
+      l2 += e;
+    }
+    l2 += __shfl_xor(l2, 32);
+    const float inv_l2 = 1.0f / l2;
+    u16x8 pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j] * inv_l2);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      o[db] = mfma32<T16>(vlf[db], pf[0], o[db]);
+      if (p.nsrl > 16) {                             // keys 16..31 (never at nsrl = 5)
+        const float* vr = plr + 2 * hd + db * 32 + ql;
+        u16x8 vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = 16 + 8 * (j >> 2) + 4 * hi + (j & 3);
+          vl[j] = key < p.nsrl ? to16<T16>(vr[(int64_t)key * ldp]) : (unsigned short)0;
+        }
+        o[db] = mfma32<T16>(vl, pf[1], o[db]);
+      }
+    }
+  }
+  if (q_ok) {
+    unsigned short* orow = p.out + ((int64_t)s * Nq + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[db][g * 4 + e]);
+        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
+      }
+  }
+}
+
+template <typename T16, int NDB>
+static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
+  const int nqb = (p.nsrl * p.nppf + 31) / 32;
+  const size_t lds = (size_t)p.npad_kv * sizeof(float);
+  if (lds > 64 * 1024) VOG_FAIL(-1, "struct attention: %d visual keys exceed the LDS budget", p.nppf);
+  dim3 grid(p.S * p.H * ((nqb + 3) / 4));
+  ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T16>
+static int attn_struct_dispatch(const AttnStructParams& p, hipStream_t st) {
+  switch (p.dp) {
+    case 32: return launch_attn_struct<T16, 1>(p, st);
+    case 64: return launch_attn_struct<T16, 2>(p, st);
+    case 128: return launch_attn_struct<T16, 4>(p, st);
+    case 192: return launch_attn_struct<T16, 6>(p, st);
+    case 256: return launch_attn_struct<T16, 8>(p, st);
+    default: VOG_FAIL(-1, "struct attention: unsupported padded head dim %d (32/64/128/192/256)", p.dp);
+  }
+}
+
+int attn_struct_run(const vog_attn_struct_args* a, hipStream_t st) {
+  VOG_CHECK_ARG(a && a->q && a->kv && a->vv && a->pl && a->out16);
+  VOG_CHECK_ARG(a->S > 0 && a->H > 0 && a->nsrl > 0 && a->nsrl <= 32 && a->nppf > 0 && a->nfrm > 0 && a->nc_v > 0);
+  VOG_CHECK_ARG((a->npad_q % 32) == 0 && a->npad_q >= a->nsrl * a->nppf && (a->npad_kv % 32) == 0 && a->npad_kv >= a->nppf);
+  VOG_CHECK_ARG(!a->use_rel || (a->u && a->pe_b && a->seq_per_vid > 0));
+  AttnStructParams p{(const unsigned short*)a->q, (const unsigned short*)a->kv, (const unsigned short*)a->vv, a->pl,
+                     (unsigned short*)a->out16, a->u, a->pe_b, a->S, a->H, a->dp, a->nsrl, a->nppf, a->npad_q,
+                     a->npad_kv, a->nfrm, a->lang_per_vid, a->nc_v, a->use_rel, a->seq_per_vid, a->NP, a->inv_scale};
+  VOG_DISPATCH_DTYPE(a->dtype, return (attn_struct_dispatch<T16>(p, st)));
+  return 0;
+}
+
 template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   static int force_general = -2;      // VOG_ATTN_GENERAL=1: perf experiments only
@@ -624,6 +888,10 @@ int attn_run(const vog_attn_args* a, hipStream_t st) {
 }
 
 }  // namespace vog
+
+extern "C" int vog_rel_attention_struct_fwd(const vog_attn_struct_args* a, void* stream) {
+  return vog::attn_struct_run(a, (hipStream_t)stream);
+}
 
 extern "C" int vog_rel_attention_fwd(const vog_attn_args* a, void* stream) {
   return vog::attn_run(a, (hipStream_t)stream);

@@ -368,7 +368,16 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       qs.x16 = vis16; qs.ldx = sv.dv; qs.K = sv.dv;          // visual rows x first d_vis weight columns
       qs.pl = ws.at<float>(n + "_pl"); qs.nsrl = sv.nsrl; qs.nppf = sv.nppf; qs.nfrm = sv.nfrm;
       qs.lang_per_vid = sv.lang_per_vid; qs.nc_v = sv.nc_v;
+      // K / V only for the visual tokens: the attention below is the separable form
+      qs.kv_visual_only = 1; qs.npad_kv = (int)round_up64(sv.nppf, 32);
       steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_qkv_proj(&qs, st); }});
+      vog_attn_struct_args sa{};
+      sa.q = qa.q; sa.kv = qa.k; sa.vv = qa.vt; sa.pl = qs.pl; sa.out16 = ws.at<void>(n + "_attn16");
+      sa.u = u; sa.pe_b = tw.pe_b; sa.S = S; sa.H = tw.H; sa.dp = tw.dp; sa.nsrl = sv.nsrl; sa.nppf = sv.nppf;
+      sa.npad_q = npad; sa.npad_kv = qs.npad_kv; sa.nfrm = sv.nfrm; sa.lang_per_vid = sv.lang_per_vid;
+      sa.nc_v = sv.nc_v; sa.use_rel = tw.use_rel; sa.seq_per_vid = spv; sa.NP = g.NP;
+      sa.inv_scale = 1.0f / sqrtf((float)tw.d); sa.dtype = dt;
+      steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_struct_fwd(&sa, st); }});
     } else {
       steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
     }
@@ -377,7 +386,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.u = u; aa.pe_b = tw.pe_b; aa.S = S; aa.N = N; aa.H = tw.H; aa.dp = tw.dp; aa.npad = npad;
     aa.use_rel = tw.use_rel; aa.n_box = n_box; aa.seq_per_vid = spv; aa.NP = g.NP;
     aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
-    steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
+    if (!fact)
+      steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
     vog_gemm_args wo{}; wo.c16_dtype = -1;
     wo.a = aa.out16; wo.a_is_f32 = 0; wo.lda = (int64_t)tw.H * tw.dp; wo.w = L.wo; wo.ldw = (int64_t)tw.H * tw.dp;
     wo.residual = cur32; wo.ldr = tw.d; wo.c32 = ws.at<float>(n + "_tmp"); wo.ldc = tw.d;

@@ -44,6 +44,9 @@ struct GemmParams {
   int ntok, H, dp, npad;
   // structured QKV (pl != nullptr): rows are visual rows, fan out over nsrl arguments
   const float* pl; int st_nsrl, st_nppf, st_nfrm, st_lpv, st_ncv;
+  // st_kv_vis: K and V fragments only for the VISUAL rows (ntok = nppf per sequence, npad_kv), no
+  // language part added: the separable attention (attention.hip, attn_struct_kernel) adds it itself
+  int st_kv_vis, npad_kv;
 };
 
 template <typename T16, bool A_F32>
@@ -432,7 +435,10 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
       const int which = nb / hd;
       const int h = (nb - which * hd) / p.dp;
       const int dd0 = nb % p.dp;
-      if (p.pl) {
+      // (token count per sequence, padded count) of the plain fragment writers below
+      const bool kv_vis = p.pl && p.st_kv_vis && which >= 1;
+      const int ntok_w = kv_vis ? p.st_nppf : p.ntok, npad_w = kv_vis ? p.npad_kv : p.npad;
+      if (p.pl && !kv_vis) {
         // structured layer 0: row m = visual row (v, f, p'); token(arg) = arg*nppf + p'
         const int ldp = 3 * hd;
         if (which < 2) {
@@ -514,9 +520,9 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
           const int m = mw + rl;
           if (m >= p.M) continue;
           const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
-          const int sq = m / p.ntok, tok = m - sq * p.ntok;
+          const int sq = m / ntok_w, tok = m - sq * ntok_w;
           const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
-          *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * p.npad * p.dp +
+          *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * npad_w * p.dp +
                                     frag_qk(tok, dd0 + 4 * c, p.dp)) = o;
         }
       } else {
@@ -526,9 +532,9 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
           const int rl = th * 64 + lane;
           const int m = mw + rl;
           if (rl < WTM && m < p.M) {
-            const int sq = m / p.ntok, tok = m - sq * p.ntok;
+            const int sq = m / ntok_w, tok = m - sq * ntok_w;
             // dd0 % 32 == 0: the 32 columns of this group are one d-block of the V fragment
-            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp + frag_v(tok, dd0, p.dp);
+            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_v(tok, dd0, p.dp);
 #pragma unroll 8
             for (int dd = 0; dd < 32; ++dd)
               dst[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd]);
@@ -790,6 +796,8 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
     p.pl = a->pl; p.st_nsrl = a->nsrl; p.st_nppf = a->nppf; p.st_nfrm = a->nfrm; p.st_lpv = a->lang_per_vid;
     p.st_ncv = a->nc_v;
     p.M = a->S * a->nppf;                        // visual rows
+    p.st_kv_vis = a->kv_visual_only ? 1 : 0; p.npad_kv = a->npad_kv;
+    VOG_CHECK_ARG(!a->kv_visual_only || (a->npad_kv >= a->nppf && (a->npad_kv % 32) == 0));
     if (!pipe_ok(p, false) || p.M <= 64)
       VOG_FAIL(-1, "structured QKV needs the LDS-DMA GEMM (K %% 64 == 0, > 64 visual rows)");
   }

@@ -56,7 +56,14 @@ class QkvArgs(C.Structure):
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
                 ("K", c_i32), ("dtype", c_i32),
                 ("pl", c_vp), ("nsrl", c_i32), ("nppf", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32),
-                ("nc_v", c_i32)]
+                ("nc_v", c_i32), ("kv_visual_only", c_i32), ("npad_kv", c_i32)]
+
+
+class AttnStructArgs(C.Structure):
+    _fields_ = [("q", c_vp), ("kv", c_vp), ("vv", c_vp), ("pl", c_vp), ("out16", c_vp), ("u", c_vp), ("pe_b", c_vp),
+                ("S", c_i32), ("H", c_i32), ("dp", c_i32), ("nsrl", c_i32), ("nppf", c_i32), ("npad_q", c_i32),
+                ("npad_kv", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32), ("nc_v", c_i32),
+                ("use_rel", c_i32), ("seq_per_vid", c_i32), ("NP", c_i32), ("inv_scale", c_f32), ("dtype", c_i32)]
 
 
 class QkvCombArgs(C.Structure):
@@ -147,6 +154,7 @@ SYMBOLS = {
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),
     "vog_rel_attention_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
+    "vog_rel_attention_struct_fwd": (c_i32, [C.POINTER(AttnStructArgs), c_vp]),
     "vog_residual_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vog_cast_f32_to_t16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "vog_box_u": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp]),
