@@ -141,3 +141,38 @@ def test_shard_matches_distributed_sampler():
             idx += idx[: total - n] if total - n <= n else (idx * (total // n + 1))[: total - n]
             ref = idx[ds.num_samples * r: ds.num_samples * (r + 1)]
             assert D.shard_indices(n, r, w) == ref, (n, w, r)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """sizeof and the offset of the LAST member of every struct of include/vog_hip.h, as gcc lays
+    them out, against the ctypes mirrors in lib.py (a missing trailing field would make the library
+    read garbage past the Python struct)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    L = importlib.import_module("vognet-pytorch_amd.lib")
+    pairs = {"vog_gemm_args": L.GemmArgs, "vog_splitk_prob": L.SplitkProb, "vog_qkv_args": L.QkvArgs,
+             "vog_qkvcomb_args": L.QkvCombArgs, "vog_attn_args": L.AttnArgs,
+             "vog_attn_struct_args": L.AttnStructArgs, "vog_visprep_args": L.VisprepArgs,
+             "vog_lstm_step_args": L.LstmStepArgs, "vog_lstm_layer_args": L.LstmLayerArgs,
+             "vog_vislang_args": L.VislangArgs, "vog_score_args": L.ScoreArgs,
+             "vog_predcmp_args": L.PredcmpArgs, "vog_pred_args": L.PredArgs,
+             "vog_model_desc": L.ModelDesc, "vog_batch": L.Batch}
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vog_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        last = cls._fields_[-1][0]
+        src.append(f'  printf("{cname} %zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));')
+    src += ['  return 0;', '}']
+    cfile = tmp_path / "abi.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "abi"
+    subprocess.run([gcc, "-I", os.path.join(root, "include"), str(cfile), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        cname, size, off = line.split()
+        cls = pairs[cname]
+        assert C.sizeof(cls) == int(size), (cname, C.sizeof(cls), size)
+        assert getattr(cls, cls._fields_[-1][0]).offset == int(off), (cname, off)
