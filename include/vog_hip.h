@@ -171,6 +171,10 @@ typedef struct vog_attn_struct_args {
   const float* u; const float* pe_b;
   int S, H, dp, nsrl, nppf, npad_q, npad_kv, nfrm, lang_per_vid, nc_v;
   int use_rel, seq_per_vid, NP; float inv_scale; vog_dtype dtype;
+  /* q_visual = 1: q holds only the nppf VISUAL query parts Qv ([S,H,npad_kv*dp], like kv) and the
+   * kernel forms q(a, p) = Qv[p] + Ql[a] itself (Ql = pl columns [0, H*dp)): nothing is fanned out
+   * in HBM (plain vog_qkv_proj over the visual rows, pl = NULL). npad_q is ignored. */
+  int q_visual;
 } vog_attn_struct_args;
 int vog_rel_attention_struct_fwd(const vog_attn_struct_args* a, void* stream);
 

@@ -453,7 +453,8 @@ def test_pred_head_exact(conc):
 @pytest.mark.parametrize("S,nfrm,nsrl,nppf,H,dh,dp,use_rel,lpv", [
     (8, 4, 5, 20, 3, 128, 128, 1, 0), (6, 3, 5, 7, 3, 16, 32, 1, 1), (4, 2, 5, 100, 2, 100, 128, 1, 0),
     (4, 4, 3, 40, 1, 64, 64, 0, 0), (2, 1, 5, 400, 2, 128, 128, 1, 0)])
-def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype):
+@pytest.mark.parametrize("qvis", [0, 1])
+def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, qvis):
     """Separable mul_tx layer-0 attention: token (a, p) has k = Kv[p] + Kl[a], v = Vv[p] + Vl[a]; the
     softmax over all nsrl*nppf keys must equal softmax_p'(.)Vv + softmax_a'(.)Vl."""
     lib = _lib()
@@ -475,14 +476,18 @@ def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, 
     pls = pl.view(n_lang, nsrl, 3, H, dp)[lrow]                     # [S, nsrl, 3, H, dp]
     ql, kl, vl = (pls[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # [S, H, nsrl, dp]
     # what the structured QKV epilogue stores: q fanned out (one rounding of the sum), k / v visual only
-    q_tok = (qv.unsqueeze(2) + ql.unsqueeze(3)).reshape(S, H, Nq, dp).to(td)
+    if qvis:   # queries formed in the kernel from the 16-bit visual part + the fp32 language part
+        q_tok = (qv.to(td).float().unsqueeze(2) + ql.unsqueeze(3)).reshape(S, H, Nq, dp).to(td)
+    else:
+        q_tok = (qv.unsqueeze(2) + ql.unsqueeze(3)).reshape(S, H, Nq, dp).to(td)
     kv16, vv16 = kvv.to(td), vvv.to(td)
     u_box = torch.randn(n_vid, nfrm * nppf, H, device="cuda") * 2
     peb = torch.randn(H, device="cuda")
     out = torch.full((S * Nq, hd), float("nan"), device="cuda").to(td)
     inv_scale = 1.0 / math.sqrt(H * dh)
     a = L.AttnStructArgs()
-    qf, kf, vf = to_frag(q_tok, "qk"), to_frag(kv16, "qk"), to_frag(vv16, "v")
+    qf, kf, vf = to_frag(qv.to(td) if qvis else q_tok, "qk"), to_frag(kv16, "qk"), to_frag(vv16, "v")
+    a.q_visual = qvis
     plc = pl.reshape(n_lang * nsrl, 3 * hd).contiguous()
     a.q, a.kv, a.vv, a.pl, a.out16 = L.ptr(qf), L.ptr(kf), L.ptr(vf), L.ptr(plc), L.ptr(out)
     a.u, a.pe_b = L.ptr(u_box), L.ptr(peb)

@@ -553,7 +553,7 @@ struct AttnStructParams {
   const unsigned short* q; const unsigned short* kv; const unsigned short* vv; const float* pl;
   unsigned short* out; const float* u; const float* pe_b;
   int S, H, dp, nsrl, nppf, npad_q, npad_kv, nfrm, lpv, ncv, use_rel, seq_per_vid, NP;
-  float inv_scale;
+  float inv_scale; int q_visual;
 };
 
 template <typename T16, int NDB>
@@ -581,14 +581,38 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
   // every load of this wave is requested up front (Q, the first visual key block, the language K
   // and V fragments, the bias precursors): the kernel is one memory round trip deep
   const int qbs = wave_ok ? qb : 0;
-  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) +
-                    (int64_t)qbs * KS * 64 + lane;
   const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
   const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
   const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
   u16x8 qf[KS], kf0[KS], vf0[NDB * 2];
+  if (p.q_visual) {
+    // query (a, p) = Qv[p] + Ql[a]: the visual part is this token's 16-byte chunk of the fragment-
+    // ordered Qv (tokens of a block are consecutive p: mostly one contiguous run), the language part
+    // 8 floats of the projection row of argument a (a handful of distinct rows per wave)
+    const int t = qbs * 32 + ql;
+    int a = t / p.nppf;
+    const int pp = t - a * p.nppf;
+    a = a < p.nsrl ? a : p.nsrl - 1;                  // tokens past the end are never stored
+    const unsigned short* qv = p.q + kvbase;
+    const float* qlr = plr + (int64_t)a * ldp + hi * 8;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) { qf[ks] = Qf[ks * 64]; kf0[ks] = Kf[ks * 64]; }
+    for (int ks = 0; ks < KS; ++ks) {
+      const u16x8 v = *reinterpret_cast<const u16x8*>(qv + frag_qk(pp, ks * 16 + hi * 8, DP));
+      const float4 l0 = *reinterpret_cast<const float4*>(qlr + ks * 16);
+      const float4 l1 = *reinterpret_cast<const float4*>(qlr + ks * 16 + 4);
+      qf[ks] = u16x8{to16<T16>(from16<T16>(v[0]) + l0.x), to16<T16>(from16<T16>(v[1]) + l0.y),
+                     to16<T16>(from16<T16>(v[2]) + l0.z), to16<T16>(from16<T16>(v[3]) + l0.w),
+                     to16<T16>(from16<T16>(v[4]) + l1.x), to16<T16>(from16<T16>(v[5]) + l1.y),
+                     to16<T16>(from16<T16>(v[6]) + l1.z), to16<T16>(from16<T16>(v[7]) + l1.w)};
+    }
+  } else {
+    const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) +
+                      (int64_t)qbs * KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kf0[ks] = Kf[ks * 64];
 #pragma unroll
   for (int i = 0; i < NDB * 2; ++i) vf0[i] = Vf[i * 64];
   // language K fragments: lane = key a (rows >= nsrl are zero), 8 consecutive head columns
@@ -793,11 +817,13 @@ static int attn_struct_dispatch(const AttnStructParams& p, hipStream_t st) {
 int attn_struct_run(const vog_attn_struct_args* a, hipStream_t st) {
   VOG_CHECK_ARG(a && a->q && a->kv && a->vv && a->pl && a->out16);
   VOG_CHECK_ARG(a->S > 0 && a->H > 0 && a->nsrl > 0 && a->nsrl <= 32 && a->nppf > 0 && a->nfrm > 0 && a->nc_v > 0);
-  VOG_CHECK_ARG((a->npad_q % 32) == 0 && a->npad_q >= a->nsrl * a->nppf && (a->npad_kv % 32) == 0 && a->npad_kv >= a->nppf);
+  VOG_CHECK_ARG((a->npad_kv % 32) == 0 && a->npad_kv >= a->nppf);
+  VOG_CHECK_ARG(a->q_visual || ((a->npad_q % 32) == 0 && a->npad_q >= a->nsrl * a->nppf));
   VOG_CHECK_ARG(!a->use_rel || (a->u && a->pe_b && a->seq_per_vid > 0));
   AttnStructParams p{(const unsigned short*)a->q, (const unsigned short*)a->kv, (const unsigned short*)a->vv, a->pl,
                      (unsigned short*)a->out16, a->u, a->pe_b, a->S, a->H, a->dp, a->nsrl, a->nppf, a->npad_q,
-                     a->npad_kv, a->nfrm, a->lang_per_vid, a->nc_v, a->use_rel, a->seq_per_vid, a->NP, a->inv_scale};
+                     a->npad_kv, a->nfrm, a->lang_per_vid, a->nc_v, a->use_rel, a->seq_per_vid, a->NP, a->inv_scale,
+                     a->q_visual ? 1 : 0};
   VOG_DISPATCH_DTYPE(a->dtype, return (attn_struct_dispatch<T16>(p, st)));
   return 0;
 }

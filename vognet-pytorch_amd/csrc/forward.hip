@@ -366,15 +366,17 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       const vog_vislang_args sv = *structured;
       vog_qkv_args qs = qa;
       qs.x16 = vis16; qs.ldx = sv.dv; qs.K = sv.dv;          // visual rows x first d_vis weight columns
-      qs.pl = ws.at<float>(n + "_pl"); qs.nsrl = sv.nsrl; qs.nppf = sv.nppf; qs.nfrm = sv.nfrm;
-      qs.lang_per_vid = sv.lang_per_vid; qs.nc_v = sv.nc_v;
-      // K / V only for the visual tokens: the attention below is the separable form
-      qs.kv_visual_only = 1; qs.npad_kv = (int)round_up64(sv.nppf, 32);
+      // nothing is fanned out: q, k, v fragments of the nppf VISUAL tokens of every sequence (a plain
+      // QKV projection of the visual rows); the separable attention below adds the language parts
+      const float* plang = ws.at<float>(n + "_pl");
+      const int npad_kv = (int)round_up64(sv.nppf, 32);
+      qs.N = sv.nppf; qs.npad = npad_kv;
       steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_qkv_proj(&qs, st); }});
       vog_attn_struct_args sa{};
-      sa.q = qa.q; sa.kv = qa.k; sa.vv = qa.vt; sa.pl = qs.pl; sa.out16 = ws.at<void>(n + "_attn16");
+      sa.q_visual = 1;
+      sa.q = qa.q; sa.kv = qa.k; sa.vv = qa.vt; sa.pl = plang; sa.out16 = ws.at<void>(n + "_attn16");
       sa.u = u; sa.pe_b = tw.pe_b; sa.S = S; sa.H = tw.H; sa.dp = tw.dp; sa.nsrl = sv.nsrl; sa.nppf = sv.nppf;
-      sa.npad_q = npad; sa.npad_kv = qs.npad_kv; sa.nfrm = sv.nfrm; sa.lang_per_vid = sv.lang_per_vid;
+      sa.npad_q = npad; sa.npad_kv = npad_kv; sa.nfrm = sv.nfrm; sa.lang_per_vid = sv.lang_per_vid;
       sa.nc_v = sv.nc_v; sa.use_rel = tw.use_rel; sa.seq_per_vid = spv; sa.NP = g.NP;
       sa.inv_scale = 1.0f / sqrtf((float)tw.d); sa.dtype = dt;
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_struct_fwd(&sa, st); }});
