@@ -556,35 +556,19 @@ struct AttnStructParams {
   float inv_scale; int q_visual;
 };
 
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(AttnStructParams p) {
-  constexpr int DP = NDB * 32, KS = DP / 16;
-  extern __shared__ __attribute__((aligned(16))) float ssm[];
-  float* us = ssm;                                   // [npad_kv] bias precursor of the visual keys
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, ql = lane & 31;
-  const int Nq = p.nsrl * p.nppf;
-  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
-  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
-  const int s = pair / p.H, h = pair - s * p.H;
-  const int qb = qg * 4 + wid;
-  const bool wave_ok = qb < nqb;
-  const int qi = qb * 32 + ql;
-  const bool q_ok = wave_ok && qi < Nq;
-  const int nkb = p.npad_kv >> 5;
-  const int hd = p.H * DP, ldp = 3 * hd;
-  const int vid = s / p.nfrm;
-  const int lv = p.lpv ? vid : vid / p.ncv;
-  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
+#ifdef VOG_TS_ATTN   // scratch/ts_attn.hip: wall-clock stamps (100 MHz) per wave
+__device__ unsigned long long g_ats[4096][8];
+#define VOG_ATS(slot) do { if (lane == 0) g_ats[(blockIdx.x * 4 + wid) & 4095][slot] = wall_clock64(); } while (0)
+#else
+#define VOG_ATS(slot) do { } while (0)
+#endif
 
-  // every load of this wave is requested up front (Q, the first visual key block, the language K
-  // and V fragments, the bias precursors): the kernel is one memory round trip deep
-  const int qbs = wave_ok ? qb : 0;
-  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
-  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
-  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
-  u16x8 qf[KS], kf0[KS], vf0[NDB * 2];
+// shared pieces of the two struct kernels ----------------------------------------------------------
+template <typename T16, int KS>
+__device__ __forceinline__ void struct_load_q(const AttnStructParams& p, u16x8 (&qf)[KS], int s, int h, int qbs,
+                                              int lane, const float* plr, int ldp, int64_t kvbase) {
+  constexpr int DP = KS * 16;
+  const int hi = lane >> 5, ql = lane & 31;
   if (p.q_visual) {
     // query (a, p) = Qv[p] + Ql[a]: the visual part is this token's 16-byte chunk of the fragment-
     // ordered Qv (tokens of a block are consecutive p: mostly one contiguous run), the language part
@@ -611,35 +595,202 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
   }
+}
+
+// language K fragments: lane = key a (rows >= nsrl are zero), 8 consecutive head columns
+template <typename T16, int KS>
+__device__ __forceinline__ void struct_load_kl(const AttnStructParams& p, u16x8 (&klf)[KS], int lane,
+                                               const float* plr, int hd, int ldp) {
+  const int hi = lane >> 5, ql = lane & 31;
+  const bool a_ok = ql < p.nsrl;
+  const float* kr = plr + hd + (int64_t)ql * ldp + hi * 8;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kf0[ks] = Kf[ks * 64];
-#pragma unroll
-  for (int i = 0; i < NDB * 2; ++i) vf0[i] = Vf[i * 64];
-  // language K fragments: lane = key a (rows >= nsrl are zero), 8 consecutive head columns
-  u16x8 klf[KS];
-  {
-    const bool a_ok = ql < p.nsrl;
-    const float* kr = plr + hd + (int64_t)ql * ldp + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-      if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
-      klf[ks] = u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
-                      to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
-    }
+  for (int ks = 0; ks < KS; ++ks) {
+    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+    if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
+    klf[ks] = u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
+                    to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
   }
-  // language V fragments of k-step 0 (keys 0..15; nsrl > 16 adds k-step 1 below): lane = (hi, head
-  // column), register j = key 8*(j>>2) + 4*hi + (j&3)
-  u16x8 vlf[NDB];
+}
+
+// language V fragment of d-block db, k-step ks: lane = (hi, head column), register j = key
+// 16*ks + 8*(j>>2) + 4*hi + (j&3)
+template <typename T16>
+__device__ __forceinline__ u16x8 struct_load_vl(const AttnStructParams& p, int db, int ks, int lane,
+                                                const float* plr, int hd, int ldp) {
+  const int hi = lane >> 5, ql = lane & 31;
+  const float* vr = plr + 2 * hd + db * 32 + ql;
+  u16x8 vl;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int key = ks * 16 + 8 * (j >> 2) + 4 * hi + (j & 3);
+    vl[j] = key < p.nsrl ? to16<T16>(vr[(int64_t)key * ldp]) : (unsigned short)0;
+  }
+  return vl;
+}
+
+template <typename T16>
+__device__ __forceinline__ void struct_store(const AttnStructParams& p, const f32x16& o, int db, int64_t row,
+                                             int h, int DP, int hi) {
+  unsigned short* orow = p.out + row * ((int64_t)p.H * DP) + (int64_t)h * DP;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    u16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[g * 4 + e]);
+    *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
+  }
+}
+
+// ---- ONE visual key block (nppf <= 32: every gt5 shape). Both softmaxes are complete before any
+// P.V product, so the output is produced d-block by d-block with ONE accumulator: the kernel holds
+// Q, K, K_lang (3 x KS fragments) in its first phase and V, V_lang + 16 accumulator registers in the
+// second, instead of the flash kernel's NDB accumulators alive through everything (dp = 256: 512
+// registers and 104 spills, 23 us).
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  extern __shared__ __attribute__((aligned(16))) float ssm[];
+  float* us = ssm;                                   // [32] bias precursor of the visual keys
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  VOG_ATS(0);
+  const int Nq = p.nsrl * p.nppf;
+  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
+  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qb = qg * 4 + wid;
+  const bool wave_ok = qb < nqb;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = wave_ok && qi < Nq;
+  const int hd = p.H * DP, ldp = 3 * hd;
+  const int vid = s / p.nfrm;
+  const int lv = p.lpv ? vid : vid / p.ncv;
+  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
+  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
+
+  u16x8 qf[KS], kf[KS], klf[KS];
+  struct_load_q<T16, KS>(p, qf, s, h, wave_ok ? qb : 0, lane, plr, ldp, kvbase);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[ks * 64];
+  struct_load_kl<T16, KS>(p, klf, lane, plr, hd, ldp);
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
+    peb = p.pe_b[h];
+    if (tid < 32) us[tid] = tid < p.nppf ? p.u[(u_base + tid) * p.H + h] : 0.f;
+    if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
+  }
+  VOG_ATS(1);
+  __syncthreads();
+  if (!wave_ok) return;
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+  // ---- both logit blocks
+  f32x16 sv, sl;
+  {
+    f32x16 s1, l1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = 0.f; s1[r] = 0.f; sl[r] = 0.f; l1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      sv = mfma32<T16>(kf[ks], qf[ks], sv);
+      sl = mfma32<T16>(klf[ks], qf[ks], sl);
+      if (ks + 1 < KS) {
+        s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+        l1 = mfma32<T16>(klf[ks + 1], qf[ks + 1], l1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] += s1[r]; sl[r] += l1[r]; }
+  }
+  VOG_ATS(2);
+  // ---- two independent softmaxes, probabilities normalised before P.V
+  u16x8 pv_[2], pl_[2];
+  {
+    float mv = -1e30f, ml = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = c32_row(r, lane);
+      float x = sv[r];
+      if (p.use_rel) x += fmaxf(uqp - us[key], 0.f);
+      x = key < p.nppf ? x * c2 : -1e30f;
+      const float y = key < p.nsrl ? sl[r] * c2 : -1e30f;
+      sv[r] = x; sl[r] = y;
+      mv = fmaxf(mv, x); ml = fmaxf(ml, y);
+    }
+    mv = fmaxf(mv, __shfl_xor(mv, 32));
+    ml = fmaxf(ml, __shfl_xor(ml, 32));
+    float lv_ = 0.f, ll = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = __builtin_amdgcn_exp2f(sv[r] - mv); lv_ += sv[r];
+      sl[r] = __builtin_amdgcn_exp2f(sl[r] - ml); ll += sl[r];
+    }
+    lv_ += __shfl_xor(lv_, 32);
+    ll += __shfl_xor(ll, 32);
+    const float iv = 1.0f / lv_, il = 1.0f / ll;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pv_[ks][j] = to16<T16>(sv[ks * 8 + j] * iv);
+        pl_[ks][j] = to16<T16>(sl[ks * 8 + j] * il);
+      }
+  }
+  VOG_ATS(3);
+  // ---- output, one d-block at a time
+  const int nksl = p.nsrl > 16 ? 2 : 1;
 #pragma unroll
   for (int db = 0; db < NDB; ++db) {
-    const float* vr = plr + 2 * hd + db * 32 + ql;
+    const u16x8 v0 = Vf[(db * 2) * 64], v1 = Vf[(db * 2 + 1) * 64];
+    const u16x8 w0 = struct_load_vl<T16>(p, db, 0, lane, plr, hd, ldp);
+    f32x16 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int key = 8 * (j >> 2) + 4 * hi + (j & 3);
-      vlf[db][j] = key < p.nsrl ? to16<T16>(vr[(int64_t)key * ldp]) : (unsigned short)0;
-    }
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    o = mfma32<T16>(v0, pv_[0], o);
+    o = mfma32<T16>(v1, pv_[1], o);
+    o = mfma32<T16>(w0, pl_[0], o);
+    if (nksl > 1) o = mfma32<T16>(struct_load_vl<T16>(p, db, 1, lane, plr, hd, ldp), pl_[1], o);
+    if (q_ok) struct_store<T16>(p, o, db, (int64_t)s * Nq + qi, h, DP, hi);
   }
+  VOG_ATS(4);
+#ifdef VOG_TS_ATTN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VOG_ATS(5);
+#endif
+}
+
+// ---- general form: flash loop over the visual key blocks (p100), then the language block
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(AttnStructParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  extern __shared__ __attribute__((aligned(16))) float ssm[];
+  float* us = ssm;                                   // [npad_kv] bias precursor of the visual keys
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int Nq = p.nsrl * p.nppf;
+  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
+  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qb = qg * 4 + wid;
+  const bool wave_ok = qb < nqb;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = wave_ok && qi < Nq;
+  const int nkb = p.npad_kv >> 5;
+  const int hd = p.H * DP, ldp = 3 * hd;
+  const int vid = s / p.nfrm;
+  const int lv = p.lpv ? vid : vid / p.ncv;
+  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
+  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
+  u16x8 qf[KS];
+  struct_load_q<T16, KS>(p, qf, s, h, wave_ok ? qb : 0, lane, plr, ldp, kvbase);
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
@@ -659,28 +810,23 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  // ---- visual keys: flash loop (one block at gt5)
   for (int kb = 0; kb < nkb; ++kb) {
-    u16x8 kf[KS], vf[NDB * 2];
-    if (kb == 0) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = kf0[ks];
-#pragma unroll
-      for (int i = 0; i < NDB * 2; ++i) vf[i] = vf0[i];
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
-#pragma unroll
-      for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
-    }
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    {
+      u16x8 kf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      s0 = mfma32<T16>(kf[ks], qf[ks], s0);
-      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
+#pragma unroll
+      for (int ks = 0; ks < KS; ks += 2) {
+        s0 = mfma32<T16>(kf[ks], qf[ks], s0);
+        if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+      }
     }
+    u16x8 vf[NDB * 2];
+#pragma unroll
+    for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
     f32x16 sacc;
     float mloc = -1e30f;
 #pragma unroll
@@ -728,8 +874,11 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[i][r] *= inv_l;
   }
-  // ---- language keys: one masked block, its own softmax
+  // ---- language keys: one masked block, its own softmax, probabilities normalised before P.V so
+  // that it accumulates into the normalised visual output
   {
+    u16x8 klf[KS];
+    struct_load_kl<T16, KS>(p, klf, lane, plr, hd, ldp);
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -762,32 +911,17 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j] * inv_l2);
+    const int nksl = p.nsrl > 16 ? 2 : 1;
 #pragma unroll
     for (int db = 0; db < NDB; ++db) {
-      o[db] = mfma32<T16>(vlf[db], pf[0], o[db]);
-      if (p.nsrl > 16) {                             // keys 16..31 (never at nsrl = 5)
-        const float* vr = plr + 2 * hd + db * 32 + ql;
-        u16x8 vl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int key = 16 + 8 * (j >> 2) + 4 * hi + (j & 3);
-          vl[j] = key < p.nsrl ? to16<T16>(vr[(int64_t)key * ldp]) : (unsigned short)0;
-        }
-        o[db] = mfma32<T16>(vl, pf[1], o[db]);
-      }
+      o[db] = mfma32<T16>(struct_load_vl<T16>(p, db, 0, lane, plr, hd, ldp), pf[0], o[db]);
+      if (nksl > 1) o[db] = mfma32<T16>(struct_load_vl<T16>(p, db, 1, lane, plr, hd, ldp), pf[1], o[db]);
     }
   }
   if (q_ok) {
-    unsigned short* orow = p.out + ((int64_t)s * Nq + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[db][g * 4 + e]);
-        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
-      }
+      struct_store<T16>(p, o[db], db, (int64_t)s * Nq + qi, h, DP, hi);
   }
 }
 
@@ -797,7 +931,8 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
   const size_t lds = (size_t)p.npad_kv * sizeof(float);
   if (lds > 64 * 1024) VOG_FAIL(-1, "struct attention: %d visual keys exceed the LDS budget", p.nppf);
   dim3 grid(p.S * p.H * ((nqb + 3) / 4));
-  ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+  if (p.npad_kv == 32) ::vog::launch((attn_struct1_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+  else ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
