@@ -672,11 +672,38 @@ __global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
   const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
   const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
 
+  // The language projection rows of this (video, head) - nsrl x {Q, K, V} x DP floats - are staged in
+  // LDS once per workgroup (a few 16-byte loads per thread) instead of ~70 small global loads per
+  // wave; Qv and K fragments go straight to registers meanwhile.
+  float* pls = ssm + 32;                             // [nsrl][3][DP]
+  {
+    const int per_row = 3 * DP / 4;                  // float4 per argument
+    for (int i = tid; i < p.nsrl * per_row; i += 256) {
+      const int a = i / per_row, c = i - a * per_row;
+      const int part = c / (DP / 4), dd4 = c - part * (DP / 4);
+      *reinterpret_cast<float4*>(&pls[(a * 3 + part) * DP + dd4 * 4]) =
+          *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + part * hd + dd4 * 4);
+    }
+  }
   u16x8 qf[KS], kf[KS], klf[KS];
-  struct_load_q<T16, KS>(p, qf, s, h, wave_ok ? qb : 0, lane, plr, ldp, kvbase);
+  const int qbs = wave_ok ? qb : 0;
+  int qa = 0, qp = 0;
+  if (p.q_visual) {
+    const int t = qbs * 32 + ql;
+    qa = t / p.nppf;
+    qp = t - qa * p.nppf;
+    qa = qa < p.nsrl ? qa : p.nsrl - 1;              // tokens past the end are never stored
+    const unsigned short* qv = p.q + kvbase;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qv + frag_qk(qp, ks * 16 + hi * 8, DP));
+  } else {
+    const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) +
+                      (int64_t)qbs * KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[ks * 64];
-  struct_load_kl<T16, KS>(p, klf, lane, plr, hd, ldp);
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
@@ -687,6 +714,30 @@ __global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
   VOG_ATS(1);
   __syncthreads();
   if (!wave_ok) return;
+  if (p.q_visual) {                                  // q(a, p) = Qv[p] + Ql[a]
+    const float* qlr = pls + (qa * 3 + 0) * DP + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u16x8 v = qf[ks];
+      const float4 l0 = *reinterpret_cast<const float4*>(qlr + ks * 16);
+      const float4 l1 = *reinterpret_cast<const float4*>(qlr + ks * 16 + 4);
+      qf[ks] = u16x8{to16<T16>(from16<T16>(v[0]) + l0.x), to16<T16>(from16<T16>(v[1]) + l0.y),
+                     to16<T16>(from16<T16>(v[2]) + l0.z), to16<T16>(from16<T16>(v[3]) + l0.w),
+                     to16<T16>(from16<T16>(v[4]) + l1.x), to16<T16>(from16<T16>(v[5]) + l1.y),
+                     to16<T16>(from16<T16>(v[6]) + l1.z), to16<T16>(from16<T16>(v[7]) + l1.w)};
+    }
+  }
+  {                                                  // language K fragments: lane = key a
+    const bool a_ok = ql < p.nsrl;
+    const float* kr = pls + ((a_ok ? ql : 0) * 3 + 1) * DP + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
+      klf[ks] = u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
+                      to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
+    }
+  }
   const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
   const float uqp = uq + peb;
   // ---- both logit blocks
@@ -747,7 +798,12 @@ __global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
 #pragma unroll
   for (int db = 0; db < NDB; ++db) {
     const u16x8 v0 = Vf[(db * 2) * 64], v1 = Vf[(db * 2 + 1) * 64];
-    const u16x8 w0 = struct_load_vl<T16>(p, db, 0, lane, plr, hd, ldp);
+    u16x8 w0;                                        // language V fragment from the staged rows
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = 8 * (j >> 2) + 4 * hi + (j & 3);
+      w0[j] = key < p.nsrl ? to16<T16>(pls[(key * 3 + 2) * DP + db * 32 + ql]) : (unsigned short)0;
+    }
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -928,7 +984,8 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
 template <typename T16, int NDB>
 static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
   const int nqb = (p.nsrl * p.nppf + 31) / 32;
-  const size_t lds = (size_t)p.npad_kv * sizeof(float);
+  const size_t lds = p.npad_kv == 32 ? (size_t)(32 + p.nsrl * 3 * NDB * 32) * sizeof(float)
+                                     : (size_t)p.npad_kv * sizeof(float);
   if (lds > 64 * 1024) VOG_FAIL(-1, "struct attention: %d visual keys exceed the LDS budget", p.nppf);
   dim3 grid(p.S * p.H * ((nqb + 3) / 4));
   if (p.npad_kv == 32) ::vog::launch((attn_struct1_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
