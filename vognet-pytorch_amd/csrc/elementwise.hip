@@ -173,22 +173,28 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int o0 = blockIdx.y * 16 + wid * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  // 2L <= 1024: up to 16 strided elements per lane, all loads issued before the FMAs
-  constexpr int MAXI = 16;
-  float xv[MAXI], wv[4][MAXI];
+  // 2L <= 1024, L % 4 == 0: 16 bytes per lane per access (4 x fewer load instructions than one
+  // float per lane: the kernel is latency bound and every load instruction costs issue time),
+  // all loads issued before the FMAs
+  constexpr int MAXQ = 4;
+  const int nq = (2 * L) >> 2, lq = L >> 2;
+  float4 xv[MAXQ], wv[4][MAXQ];
 #pragma unroll
-  for (int it = 0; it < MAXI; ++it) {
+  for (int it = 0; it < MAXQ; ++it) {
     const int i = lane + it * 64;
-    const bool ok = i < 2 * L;
-    xv[it] = ok ? (i < L ? x0[i] : x1[i - L]) : 0.f;
+    const bool ok = i < nq;
+    xv[it] = ok ? (i < lq ? reinterpret_cast<const float4*>(x0)[i] : reinterpret_cast<const float4*>(x1)[i - lq])
+                : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      wv[k][it] = (ok && o0 + k < L) ? w[(int64_t)(o0 + k) * 2 * L + i] : 0.f;
+      wv[k][it] = (ok && o0 + k < L) ? reinterpret_cast<const float4*>(w + (int64_t)(o0 + k) * 2 * L)[i]
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
-  for (int it = 0; it < MAXI; ++it)
+  for (int it = 0; it < MAXQ; ++it)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += wv[k][it] * xv[it];
+    for (int k = 0; k < 4; ++k)
+      acc[k] += (wv[k][it].x * xv[it].x + wv[k][it].y * xv[it].y) + (wv[k][it].z * xv[it].z + wv[k][it].w * xv[it].w);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float v = wave_sum(acc[k]);
@@ -618,7 +624,7 @@ extern "C" int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask
 extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const int64_t* inds_msk,
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
-  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512);
+  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512 && (L % 4) == 0);
   ::vog::launch(argvec_kernel, dim3(Bn * nsrl, ceil_div(L, 16)), dim3(256), 0,
                      (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L);
   VOG_LAUNCH_CHECK();
