@@ -551,12 +551,15 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
 // SK_CH = k-steps (of 32) per register chunk. The W panel is the HBM-bound stream of this
 // kernel: with K = 2048 a wave owns 16 k-steps, and all 16 of its weight fragments are
 // requested before anything else (one round trip instead of two).
-template <typename T16, bool A_F32, int SK_CH, int NT>
-__global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4>
+__global__ __launch_bounds__(KW * 64) void gemm_skinny(GemmParams p) {
   // NT 16-column tiles per workgroup: every A fragment a wave loads feeds NT MFMAs, so the
-  // L2 traffic for A (re-read by every workgroup) drops by NT; used when there are enough
-  // column tiles to still fill the chip.
-  __shared__ float red[4][NT][4][64][4];      // [wave][ntile][mtile][lane][reg]
+  // L2 traffic for A (re-read by every workgroup) drops by NT. KW waves split K. (NT, KW) = (1, 4)
+  // is the general form; (2, 8) keeps the wave count of (1, 4) with half the workgroups, i.e. half
+  // the re-reads of the activation panel, for the N >= 8192 LSTM input projections whose L2->CU
+  // traffic was 80 % activation re-reads.
+  extern __shared__ __attribute__((aligned(16))) float red_raw[];
+  float (*red)[NT][4][64][4] = reinterpret_cast<float (*)[NT][4][64][4]>(red_raw);   // [wave][ntile][mtile][lane][reg]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ct0 = blockIdx.x * NT;            // first 16-column tile
   const int kg = (lane >> 4) * 8;
@@ -589,13 +592,13 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
   }
 
   // wave `wid` owns k-steps wid, wid+4, ... ; processed SK_CH at a time
-  for (int base = wid; base < ksteps; base += 4 * SK_CH) {
+  for (int base = wid; base < ksteps; base += KW * SK_CH) {
     u16x8 fw[NT][SK_CH];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int c = 0; c < SK_CH; ++c) {
-        const int ks = base + c * 4;
+        const int ks = base + c * KW;
         if (p.w_frag) {   // one contiguous KiB per (column tile, k-step)
           u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
           fw[t][c] = (ks < ksteps && n_ok[t]) ? *reinterpret_cast<const u16x8*>(
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
         u16x8 fa[SK_CH];
 #pragma unroll
         for (int c = 0; c < SK_CH; ++c) {
-          const int ks = base + c * 4;
+          const int ks = base + c * KW;
           if (!A_F32 && p.a_frag) {   // contiguous KiB per (row tile, k-step); pad rows are zero-filled
             u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             fa[c] = ks < ksteps ? *reinterpret_cast<const u16x8*>(reinterpret_cast<const unsigned short*>(p.a) +
@@ -633,17 +636,21 @@ __global__ __launch_bounds__(256) void gemm_skinny(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wid][t][mt][lane][r] = acc[t][mt][r];
   __syncthreads();
-  // wave w finishes m-tile w
-  const int mt = wid;
+  // wave w finishes m-tile w % 4 of column tile(s) w / 4, w / 4 + KW / 4, ...
+  const int mt = wid & 3;
   if (mt >= mt_lo && mt < mt_n) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      if ((t % (KW / 4)) != (wid >> 2)) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = red[0][t][mt][lane][r] + red[1][t][mt][lane][r] + red[2][t][mt][lane][r] + red[3][t][mt][lane][r];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) v += red[w][t][mt][lane][r];
         const int row = mt * 16 + (lane >> 4) * 4 + r;
         epilogue_store<T16>(p, row, (ct0 + t) * 16 + (lane & 15), v);
       }
+    }
   }
 }
 
@@ -755,14 +762,31 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
     // NT = 2 halves the L2 re-reads of A but also the workgroup count: measured SLOWER at
     // M=48,N=8192,K=2048 (12.7 vs 11.1 us) and much slower at small N -> opt-in for experiments
     const int nt = nt_env == 2 ? 2 : 1;
-    if (nt == 2) {
+    const size_t lds1 = (size_t)4 * 1 * 4 * 64 * 4 * sizeof(float), lds2 = (size_t)4 * 2 * 4 * 64 * 4 * sizeof(float);
+    // wide projections (LSTM input GEMMs, N = 8192): 8 waves split K, 2 column tiles per workgroup
+    const bool wide = ncol >= 512 && (ncol % 2) == 0 && p.K / 32 >= 64 && nt_env != 1;
+    if (wide) {
+      dim3 grid(ncol / 2, 1);
+      const size_t lds8 = (size_t)8 * 2 * 4 * 64 * 4 * sizeof(float);          // 64 KiB
+      if (g->a_is_f32) {
+        auto kern = gemm_skinny<T16, true, 8, 2, 8>;
+        static bool attr = false;
+        if (!attr) { VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); attr = true; }
+        ::vog::launch(kern, grid, dim3(512), lds8, st, p);
+      } else {
+        auto kern = gemm_skinny<T16, false, 8, 2, 8>;
+        static bool attr = false;
+        if (!attr) { VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); attr = true; }
+        ::vog::launch(kern, grid, dim3(512), lds8, st, p);
+      }
+    } else if (nt == 2) {
       dim3 grid(ceil_div(ncol, 2), 1);
-      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 2>), grid, dim3(256), 0, st, p);
-      else ::vog::launch((gemm_skinny<T16, false, 8, 2>), grid, dim3(256), 0, st, p);
+      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 2>), grid, dim3(256), lds2, st, p);
+      else ::vog::launch((gemm_skinny<T16, false, 8, 2>), grid, dim3(256), lds2, st, p);
     } else {
       dim3 grid(ncol, ncol < 128 ? ceil_div(p.M, 16) : 1);
-      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), 0, st, p);
-      else ::vog::launch((gemm_skinny<T16, false, 8, 1>), grid, dim3(256), 0, st, p);
+      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), lds1, st, p);
+      else ::vog::launch((gemm_skinny<T16, false, 8, 1>), grid, dim3(256), lds1, st, p);
     }
     VOG_LAUNCH_CHECK();
     return 0;
