@@ -39,6 +39,8 @@ struct GemmParams {
   int splitk; int w_frag; int a_frag;
   // implicit vis||lang residual (res_vis != nullptr)
   const float* res_vis; const float* res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
+  // division of a row index by loop-invariant counts: q = (umulhi(n, mul) + n) >> shr (n < 2^31)
+  unsigned fdN_mul, fdN_shr, fdP_mul, fdP_shr, fdF_mul, fdF_shr, fdC_mul, fdC_shr;
   // QKV epilogue
   unsigned short* q; unsigned short* k; unsigned short* vt;
   int ntok, H, dp, npad;
@@ -66,14 +68,18 @@ __device__ __forceinline__ u16x8 load_a_chunk(const void* a, int64_t row_off, in
 
 // residual pointer of token row m, column n, for the implicit vis||lang token matrix
 // (row m = (s=(v,f), j=a*nppf+p); a 4-column chunk never straddles dv since dv % 4 == 0)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+  return (int)(((unsigned long long)__umulhi((unsigned)n, mul) + (unsigned)n) >> shr);
+}
+// (three hardware integer divisions per 16-byte chunk here were ~70 of the 250 us of the p100 Wo GEMM)
 __device__ __forceinline__ const float* vislang_res_ptr(const GemmParams& p, int m, int n) {
   const int N = p.rv_nsrl * p.rv_nppf;
-  const int s = m / N, j = m - s * N;
-  const int v = s / p.rv_nfrm, f = s - v * p.rv_nfrm;
-  const int a = j / p.rv_nppf, pp = j - a * p.rv_nppf;
-  if (n < p.rv_dv)
-    return p.res_vis + ((int64_t)v * p.rv_nfrm * p.rv_nppf + (int64_t)f * p.rv_nppf + pp) * p.rv_dv + n;
-  const int lv = p.rv_lpv ? v : v / p.rv_ncv;
+  const int s = fast_div(m, p.fdN_mul, p.fdN_shr), j = m - s * N;
+  const int a = fast_div(j, p.fdP_mul, p.fdP_shr), pp = j - a * p.rv_nppf;
+  if (n < p.rv_dv)       // visual row of sequence s = (v, f): v*nfrm*nppf + f*nppf + pp = s*nppf + pp
+    return p.res_vis + ((int64_t)s * p.rv_nppf + pp) * p.rv_dv + n;
+  const int v = fast_div(s, p.fdF_mul, p.fdF_shr);
+  const int lv = p.rv_lpv ? v : fast_div(v, p.fdC_mul, p.fdC_shr);
   return p.res_lang + ((int64_t)lv * p.rv_nsrl + a) * p.rv_dl + (n - p.rv_dv);
 }
 
@@ -741,6 +747,14 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   p.splitk = g->splitk;
   if (g->res_vislang) {
     const vog_vislang_args* r = g->res_vislang;
+    auto mk = [](int d, unsigned* mul, unsigned* shr) {
+      unsigned sh = 0;
+      while ((1ull << sh) < (unsigned long long)d) ++sh;
+      *shr = sh;
+      *mul = d <= 1 ? 0u : (unsigned)((((1ull << 32) * ((1ull << sh) - (unsigned long long)d)) / (unsigned long long)d) + 1ull);
+    };
+    mk(r->nsrl * r->nppf, &p.fdN_mul, &p.fdN_shr); mk(r->nppf, &p.fdP_mul, &p.fdP_shr);
+    mk(r->nfrm, &p.fdF_mul, &p.fdF_shr); mk(r->nc_v, &p.fdC_mul, &p.fdC_shr);
     p.res_vis = r->vis; p.res_lang = r->lang; p.rv_nfrm = r->nfrm; p.rv_nppf = r->nppf; p.rv_nsrl = r->nsrl;
     p.rv_dv = r->dv; p.rv_dl = r->dl; p.rv_lpv = r->lang_per_vid; p.rv_ncv = r->nc_v;
   }
