@@ -41,6 +41,7 @@ struct GemmParams {
   const float* res_vis; const float* res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
   // division of a row index by loop-invariant counts: q = (umulhi(n, mul) + n) >> shr (n < 2^31)
   unsigned fdN_mul, fdN_shr, fdP_mul, fdP_shr, fdF_mul, fdF_shr, fdC_mul, fdC_shr;
+  unsigned fdT_mul, fdT_shr;           // QKV epilogue: row / tokens-per-sequence (plain fragment writers)
   // QKV epilogue
   unsigned short* q; unsigned short* k; unsigned short* vt;
   int ntok, H, dp, npad;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
           const int m = mw + rl;
           if (m >= p.M) continue;
           const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
-          const int sq = m / ntok_w, tok = m - sq * ntok_w;
+          const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
           const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
           *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * npad_w * p.dp +
                                     frag_qk(tok, dd0 + 4 * c, p.dp)) = o;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
           const int rl = th * 64 + lane;
           const int m = mw + rl;
           if (rl < WTM && m < p.M) {
-            const int sq = m / ntok_w, tok = m - sq * ntok_w;
+            const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
             // dd0 % 32 == 0: the 32 columns of this group are one d-block of the V fragment
             unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_v(tok, dd0, p.dp);
 #pragma unroll 8
@@ -841,6 +842,13 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
   }
   p.q = (unsigned short*)a->q; p.k = (unsigned short*)a->k; p.vt = (unsigned short*)a->vt;
   p.ntok = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad;
+  {   // tokens per sequence seen by the plain fragment writers (visual-only K/V use nppf)
+    const int d = (a->pl && a->kv_visual_only) ? a->nppf : a->N;
+    unsigned sh = 0;
+    while ((1ull << sh) < (unsigned long long)d) ++sh;
+    p.fdT_shr = sh;
+    p.fdT_mul = d <= 1 ? 0u : (unsigned)((((1ull << 32) * ((1ull << sh) - (unsigned long long)d)) / (unsigned long long)d) + 1ull);
+  }
   p.debug = gemm_debug_flags();
   VOG_DISPATCH_DTYPE(a->dtype, return (launch_tiled<T16, false, EPI_QKV>(p, st)));
   return 0;
