@@ -228,6 +228,12 @@ typedef struct vog_visprep_args {
   const float* w_pe1; float* u1; int H1; float nfrm_div1;
 } vog_visprep_args;
 int vog_vis_prep(const vog_visprep_args* a, void* stream);
+/* vog_lang_prep + vog_vis_prep in ONE launch (the two prologues are independent of each other;
+ * one launch less on the forward's dependent chain). Arguments as for the two entries. */
+int vog_prep_fused(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+                   const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
+                   int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
+                   const vog_visprep_args* vis, void* stream);
 
 /* One time step of one BiLSTM layer, both directions, packed-sequence
  * semantics (LSTMEncoder.forward mdl_srl_utils.py:134-148; nn.LSTM gate order

@@ -460,16 +460,20 @@ __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
 // ---------------------------------------------------------------------------
 // fused prologues (one graph node each instead of 3)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lang_prep_kernel(uint4* __restrict__ zero, int64_t zero16,
-                                                        const int64_t* __restrict__ words,
-                                                        const int64_t* __restrict__ mask,
-                                                        const int64_t* __restrict__ lens,
-                                                        int32_t* __restrict__ tok, int32_t* __restrict__ rows,
-                                                        int Bn, int T, int nsrl, int seq_len, int vocab,
-                                                        const unsigned short* __restrict__ emb16,
-                                                        unsigned short* __restrict__ a0, int E) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+struct LangPrepArgs {
+  uint4* zero; int64_t zero16; const int64_t* words; const int64_t* mask; const int64_t* lens;
+  int32_t* tok; int32_t* rows; int Bn, T, nsrl, seq_len, vocab;
+  const unsigned short* emb16; unsigned short* a0; int E;
+};
+
+__device__ __forceinline__ void lang_prep_body(const LangPrepArgs& a, int bid, int nblocks) {
+  uint4* __restrict__ zero = a.zero; const int64_t zero16 = a.zero16;
+  const int64_t* __restrict__ words = a.words; const int64_t* __restrict__ mask = a.mask;
+  const int64_t* __restrict__ lens = a.lens; int32_t* __restrict__ tok = a.tok; int32_t* __restrict__ rows = a.rows;
+  const int Bn = a.Bn, T = a.T, nsrl = a.nsrl, seq_len = a.seq_len, vocab = a.vocab;
+  const unsigned short* __restrict__ emb16 = a.emb16; unsigned short* __restrict__ a0 = a.a0; const int E = a.E;
+  const int64_t gid = (int64_t)bid * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblocks * blockDim.x;
   for (int64_t i = gid; i < zero16; i += stride) zero[i] = make_uint4(0, 0, 0, 0);
   if (a0) {
     // embedding rows of the Bn*T tokens, 16 bit, in the A-fragment order of the M <= 64 GEMM:
@@ -496,16 +500,18 @@ __global__ __launch_bounds__(256) void lang_prep_kernel(uint4* __restrict__ zero
   }
 }
 
+__global__ __launch_bounds__(256) void lang_prep_kernel(LangPrepArgs a) { lang_prep_body(a, blockIdx.x, gridDim.x); }
+
 template <typename T16>
-__global__ __launch_bounds__(256) void vis_prep_kernel(vog_visprep_args a, int cast_blocks) {
-  if ((int)blockIdx.x < cast_blocks) {
+__device__ __forceinline__ void vis_prep_body(const vog_visprep_args& a, int cast_blocks, int bid) {
+  if (bid < cast_blocks) {
     const int64_t q0 = a.n0 / 4, q1 = a.n1 / 4;
     const int64_t stride = (int64_t)cast_blocks * blockDim.x;
     const float4* s0 = reinterpret_cast<const float4*>(a.src0);
     const float4* s1 = reinterpret_cast<const float4*>(a.src1);
     u16x4* d0 = reinterpret_cast<u16x4*>(a.dst0);
     u16x4* d1 = reinterpret_cast<u16x4*>(a.dst1);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q0 + q1; i += stride) {
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < q0 + q1; i += stride) {
       const bool first = i < q0;
       const float4 v = first ? s0[i] : s1[i - q0];
       u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void vis_prep_kernel(vog_visprep_args a, int c
     }
     return;
   }
-  const int i = ((int)blockIdx.x - cast_blocks) * blockDim.x + threadIdx.x;
+  const int i = (bid - cast_blocks) * blockDim.x + threadIdx.x;
   const int n0 = a.w_pe0 ? a.n_rows * a.H0 : 0, n1 = a.w_pe1 ? a.n_rows * a.H1 : 0;
   if (i >= n0 + n1) return;
   const bool second = i >= n0;
@@ -525,6 +531,52 @@ __global__ __launch_bounds__(256) void vis_prep_kernel(vog_visprep_args a, int c
   const float v = w[0] * (b[0] / a.vid_w) + w[1] * (b[1] / a.vid_h) + w[2] * (b[2] / a.vid_w) +
                   w[3] * (b[3] / a.vid_h) + w[4] * (b[4] / fd);
   (second ? a.u1 : a.u0)[k] = v;
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void vis_prep_kernel(vog_visprep_args a, int cast_blocks) {
+  vis_prep_body<T16>(a, cast_blocks, blockIdx.x);
+}
+
+// both prologues of a forward in one launch (they are independent of each other; one launch less on
+// the dependent chain): blocks [0, lang_blocks) run the language part, the rest the visual part
+template <typename T16>
+__global__ __launch_bounds__(256) void prep_fused_kernel(LangPrepArgs la, int lang_blocks, vog_visprep_args va,
+                                                         int cast_blocks) {
+  if ((int)blockIdx.x < lang_blocks) lang_prep_body(la, blockIdx.x, lang_blocks);
+  else vis_prep_body<T16>(va, cast_blocks, (int)blockIdx.x - lang_blocks);
+}
+
+static int lang_prep_setup(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+                           const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
+                           int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
+                           LangPrepArgs* la, int* blocks_out) {
+  VOG_CHECK_ARG(words_ind && word_mask && lens && tok && rows && Bn > 0 && T > 0 && T <= seq_len);
+  VOG_CHECK_ARG(!a0_frag || (emb16 && emb_dim > 0 && (emb_dim % 32) == 0));
+  VOG_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && (zero_bytes == 0 || zero));
+  const int64_t z16 = zero_bytes / 16;
+  int64_t blocks = (z16 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  int64_t need = ((int64_t)Bn * T + 255) / 256;
+  if (a0_frag) { const int64_t n2 = ((int64_t)Bn * T * (emb_dim / 8) + 255) / 256; need = n2 > need ? n2 : need; }
+  if (need > 1024) need = 1024;
+  if (blocks < need) blocks = need;
+  *la = LangPrepArgs{(uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size,
+                     (const unsigned short*)emb16, (unsigned short*)a0_frag, emb_dim};
+  *blocks_out = (int)blocks;
+  return 0;
+}
+
+static int vis_prep_setup(const vog_visprep_args* a, int* cast_blocks, int* u_blocks) {
+  VOG_CHECK_ARG(a && (a->n0 % 4) == 0 && (a->n1 % 4) == 0 && (a->n0 == 0 || (a->src0 && a->dst0)) &&
+                (a->n1 == 0 || (a->src1 && a->dst1)));
+  VOG_CHECK_ARG((!a->w_pe0 && !a->w_pe1) || (a->props && a->n_rows > 0));
+  VOG_CHECK_ARG((!a->w_pe0 || (a->u0 && a->H0 > 0)) && (!a->w_pe1 || (a->u1 && a->H1 > 0)));
+  const int64_t q = (a->n0 + a->n1) / 4;
+  *cast_blocks = (int)((q + 255) / 256 < 2048 ? (q + 255) / 256 : 2048);
+  const int nu = (a->w_pe0 ? a->n_rows * a->H0 : 0) + (a->w_pe1 ? a->n_rows * a->H1 : 0);
+  *u_blocks = ceil_div(nu, 256);
+  return 0;
 }
 
 }  // namespace vog
@@ -556,32 +608,31 @@ extern "C" int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* word
                              const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
                              int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
                              void* stream) {
-  VOG_CHECK_ARG(words_ind && word_mask && lens && tok && rows && Bn > 0 && T > 0 && T <= seq_len);
-  VOG_CHECK_ARG(!a0_frag || (emb16 && emb_dim > 0 && (emb_dim % 32) == 0));
-  VOG_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && (zero_bytes == 0 || zero));
-  const int64_t z16 = zero_bytes / 16;
-  int64_t blocks = (z16 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  int64_t need = ((int64_t)Bn * T + 255) / 256;
-  if (a0_frag) { const int64_t n2 = ((int64_t)Bn * T * (emb_dim / 8) + 255) / 256; need = n2 > need ? n2 : need; }
-  if (need > 1024) need = 1024;
-  if (blocks < need) blocks = need;
-  ::vog::launch(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size,
-                     (const unsigned short*)emb16, (unsigned short*)a0_frag, emb_dim);
+  LangPrepArgs la; int blocks = 0;
+  VOG_TRY(lang_prep_setup(zero, zero_bytes, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len,
+                          vocab_size, emb16, a0_frag, emb_dim, &la, &blocks));
+  ::vog::launch(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, la);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_prep_fused(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+                              const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
+                              int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
+                              const vog_visprep_args* vis, void* stream) {
+  LangPrepArgs la; int lblocks = 0, cast_blocks = 0, u_blocks = 0;
+  VOG_TRY(lang_prep_setup(zero, zero_bytes, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len,
+                          vocab_size, emb16, a0_frag, emb_dim, &la, &lblocks));
+  VOG_TRY(vis_prep_setup(vis, &cast_blocks, &u_blocks));
+  VOG_DISPATCH_DTYPE(vis->dtype, ::vog::launch((prep_fused_kernel<T16>), dim3(lblocks + cast_blocks + u_blocks),
+                     dim3(256), 0, (hipStream_t)stream, la, lblocks, *vis, cast_blocks));
   VOG_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vog_vis_prep(const vog_visprep_args* a, void* stream) {
-  VOG_CHECK_ARG(a && (a->n0 % 4) == 0 && (a->n1 % 4) == 0 && (a->n0 == 0 || (a->src0 && a->dst0)) &&
-                (a->n1 == 0 || (a->src1 && a->dst1)));
-  VOG_CHECK_ARG((!a->w_pe0 && !a->w_pe1) || (a->props && a->n_rows > 0));
-  VOG_CHECK_ARG((!a->w_pe0 || (a->u0 && a->H0 > 0)) && (!a->w_pe1 || (a->u1 && a->H1 > 0)));
-  const int64_t q = (a->n0 + a->n1) / 4;
-  int cast_blocks = (int)((q + 255) / 256 < 2048 ? (q + 255) / 256 : 2048);
-  const int nu = (a->w_pe0 ? a->n_rows * a->H0 : 0) + (a->w_pe1 ? a->n_rows * a->H1 : 0);
-  const int u_blocks = ceil_div(nu, 256);
+  int cast_blocks = 0, u_blocks = 0;
+  VOG_TRY(vis_prep_setup(a, &cast_blocks, &u_blocks));
   if (cast_blocks + u_blocks == 0) return 0;
   VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_prep_kernel<T16>), dim3(cast_blocks + u_blocks), dim3(256), 0,
                      (hipStream_t)stream, *a, cast_blocks));

@@ -463,6 +463,23 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   const size_t lang_begin = steps.size();
   const bool structured = has_mul(d) && (g.d_obj % 64) == 0 && (g.L % 32) == 0 && g.rows_obj > 64;
   float* const lang_vec = shared ? const_cast<float*>(b->shared_lang) : ws.at<float>("lang");
+  // the language and the visual prologue are independent: one launch for both (not when the language
+  // chain is captured as its own graph branch, and not in the group forms, where they live in
+  // different programs)
+  const bool fuse_prep = !shared && !lang_only && !c->graph_dag;
+  auto make_visprep = [&]() {
+    vog_visprep_args vp{};
+    vp.src0 = b->pad_region_feature; vp.dst0 = ws.at<void>("prop16"); vp.n0 = g.rows_obj * d.prop_dim;
+    vp.src1 = b->seg_feature_for_frms; vp.dst1 = ws.at<void>("seg16"); vp.n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
+    vp.dtype = et; vp.props = b->pad_proposals; vp.n_rows = (int)g.rows_obj; vp.vid_w = d.vid_w; vp.vid_h = d.vid_h;
+    if (has_obj(d) && c->obj.use_rel) {
+      vp.w_pe0 = c->obj.pe_w; vp.u0 = ws.at<float>("obj_u"); vp.H0 = c->obj.H; vp.nfrm_div0 = g.fdiv_obj;
+    }
+    if (has_mul(d) && c->mul.use_rel) {
+      vp.w_pe1 = c->mul.pe_w; vp.u1 = ws.at<float>("mul_u"); vp.H1 = c->mul.H; vp.nfrm_div1 = (float)g.nfrm;
+    }
+    return vp;
+  };
   if (!shared) {
     char* z = ws.base + plan.zero_off;
     const int64_t zb = plan.zero_bytes;
@@ -477,8 +494,14 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       const void* e16 = c->emb16;
       void* a0 = a0f ? ws.at<void>("emb_a0") : nullptr;
       const int E = g.E;
-      steps.push_back({"lang_prep", [=](hipStream_t st) {
-        return vog_lang_prep(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, st); }});
+      if (fuse_prep) {
+        const vog_visprep_args vp = make_visprep();
+        steps.push_back({"prep", [=](hipStream_t st) {
+          return vog_prep_fused(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, &vp, st); }});
+      } else {
+        steps.push_back({"lang_prep", [=](hipStream_t st) {
+          return vog_lang_prep(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, st); }});
+      }
     }
     for (int l = 0; l < d.rnn_layers; ++l) {
       vog_gemm_args ga{}; ga.c16_dtype = -1;
@@ -571,7 +594,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       steps.push_back({"mul_pl", [=](hipStream_t st) { return vog_gemm_bias_act(&gl, st); }});
     }
   }
-  for (size_t i = lang_begin; i < steps.size(); ++i) steps[i].branch = 1;
+  for (size_t i = lang_begin; i < steps.size(); ++i) steps[i].branch = steps[i].name == "prep" ? 2 : 1;   // 2: before both chains
   if (lang_only) return 0;
   // ---- visual encoders (a12, a13)
   float* ps32 = ws.at<float>("prop_seg");
@@ -579,17 +602,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   {
     // fused visual prologue: raw features -> encoder operand type (the LDS-DMA GEMM cannot
     // convert in flight) + the box-bias precursors of both transformers
-    {
-      vog_visprep_args vp{};
-      vp.src0 = b->pad_region_feature; vp.dst0 = ws.at<void>("prop16"); vp.n0 = g.rows_obj * d.prop_dim;
-      vp.src1 = b->seg_feature_for_frms; vp.dst1 = ws.at<void>("seg16"); vp.n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
-      vp.dtype = et; vp.props = b->pad_proposals; vp.n_rows = (int)g.rows_obj; vp.vid_w = d.vid_w; vp.vid_h = d.vid_h;
-      if (has_obj(d) && c->obj.use_rel) {
-        vp.w_pe0 = c->obj.pe_w; vp.u0 = ws.at<float>("obj_u"); vp.H0 = c->obj.H; vp.nfrm_div0 = g.fdiv_obj;
-      }
-      if (has_mul(d) && c->mul.use_rel) {
-        vp.w_pe1 = c->mul.pe_w; vp.u1 = ws.at<float>("mul_u"); vp.H1 = c->mul.H; vp.nfrm_div1 = (float)g.nfrm;
-      }
+    if (!fuse_prep) {
+      const vog_visprep_args vp = make_visprep();
       steps.push_back({"vis_prep", [=](hipStream_t st) { return vog_vis_prep(&vp, st); }});
     }
     // the two encoders have 52 / 12 output tiles and K = 2048 / 3072: split K so every CU
@@ -1134,20 +1148,21 @@ extern "C" int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* ws, 
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
   // three chains: language (branch 1) and vision (branch 0) before the join marker are
   // independent of each other; everything after the join is one chain
-  std::vector<LaunchRecord> lang, vis, tail;
+  std::vector<LaunchRecord> pre, lang, vis, tail;
   vog::ChainRecorder rec;
   bool joined = false;
   int rc = 0;
   vog::g_recorder = &rec;
   for (auto& s : steps) {
     if (s.branch < 0) { joined = true; continue; }
-    rec.dst = joined ? &tail : (s.branch == 1 ? &lang : &vis);
+    rec.dst = joined ? &tail : (s.branch == 2 ? &pre : (s.branch == 1 ? &lang : &vis));
     rc = s.fn(vog::recorder_stream());
     if (rc != 0) break;
   }
   vog::g_recorder = nullptr;
   if (rc != 0) return rc;
   std::vector<std::vector<LaunchRecord>> rows;
+  for (auto& r : pre) rows.push_back({r});      // the fused prologue feeds both chains
   if (split_chains) {
     const size_t n = lang.size() > vis.size() ? lang.size() : vis.size();
     for (size_t i = 0; i < n; ++i) {
@@ -1257,7 +1272,7 @@ extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t 
   // time (lang_prep + layer) pairs and subtract lang_prep timed alone the same way
   const Step* reset = nullptr;
   if (s->name == "lstm_layer")
-    for (auto& x : steps) if (x.name == "lang_prep") { reset = &x; break; }
+    for (auto& x : steps) if (x.name == "lang_prep" || x.name == "prep") { reset = &x; break; }
   hipEvent_t e0, e1;
   VOG_HIP(hipEventCreate(&e0));
   VOG_HIP(hipEventCreate(&e1));

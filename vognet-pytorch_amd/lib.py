@@ -164,6 +164,8 @@ SYMBOLS = {
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vog_lstm_pack_whh": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32]),
+    "vog_prep_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                               c_vp, c_vp, c_i32, C.POINTER(VisprepArgs), c_vp]),
     "vog_lang_prep": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                               c_vp, c_vp, c_i32, c_vp]),
     "vog_vis_prep": (c_i32, [C.POINTER(VisprepArgs), c_vp]),
