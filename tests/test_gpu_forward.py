@@ -60,7 +60,17 @@ def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
     assert idx.dtype == g["indexs"].dtype and idx.shape == g["indexs"].shape
     d_idx = idx != g["indexs"]
     if d_idx.any():
-        assert d_idx.mean() < 0.05, f"{name}: {d_idx.mean():.3f} of pred_cmp indices differ"
+        # pred_cmp is an arg-max over the ncmp videos (spat: of the per-frame max score,
+        # eval_vsrl_corr.py:399-411; sep: of fin_scores, :172,213-214): a flip is only allowed where
+        # the REFERENCE score of the video we picked is within 2e-3 (relative) of the reference maximum
+        if "fin_scores" in g.files:
+            ref = np.broadcast_to(g["fin_scores"][:, None, None, :], idx.shape + (g["fin_scores"].shape[1],))
+        else:
+            ref = np.moveaxis(g["scores"], 2, -1)                      # [B, nsrl, nfrm, ncmp]
+        picked = np.take_along_axis(ref, idx[..., None].astype(np.int64), -1)[..., 0]
+        best = ref.max(-1)
+        bad = d_idx & (rel_err(picked, best) > 2e-3)
+        assert not bad.any(), f"{name}: {int(bad.sum())} pred_cmp flips outside the near-tie tolerance"
     return nflip
 
 
@@ -92,7 +102,7 @@ def test_forward_full_vs_reference_golden(name):
 @pytest.mark.parametrize("name", SMALL)
 def test_forward_small_vs_reference_golden(name):
     out, pred, g, _ = _run(name)
-    _check_against(name, out, pred, g, None, tol_rel=2e-3, tol_logit=1.2e-2)
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
 @pytest.mark.parametrize("name", ["full/cfg2_ragged", "small/vog_spat_r128", "small/vog_sep_r64"])
@@ -124,7 +134,7 @@ def test_forward_step_launch_lstm_vs_reference_golden(name):
     ncmp = batch["new_srl_idxs"].shape[1]
     pred = eng.unpack_pred(out["pred_rec"], ncmp)
     g = np.load(cases.golden_path(name))
-    tol = (1e-3, 6e-3) if name.startswith("full/") else (2e-3, 1.2e-2)
+    tol = (1e-3, 6e-3)
     _check_against(name, out, pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
 
 
@@ -314,7 +324,7 @@ def test_group_language_encoder_matches_standalone_forwards(name, n, mode):
     # member 0 is the golden case: the reference-parity bound holds for the grouped path too
     g = np.load(cases.golden_path(name))
     pred = eng.unpack_pred(outs[0]["pred_rec"], ncmp)
-    tol = (1e-3, 6e-3) if name.startswith("full/") else (2e-3, 1.2e-2)
+    tol = (1e-3, 6e-3)
     _check_against(name, outs[0], pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
 
 
