@@ -185,6 +185,44 @@ int vog_residual_layernorm(const float* x, const float* gamma, const float* beta
                            float* y32, void* y16, int rows, int d, vog_dtype dtype,
                            void* stream);
 
+/* ---- fused encoder-layer tail ---------------------------------------------------------------
+ * Everything of one (Rel)EncoderLayer after the attention is row-local, so ONE launch does
+ *     x1 = LayerNorm(x + attn Wo^T)                    (RelMultiHead.forward tail transformer_code.py:184-186
+ *                                                       + ResidualBlock.forward :30-31)
+ *     y  = LayerNorm(x1 + W2 relu(W1 x1 + b1) + b2)    (FeedForward.forward :80-81 + ResidualBlock)
+ * and, for the last mul_tx layer (score != NULL), the score head on top of it
+ *     logit = lin2.2 . relu(lin2.0 y + b) + b          (mdl_vog.py:224-230,675-677)
+ *     mdl_outs / mdl_outs_eval = inverse regroup + sigmoid * masks   (as vog_score_head)
+ * for 64 token rows per workgroup: replaces vog_gemm_bias_act x 3, vog_residual_layernorm x 2
+ * (+ the lin2 GEMM and vog_score_head) and all their intermediates in HBM.
+ *   attn16  [M, kwo] t16 row-major = out16 of vog_rel_attention(_struct)_fwd (kwo = H*dp, kwo % 64 == 0)
+ *   wo_p / w1_p / w2_p / wl_p: Wo_pad [d, kwo], linear1 [dh, d], linear2 [d, dh], lin2.0 [256, d] in
+ *           the 32x16 fragment order of vog_pack_w_frag32 (types: dtype, dtype, dtype, head_dtype)
+ *   residual [M, ldr] fp32, or res_vislang = the implicit vis||lang token matrix (exactly one of them)
+ *   y32 / y16 (type y16_dtype, -1 = dtype): [M, d] outputs, either may be NULL
+ *   x1_scratch: vog_tx_tail_scratch_bytes(M, d) bytes (0 for d = 512), workgroup-private spill slab
+ * Shapes: d in {512, 768}, dh = d/2 (vog_tx_tail_supported); other shapes use the unfused entries. */
+struct vog_score_args;
+typedef struct vog_tx_tail_args {
+  const void* attn16; int kwo;
+  const void* wo_p; const void* w1_p; const void* w2_p;
+  const float* residual; int64_t ldr;
+  const struct vog_vislang_args* res_vislang;
+  const float* ln1g; const float* ln1b; const float* b1; const float* b2; const float* ln2g; const float* ln2b;
+  float* y32; void* y16; int y16_dtype;
+  const void* wl_p; const float* bl;            /* score head (with `score`): lin2.0 packed / bias */
+  const struct vog_score_args* score;            /* h1 is ignored; w2 / b2 = lin2.2 */
+  int head_dtype;                                /* vog_dtype of wl_p (VOG_F16) */
+  float* x1_scratch;
+  int M, d, dh; vog_dtype dtype;
+} vog_tx_tail_args;
+int vog_tx_tail_supported(int d, int dh, int kwo);
+int64_t vog_tx_tail_scratch_bytes(int M, int d);
+int vog_tx_tail_fwd(const vog_tx_tail_args* a, void* stream);
+/* host: fp32 [N, ld] (first K columns) -> 16-bit 32x16 fragment order, N*K halfwords:
+ * [N/32][K/16][lane = ((k%16)/8)*32 + n%32][k%8]  (N % 32 == 0, K % 16 == 0). */
+int vog_pack_w_frag32(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);
+
 /* dst[i] = (t16) src[i] for two arrays in one launch (raw proposal / segment
  * features -> the encoders' MFMA operand type; replaces the implicit fp32 read
  * of nn.Linear in prop_feats_encode / seg_feats_encode mdl_vog.py:291-314).
@@ -404,7 +442,10 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * "lstm_persistent" (default 1; env VOG_LSTM_PERSISTENT presets it): use vog_bilstm_layer instead
  * of T step launches where vog_bilstm_layer_supported. Its co-residency limit (4 instances) is met
  * automatically on HIP streams (4 hardware queues execute at most 4 kernels at once); set it to 0
- * when submitting through more than 4 AQL queues or with GPU_MAX_HW_QUEUES > 4. */
+ * when submitting through more than 4 AQL queues or with GPU_MAX_HW_QUEUES > 4.
+ * "fused_tail" (default 1): run everything after the attention of an encoder layer (and, for the
+ * last mul_tx layer, lin2 + the score head) as ONE vog_tx_tail_fwd launch where
+ * vog_tx_tail_supported; 0 = the separate GEMM / LayerNorm / score launches (always used for other shapes). */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 

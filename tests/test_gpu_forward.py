@@ -138,6 +138,19 @@ def test_forward_step_launch_lstm_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
 
 
+@pytest.mark.parametrize("name", FULL + ["small/vog_spat"])
+def test_forward_unfused_tail_vs_reference_golden(name):
+    """fused_tail = 0: the separate Wo / LayerNorm / FFN / lin2 / score launches (the path of every
+    shape the fused kernel does not cover) against the same goldens."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("fused_tail", 0)
+    out = eng.forward(dev)
+    torch.cuda.synchronize()
+    pred = eng.unpack_pred(out["pred_rec"], batch["new_srl_idxs"].shape[1])
+    g = np.load(cases.golden_path(name))
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
 def test_forward_f16_transformers():
     """cfg 5 flavour: fp16 MFMA path with fp32 accumulate."""
     name = "full/cfg5_vog_svsq_gt5_bs16"
@@ -159,10 +172,13 @@ def test_forward_p100_vs_reference_golden():
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
-def test_stages_vs_oracle():
-    """Stage-by-stage localisation on cfg 2 (which kernel is off, if any)."""
+@pytest.mark.parametrize("fused", [1, 0])
+def test_stages_vs_oracle(fused):
+    """Stage-by-stage localisation on cfg 2 (which kernel is off, if any), with the fused encoder
+    tails (default) and with the unfused GEMM / LayerNorm launches."""
     name = "full/cfg2_vog_spat_gt5_bs4"
     eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("fused_tail", fused)
     out = eng.forward(dev)
     torch.cuda.synchronize()
     ora = oracle_run(cfg, sd, batch, c, keep_stages=True)
@@ -189,6 +205,8 @@ def test_stages_vs_oracle():
     e = (oo - st["obj_out"]).abs().max().item()
     print("obj_out abs err", e)
     assert e < 3e-2
+    if fused:
+        return        # the fused mul_tx tail runs lin2 + the score head itself: its output never leaves the chip
     # the last mul_tx layer writes only the 16-bit copy its consumer (the f16 score head) reads
     mo = eng.stage(B, ncmp, T, "mul_outA16", torch.float16, (40, 100, 768)).cpu().float()
     e = (mo - st["mul_out"]).abs().max().item()

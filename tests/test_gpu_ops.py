@@ -512,3 +512,109 @@ def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, 
     err = (got - ref).abs().max().item()
     tol = (3e-2 if dtype == "bf16" else 5e-3) * max(1.0, ref.abs().max().item())
     assert err <= tol, (err, tol)
+
+
+# ---- fused encoder tail (csrc/txtail.hip): Wo + residual + LN + FFN + residual + LN (+ lin2 + score) ----
+def _pack32(w, dtype):
+    """host fp32 [N, K] -> device tensor in the 32x16 fragment order of vog_pack_w_frag32."""
+    w = np.ascontiguousarray(w.detach().cpu().numpy(), dtype=np.float32)
+    N, K = w.shape
+    dst = np.empty(N * K, dtype=np.uint16)
+    L.check(_lib().vog_pack_w_frag32(w.ctypes.data, K, N, K, dst.ctypes.data, DT[dtype]), "pack32")
+    return torch.from_numpy(dst.view(np.int16)).cuda()
+
+
+def _ln(x, g, b):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), g, b, 1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,d,kwo,mode", [(800, 512, 576, "plain"), (1000, 768, 768, "vislang"),
+                                          (1000, 768, 768, "score"), (77, 512, 576, "plain"),
+                                          (4000, 768, 768, "score")])
+def test_tx_tail_matches_torch_chain(M, d, kwo, mode, dtype):
+    """One launch == the unfused chain with the same rounding points (attention output, x1, hidden and
+    head operand rounded to 16 bit; everything else fp32). Tolerance: a 16-bit rounding flip of an
+    operand element moves a 768-term fp32 dot product by ~1e-4 relative; LayerNorm outputs are O(1)."""
+    torch.manual_seed(M + d)
+    lib, T = _lib(), t16(dtype)
+    dh = d // 2
+    attn = (torch.randn(M, kwo, device="cuda") * 0.5).to(T)
+    wo = torch.randn(d, kwo) / math.sqrt(kwo)
+    w1 = torch.randn(dh, d) / math.sqrt(d)
+    w2 = torch.randn(d, dh) / math.sqrt(dh)
+    b1, b2 = torch.randn(dh, device="cuda") * 0.1, torch.randn(d, device="cuda") * 0.1
+    g1, be1 = 1 + 0.1 * torch.randn(d, device="cuda"), 0.1 * torch.randn(d, device="cuda")
+    g2, be2 = 1 + 0.1 * torch.randn(d, device="cuda"), 0.1 * torch.randn(d, device="cuda")
+    a = L.TxTailArgs()
+    keep = [attn, b1, b2, g1, be1, g2, be2]
+    a.attn16, a.kwo = L.ptr(attn), kwo
+    wo_p, w1_p, w2_p = _pack32(wo, dtype), _pack32(w1, dtype), _pack32(w2, dtype)
+    a.wo_p, a.w1_p, a.w2_p = L.ptr(wo_p), L.ptr(w1_p), L.ptr(w2_p)
+    a.ln1g, a.ln1b, a.b1, a.b2, a.ln2g, a.ln2b = (L.ptr(g1), L.ptr(be1), L.ptr(b1), L.ptr(b2), L.ptr(g2),
+                                                  L.ptr(be2))
+    if mode == "plain":
+        res = torch.randn(M, d, device="cuda")
+        a.residual, a.ldr = L.ptr(res), d
+    else:
+        # implicit vis||lang token rows: M = n_vid*nfrm*nsrl*nppf
+        nfrm, nsrl, nppf = 10, 5, 20
+        n_vid = M // (nfrm * nsrl * nppf)
+        assert n_vid * nfrm * nsrl * nppf == M
+        dv, dl = 512, 256
+        vis = torch.randn(n_vid * nfrm * nppf, dv, device="cuda")
+        lang = torch.randn(n_vid * nsrl, dl, device="cuda")
+        va = L.VislangArgs()
+        va.vis, va.lang = L.ptr(vis), L.ptr(lang)
+        va.n_vid, va.nfrm, va.nppf, va.nsrl, va.dv, va.dl = n_vid, nfrm, nppf, nsrl, dv, dl
+        va.lang_per_vid, va.nc_v, va.dtype = 0, 1, DT[dtype]
+        a.res_vislang = C.addressof(va)
+        v4 = vis.view(n_vid, nfrm, 1, nppf, dv).expand(-1, -1, nsrl, -1, -1)
+        l4 = lang.view(n_vid, 1, nsrl, 1, dl).expand(-1, nfrm, -1, nppf, -1)
+        res = torch.cat([v4, l4], -1).reshape(M, d)
+    y32 = torch.full((M, d), float("nan"), device="cuda")
+    y16 = torch.zeros(M, d, dtype=T, device="cuda")
+    nscr = int(lib.vog_tx_tail_scratch_bytes(M, d))
+    scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device="cuda")
+    a.x1_scratch = L.ptr(scr)
+    a.M, a.d, a.dh, a.dtype = M, d, dh, DT[dtype]
+    # torch reference, same rounding points
+    wo_r, w1_r, w2_r = (w.cuda().to(T).float() for w in (wo, w1, w2))
+    x1 = _ln(attn.float() @ wo_r.t() + res, g1, be1)
+    hid = torch.relu(x1.to(T).float() @ w1_r.t() + b1).to(T).float()
+    y = _ln(x1 + hid @ w2_r.t() + b2, g2, be2)
+    if mode == "score":
+        wl = torch.randn(256, d) / math.sqrt(d)
+        bl = torch.randn(256, device="cuda") * 0.1
+        wl2 = torch.randn(256, device="cuda") / 16
+        bl2 = torch.randn(1, device="cuda")
+        wl_p = _pack32(wl, "f16")
+        arg_msk = torch.randint(0, 2, (n_vid, nsrl), device="cuda", dtype=torch.int64)
+        cmp_msk = torch.randint(0, 2, (n_vid, 4), device="cuda", dtype=torch.int64)
+        outs = torch.full((n_vid, 1, nsrl, nfrm * nppf), float("nan"), device="cuda")
+        outs_eval = torch.full_like(outs, float("nan"))
+        sa = L.ScoreArgs()
+        sa.w2, sa.b2, sa.arg_msk, sa.cmp_msk = L.ptr(wl2), L.ptr(bl2), L.ptr(arg_msk), L.ptr(cmp_msk)
+        sa.outs, sa.outs_eval = L.ptr(outs), L.ptr(outs_eval)
+        sa.n_vid, sa.nfrm, sa.nppf, sa.nsrl, sa.dh = n_vid, nfrm, nppf, nsrl, 256
+        sa.conc_type, sa.ncmp, sa.nc_v, sa.nvl, sa.nfrm0, sa.nppf0 = L.CONC_TYPE["spat"], 4, 1, 1, 10, 5
+        a.wl_p, a.bl, a.score, a.head_dtype = L.ptr(wl_p), L.ptr(bl), C.addressof(sa), L.VOG_F16
+    else:
+        a.y32, a.y16 = L.ptr(y32), L.ptr(y16)
+    L.check(lib.vog_tx_tail_fwd(C.byref(a), _sp()), "tx_tail")
+    torch.cuda.synchronize()
+    if mode != "score":
+        err = (y32 - y).abs().max().item()
+        print("tail y32 max abs err", err)
+        assert err <= 4e-3, err
+        assert (y16.float() - y).abs().max().item() <= 3e-2
+        return
+    h1 = torch.relu(y.half().float() @ wl.cuda().half().float().t() + bl)
+    logit = (h1 @ wl2 + bl2).view(n_vid, nfrm, nsrl, nppf).permute(0, 2, 1, 3).reshape(n_vid, 1, nsrl, nfrm * nppf)
+    err = (outs - logit).abs().max().item()
+    print("tail logit max abs err", err)
+    assert err <= 4e-3, err
+    cmp = (torch.arange(nfrm * nppf, device="cuda") // 5) % 4
+    ref_eval = torch.sigmoid(logit) * arg_msk.view(n_vid, 1, nsrl, 1).float() * cmp_msk[:, cmp].view(n_vid, 1, 1, -1).float()
+    assert (outs_eval - ref_eval).abs().max().item() <= 1.5e-3
+    assert torch.all(outs_eval[ref_eval == 0] == 0)

@@ -25,6 +25,8 @@ void set_error(const char* fmt, ...) {
 }
 
 int attn_head_pad(int dh);
+int tx_tail_supported(int d, int dh, int kwo);
+int64_t tx_tail_scratch_bytes(int M, int d);
 
 // ---- host fp32 -> 16 bit ------------------------------------------------------
 static unsigned short h_to16(float f, int dt) {
@@ -49,6 +51,7 @@ struct DevBuf {
 struct TxLayer {
   unsigned short *wqkv, *wo, *w1, *w2;     // 16-bit, padded
   unsigned short* wqkv_lang_f;             // Wqkv[:, d_vis:] in fragment order (structured layer 0)
+  unsigned short *wo_p, *w1_p, *w2_p;      // 32x16 fragment order (fused encoder tail, txtail.hip), or null
   float *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 struct TxWeights {
@@ -71,6 +74,7 @@ struct vog_ctx {
   bool finalized = false;
   int graph_dag = 0;                    // capture the language chain as a parallel branch
   int lstm_persistent = 1;              // one launch per BiLSTM layer where supported (W_hh resident on chip; vog_hip.h)
+  int fused_tail = 1;                   // Wo..LN2 (+ lin2 + score) of an encoder layer as one launch where supported
   hipStream_t side = nullptr;           // language branch during graph capture
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
@@ -82,6 +86,7 @@ struct vog_ctx {
   std::vector<unsigned short*> whh;                     // [layer] [2][4R][R]
   std::vector<float*> bsum;                             // [layer] [8R]
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
+  unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
   float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
   float *w_sv0 = nullptr, *b_sv0 = nullptr, *w_sv2 = nullptr, *b_sv2 = nullptr;
@@ -135,6 +140,13 @@ static int up16(vog_ctx* c, const std::string& n, int dt, unsigned short** out) 
   const auto& w = W(c, n);
   std::vector<unsigned short> h(w.size());
   for (size_t i = 0; i < w.size(); ++i) h[i] = h_to16(w[i], dt);
+  return upload<unsigned short>(c, h, out);
+}
+
+// fp32 [N, ld] host matrix -> 32x16 fragment order on the device (vog_pack_w_frag32)
+static int up_frag32(vog_ctx* c, const float* w, int64_t ld, int N, int K, int dt, unsigned short** out) {
+  std::vector<unsigned short> h((size_t)N * K);
+  VOG_TRY(vog_pack_w_frag32(w, ld, N, K, h.data(), (vog_dtype)dt));
   return upload<unsigned short>(c, h, out);
 }
 
@@ -197,6 +209,19 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
             wo[(size_t)o * H * dp + (size_t)h * dp + dd] = h_to16(w[(size_t)o * d + tw->head_off[h] + dd], dt);
     }
     VOG_TRY(upload<unsigned short>(c, wo, &L.wo));
+    L.wo_p = L.w1_p = L.w2_p = nullptr;
+    if (tx_tail_supported(d, dh, H * dp)) {
+      // the padded Wo again as fp32 (zero columns for the head padding), then fragment order
+      std::vector<float> wof((size_t)d * H * dp, 0.f);
+      const auto& w = W(c, p + ".selfattn.layer.wo.weight");
+      for (int o = 0; o < d; ++o)
+        for (int h = 0; h < H; ++h)
+          for (int dd = 0; dd < tw->head_dim[h]; ++dd)
+            wof[(size_t)o * H * dp + (size_t)h * dp + dd] = w[(size_t)o * d + tw->head_off[h] + dd];
+      VOG_TRY(up_frag32(c, wof.data(), (int64_t)H * dp, d, H * dp, dt, &L.wo_p));
+      VOG_TRY(up_frag32(c, W(c, p + ".feedforward.layer.linear1.weight").data(), d, dh, d, dt, &L.w1_p));
+      VOG_TRY(up_frag32(c, W(c, p + ".feedforward.layer.linear2.weight").data(), dh, d, dh, dt, &L.w2_p));
+    }
     VOG_TRY(up16(c, p + ".feedforward.layer.linear1.weight", dt, &L.w1));
     VOG_TRY(up16(c, p + ".feedforward.layer.linear2.weight", dt, &L.w2));
     VOG_TRY(up32(c, p + ".feedforward.layer.linear1.bias", &L.b1));
@@ -305,6 +330,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add(n + "_ffn16", rows * tw.dh * 2);
     p.add(n + "_outA", rows * tw.d * 4);
     p.add(n + "_outA16", rows * tw.d * 2);
+    p.add(n + "_x1s", tx_tail_scratch_bytes((int)rows, tw.d) + 16);
     if (tw.n_layers > 1) {
       p.add(n + "_outB", rows * tw.d * 4);
       p.add(n + "_outB16", rows * tw.d * 2);
@@ -342,7 +368,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
                      int npad, int spv, int n_box, float fdiv, int last_dt, std::vector<Step>& steps,
                      const float** out32, const void** out16,
                      const vog_vislang_args* structured = nullptr, const void* vis16 = nullptr,
-                     bool last_needs_f32 = true) {
+                     bool last_needs_f32 = true, const vog_score_args* score = nullptr) {
   const std::string n(nm);
   const vog_model_desc& d = c->d;
   const vog_dtype dt = (vog_dtype)d.tx_dtype;
@@ -390,6 +416,40 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
     if (!fact)
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
+    const bool last = l == tw.n_layers - 1;
+    // 16-bit copy of the LAST layer's output: typed for its consumer (none for obj_tx,
+    // the f16 score head for mul_tx)
+    void* o16w = (last && last_dt < 0) ? nullptr : o16;
+    const vog_dtype odt = last && last_dt >= 0 ? (vog_dtype)last_dt : dt;
+    // the last layer's fp32 output is written only if somebody reads it (mul_tx: the score
+    // head takes the 16-bit copy -> 12 MB less HBM traffic per forward at cfg 2)
+    float* o32w = (last && !last_needs_f32 && o16w) ? nullptr : o32;
+    if (c->fused_tail && L.wo_p && tx_tail_supported(tw.d, tw.dh, tw.H * tw.dp)) {
+      // everything after the attention is row-local: one launch (txtail.hip); with `score` the
+      // last layer also runs lin2 + the score head and its output never leaves the chip
+      vog_tx_tail_args ta{};
+      ta.attn16 = aa.out16; ta.kwo = tw.H * tw.dp; ta.wo_p = L.wo_p; ta.w1_p = L.w1_p; ta.w2_p = L.w2_p;
+      ta.residual = fact ? nullptr : cur32; ta.ldr = tw.d;
+      ta.ln1g = L.ln1g; ta.ln1b = L.ln1b; ta.b1 = L.b1; ta.b2 = L.b2; ta.ln2g = L.ln2g; ta.ln2b = L.ln2b;
+      ta.y32 = o32w; ta.y16 = o16w; ta.y16_dtype = (int)odt;
+      ta.x1_scratch = ws.at<float>(n + "_x1s");
+      ta.M = (int)rows; ta.d = tw.d; ta.dh = tw.dh; ta.dtype = dt; ta.head_dtype = d.enc_dtype;
+      const bool with_score = last && score && c->w_lin2_p;
+      vog_score_args sc{};
+      if (with_score) { sc = *score; ta.wl_p = c->w_lin2_p; ta.bl = c->b_lin2; ta.y32 = nullptr; ta.y16 = nullptr; }
+      vog_vislang_args sv{};
+      if (fact) sv = *structured;
+      steps.push_back({n + "_tail", [=](hipStream_t st) {
+        vog_tx_tail_args t2 = ta;
+        if (fact) t2.res_vislang = &sv;
+        if (with_score) t2.score = &sc;
+        return vog_tx_tail_fwd(&t2, st); }});
+      if (with_score) *out16 = nullptr;            // tells the caller that lin2 + score already ran
+      cur32 = o32;
+      cur16 = o16;
+      if (last) { *out32 = cur32; if (!with_score) *out16 = cur16; return; }
+      continue;
+    }
     vog_gemm_args wo{}; wo.c16_dtype = -1;
     wo.a = aa.out16; wo.a_is_f32 = 0; wo.lda = (int64_t)tw.H * tw.dp; wo.w = L.wo; wo.ldw = (int64_t)tw.H * tw.dp;
     wo.residual = cur32; wo.ldr = tw.d; wo.c32 = ws.at<float>(n + "_tmp"); wo.ldc = tw.d;
@@ -418,14 +478,6 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     f2.ldr = tw.d; f2.c32 = tmp; f2.ldc = tw.d; f2.M = (int)rows; f2.N = tw.d; f2.K = tw.dh; f2.rep = 1;
     f2.dtype = dt;
     steps.push_back({n + "_ffn2", [=](hipStream_t st) { return vog_gemm_bias_act(&f2, st); }});
-    // 16-bit copy of the LAST layer's output: typed for its consumer (none for obj_tx,
-    // the f16 score head for mul_tx)
-    const bool last = l == tw.n_layers - 1;
-    void* o16w = (last && last_dt < 0) ? nullptr : o16;
-    const vog_dtype odt = last && last_dt >= 0 ? (vog_dtype)last_dt : dt;
-    // the last layer's fp32 output is written only if somebody reads it (mul_tx: the score
-    // head takes the 16-bit copy -> 12 MB less HBM traffic per forward at cfg 2)
-    float* o32w = (last && !last_needs_f32 && o16w) ? nullptr : o32;
     steps.push_back({n + "_ln2", [=](hipStream_t st) {
       return vog_residual_layernorm(tmp, L.ln2g, L.ln2b, o32w, o16w, (int)rows, d_, odt, st); }});
     cur32 = o32;
@@ -668,12 +720,18 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   const float* x32 = ws.at<float>("xmul");
   const void* x16 = ws.at<void>("xmul16");
   int head_dt = d.enc_dtype;   // the 16-bit copy feeding lin2 is always written in the head's type
+  vog_score_args sa{};
+  sa.w2 = c->w_lin2b; sa.b2 = c->b_lin2b; sa.arg_msk = b->srl_arg_inds_msk;
+  sa.cmp_msk = b->num_cmp_msk; sa.outs = b->mdl_outs; sa.outs_eval = b->mdl_outs_eval;
+  sa.n_vid = g.n_vid; sa.nfrm = g.nfrm; sa.nppf = g.nppf; sa.nsrl = d.nsrl; sa.dh = 256;
+  sa.conc_type = d.conc_type; sa.ncmp = g.ncmp; sa.nc_v = g.nc_v; sa.nvl = g.nvl;
+  sa.nfrm0 = d.nfrm0; sa.nppf0 = d.nppf0;
   if (has_mul(d))
     tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
              (float)g.nfrm, d.enc_dtype, steps, &x32, &x16, structured ? &va : nullptr, vis16,
-             /*last_needs_f32=*/false);
-  // ---- score head (a9 tail / a20 / a17)
-  {
+             /*last_needs_f32=*/false, d.enc_dtype == VOG_F16 ? &sa : nullptr);
+  // ---- score head (a9 tail / a20 / a17); x16 == NULL: the fused mul_tx tail already ran it
+  if (x16 != nullptr) {
     vog_gemm_args l2{}; l2.c16_dtype = -1;
     if (head_dt == d.enc_dtype) { l2.a = x16; l2.a_is_f32 = 0; }
     else { l2.a = x32; l2.a_is_f32 = 1; }               // re-round from fp32 in the head's own type
@@ -681,12 +739,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     l2.c32 = ws.at<float>("h1"); l2.ldc = 256; l2.M = (int)g.rows_mul; l2.N = 256; l2.K = g.d_mul;
     l2.rep = 1; l2.dtype = et;
     steps.push_back({"lin2", [=](hipStream_t st) { return vog_gemm_bias_act(&l2, st); }});
-    vog_score_args sa{};
-    sa.h1 = l2.c32; sa.w2 = c->w_lin2b; sa.b2 = c->b_lin2b; sa.arg_msk = b->srl_arg_inds_msk;
-    sa.cmp_msk = b->num_cmp_msk; sa.outs = b->mdl_outs; sa.outs_eval = b->mdl_outs_eval;
-    sa.n_vid = g.n_vid; sa.nfrm = g.nfrm; sa.nppf = g.nppf; sa.nsrl = d.nsrl; sa.dh = 256;
-    sa.conc_type = d.conc_type; sa.ncmp = g.ncmp; sa.nc_v = g.nc_v; sa.nvl = g.nvl;
-    sa.nfrm0 = d.nfrm0; sa.nppf0 = d.nppf0;
+    sa.h1 = l2.c32;
     steps.push_back({"score", [=](hipStream_t st) { return vog_score_head(&sa, st); }});
   }
   if (g.sep) {
@@ -890,6 +943,12 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
   VOG_TRY(up32(c, "seg_encoder.0.bias", &c->b_seg));
   VOG_TRY(up16(c, "lin2.0.weight", et, &c->w_lin2));
   VOG_TRY(up32(c, "lin2.0.bias", &c->b_lin2));
+  c->w_lin2_p = nullptr;
+  {
+    const int dm = d.prop_enc + d.seg_enc + d.lang_enc;
+    if (has_mul(d) && tx_tail_supported(dm, dm / 2, 64))
+      VOG_TRY(up_frag32(c, W(c, "lin2.0.weight").data(), dm, 256, dm, et, &c->w_lin2_p));
+  }
   VOG_TRY(up32(c, "lin2.2.weight", &c->w_lin2b));
   VOG_TRY(up32(c, "lin2.2.bias", &c->b_lin2b));
   VOG_TRY(up32(c, "srl_arg_words_out_enc.0.weight", &c->w_arg));
@@ -1109,6 +1168,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   VOG_CHECK_ARG(c && name);
   if (strcmp(name, "graph_dag") == 0) { c->graph_dag = value ? 1 : 0; return 0; }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
+  if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 

@@ -226,7 +226,7 @@ class VogEngine:
         return Group(self, inps, with_pred, graph, pred_rec)
 
     def set_option(self, name: str, value: int) -> None:
-        """Integer options of the context: 'graph_dag', 'lstm_persistent' (include/vog_hip.h)."""
+        """Integer options of the context: 'graph_dag', 'lstm_persistent', 'fused_tail' (include/vog_hip.h)."""
         L.check(self.lib.vog_ctx_set_int(self.ctx, name.encode(), int(value)), f"vog_ctx_set_int({name})")
 
     def time_kernel(self, slot: "Slot", name: str, iters: int = 50) -> float:

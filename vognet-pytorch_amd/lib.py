@@ -107,6 +107,20 @@ class ScoreArgs(C.Structure):
                 ("nfrm0", c_i32), ("nppf0", c_i32)]
 
 
+class TxTailArgs(C.Structure):
+    _fields_ = [("attn16", c_vp), ("kwo", c_i32), ("wo_p", c_vp), ("w1_p", c_vp), ("w2_p", c_vp),
+                ("residual", c_vp), ("ldr", c_i64), ("res_vislang", c_vp),
+                ("ln1g", c_vp), ("ln1b", c_vp), ("b1", c_vp), ("b2", c_vp), ("ln2g", c_vp), ("ln2b", c_vp),
+                ("y32", c_vp), ("y16", c_vp), ("y16_dtype", c_i32), ("wl_p", c_vp), ("bl", c_vp),
+                ("score", c_vp), ("head_dtype", c_i32), ("x1_scratch", c_vp),
+                ("M", c_i32), ("d", c_i32), ("dh", c_i32), ("dtype", c_i32)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.y16_dtype = -1
+        self.head_dtype = VOG_F16
+
+
 class PredcmpArgs(C.Structure):
     _fields_ = [("final_hidden", c_vp), ("prop_seg", c_vp), ("w0", c_vp), ("b0", c_vp),
                 ("w2", c_vp), ("b2", c_vp), ("outs", c_vp), ("arg_msk", c_vp), ("cmp_msk", c_vp),
@@ -151,6 +165,10 @@ SYMBOLS = {
     "vog_last_error": (C.c_char_p, []),
     "vog_gemm_bias_act": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "vog_pack_w_frag": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32]),
+    "vog_pack_w_frag32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32]),
+    "vog_tx_tail_supported": (c_i32, [c_i32, c_i32, c_i32]),
+    "vog_tx_tail_scratch_bytes": (c_i64, [c_i32, c_i32]),
+    "vog_tx_tail_fwd": (c_i32, [C.POINTER(TxTailArgs), c_vp]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),
