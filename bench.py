@@ -91,13 +91,16 @@ def kernel_flops(w, T):
         "lstm_ih1": 2.0 * B * (ncmp if w["conc"] in ("sep", "svsq") else 1) * T * 8192 * 2048,
         "lstm_outproj": 2.0 * B * (ncmp if w["conc"] in ("sep", "svsq") else 1) * (T + 1) * 2048 * 256,
         "obj_ffn1": 2.0 * ro * d_obj * (d_obj // 2), "obj_ffn2": 2.0 * ro * d_obj * (d_obj // 2),
+        "obj_tail": 2.0 * ro * d_obj * d_obj + 4.0 * ro * d_obj * (d_obj // 2),
+        "mul_tail": 2.0 * rm * d_mul * d_mul + 4.0 * rm * d_mul * (d_mul // 2) + 2.0 * rm * d_mul * 256,
+        "vis_enc": 2.0 * ro * 2048 * 256 + 2.0 * n_vid * (NP // nppf0) * 3072 * 256,
         "argvec": 0.0, "enc_finish": 0.0, "cast_feats": 0.0, "mul_ln1": 0.0, "mul_ln2": 0.0,
         "obj_ln1": 0.0, "obj_ln2": 0.0, "score": 0.0, "pred_head": 0.0,
     }
     Bn = B * (ncmp if w["conc"] in ("sep", "svsq") else 1)
     lstm = 2.0 * Bn * T * (2 * 4096 * 512 + 2 * 4096 * 2048 + 4 * 4096 * 1024)
     dense = {k: v for k, v in f.items() if k not in ("mul_pv", "mul_pl", "mul_combine", "lstm_ih0", "lstm_ih1",
-                                                     "lstm_outproj")}
+                                                     "lstm_outproj", "obj_tail", "mul_tail", "vis_enc")}
     total = sum(dense.values()) + lstm + f["lstm_outproj"]
     return f, total
 

@@ -223,6 +223,23 @@ int vog_tx_tail_fwd(const vog_tx_tail_args* a, void* stream);
  * [N/32][K/16][lane = ((k%16)/8)*32 + n%32][k%8]  (N % 32 == 0, K % 16 == 0). */
 int vog_pack_w_frag32(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);
 
+/* Proposal + segment encoders + their concat in ONE launch (prop_feats_encode / seg_feats_encode
+ * mdl_vog.py:291-314, Linear+ReLU :202-207; concat_prop_seg_feats mdl_conc_single.py:51-66,156-174,
+ * mdl_conc_sep.py:44-62): out[r, :prop_enc] = relu(W_p prop[r] + b_p), out[r, prop_enc:] =
+ * relu(W_s seg[r / nppf0] + b_s). prop: [n_prop_rows, prop_dim] fp32, seg: [n_prop_rows/nppf0, seg_dim]
+ * fp32 (read once, rounded to `dtype` in registers); w_*_f: weights in the fragment order of
+ * vog_pack_w_frag, type `dtype`; c32 / c16 (type c16_dtype): [n_prop_rows, ldc], either may be NULL.
+ * Needs feature dims % 256 == 0, encode sizes % 32 == 0 and <= 256 (vog_vis_encode_supported);
+ * other shapes use vog_cast_f32_to_t16 + vog_gemm_bias_act (+ vog_splitk_finish). */
+typedef struct vog_visenc_args {
+  const float* prop; const float* seg;
+  const void* w_prop_f; const void* w_seg_f; const float* b_prop; const float* b_seg;
+  float* c32; void* c16; int64_t ldc; int c16_dtype;
+  int n_prop_rows, nppf0, prop_dim, seg_dim, prop_enc, seg_enc; vog_dtype dtype;
+} vog_visenc_args;
+int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
+int vog_vis_encode(const vog_visenc_args* a, void* stream);
+
 /* dst[i] = (t16) src[i] for two arrays in one launch (raw proposal / segment
  * features -> the encoders' MFMA operand type; replaces the implicit fp32 read
  * of nn.Linear in prop_feats_encode / seg_feats_encode mdl_vog.py:291-314).

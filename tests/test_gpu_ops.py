@@ -618,3 +618,41 @@ def test_tx_tail_matches_torch_chain(M, d, kwo, mode, dtype):
     ref_eval = torch.sigmoid(logit) * arg_msk.view(n_vid, 1, nsrl, 1).float() * cmp_msk[:, cmp].view(n_vid, 1, 1, -1).float()
     assert (outs_eval - ref_eval).abs().max().item() <= 1.5e-3
     assert torch.all(outs_eval[ref_eval == 0] == 0)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("rows,nppf0", [(800, 5), (75, 5), (1600, 100)])
+def test_vis_encode_fused(rows, nppf0, dtype):
+    """Both feature encoders + the prop||seg concat in one launch, from the fp32 features, against
+    relu(Linear) on the same 16-bit-rounded operands (mdl_vog.py:291-314, mdl_conc_single.py:51-66)."""
+    torch.manual_seed(rows)
+    lib, T = _lib(), t16(dtype)
+    Kp, Ks, Np, Ns = 2048, 3072, 256, 256
+    prop = torch.randn(rows, Kp, device="cuda")
+    seg = torch.randn(rows // nppf0, Ks, device="cuda")
+    wp, wsg = torch.randn(Np, Kp) / math.sqrt(Kp), torch.randn(Ns, Ks) / math.sqrt(Ks)
+    bp, bs = torch.randn(Np, device="cuda") * 0.1, torch.randn(Ns, device="cuda") * 0.1
+
+    def pack(w):
+        w = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+        dst = np.empty(w.size, dtype=np.uint16)
+        L.check(lib.vog_pack_w_frag(w.ctypes.data, w.shape[1], w.shape[0], w.shape[1], dst.ctypes.data, DT[dtype]), "pack")
+        return torch.from_numpy(dst.view(np.int16)).cuda()
+
+    wpf, wsf = pack(wp), pack(wsg)
+    c32 = torch.full((rows, Np + Ns), float("nan"), device="cuda")
+    c16 = torch.zeros(rows, Np + Ns, dtype=torch.bfloat16, device="cuda")
+    a = L.VisencArgs()
+    a.prop, a.seg, a.w_prop_f, a.w_seg_f, a.b_prop, a.b_seg = (L.ptr(prop), L.ptr(seg), L.ptr(wpf), L.ptr(wsf),
+                                                                L.ptr(bp), L.ptr(bs))
+    a.c32, a.c16, a.ldc, a.c16_dtype = L.ptr(c32), L.ptr(c16), Np + Ns, L.VOG_BF16
+    a.n_prop_rows, a.nppf0, a.prop_dim, a.seg_dim, a.prop_enc, a.seg_enc, a.dtype = rows, nppf0, Kp, Ks, Np, Ns, DT[dtype]
+    assert lib.vog_vis_encode_supported(Kp, Ks, Np, Ns) == 1
+    L.check(lib.vog_vis_encode(C.byref(a), _sp()), "vis_encode")
+    torch.cuda.synchronize()
+    rp = torch.relu(prop.to(T).float() @ wp.cuda().to(T).float().t() + bp)
+    rs = torch.relu(seg.to(T).float() @ wsg.cuda().to(T).float().t() + bs).repeat_interleave(nppf0, dim=0)
+    ref = torch.cat([rp, rs], 1)
+    err = (c32 - ref).abs().max().item()
+    assert err <= 2e-3, err
+    assert (c16.float() - ref).abs().max().item() <= 3e-2

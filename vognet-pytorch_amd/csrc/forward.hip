@@ -27,6 +27,7 @@ void set_error(const char* fmt, ...) {
 int attn_head_pad(int dh);
 int tx_tail_supported(int d, int dh, int kwo);
 int64_t tx_tail_scratch_bytes(int M, int d);
+int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
 
 // ---- host fp32 -> 16 bit ------------------------------------------------------
 static unsigned short h_to16(float f, int dt) {
@@ -87,6 +88,8 @@ struct vog_ctx {
   std::vector<float*> bsum;                             // [layer] [8R]
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
+  unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
+  int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
   float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
   float *w_sv0 = nullptr, *b_sv0 = nullptr, *w_sv2 = nullptr, *b_sv2 = nullptr;
@@ -519,10 +522,14 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // chain is captured as its own graph branch, and not in the group forms, where they live in
   // different programs)
   const bool fuse_prep = !shared && !lang_only && !c->graph_dag;
+  // one launch for both encoders + the concat, straight from the fp32 features (visenc.hip)
+  const bool enc_fused = c->fused_enc && c->w_prop_f && c->w_seg_f && !lang_only;
   auto make_visprep = [&]() {
     vog_visprep_args vp{};
-    vp.src0 = b->pad_region_feature; vp.dst0 = ws.at<void>("prop16"); vp.n0 = g.rows_obj * d.prop_dim;
-    vp.src1 = b->seg_feature_for_frms; vp.dst1 = ws.at<void>("seg16"); vp.n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
+    if (!enc_fused) {
+      vp.src0 = b->pad_region_feature; vp.dst0 = ws.at<void>("prop16"); vp.n0 = g.rows_obj * d.prop_dim;
+      vp.src1 = b->seg_feature_for_frms; vp.dst1 = ws.at<void>("seg16"); vp.n1 = (int64_t)g.n_vid * g.Fv * d.seg_dim;
+    }
     vp.dtype = et; vp.props = b->pad_proposals; vp.n_rows = (int)g.rows_obj; vp.vid_w = d.vid_w; vp.vid_h = d.vid_h;
     if (has_obj(d) && c->obj.use_rel) {
       vp.w_pe0 = c->obj.pe_w; vp.u0 = ws.at<float>("obj_u"); vp.H0 = c->obj.H; vp.nfrm_div0 = g.fdiv_obj;
@@ -669,7 +676,16 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       return sp < 1 ? 1 : sp;
     };
     const int Mp = (int)g.rows_obj, Ms = g.n_vid * g.Fv;
-    const bool can_split = (d.prop_dim % 64) == 0 && (d.seg_dim % 64) == 0 && Mp > 64 && Ms > 64 &&
+    if (enc_fused) {
+      vog_visenc_args ve{};
+      ve.prop = b->pad_region_feature; ve.seg = b->seg_feature_for_frms;
+      ve.w_prop_f = c->w_prop_f; ve.w_seg_f = c->w_seg_f; ve.b_prop = c->b_prop; ve.b_seg = c->b_seg;
+      ve.c32 = ps32; ve.c16 = ps16; ve.ldc = g.d_obj; ve.c16_dtype = d.tx_dtype;
+      ve.n_prop_rows = Mp; ve.nppf0 = d.nppf0; ve.prop_dim = d.prop_dim; ve.seg_dim = d.seg_dim;
+      ve.prop_enc = d.prop_enc; ve.seg_enc = d.seg_enc; ve.dtype = et;
+      steps.push_back({"vis_enc", [=](hipStream_t st) { return vog_vis_encode(&ve, st); }});
+    }
+    const bool can_split = !enc_fused && (d.prop_dim % 64) == 0 && (d.seg_dim % 64) == 0 && Mp > 64 && Ms > 64 &&
                            (d.prop_enc % 4) == 0 && (d.seg_enc % 4) == 0;
     const int sp_p = can_split ? pick_split(Mp, d.prop_enc, d.prop_dim) : 1;
     const int sp_s = can_split ? pick_split(Ms, d.seg_enc, d.seg_dim) : 1;
@@ -693,7 +709,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       f1.c32 = ps32 + d.prop_enc; f1.c16 = (unsigned short*)ps16 + d.prop_enc; f1.ldc = g.d_obj; f1.ldc16 = g.d_obj;
       f1.c16_dtype = d.tx_dtype;
       steps.push_back({"enc_finish", [=](hipStream_t st) { return vog_splitk_finish(&f0, &f1, st); }});
-    } else {
+    } else if (!enc_fused) {
       pe.bias = c->b_prop; pe.relu = 1; pe.c32 = ps32; pe.c16 = ps16; pe.ldc = g.d_obj; pe.ldc16 = g.d_obj;
       steps.push_back({"prop_enc", [=](hipStream_t st) { return vog_gemm_bias_act(&pe, st); }});
       se.bias = c->b_seg; se.relu = 1; se.c32 = ps32 + d.prop_enc;
@@ -940,6 +956,14 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
   VOG_TRY(up16(c, "prop_encoder.0.weight", et, &c->w_prop));
   VOG_TRY(up32(c, "prop_encoder.0.bias", &c->b_prop));
   VOG_TRY(up16(c, "seg_encoder.0.weight", et, &c->w_seg));
+  c->w_prop_f = c->w_seg_f = nullptr;
+  if (vis_encode_supported(d.prop_dim, d.seg_dim, d.prop_enc, d.seg_enc)) {
+    std::vector<unsigned short> wf((size_t)d.prop_enc * d.prop_dim), ws((size_t)d.seg_enc * d.seg_dim);
+    VOG_TRY(vog_pack_w_frag(W(c, "prop_encoder.0.weight").data(), d.prop_dim, d.prop_enc, d.prop_dim, wf.data(), (vog_dtype)et));
+    VOG_TRY(vog_pack_w_frag(W(c, "seg_encoder.0.weight").data(), d.seg_dim, d.seg_enc, d.seg_dim, ws.data(), (vog_dtype)et));
+    VOG_TRY(upload<unsigned short>(c, wf, &c->w_prop_f));
+    VOG_TRY(upload<unsigned short>(c, ws, &c->w_seg_f));
+  }
   VOG_TRY(up32(c, "seg_encoder.0.bias", &c->b_seg));
   VOG_TRY(up16(c, "lin2.0.weight", et, &c->w_lin2));
   VOG_TRY(up32(c, "lin2.0.bias", &c->b_lin2));
@@ -1169,6 +1193,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "graph_dag") == 0) { c->graph_dag = value ? 1 : 0; return 0; }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
+  if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 
@@ -1226,9 +1251,13 @@ extern "C" int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* ws, 
   if (split_chains) {
     const size_t n = lang.size() > vis.size() ? lang.size() : vis.size();
     for (size_t i = 0; i < n; ++i) {
+      // language kernel first: the persistent BiLSTM layer needs 64 completely EMPTY CUs (its waves
+      // hold ~440 registers per lane, nothing else fits beside them on a SIMD), which it only finds
+      // right behind the row's barrier; dispatched second it waits until the vision kernel of the row
+      // has drained and the row runs serially (measured: 290 us per forward either way)
       std::vector<LaunchRecord> row;
-      if (i < vis.size()) row.push_back(vis[i]);
       if (i < lang.size()) row.push_back(lang[i]);
+      if (i < vis.size()) row.push_back(vis[i]);
       rows.push_back(row);
     }
   } else {

@@ -1,0 +1,148 @@
+// Proposal / segment feature encoders + concat_prop_seg_feats as ONE kernel (vog_vis_encode):
+//
+//   prop_seg[r, :Np]  = relu(W_p . pad_region_feature[r] + b_p)                 (prop_feats_encode mdl_vog.py:291-301)
+//   prop_seg[r, Np:]  = relu(W_s . seg_feature_for_frms[r / nppf0] + b_s)       (seg_feats_encode :303-314 +
+//                                                                                concat_prop_seg_feats
+//                                                                                mdl_conc_single.py:51-66)
+//
+// The unfused path needed four launches (fp32 -> 16-bit cast of the 8.7 MB of raw features, two
+// split-K GEMMs writing 16 fp32 slabs, a finishing pass) and moved the features three times. Here the
+// raw fp32 rows are read ONCE, rounded to the MFMA operand type in registers, and the result is
+// written straight into the [rows, d_obj] matrix (fp32 + the 16-bit copy obj_tx / mul_tx consume).
+//
+// Work item = (16-row tile, 32 output columns); its 8 waves split K (v_mfma_f32_16x16x32, activations
+// = A operand straight from the fp32 rows, weights = B operand in the fragment order of
+// vog_pack_w_frag: one contiguous KiB per load), partial sums meet in LDS. The eight column slices
+// of a row tile run on the same XCD (block b is observed on XCD b % 8), so the 128-192 KB of fp32
+// features of the tile come from HBM once and from that L2 three times. HBM-bound by construction:
+// 8.7 MB of features + 2.6 MB of weights per cfg-2 forward, 240 workgroups.
+#include "common.h"
+
+namespace vog {
+
+struct VisEncProb {
+  const float* x; const unsigned short* w; const float* bias;
+  int M, N, K, rep, col0;        // output rows m*rep + j, columns [col0, col0 + N)
+};
+struct VisEncParams {
+  VisEncProb p[2];
+  int tiles0, tiles_all;         // 16-row tiles of problem 0, of both
+  float* c32; unsigned short* c16; int64_t ldc; int c16_bf16;
+};
+
+template <typename T16>
+__global__ __launch_bounds__(512) void vis_enc_kernel(VisEncParams a) {
+  // 8 waves split K, 2 column tiles (32 columns) per workgroup: with K/8 = 256 (8 k-steps) a wave's
+  // whole slice - 16 fp32 row pieces + 16 weight fragments - is requested in ONE round trip.
+  // (First form: 4 waves x 64 columns, 4 rounds of 4 k-steps, one workgroup per CU: 17 us, every
+  // round's HBM latency exposed.)
+  __shared__ __attribute__((aligned(16))) float red[8][2][64][4];   // [wave][col tile][lane][reg]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware item order: the 8 column slices of a row tile share an XCD (speed only)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tile = (idx >> 3) * 8 + xcd, slice = idx & 7;
+  if (tile >= a.tiles_all) return;
+  const bool second = tile >= a.tiles0;
+  // (explicit selects: indexing the by-value array with a runtime value would put it in scratch)
+  const float* qx = second ? a.p[1].x : a.p[0].x;
+  const unsigned short* qw = second ? a.p[1].w : a.p[0].w;
+  const float* qb = second ? a.p[1].bias : a.p[0].bias;
+  const int qM = second ? a.p[1].M : a.p[0].M, qN = second ? a.p[1].N : a.p[0].N;
+  const int qK = second ? a.p[1].K : a.p[0].K, qrep = second ? a.p[1].rep : a.p[0].rep;
+  const int qcol0 = second ? a.p[1].col0 : a.p[0].col0;
+  const int m0 = (second ? tile - a.tiles0 : tile) * 16;
+  const int n0 = slice * 32;
+  if (n0 >= qN) return;
+  const int ksteps = qK >> 5;                  // K % 256 == 0
+  const int kw = ksteps >> 3;                  // k-steps per wave (contiguous slice)
+  const int ml = lane & 15, kg = lane >> 4;
+  int m = m0 + ml;
+  m = m < qM ? m : qM - 1;
+  const float* xr = qx + (int64_t)m * qK + (w * kw) * 32 + kg * 8;
+  const u16x8* wf = reinterpret_cast<const u16x8*>(qw) + ((int64_t)(n0 >> 4) * ksteps + w * kw) * 64 + lane;
+  f32x4 acc[2];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int UN = 8;
+  for (int ks = 0; ks < kw; ks += UN) {
+    float4 xa[UN][2];
+    u16x8 wq[UN][2];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      const bool ok = ks + j < kw;
+      xa[j][0] = ok ? *reinterpret_cast<const float4*>(xr + (ks + j) * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xa[j][1] = ok ? *reinterpret_cast<const float4*>(xr + (ks + j) * 32 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        wq[j][ct] = ok ? wf[((int64_t)ct * ksteps + ks + j) * 64] : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      const u16x8 af = {to16<T16>(xa[j][0].x), to16<T16>(xa[j][0].y), to16<T16>(xa[j][0].z), to16<T16>(xa[j][0].w),
+                        to16<T16>(xa[j][1].x), to16<T16>(xa[j][1].y), to16<T16>(xa[j][1].z), to16<T16>(xa[j][1].w)};
+      acc[0] = mfma16<T16>(af, wq[j][0], acc[0]);
+      acc[1] = mfma16<T16>(af, wq[j][1], acc[1]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[w][0][lane][0]) = acc[0];
+  *reinterpret_cast<f32x4*>(&red[w][1][lane][0]) = acc[1];
+  __syncthreads();
+  // waves 0/1 finish column tile 0/1: lane = (row group, column), 4 rows per lane
+  if (w >= 2) return;
+  const int col = n0 + w * 16 + ml;
+  if (col >= qN) return;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ww = 0; ww < 8; ++ww) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(&red[ww][w][lane][0]);
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  const float b = qb[col];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + kg * 4 + r;
+    if (row >= qM) continue;
+    const float o = fmaxf(v[r] + b, 0.f);
+    const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+    for (int j = 0; j < qrep; ++j) {
+      const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
+      if (a.c32) a.c32[off] = o;
+      if (a.c16) a.c16[off] = h;
+    }
+  }
+}
+
+int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
+  return (prop_dim % 256) == 0 && (seg_dim % 256) == 0 && (prop_enc % 32) == 0 && (seg_enc % 32) == 0 &&
+         prop_enc <= 256 && seg_enc <= 256;
+}
+
+int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
+  VOG_CHECK_ARG(a && a->prop && a->seg && a->w_prop_f && a->w_seg_f && a->b_prop && a->b_seg && (a->c32 || a->c16));
+  VOG_CHECK_ARG(a->n_prop_rows > 0 && a->nppf0 > 0 && (a->n_prop_rows % a->nppf0) == 0);
+  if (!vis_encode_supported(a->prop_dim, a->seg_dim, a->prop_enc, a->seg_enc))
+    VOG_FAIL(-1, "fused encoders: unsupported dims (feature dims %% 256, encode sizes %% 32 and <= 256)");
+  VisEncParams p{};
+  p.p[0] = VisEncProb{a->prop, (const unsigned short*)a->w_prop_f, a->b_prop, a->n_prop_rows, a->prop_enc,
+                      a->prop_dim, 1, 0};
+  p.p[1] = VisEncProb{a->seg, (const unsigned short*)a->w_seg_f, a->b_seg, a->n_prop_rows / a->nppf0, a->seg_enc,
+                      a->seg_dim, a->nppf0, a->prop_enc};
+  p.tiles0 = ceil_div(p.p[0].M, 16);
+  p.tiles_all = p.tiles0 + ceil_div(p.p[1].M, 16);
+  p.c32 = a->c32; p.c16 = (unsigned short*)a->c16; p.ldc = a->ldc;
+  p.c16_bf16 = a->c16_dtype == VOG_BF16;
+  const int groups = ceil_div(p.tiles_all, 8);
+  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_kernel<T16>), dim3(groups * 8 * 8), dim3(512), 0, st, p));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace vog
+
+extern "C" int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
+  return vog::vis_encode_supported(prop_dim, seg_dim, prop_enc, seg_enc);
+}
+extern "C" int vog_vis_encode(const vog_visenc_args* a, void* stream) {
+  return vog::vis_encode_run(a, (hipStream_t)stream);
+}

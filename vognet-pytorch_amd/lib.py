@@ -121,6 +121,13 @@ class TxTailArgs(C.Structure):
         self.head_dtype = VOG_F16
 
 
+class VisencArgs(C.Structure):
+    _fields_ = [("prop", c_vp), ("seg", c_vp), ("w_prop_f", c_vp), ("w_seg_f", c_vp), ("b_prop", c_vp),
+                ("b_seg", c_vp), ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("c16_dtype", c_i32),
+                ("n_prop_rows", c_i32), ("nppf0", c_i32), ("prop_dim", c_i32), ("seg_dim", c_i32),
+                ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32)]
+
+
 class PredcmpArgs(C.Structure):
     _fields_ = [("final_hidden", c_vp), ("prop_seg", c_vp), ("w0", c_vp), ("b0", c_vp),
                 ("w2", c_vp), ("b2", c_vp), ("outs", c_vp), ("arg_msk", c_vp), ("cmp_msk", c_vp),
@@ -169,6 +176,8 @@ SYMBOLS = {
     "vog_tx_tail_supported": (c_i32, [c_i32, c_i32, c_i32]),
     "vog_tx_tail_scratch_bytes": (c_i64, [c_i32, c_i32]),
     "vog_tx_tail_fwd": (c_i32, [C.POINTER(TxTailArgs), c_vp]),
+    "vog_vis_encode_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    "vog_vis_encode": (c_i32, [C.POINTER(VisencArgs), c_vp]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),
