@@ -462,7 +462,13 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * when submitting through more than 4 AQL queues or with GPU_MAX_HW_QUEUES > 4.
  * "fused_tail" (default 1): run everything after the attention of an encoder layer (and, for the
  * last mul_tx layer, lin2 + the score head) as ONE vog_tx_tail_fwd launch where
- * vog_tx_tail_supported; 0 = the separate GEMM / LayerNorm / score launches (always used for other shapes). */
+ * vog_tx_tail_supported; 0 = the separate GEMM / LayerNorm / score launches (always used for other shapes).
+ * "fused_enc" (default 1): vog_vis_encode instead of cast + two split-K GEMMs + finish where supported.
+ * "pair_launches" (default 1): step i of the language chain (input projection / BiLSTM layer / out-projection)
+ * and step i of the visual chain (encoders / obj_tx QKV, attention, tail / mul_tx QKV) - independent until
+ * mul_tx's attention - share ONE launch (csrc/pair.hip: blocks [0, nA) run one kernel body, the rest the
+ * other) wherever a pair kernel exists for the two shapes; 0 = every step its own launch. Same kernels
+ * bodies either way: results are bit-identical (tests/test_gpu_forward.py). */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 

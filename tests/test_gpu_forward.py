@@ -151,6 +151,20 @@ def test_forward_unfused_tail_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
+@pytest.mark.parametrize("name", FULL)
+def test_paired_launches_equal_separate_launches(name):
+    """pair_launches: two independent steps in one grid (csrc/pair.hip) run the same kernel bodies as
+    the stand-alone launches -> bit-identical outputs."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("pair_launches", 0)
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("pair_launches", 1)
+    b = eng.forward(dev)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), (name, k)
+
+
 def test_forward_f16_transformers():
     """cfg 5 flavour: fp16 MFMA path with fp32 accumulate."""
     name = "full/cfg5_vog_svsq_gt5_bs16"
@@ -247,19 +261,23 @@ def test_aql_program_equals_stream_forward(name, split):
 
 
 def test_aql_interleaved_programs_and_queues():
-    """Four forwards row-interleaved behind shared barrier packets, on two queues at once."""
+    """Two forwards row-interleaved behind shared barrier packets on each of two queues at once."""
     name = "full/cfg2_vog_spat_gt5_bs4"
     eng, cfg, sd, batch, c, dev = build_engine(name)
     ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
     torch.cuda.synchronize()
     eng.aql_open(2)
-    slots = [eng.make_slot(dev, graph=False).build_aql(split_chains=True) for _ in range(6)]
+    slots = [eng.make_slot(dev, graph=False).build_aql(split_chains=True) for _ in range(5)]
+    # co-residency guard: 2 queues open -> at most 2 persistent-BiLSTM programs per (concurrent) submission
+    with pytest.raises(Exception):
+        eng.aql_submit(slots[:3], 0)
+    slots = slots[:4]
     for rep in range(3):
         for s in slots:
             s.out["pred_rec"].fill_(float("nan"))
         torch.cuda.synchronize()
-        eng.aql_submit(slots[:4], 0)
-        eng.aql_submit(slots[4:], 1)
+        eng.aql_submit(slots[:2], 0)
+        eng.aql_submit(slots[2:], 1)
         with pytest.raises(Exception):
             eng.aql_submit(slots[:1], 1)         # still in flight: refused, not re-queued
         for s in slots:

@@ -75,6 +75,7 @@ struct AqlProgram {
   hsa_signal_t done{};
   int n_packets = 0;
   bool in_flight = false;
+  bool persistent = false;     // contains a persistent BiLSTM layer (co-residency: <= 4 such programs in flight)
 };
 
 // ---- runtime bring-up ------------------------------------------------------------------------------
@@ -244,6 +245,8 @@ int aql_program_build(const std::vector<std::vector<LaunchRecord>>& rows, AqlPro
     for (const LaunchRecord& r : row) {
       std::string nm;
       const KernelInfo* k = find_kernel(rt, r.host_fn, nm);
+      if (nm.find("lstm_layer_kernel") != std::string::npos || nm.find("LstmLayerBody") != std::string::npos)
+        p->persistent = true;
       if (!k) { set_error("AQL path: kernel '%s' not found in the device code objects", nm.c_str()); rc = -2004; break; }
       if (r.arg_bytes == 0xffffffffu || r.arg_bytes > k->karg) {
         set_error("AQL path: kernel '%s': %u argument bytes recorded, kernarg segment is %u", nm.c_str(), r.arg_bytes, k->karg);
@@ -346,6 +349,19 @@ int aql_submit(AqlProgram* const* progs, int n, int queue) {
     if (progs[i]->in_flight) VOG_FAIL(-2007, "AQL path: program %d is still in flight (wait for it first)", i);
     for (int j = 0; j < i; ++j) VOG_CHECK_ARG(progs[j] != progs[i]);
     max_rows = progs[i]->rows.size() > max_rows ? progs[i]->rows.size() : max_rows;
+  }
+  {
+    // The persistent BiLSTM layer needs its 64 workgroups (one CU each) resident together: at most 4
+    // instances may EXECUTE at once on a 256-CU part. Programs of one submission are row-interleaved
+    // (concurrent); submissions on one queue run one after the other; queues run concurrently. So a
+    // submission may hold at most 4 / (open queues) such programs - enforced here, not left to the
+    // caller (a 5th instance would spin until its timeout and poison its output with NaN).
+    int add = 0;
+    for (int i = 0; i < n; ++i) add += progs[i]->persistent ? 1 : 0;
+    const int nq = (int)rt.queues.size();
+    if (add > 0 && (nq > 4 || add > 4 / nq))
+      VOG_FAIL(-2009, "AQL path: %d programs with a persistent BiLSTM in one submission with %d queues open exceed "
+               "the co-residency limit of 4 concurrent instances (interleave fewer, or set lstm_persistent = 0)", add, nq);
   }
   std::lock_guard<std::mutex> lk(*rt.qlocks[queue]);
   hsa_queue_t* q = rt.queues[queue];

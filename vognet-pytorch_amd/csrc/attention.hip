@@ -8,8 +8,12 @@
 // the Linear is affine in the box, so pe[i,j,h] = relu(u[i,h] - u[j,h] + b[h])
 // with u = W_pe . box — three VALU ops per (i,j), nothing stored.
 //
-// Mapping (wave64, v_mfma_f32_32x32x16): one workgroup = 32 queries; its 4 waves split
-// the key blocks and merge their partial (max, sum, O^T) through LDS at the end:
+// Four kernels share the math below and differ in how K / V reach the MFMA (csrc/attention_dev.h):
+// attn_sb (N <= 128: one workgroup per (sequence, head), keys split over the 4 waves, global softmax
+// statistics exchanged through LDS before P.V), attn_frag (128 < N < 512: per-wave running softmax,
+// LDS tree merge), attn_tile (N >= 512: K / V^T blocks staged once per workgroup by LDS-DMA, double
+// buffered) and attn_struct / attn_struct1 (mul_tx layer 0: separable softmax over visual + language keys).
+// Common mapping (wave64, v_mfma_f32_32x32x16): a wave owns 32 queries;
 //   * "swapped" products so a query's softmax row lives in one lane:
 //       S^T[key][q] = K_blk . Q^T        (A = K fragment, B = Q fragment)
 //       O^T[d][q]  += V^T_blk . P^T      (A = V fragment, B = P from registers)
@@ -21,965 +25,11 @@
 //     movement, no LDS round trip for P.
 //   * q, k, v arrive in MFMA-fragment order (written that way by the QKV GEMM
 //     epilogue / vog_qkv_combine): every operand fragment is one contiguous KiB,
-//     loaded straight into registers with a 16-byte-per-lane coalesced load. No
-//     LDS staging, no barriers: at the sequence lengths of this model (25..200
-//     tokens, K+V = 100..200 KB per head, L2-resident) the shared-tile kernel
-//     this replaces spent its time in stage->barrier->compute serialisation on
-//     24..120 workgroups; here every 32-query block is an independent wave
-//     (84..480 of them) with all loads of a key block in flight at once.
-//     (For p100, N = 2000..4000, K/V are re-read once per 32-query block from L2;
-//     an LDS-DMA shared-tile variant over the same fragment layout is the next step.)
-#include <stdlib.h>
-#include <stdlib.h>
-#include "common.h"
+//     loaded straight into registers (or, for attn_tile, into LDS by global_load_lds) with
+//     16-byte-per-lane coalesced accesses: no transposes, no swizzles.
+#include "attention_dev.h"
 
 namespace vog {
-
-struct AttnParams {
-  const unsigned short* q; const unsigned short* k; const unsigned short* vt;
-  unsigned short* out;
-  const float* u; const float* pe_b;
-  int S, N, H, dp, npad, use_rel, n_box, seq_per_vid, NP;
-  float inv_scale;
-};
-
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
-  constexpr int DP = NDB * 32, KS = DP / 16;
-  constexpr int OSLOT = NDB * 16 * 64;               // floats of one wave's O^T partial
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* obuf = smem;                                // [2][OSLOT]
-  float* mlbuf = smem + 2 * OSLOT;                   // [4][2][64]  (m, l) per wave
-  float* us = mlbuf + 4 * 2 * 64;                    // [npad] bias precursor of every key
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, ql = lane & 31;
-  // 1-D grid. Workgroup b runs on XCD b % 8 (observed; speed only): give the 8 XCDs 8
-  // different (sequence, head) pairs and keep all query blocks of a pair on ONE XCD, so
-  // its K/V fragments are fetched into one L2 instead of up to eight.
-  const int nqb = (p.N + 31) >> 5;
-  const int npair = p.S * p.H;
-  int pair, qb;
-  {
-    const int b = blockIdx.x;
-    const int full = (npair / 8) * 8;                 // pairs that form complete groups of 8
-    const int grp = b / (8 * nqb);
-    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qb = (b >> 3) % nqb; }
-    else { const int r = b - full * nqb; pair = full + r / nqb; qb = r % nqb; }
-  }
-  const int s = pair / p.H, h = pair - s * p.H;
-  const int qi = qb * 32 + ql;
-  const bool q_ok = qi < p.N;
-  const int nkb = nqb;
-  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
-  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
-  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + lane;
-  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + lane;
-
-  float uq = 0.f, peb = 0.f;
-  if (p.use_rel) {
-    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
-    peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
-    if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
-  }
-  __syncthreads();
-
-  f32x16 o[NDB];
-#pragma unroll
-  for (int i = 0; i < NDB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  // ---- the 4 waves of the workgroup split the KEY blocks of this query block (wave w
-  // takes kb = w, w+4, ...): at N = 100 every wave has exactly one block, so the whole
-  // attention is one round of loads + 32 MFMAs per wave, then a merge. No wave waits on
-  // another until the merge. (Variants measured and rejected on MI355X: one wave per
-  // query block walking all key blocks 23.8 us; + software-prefetched next K block 30 us
-  // — the extra 64 registers spill; K/V register-resident across 2 query blocks with Q
-  // shared through LDS 25-31 us — spills again. This form: 21.9 us mul, 10.5 us obj.)
-  for (int kb = wid; kb < nkb; kb += 4) {
-    u16x8 kf[KS], qf[KS], vf[NDB * 2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
-#pragma unroll
-    for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
-    // ---- S^T block [32 keys x 32 queries]; two chains halve the dependent-MFMA latency
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      s0 = mfma32<T16>(kf[ks], qf[ks], s0);
-      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
-    }
-    // ---- bias, scale, mask, block max
-    f32x16 sacc;
-    float mloc = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + c32_row(r, lane);
-      float x = s0[r] + s1[r];
-      if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
-      x *= p.inv_scale;
-      x = key < p.N ? x : -1e30f;
-      sacc[r] = x;
-      mloc = fmaxf(mloc, x);
-    }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __expf(m_run - m_new);
-    float lsum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __expf(sacc[r] - m_new);
-      sacc[r] = e;
-      lsum += e;
-    }
-    lsum += __shfl_xor(lsum, 32);
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-    if (kb >= 4 && !__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int i = 0; i < NDB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    // ---- P^T fragments straight from the accumulator registers
-    u16x8 pf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
-    // pad keys of the last block carry p = 0 but their V fragment entries are
-    // whatever the (zero-initialised, never written) buffer holds: finite by contract
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) o[db] = mfma32<T16>(vf[db * 2 + ks], pf[ks], o[db]);
-  }
-
-  // ---- merge the 4 partial (m, l, O^T) with a two-level tree through LDS
-  auto publish = [&](int slot) {
-    float* ob = obuf + slot * OSLOT;
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ob[(i * 16 + r) * 64 + lane] = o[i][r];
-    mlbuf[(wid * 2 + 0) * 64 + lane] = m_run;
-    mlbuf[(wid * 2 + 1) * 64 + lane] = l_run;
-  };
-  auto absorb = [&](int slot, int other) {
-    const float* ob = obuf + slot * OSLOT;
-    const float mb = mlbuf[(other * 2 + 0) * 64 + lane], lb = mlbuf[(other * 2 + 1) * 64 + lane];
-    const float m = fmaxf(m_run, mb);
-    const float fa = __expf(m_run - m), fb = __expf(mb - m);
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * fa + ob[(i * 16 + r) * 64 + lane] * fb;
-    l_run = l_run * fa + lb * fb;
-    m_run = m;
-  };
-  if (nkb > 2) {                      // waves 2,3 hold something only then
-    if (wid >= 2) publish(wid - 2);
-    __syncthreads();
-    if (wid < 2) absorb(wid, wid + 2);
-    __syncthreads();
-  }
-  if (nkb > 1) {
-    if (wid == 1) publish(0);
-    __syncthreads();
-    if (wid == 0) absorb(0, 1);
-  }
-  // ---- normalise and store: O^T[d][q] -> out[(s*N+q), h*DP + d], 4 consecutive d per store
-  if (wid == 0 && q_ok) {
-    const float inv_l = 1.0f / l_run;
-    unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[db][g * 4 + e] * inv_l);
-        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
-      }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// Single-pass variant for N <= 128 (<= 4 key blocks: every mul_tx shape of gt5, where this
-// kernel is the largest single item of the forward). Wave w owns key block w, so nothing
-// has to persist across key blocks, and the kernel is shaped around OCCUPANCY: the general
-// kernel needs 462 registers per wave = one workgroup per CU, i.e. 480 workgroups run as
-// two serial rounds of ~8.5 us that are each >50 % load wait (measured: SQ_WAIT_ANY 53 %).
-// Here the softmax is made global BEFORE the PV product (the 4 waves exchange (max, sum)
-// through LDS and fold exp(m_w - m*) into P), so the partial O^T of the waves are plain
-// summands; PV runs in two head-dim halves that reuse the same 32 + 64 registers, and the
-// 4 waves reduce the halves in parallel (wave w sums and stores d-block w). <= 256
-// registers => two workgroups per CU overlap each other's load round trip.
-// ----------------------------------------------------------------------------
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
-  constexpr int DP = NDB * 32, KS = DP / 16;
-  constexpr int HB = (NDB + 1) / 2;                  // d-blocks per half
-  constexpr int SLOT = HB * 16 * 64;                 // floats of one wave's half partial
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* slots = smem;                               // [4][SLOT]
-  float* mlbuf = smem + 4 * SLOT;                    // [4][2][64]
-  float* us = mlbuf + 4 * 2 * 64;                    // [npad]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, ql = lane & 31;
-  const int nqb = (p.N + 31) >> 5;                   // = number of key blocks <= 4
-  const int npair = p.S * p.H;
-  int pair, qb;
-  {
-    const int b = blockIdx.x;
-    const int full = (npair / 8) * 8;
-    const int grp = b / (8 * nqb);
-    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qb = (b >> 3) % nqb; }
-    else { const int r = b - full * nqb; pair = full + r / nqb; qb = r % nqb; }
-  }
-  const int s = pair / p.H, h = pair - s * p.H;
-  const int qi = qb * 32 + ql;
-  const bool q_ok = qi < p.N;
-  const bool active = wid < nqb;                     // wave-uniform: has a key block
-  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
-  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
-  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + (int64_t)wid * KS * 64 + lane;
-  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + (int64_t)wid * NDB * 2 * 64 + lane;
-
-  // requests first: K and Q (needed at once), then the first V half
-  u16x8 kf[KS], qf[KS], vf[HB * 2];
-  if (active) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { kf[ks] = Kf[ks * 64]; qf[ks] = Qf[ks * 64]; }
-#pragma unroll
-    for (int i = 0; i < HB * 2; ++i) vf[i] = Vf[i * 64];
-  }
-  float uq = 0.f, peb = 0.f;
-  if (p.use_rel) {
-    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
-    peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
-    if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
-  }
-  __syncthreads();
-
-  float m_w = -1e30f, l_w = 0.f;
-  f32x16 sacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-  if (active) {
-    f32x16 s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      sacc = mfma32<T16>(kf[ks], qf[ks], sacc);
-      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = wid * 32 + c32_row(r, lane);
-      float x = sacc[r] + s1[r];
-      if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
-      x *= p.inv_scale;
-      x = key < p.N ? x : -1e30f;
-      sacc[r] = x;
-      m_w = fmaxf(m_w, x);
-    }
-    m_w = fmaxf(m_w, __shfl_xor(m_w, 32));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __expf(sacc[r] - m_w);
-      sacc[r] = e;
-      l_w += e;
-    }
-    l_w += __shfl_xor(l_w, 32);
-  }
-  mlbuf[(wid * 2 + 0) * 64 + lane] = m_w;
-  mlbuf[(wid * 2 + 1) * 64 + lane] = l_w;
-  __syncthreads();
-  // global softmax statistics of this query (same in every wave)
-  float m_all = -1e30f;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, mlbuf[(w * 2) * 64 + lane]);
-  float l_all = 0.f;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) l_all += mlbuf[(w * 2 + 1) * 64 + lane] * __expf(mlbuf[(w * 2) * 64 + lane] - m_all);
-  const float f_w = __expf(m_w - m_all);
-  const float inv_l = 1.0f / l_all;
-  // P^T fragments, already on the global scale
-  u16x8 pf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j] * f_w);
-
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int nb = half == 0 ? HB : NDB - HB;        // d-blocks in this half
-    if (nb <= 0) break;
-    if (half == 1) {
-      __syncthreads();                               // slots consumed by the previous half
-      if (active) {
-#pragma unroll
-        for (int i = 0; i < (NDB - HB) * 2; ++i) vf[i] = Vf[(HB * 2 + i) * 64];
-      }
-    }
-    float* mine = slots + wid * SLOT;
-    if (active) {
-#pragma unroll
-      for (int db = 0; db < HB; ++db) {
-        if (db < nb) {
-          f32x16 o;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[r] = 0.f;
-          o = mfma32<T16>(vf[db * 2], pf[0], o);
-          o = mfma32<T16>(vf[db * 2 + 1], pf[1], o);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64 + lane] = o[r];
-        }
-      }
-    }
-    __syncthreads();
-    // wave w reduces and stores d-block w (w + 4, ...) of this half
-    for (int db = wid; db < nb; db += 4) {
-      float acc[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int w = 0; w < nqb; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += slots[w * SLOT + (db * 16 + r) * 64 + lane];
-      if (q_ok) {
-        unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP +
-                               (half * HB + db) * 32;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = to16<T16>(acc[g * 4 + e] * inv_l);
-          *reinterpret_cast<u16x4*>(orow + g * 8 + hi * 4) = v;
-        }
-      }
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// Shared-tile variant for long sequences (p100: N = 2000 / 4000). The kernels above give every
-// 32-query block its own pass over K and V (fine up to a few hundred tokens: everything is
-// L2-resident and parallelism matters more); at N = 2000 that is 1 MiB of K/V per 32 queries and the
-// kernel becomes L2-bandwidth bound (measured: 345 TFLOP/s = 14 % of the MFMA peak). Here a workgroup
-// owns 128 queries (one 32-query block per wave, Q fragments in registers for the whole pass) and the
-// 4 waves walk the key blocks TOGETHER: each 32-key block of K and V^T fragments is brought into LDS
-// once per workgroup by LDS-DMA (the fragment order is lane-linear, i.e. exactly what
-// global_load_lds writes), double buffered, one barrier per block; every wave reads its MFMA A
-// operands from LDS (conflict-free 16-byte lane-linear reads). No merge at the end: a wave owns
-// its queries' whole softmax row. K/V traffic per query drops 4x, Q is read once.
-// ----------------------------------------------------------------------------
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
-  constexpr int DP = NDB * 32, KS = DP / 16;
-  constexpr int NF = KS + 2 * NDB;                   // KiB fragments per key block (K then V^T)
-  extern __shared__ __attribute__((aligned(1024))) unsigned char tsm[];
-  unsigned char* kv = tsm;                           // [2][NF][1024]
-  float* us = reinterpret_cast<float*>(tsm + 2 * NF * 1024);   // [npad] bias precursor of every key
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, ql = lane & 31;
-  const int nkb = (p.N + 31) >> 5;
-  const int nqg = (p.N + 127) >> 7;                  // 128-query groups per (sequence, head)
-  const int npair = p.S * p.H;
-  int pair, qg;
-  {   // XCD-aware: the query groups of one (sequence, head) stay on one XCD (its K/V in one L2)
-    const int b = blockIdx.x;
-    const int full = (npair / 8) * 8;
-    const int grp = b / (8 * nqg);
-    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qg = (b >> 3) % nqg; }
-    else { const int r = b - full * nqg; pair = full + r / nqg; qg = r % nqg; }
-  }
-  const int s = pair / p.H, h = pair - s * p.H;
-  const int qb = qg * 4 + wid;                       // this wave's 32-query block
-  const bool wave_ok = qb < nkb;                     // a wave past the end still helps with the DMA
-  const int qi = qb * 32 + ql;
-  const bool q_ok = qi < p.N;
-  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
-  const unsigned short* Kg = p.k + base;
-  const unsigned short* Vg = p.vt + base;
-
-  float uq = 0.f, peb = 0.f;
-  if (p.use_rel) {
-    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
-    peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
-    if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
-  }
-  // Q fragments of this wave's block: registers for the whole pass
-  u16x8 qf[KS];
-  {
-    const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)(wave_ok ? qb : 0) * KS * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
-  }
-  // fragment f of key block kb: f < KS -> K fragment, else V^T fragment f - KS
-  auto issue = [&](int kb, int buf) {
-    for (int f = wid; f < NF; f += 4) {
-      const unsigned short* src = f < KS ? Kg + ((int64_t)kb * KS + f) * 512
-                                         : Vg + ((int64_t)kb * NDB * 2 + (f - KS)) * 512;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + lane * 8),
-          (__attribute__((address_space(3))) void*)(kv + (buf * NF + f) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 o[NDB];
-#pragma unroll
-  for (int i = 0; i < NDB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
-  const float uqp = uq + peb;
-  // (a 3-buffer software pipeline that issues S^T of block kb+1 before the softmax of block kb was
-  // measured equal: mul 1151 vs 1166 us, obj 497 vs 474 us at p100 - kept simple)
-
-  issue(0, 0);
-  for (int kb = 0; kb < nkb; ++kb) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of block kb has landed
-    __syncthreads();                                      // ... everybody's; and block kb-1 is consumed
-    if (kb + 1 < nkb) issue(kb + 1, (kb + 1) & 1);
-    if (!wave_ok) continue;
-    const unsigned char* blk = kv + ((kb & 1) * NF) * 1024 + lane * 16;
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      s0 = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + ks * 1024), qf[ks], s0);
-      if (ks + 1 < KS) s1 = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + (ks + 1) * 1024), qf[ks + 1], s1);
-    }
-    // softmax in the log2 domain: x2 = (s + bias) * (inv_scale * log2 e), p = 2^(x2 - m2). The row
-    // of register r is (r&3) + 8*(r>>2) + 4*hi: the 4 bias precursors of a register quad are one
-    // 16-byte LDS read; keys >= N exist only in the last block (uniform branch).
-    f32x16 sacc;
-    float mloc = -1e30f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 ub = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.use_rel) ub = *reinterpret_cast<const float4*>(&us[kb * 32 + 8 * g + 4 * hi]);
-      const float ubv[4] = {ub.x, ub.y, ub.z, ub.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = g * 4 + e;
-        float x = s0[r] + s1[r];
-        if (p.use_rel) x += fmaxf(uqp - ubv[e], 0.f);
-        sacc[r] = x * c2;
-      }
-    }
-    if (kb == nkb - 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kb * 32 + c32_row(r, lane) >= p.N) sacc[r] = -1e30f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float lsum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
-      sacc[r] = e;
-      lsum += e;
-    }
-    lsum += __shfl_xor(lsum, 32);
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-    if (kb > 0 && !__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int i = 0; i < NDB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    u16x8 pf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        o[db] = mfma32<T16>(*reinterpret_cast<const u16x8*>(blk + (KS + db * 2 + ks) * 1024), pf[ks], o[db]);
-  }
-  if (wave_ok && q_ok) {
-    const float inv_l = 1.0f / l_run;
-    unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[db][g * 4 + e] * inv_l);
-        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
-      }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// Separable attention of mul_tx layer 0 (include/vog_hip.h, vog_attn_struct_args). Token (a, p) has
-// k = Kv[p] + Kl[a], v = Vv[p] + Vl[a] and a bias that depends on (p, p') only, so the softmax over
-// the nsrl*nppf keys is the product of a softmax over the nppf visual keys and one over the nsrl
-// language keys, and   out = softmax_p'(q.Kv + bias).Vv + softmax_a'(q.Kl).Vl   (exact).
-// One wave = one 32-query block, nothing shared between waves: the visual part is the flash loop of
-// the kernels above over ceil(nppf/32) key blocks (ONE at gt5), the language part one masked block
-// whose K / V fragments are assembled from the fp32 language projection (5 rows) in registers. The
-// language probabilities are normalised BEFORE their P.V product so that it accumulates into the
-// (already normalised) visual output registers.
-// ----------------------------------------------------------------------------
-struct AttnStructParams {
-  const unsigned short* q; const unsigned short* kv; const unsigned short* vv; const float* pl;
-  unsigned short* out; const float* u; const float* pe_b;
-  int S, H, dp, nsrl, nppf, npad_q, npad_kv, nfrm, lpv, ncv, use_rel, seq_per_vid, NP;
-  float inv_scale; int q_visual;
-};
-
-#ifdef VOG_TS_ATTN   // scratch/ts_attn.hip: wall-clock stamps (100 MHz) per wave
-__device__ unsigned long long g_ats[4096][8];
-#define VOG_ATS(slot) do { if (lane == 0) g_ats[(blockIdx.x * 4 + wid) & 4095][slot] = wall_clock64(); } while (0)
-#else
-#define VOG_ATS(slot) do { } while (0)
-#endif
-
-// shared pieces of the two struct kernels ----------------------------------------------------------
-template <typename T16, int KS>
-__device__ __forceinline__ void struct_load_q(const AttnStructParams& p, u16x8 (&qf)[KS], int s, int h, int qbs,
-                                              int lane, const float* plr, int ldp, int64_t kvbase) {
-  constexpr int DP = KS * 16;
-  const int hi = lane >> 5, ql = lane & 31;
-  if (p.q_visual) {
-    // query (a, p) = Qv[p] + Ql[a]: the visual part is this token's 16-byte chunk of the fragment-
-    // ordered Qv (tokens of a block are consecutive p: mostly one contiguous run), the language part
-    // 8 floats of the projection row of argument a (a handful of distinct rows per wave)
-    const int t = qbs * 32 + ql;
-    int a = t / p.nppf;
-    const int pp = t - a * p.nppf;
-    a = a < p.nsrl ? a : p.nsrl - 1;                  // tokens past the end are never stored
-    const unsigned short* qv = p.q + kvbase;
-    const float* qlr = plr + (int64_t)a * ldp + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u16x8 v = *reinterpret_cast<const u16x8*>(qv + frag_qk(pp, ks * 16 + hi * 8, DP));
-      const float4 l0 = *reinterpret_cast<const float4*>(qlr + ks * 16);
-      const float4 l1 = *reinterpret_cast<const float4*>(qlr + ks * 16 + 4);
-      qf[ks] = u16x8{to16<T16>(from16<T16>(v[0]) + l0.x), to16<T16>(from16<T16>(v[1]) + l0.y),
-                     to16<T16>(from16<T16>(v[2]) + l0.z), to16<T16>(from16<T16>(v[3]) + l0.w),
-                     to16<T16>(from16<T16>(v[4]) + l1.x), to16<T16>(from16<T16>(v[5]) + l1.y),
-                     to16<T16>(from16<T16>(v[6]) + l1.z), to16<T16>(from16<T16>(v[7]) + l1.w)};
-    }
-  } else {
-    const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) +
-                      (int64_t)qbs * KS * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
-  }
-}
-
-// language K fragments: lane = key a (rows >= nsrl are zero), 8 consecutive head columns
-template <typename T16, int KS>
-__device__ __forceinline__ void struct_load_kl(const AttnStructParams& p, u16x8 (&klf)[KS], int lane,
-                                               const float* plr, int hd, int ldp) {
-  const int hi = lane >> 5, ql = lane & 31;
-  const bool a_ok = ql < p.nsrl;
-  const float* kr = plr + hd + (int64_t)ql * ldp + hi * 8;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-    if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
-    klf[ks] = u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
-                    to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
-  }
-}
-
-// language V fragment of d-block db, k-step ks: lane = (hi, head column), register j = key
-// 16*ks + 8*(j>>2) + 4*hi + (j&3)
-template <typename T16>
-__device__ __forceinline__ u16x8 struct_load_vl(const AttnStructParams& p, int db, int ks, int lane,
-                                                const float* plr, int hd, int ldp) {
-  const int hi = lane >> 5, ql = lane & 31;
-  const float* vr = plr + 2 * hd + db * 32 + ql;
-  u16x8 vl;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int key = ks * 16 + 8 * (j >> 2) + 4 * hi + (j & 3);
-    vl[j] = key < p.nsrl ? to16<T16>(vr[(int64_t)key * ldp]) : (unsigned short)0;
-  }
-  return vl;
-}
-
-template <typename T16>
-__device__ __forceinline__ void struct_store(const AttnStructParams& p, const f32x16& o, int db, int64_t row,
-                                             int h, int DP, int hi) {
-  unsigned short* orow = p.out + row * ((int64_t)p.H * DP) + (int64_t)h * DP;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    u16x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[g * 4 + e]);
-    *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
-  }
-}
-
-// ---- ONE visual key block (nppf <= 32: every gt5 shape). Both softmaxes are complete before any
-// P.V product, so the output is produced d-block by d-block with ONE accumulator: the kernel holds
-// Q, K, K_lang (3 x KS fragments) in its first phase and V, V_lang + 16 accumulator registers in the
-// second, instead of the flash kernel's NDB accumulators alive through everything (dp = 256: 512
-// registers and 104 spills, 23 us).
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
-  constexpr int DP = NDB * 32, KS = DP / 16;
-  extern __shared__ __attribute__((aligned(16))) float ssm[];
-  float* us = ssm;                                   // [32] bias precursor of the visual keys
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, ql = lane & 31;
-  VOG_ATS(0);
-  const int Nq = p.nsrl * p.nppf;
-  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
-  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
-  const int s = pair / p.H, h = pair - s * p.H;
-  const int qb = qg * 4 + wid;
-  const bool wave_ok = qb < nqb;
-  const int qi = qb * 32 + ql;
-  const bool q_ok = wave_ok && qi < Nq;
-  const int hd = p.H * DP, ldp = 3 * hd;
-  const int vid = s / p.nfrm;
-  const int lv = p.lpv ? vid : vid / p.ncv;
-  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
-  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
-  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
-  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
-
-  // The language projection rows of this (video, head) - nsrl x {Q, K, V} x DP floats - are staged in
-  // LDS once per workgroup (a few 16-byte loads per thread) instead of ~70 small global loads per
-  // wave; Qv and K fragments go straight to registers meanwhile.
-  float* pls = ssm + 32;                             // [nsrl][3][DP]
-  {
-    const int per_row = 3 * DP / 4;                  // float4 per argument
-    for (int i = tid; i < p.nsrl * per_row; i += 256) {
-      const int a = i / per_row, c = i - a * per_row;
-      const int part = c / (DP / 4), dd4 = c - part * (DP / 4);
-      *reinterpret_cast<float4*>(&pls[(a * 3 + part) * DP + dd4 * 4]) =
-          *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + part * hd + dd4 * 4);
-    }
-  }
-  u16x8 qf[KS], kf[KS], klf[KS];
-  const int qbs = wave_ok ? qb : 0;
-  int qa = 0, qp = 0;
-  if (p.q_visual) {
-    const int t = qbs * 32 + ql;
-    qa = t / p.nppf;
-    qp = t - qa * p.nppf;
-    qa = qa < p.nsrl ? qa : p.nsrl - 1;              // tokens past the end are never stored
-    const unsigned short* qv = p.q + kvbase;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qv + frag_qk(qp, ks * 16 + hi * 8, DP));
-  } else {
-    const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) +
-                      (int64_t)qbs * KS * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = Qf[ks * 64];
-  }
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[ks * 64];
-  float uq = 0.f, peb = 0.f;
-  if (p.use_rel) {
-    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
-    peb = p.pe_b[h];
-    if (tid < 32) us[tid] = tid < p.nppf ? p.u[(u_base + tid) * p.H + h] : 0.f;
-    if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
-  }
-  VOG_ATS(1);
-  __syncthreads();
-  if (!wave_ok) return;
-  if (p.q_visual) {                                  // q(a, p) = Qv[p] + Ql[a]
-    const float* qlr = pls + (qa * 3 + 0) * DP + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u16x8 v = qf[ks];
-      const float4 l0 = *reinterpret_cast<const float4*>(qlr + ks * 16);
-      const float4 l1 = *reinterpret_cast<const float4*>(qlr + ks * 16 + 4);
-      qf[ks] = u16x8{to16<T16>(from16<T16>(v[0]) + l0.x), to16<T16>(from16<T16>(v[1]) + l0.y),
-                     to16<T16>(from16<T16>(v[2]) + l0.z), to16<T16>(from16<T16>(v[3]) + l0.w),
-                     to16<T16>(from16<T16>(v[4]) + l1.x), to16<T16>(from16<T16>(v[5]) + l1.y),
-                     to16<T16>(from16<T16>(v[6]) + l1.z), to16<T16>(from16<T16>(v[7]) + l1.w)};
-    }
-  }
-  {                                                  // language K fragments: lane = key a
-    const bool a_ok = ql < p.nsrl;
-    const float* kr = pls + ((a_ok ? ql : 0) * 3 + 1) * DP + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-      if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
-      klf[ks] = u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
-                      to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
-    }
-  }
-  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
-  const float uqp = uq + peb;
-  // ---- both logit blocks
-  f32x16 sv, sl;
-  {
-    f32x16 s1, l1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sv[r] = 0.f; s1[r] = 0.f; sl[r] = 0.f; l1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      sv = mfma32<T16>(kf[ks], qf[ks], sv);
-      sl = mfma32<T16>(klf[ks], qf[ks], sl);
-      if (ks + 1 < KS) {
-        s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
-        l1 = mfma32<T16>(klf[ks + 1], qf[ks + 1], l1);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sv[r] += s1[r]; sl[r] += l1[r]; }
-  }
-  VOG_ATS(2);
-  // ---- two independent softmaxes, probabilities normalised before P.V
-  u16x8 pv_[2], pl_[2];
-  {
-    float mv = -1e30f, ml = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = c32_row(r, lane);
-      float x = sv[r];
-      if (p.use_rel) x += fmaxf(uqp - us[key], 0.f);
-      x = key < p.nppf ? x * c2 : -1e30f;
-      const float y = key < p.nsrl ? sl[r] * c2 : -1e30f;
-      sv[r] = x; sl[r] = y;
-      mv = fmaxf(mv, x); ml = fmaxf(ml, y);
-    }
-    mv = fmaxf(mv, __shfl_xor(mv, 32));
-    ml = fmaxf(ml, __shfl_xor(ml, 32));
-    float lv_ = 0.f, ll = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sv[r] = __builtin_amdgcn_exp2f(sv[r] - mv); lv_ += sv[r];
-      sl[r] = __builtin_amdgcn_exp2f(sl[r] - ml); ll += sl[r];
-    }
-    lv_ += __shfl_xor(lv_, 32);
-    ll += __shfl_xor(ll, 32);
-    const float iv = 1.0f / lv_, il = 1.0f / ll;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        pv_[ks][j] = to16<T16>(sv[ks * 8 + j] * iv);
-        pl_[ks][j] = to16<T16>(sl[ks * 8 + j] * il);
-      }
-  }
-  VOG_ATS(3);
-  // ---- output, one d-block at a time
-  const int nksl = p.nsrl > 16 ? 2 : 1;
-#pragma unroll
-  for (int db = 0; db < NDB; ++db) {
-    const u16x8 v0 = Vf[(db * 2) * 64], v1 = Vf[(db * 2 + 1) * 64];
-    u16x8 w0;                                        // language V fragment from the staged rows
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int key = 8 * (j >> 2) + 4 * hi + (j & 3);
-      w0[j] = key < p.nsrl ? to16<T16>(pls[(key * 3 + 2) * DP + db * 32 + ql]) : (unsigned short)0;
-    }
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    o = mfma32<T16>(v0, pv_[0], o);
-    o = mfma32<T16>(v1, pv_[1], o);
-    o = mfma32<T16>(w0, pl_[0], o);
-    if (nksl > 1) o = mfma32<T16>(struct_load_vl<T16>(p, db, 1, lane, plr, hd, ldp), pl_[1], o);
-    if (q_ok) struct_store<T16>(p, o, db, (int64_t)s * Nq + qi, h, DP, hi);
-  }
-  VOG_ATS(4);
-#ifdef VOG_TS_ATTN
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VOG_ATS(5);
-#endif
-}
-
-// ---- general form: flash loop over the visual key blocks (p100), then the language block
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(AttnStructParams p) {
-  constexpr int DP = NDB * 32, KS = DP / 16;
-  extern __shared__ __attribute__((aligned(16))) float ssm[];
-  float* us = ssm;                                   // [npad_kv] bias precursor of the visual keys
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, ql = lane & 31;
-  const int Nq = p.nsrl * p.nppf;
-  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
-  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
-  const int s = pair / p.H, h = pair - s * p.H;
-  const int qb = qg * 4 + wid;
-  const bool wave_ok = qb < nqb;
-  const int qi = qb * 32 + ql;
-  const bool q_ok = wave_ok && qi < Nq;
-  const int nkb = p.npad_kv >> 5;
-  const int hd = p.H * DP, ldp = 3 * hd;
-  const int vid = s / p.nfrm;
-  const int lv = p.lpv ? vid : vid / p.ncv;
-  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
-  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
-  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
-  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
-  u16x8 qf[KS];
-  struct_load_q<T16, KS>(p, qf, s, h, wave_ok ? qb : 0, lane, plr, ldp, kvbase);
-  float uq = 0.f, peb = 0.f;
-  if (p.use_rel) {
-    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
-    peb = p.pe_b[h];
-    for (int key = tid; key < p.npad_kv; key += 256)
-      us[key] = key < p.nppf ? p.u[(u_base + key) * p.H + h] : 0.f;
-    if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
-  }
-  __syncthreads();
-  if (!wave_ok) return;
-  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
-  const float uqp = uq + peb;
-
-  f32x16 o[NDB];
-#pragma unroll
-  for (int i = 0; i < NDB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  for (int kb = 0; kb < nkb; ++kb) {
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-    {
-      u16x8 kf[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[((int64_t)kb * KS + ks) * 64];
-#pragma unroll
-      for (int ks = 0; ks < KS; ks += 2) {
-        s0 = mfma32<T16>(kf[ks], qf[ks], s0);
-        if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
-      }
-    }
-    u16x8 vf[NDB * 2];
-#pragma unroll
-    for (int i = 0; i < NDB * 2; ++i) vf[i] = Vf[((int64_t)kb * NDB * 2 + i) * 64];
-    f32x16 sacc;
-    float mloc = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + c32_row(r, lane);
-      float x = s0[r] + s1[r];
-      if (p.use_rel) x += fmaxf(uqp - us[key], 0.f);
-      x = key < p.nppf ? x * c2 : -1e30f;
-      sacc[r] = x;
-      mloc = fmaxf(mloc, x);
-    }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float lsum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
-      sacc[r] = e;
-      lsum += e;
-    }
-    lsum += __shfl_xor(lsum, 32);
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-    if (kb > 0 && !__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int i = 0; i < NDB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    u16x8 pf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j]);
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) o[db] = mfma32<T16>(vf[db * 2 + ks], pf[ks], o[db]);
-  }
-  {
-    const float inv_l = 1.0f / l_run;                // normalise the visual part in place
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= inv_l;
-  }
-  // ---- language keys: one masked block, its own softmax, probabilities normalised before P.V so
-  // that it accumulates into the normalised visual output
-  {
-    u16x8 klf[KS];
-    struct_load_kl<T16, KS>(p, klf, lane, plr, hd, ldp);
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      s0 = mfma32<T16>(klf[ks], qf[ks], s0);
-      if (ks + 1 < KS) s1 = mfma32<T16>(klf[ks + 1], qf[ks + 1], s1);
-    }
-    f32x16 sacc;
-    float m2 = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = c32_row(r, lane);
-      const float x = key < p.nsrl ? (s0[r] + s1[r]) * c2 : -1e30f;
-      sacc[r] = x;
-      m2 = fmaxf(m2, x);
-    }
-    m2 = fmaxf(m2, __shfl_xor(m2, 32));
-    float l2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(sacc[r] - m2);
-      sacc[r] = e;
-      l2 += e;
-    }
-    l2 += __shfl_xor(l2, 32);
-    const float inv_l2 = 1.0f / l2;
-    u16x8 pf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[ks][j] = to16<T16>(sacc[ks * 8 + j] * inv_l2);
-    const int nksl = p.nsrl > 16 ? 2 : 1;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      o[db] = mfma32<T16>(struct_load_vl<T16>(p, db, 0, lane, plr, hd, ldp), pf[0], o[db]);
-      if (nksl > 1) o[db] = mfma32<T16>(struct_load_vl<T16>(p, db, 1, lane, plr, hd, ldp), pf[1], o[db]);
-    }
-  }
-  if (q_ok) {
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-      struct_store<T16>(p, o[db], db, (int64_t)s * Nq + qi, h, DP, hi);
-  }
-}
 
 template <typename T16, int NDB>
 static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {

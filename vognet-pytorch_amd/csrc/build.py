@@ -14,10 +14,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRCS = ["forward.hip", "gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "aql.hip"]
+SRCS = ["forward.hip", "gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "aql.hip"]
 # translation units that hold kernels: also built device-only into libvog_hip.<tu>.co for the AQL path
-KERNEL_SRCS = ["gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip"]
-HDRS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "aql.h"), os.path.join(ROOT, "include", "vog_hip.h")]
+KERNEL_SRCS = ["gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip"]
+HDRS = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join(ROOT, "include", "vog_hip.h")]
 OUT = os.path.join(HERE, "libvog_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "../../include/vog_hip.h"
 
 namespace vog {
@@ -71,6 +72,10 @@ template <> __device__ __forceinline__ f32x4 mfma16<F16>(u16x8 a, u16x8 b, f32x4
                                                 __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+// ReLU that PROPAGATES NaN (fmaxf(NaN, 0) is 0): the persistent BiLSTM poisons its output with NaN
+// when a hand-off times out, and that poison has to reach mdl_outs through every projection.
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ int c32_row(int reg, int lane) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
@@ -98,6 +103,13 @@ __host__ __device__ __forceinline__ int64_t frag_a(int m, int k, int K) {
   return ((((int64_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64) + (((k >> 3) & 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
 
+// ---- kernel bodies ---------------------------------------------------------------------------
+// The kernels that can share a launch with another one are written as BODIES: a struct with
+// Params, THREADS and a static __device__ run(params, ctx, smem) that takes its block index and
+// grid size from `ctx` and all of its LDS from `smem`. Their own __global__ kernel calls the body
+// with the hardware indices; pair_kernel (pair.hip) calls two different bodies from one grid.
+struct BlockCtx { unsigned bx, by, gx, gy; };
+
 // ---- kernel launch: HIP stream, or recorded into an AQL program (aql.hip) -----------------------
 // Every kernel of the library is launched through vog::launch. With an ordinary stream it is
 // hipLaunchKernelGGL. With the recorder pseudo-stream (vog_aql_program_create) nothing is
@@ -115,6 +127,9 @@ struct LaunchRecorder {
   virtual ~LaunchRecorder() {}
 };
 extern thread_local LaunchRecorder* g_recorder;
+// Pair capture (pair.hip): while set, vog::launch appends here instead of launching, so that two
+// independent steps of the forward can be issued as ONE grid (horizontal fusion).
+extern thread_local std::vector<LaunchRecord>* g_pair_capture;
 static inline hipStream_t recorder_stream() { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(0x7e0c0de1)); }
 
 template <typename T>
@@ -129,6 +144,16 @@ inline void pack_arg(LaunchRecord& r, const T& v) {
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
   static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count mismatch");
+  if (g_pair_capture) {
+    LaunchRecord r;
+    r.host_fn = reinterpret_cast<const void*>(kern);
+    r.grid[0] = grid.x; r.grid[1] = grid.y; r.grid[2] = grid.z;
+    r.block[0] = block.x; r.block[1] = block.y; r.block[2] = block.z;
+    r.dyn_lds = (unsigned)lds; r.arg_bytes = 0;
+    (pack_arg<KArgs>(r, static_cast<KArgs>(args)), ...);
+    g_pair_capture->push_back(r);
+    return;
+  }
   if (st == recorder_stream() && g_recorder) {
     LaunchRecord r;
     r.host_fn = reinterpret_cast<const void*>(kern);

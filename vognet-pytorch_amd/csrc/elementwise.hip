@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(SplitkProbs a) {
     const float4 b = *reinterpret_cast<const float4*>(q.bias + n);
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
   }
-  if (q.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (q.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
   u16x4 h;
   if (q.c16) {
     if (q.c16_dtype == VOG_BF16) h = u16x4{to16<BF16>(v.x), to16<BF16>(v.y), to16<BF16>(v.z), to16<BF16>(v.w)};
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float v = wave_sum(acc[k]);
-    if (lane == 0 && o0 + k < L) lang[(int64_t)ba * L + o0 + k] = fmaxf(v + bias[o0 + k], 0.f) * mk;
+    if (lane == 0 && o0 + k < L) lang[(int64_t)ba * L + o0 + k] = relu_nan(v + bias[o0 + k]) * mk;
   }
 }
 
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void predcmp_kernel(vog_predcmp_args a) {
     float acc = 0.f;
     for (int i = lane; i < din; i += 64) acc += wr[i] * xin[i];
     acc = wave_sum(acc);
-    if (lane == 0) hid[o] = fmaxf(acc + a.b0[o], 0.f);
+    if (lane == 0) hid[o] = relu_nan(acc + a.b0[o]);
   }
   __syncthreads();
   float vid = 0.f;

@@ -4,6 +4,7 @@
 // Evaluator*.get_out_results_boxes (eval_vsrl_corr.py:162-424) with ~50 kernel
 // launches on caller-owned buffers; no allocation and no sync on the launch path.
 #include <stdarg.h>
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <map>
@@ -28,6 +29,8 @@ int attn_head_pad(int dh);
 int tx_tail_supported(int d, int dh, int kwo);
 int64_t tx_tail_scratch_bytes(int M, int d);
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
+int pair_launch(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
+                hipStream_t st, bool* fused);
 
 // ---- host fp32 -> 16 bit ------------------------------------------------------
 static unsigned short h_to16(float f, int dt) {
@@ -90,6 +93,7 @@ struct vog_ctx {
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
+  int pair_launches = 1;                // step i of the language chain shares a launch with step i of the visual chain (pair.hip)
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
   float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
   float *w_sv0 = nullptr, *b_sv0 = nullptr, *w_sv2 = nullptr, *b_sv2 = nullptr;
@@ -495,7 +499,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
 // b->shared_lang != NULL: the language chain is NOT run; argument vectors (and the final hidden
 // states for the sep head) come from a group encoder's workspace.
 static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t ws_bytes,
-                       Plan& plan, std::vector<Step>& steps, bool lang_only = false) {
+                       Plan& plan, std::vector<Step>& steps, bool lang_only = false, bool allow_pairs = true) {
   const vog_model_desc& d = c->d;
   VOG_CHECK_ARG(c->finalized);
   VOG_CHECK_ARG(b && b->B > 0 && b->ncmp > 0 && b->T > 0 && b->T <= d.seq_len);
@@ -775,6 +779,62 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
     steps.push_back({"pred_head", [=](hipStream_t st) { return vog_pred_head(&pr, st); }});
   }
+  // ---- horizontal fusion (pair.hip): the language chain and the visual chain are independent until
+  // mul_tx's attention, and neither fills the chip (the persistent BiLSTM layer holds 64 CUs for
+  // ~46 us): step i of one shares a launch with step i of the other. The visual step moves up to the
+  // language step's position (its own inputs are produced by earlier pairs); combinations without a
+  // registered pair kernel fall back to two launches inside pair_launch.
+  if (allow_pairs && c->pair_launches && !c->graph_dag && !shared && c->lstm_persistent) {
+    auto find = [&](const char* nm, int occurrence) {
+      for (size_t i = 0; i < steps.size(); ++i)
+        if (steps[i].name == nm && steps[i].branch >= 0 && occurrence-- == 0) return (int)i;
+      return -1;
+    };
+    // language step -> visual step that shares its launch (+ a visual step that follows on its own).
+    // Pairs are chosen by shape: a 512-thread body next to a 512-thread body, 256 next to 256 (a
+    // register-heavy 512-thread partner would cut the occupancy of a small-block streaming kernel:
+    // input projection + encoders in one grid measured 29.8 us against 6.4 + 16.0 apart).
+    struct Want { const char* lang; int occ; const char* vis; const char* then; };
+    const Want want[] = {{"lstm_layer", 0, "vis_enc", nullptr}, {"lstm_ih1", 0, "obj_qkv", "obj_attn"},
+                         {"lstm_layer", 1, "obj_tail", nullptr}, {"lstm_outproj", 0, "mul_pv", nullptr}};
+    struct Plan2 { int ia, ib, ic; };
+    std::vector<Plan2> plans;
+    bool ok = true;
+    int prev_vis = -1;
+    for (auto& w : want) {
+      Plan2 q{find(w.lang, w.occ), find(w.vis, 0), w.then ? find(w.then, 0) : -1};
+      // every visual step only moves EARLIER (its producers sit in earlier pairs) and the visual chain
+      // keeps its own order; any missing piece (other model variants / shapes) leaves the rest unpaired
+      if (q.ia < 0 || q.ib < 0 || q.ib < q.ia || q.ib < prev_vis || (w.then && (q.ic < q.ib))) { ok = false; break; }
+      prev_vis = w.then ? q.ic : q.ib;
+      plans.push_back(q);
+    }
+    if (ok) {
+      // nothing else of the visual chain may sit between the moved steps (it would be overtaken)
+      std::vector<int> moved;
+      for (auto& q : plans) { moved.push_back(q.ib); if (q.ic >= 0) moved.push_back(q.ic); }
+      for (int i = moved.front(); i <= moved.back() && ok; ++i)
+        if (steps[i].branch == 0 && std::find(moved.begin(), moved.end(), i) == moved.end()) ok = false;
+    }
+    if (ok) {
+      std::vector<int> role(steps.size(), 0);           // 1 = removed from its old position
+      std::vector<Step> out;
+      for (auto& q : plans) { role[q.ib] = 1; if (q.ic >= 0) role[q.ic] = 1; }
+      for (size_t i = 0; i < steps.size(); ++i) {
+        if (role[i]) continue;
+        const Plan2* q = nullptr;
+        for (auto& x : plans) if (x.ia == (int)i) q = &x;
+        if (!q) { out.push_back(steps[i]); continue; }
+        Step m = steps[i];
+        auto fa = steps[q->ia].fn, fb = steps[q->ib].fn;
+        m.name = steps[q->ia].name + "+" + steps[q->ib].name;
+        m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
+        out.push_back(m);
+        if (q->ic >= 0) { Step t = steps[q->ic]; t.branch = m.branch; out.push_back(t); }
+      }
+      steps.swap(out);
+    }
+  }
   // VOG_SKIP_STEPS=name,name,... (perf experiments only; results are WRONG): drop steps whose
   // name starts with one of the entries, to measure their marginal cost in the throughput regime
   if (const char* skip = perf_env("VOG_SKIP_STEPS")) {
@@ -813,6 +873,9 @@ extern "C" int vog_ctx_create(const vog_model_desc* d, vog_ctx** out) {
   vog_ctx* c = new vog_ctx();
   c->d = *d;
   // VOG_LSTM_PERSISTENT=0/1 presets the option (test sweeps); vog_ctx_set_int overrides it
+  // HIP streams map onto GPU_MAX_HW_QUEUES hardware queues (default 4 = the co-residency limit of the
+  // persistent BiLSTM layer kernel: 4 instances x 64 CUs): with more queues it is off by default
+  if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { if (atoi(e) > 4) c->lstm_persistent = 0; }
   if (const char* e = getenv("VOG_LSTM_PERSISTENT")) c->lstm_persistent = atoi(e) ? 1 : 0;
   const int R = d->rnn_size, E = d->emb_dim, L = d->lang_enc;
   add_w(c, "lstm_encoder.embed_tokens.weight", (int64_t)(d->vocab_size + 1) * E);
@@ -1194,6 +1257,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
+  if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 
@@ -1355,12 +1419,17 @@ extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t 
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
   const Step* s = nullptr;
   for (auto& x : steps) if (x.name == kernel && x.branch >= 0) { s = &x; break; }
+  if (!s) {     // a step that runs paired in the forward can still be timed on its own
+    steps.clear();
+    VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps, false, false));
+    for (auto& x : steps) if (x.name == kernel && x.branch >= 0) { s = &x; break; }
+  }
   if (!s) VOG_FAIL(-4, "no kernel step '%s'", kernel);
   hipStream_t st = (hipStream_t)stream;
   // the persistent layer kernel consumes per-forward state (hand-off tags zeroed by lang_prep):
   // time (lang_prep + layer) pairs and subtract lang_prep timed alone the same way
   const Step* reset = nullptr;
-  if (s->name == "lstm_layer")
+  if (s->name.rfind("lstm_layer", 0) == 0)
     for (auto& x : steps) if (x.name == "lang_prep" || x.name == "prep") { reset = &x; break; }
   hipEvent_t e0, e1;
   VOG_HIP(hipEventCreate(&e0));

@@ -1,0 +1,395 @@
+// Device side of txtail.hip (kernel bodies; also included by pair.hip, which fuses two bodies into one launch).
+#pragma once
+#include "common.h"
+
+namespace vog {
+
+struct TailParams {
+  const unsigned short* attn16; int KWO;
+  const unsigned short *wo_p, *w1_p, *w2_p, *wl_p;
+  const float* residual; int64_t ldr;
+  const float *res_vis, *res_lang; int rv_nfrm, rv_nppf, rv_nsrl, rv_dv, rv_dl, rv_lpv, rv_ncv;
+  const float *ln1g, *ln1b, *b1, *b2, *ln2g, *ln2b;
+  float* y32; unsigned short* y16; int y16_bf16;
+  const float *bl, *wl2, *bl2;
+  vog_score_args sc;
+  int M;
+  int dbgf;      // perf experiments only, read by the DBG & 4 instantiation: 1 no residual, 2 no attention staging, 4 no LayerNorm, 8 no outputs
+};
+
+// One GEMM stage of the chain: acc[i][rb] (32 columns n x 32 rows m, swapped) += W_blk(i) . X^T over
+// KS k-steps of 16. Weight fragments of n-block b start at wp + b*KS*512 halfwords.
+//  * Straight-line software pipeline, PF k-steps of weight prefetch, NO branch around a load (a
+//    conditional prefetch makes hipcc fall back to s_waitcnt vmcnt(0) in front of every k-step), and a
+//    sched_barrier behind every refill (left alone, the scheduler sinks all PF refills to the end of
+//    the unrolled body and the prefetch distance collapses to one k-step).
+//  * The k-steps are visited in ROTATED order, starting at `rot` (a function of the workgroup's
+//    position on its XCD): the ~8 workgroups that share an L2 then stream 8 different parts of the
+//    weight matrix at any moment, so a line is fetched from the Infinity Cache by ONE of them and
+//    found in L2 by the other seven (in lock-step every workgroup took the ~2 us fabric miss on
+//    every line: kernel boundaries leave the XCD L2s cold). The fp32 summation order depends on the
+//    row block only, so results stay bit-reproducible.
+template <typename TT, int NBW, int PF, bool ZERO, int DBG = 0>
+__device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][2], const unsigned short* __restrict__ wp,
+                                          int blk0, int blk_step, int KS, int rot,
+                                          const unsigned char* xl, int pitch, int lane) {
+  constexpr int KST = (DBG & 1) ? 0 : 64;     // DBG 1 (perf experiments): every weight load hits the block's first KiB
+  const int ml = lane & 31, hi = lane >> 5;
+  const u16x8* wb[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    wb[i] = reinterpret_cast<const u16x8*>(wp + ((int64_t)(blk0 + i * blk_step) * KS) * 512) + lane;
+    if constexpr (ZERO) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][rb][r] = 0.f;
+    }
+  }
+  if constexpr (DBG & 4) return;              // DBG 4: no GEMM stage at all (skeleton: loads, LayerNorms, stores)
+  auto kk = [&](int t) { const int k = t + rot; return k >= KS ? k - KS : k; };   // t < 2*KS - rot
+  u16x8 wq[PF][NBW];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int k = kk(j);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) wq[j][i] = wb[i][k * KST];
+  }
+  const unsigned char* x0 = xl + ml * pitch + hi * 16;
+  const unsigned char* x1 = x0 + 32 * pitch;
+  u16x8 xf0 = *reinterpret_cast<const u16x8*>(x0 + kk(0) * 32), xf1 = *reinterpret_cast<const u16x8*>(x1 + kk(0) * 32);
+  auto step = [&](int j, int t, bool refill) {
+    const int kn = kk(t + 1);                  // next k-step's activations (t + 1 == KS wraps to `rot`: in bounds)
+    const u16x8 n0 = *reinterpret_cast<const u16x8*>(x0 + kn * 32);
+    const u16x8 n1 = *reinterpret_cast<const u16x8*>(x1 + kn * 32);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      if constexpr (DBG & 2) {                 // DBG 2: no matrix work (keeps the operands live)
+        acc[i][0][0] += __builtin_bit_cast(float, (unsigned)wq[j][i][0] | ((unsigned)xf0[0] << 16));
+        acc[i][1][0] += __builtin_bit_cast(float, (unsigned)wq[j][i][1] | ((unsigned)xf1[0] << 16));
+      } else {
+        acc[i][0] = mfma32<TT>(wq[j][i], xf0, acc[i][0]);
+        acc[i][1] = mfma32<TT>(wq[j][i], xf1, acc[i][1]);
+      }
+    }
+    if (refill) {
+      const int kl = kk(t + PF);
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) wq[j][i] = wb[i][kl * KST];
+    }
+    xf0 = n0; xf1 = n1;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int t = 0;
+#pragma unroll 1
+  for (; t < KS - PF; t += PF) {               // KS % PF == 0, KS >= 2 * PF (not unrolled further: with a
+                                               // compile-time KS hipcc unrolls all of K and spills the addresses)
+#pragma unroll
+    for (int j = 0; j < PF; ++j) step(j, t + j, true);
+  }
+#pragma unroll
+  for (int j = 0; j < PF; ++j) step(j, t + j, false);
+}
+
+// LayerNorm over n of the swapped accumulator tile of the whole workgroup (D columns spread over the
+// 8 waves): two-pass statistics as layernorm_kernel (mean, then sum of squared deviations); gamma / beta
+// come from LDS (prefetched at kernel start: no dependent global round trip in the epilogue).
+template <int NB>
+__device__ __forceinline__ void tail_ln(f32x16 (&acc)[NB][2], const float* gamma_l, const float* beta_l,
+                                        float* red, int w, int lane, int nblk0) {
+  constexpr int D = NB * 256;
+  int ml = lane & 31, hi = lane >> 5;
+  // opaque copies: keeps hipcc from sharing the 16 exchange addresses between the two LayerNorms of
+  // the kernel (it kept them live - spilled - across two GEMM stages instead of re-deriving them)
+  asm volatile("" : "+v"(ml), "+v"(hi));
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[rb] += acc[i][rb][r];
+  s[0] += __shfl_xor(s[0], 32); s[1] += __shfl_xor(s[1], 32);
+  if (hi == 0) { red[w * 64 + ml] = s[0]; red[w * 64 + 32 + ml] = s[1]; }
+  __syncthreads();
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) t += red[ww * 64 + rb * 32 + ml];
+    mean[rb] = t / (float)D;
+  }
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float dd = acc[i][rb][r] - mean[rb]; q[rb] += dd * dd; }
+  q[0] += __shfl_xor(q[0], 32); q[1] += __shfl_xor(q[1], 32);
+  __syncthreads();                              // every wave has read the sums
+  if (hi == 0) { red[w * 64 + ml] = q[0]; red[w * 64 + 32 + ml] = q[1]; }
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) t += red[ww * 64 + rb * 32 + ml];
+    rstd[rb] = 1.0f / sqrtf(t / (float)D + 1e-5f);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = (nblk0 + i) * 32 + 8 * g + 4 * hi;
+      const float4 gm = *reinterpret_cast<const float4*>(gamma_l + n);
+      const float4 bt = *reinterpret_cast<const float4*>(beta_l + n);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        acc[i][rb][4 * g + 0] = (acc[i][rb][4 * g + 0] - mean[rb]) * rstd[rb] * gm.x + bt.x;
+        acc[i][rb][4 * g + 1] = (acc[i][rb][4 * g + 1] - mean[rb]) * rstd[rb] * gm.y + bt.y;
+        acc[i][rb][4 * g + 2] = (acc[i][rb][4 * g + 2] - mean[rb]) * rstd[rb] * gm.z + bt.z;
+        acc[i][rb][4 * g + 3] = (acc[i][rb][4 * g + 3] - mean[rb]) * rstd[rb] * gm.w + bt.w;
+      }
+    }
+}
+
+// opaque copy of a lane index: address arithmetic derived from it cannot be shared (and kept live in
+// registers, i.e. spilled) across the stages of the chain
+__device__ __forceinline__ int fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+
+template <typename TT>
+__device__ __forceinline__ u16x4 cvt4(float a, float b, float c, float d) {
+  return u16x4{to16<TT>(a), to16<TT>(b), to16<TT>(c), to16<TT>(d)};
+}
+
+__device__ __forceinline__ float tail_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0>
+struct TxTailBody {
+  using Params = TailParams;
+  static constexpr int THREADS = 512;
+  static __device__ __forceinline__ void run(const TailParams& p, const BlockCtx& cx, unsigned char* smem) {
+  constexpr int D = NB * 256, DH = D / 2;
+  constexpr int NB1 = NB == 3 ? 2 : 1;              // FFN1 n-blocks per wave (DH/32 = 8 or 12 over 8 waves)
+  const int tid = threadIdx.x, lane = tid & 63, ml = lane & 31, hi = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = cx.bx * 64;
+  const int xcols = p.KWO > D ? p.KWO : D;
+  unsigned char* X = smem;
+  unsigned char* Y = X + 64 * (xcols + 8) * 2;
+  float* red = reinterpret_cast<float*>(Y + 64 * (DH + 8) * 2);      // [8 waves][64 rows]
+  float* vec2 = red + 512;                          // ln2 gamma, ln2 beta, b2 [D each], b1 [DH]
+  float* vec1 = reinterpret_cast<float*>(Y);        // ln1 gamma, ln1 beta [D each]: parked in Y until FFN1 writes it
+  const int p1 = (p.KWO + 8) * 2, pD = (D + 8) * 2, pH = (DH + 8) * 2;
+  // position of this workgroup among the ones that share its XCD's L2 (block b runs on XCD b % 8;
+  // speed only): staggers the k order of the weight streams
+  const int xpos = (cx.bx >> 3) & 7;
+
+  // ---- stage 0: attention rows + the epilogue vectors -> LDS; residual rows -> accumulators.
+  // Everything the chain will need from memory besides the weight streams is requested here, in one
+  // round trip: no epilogue below waits for a global load.
+  {
+    const int cpr = ((DBG & 4) && (p.dbgf & 2)) ? 0 : (p.KWO >> 3);
+    for (int idx = tid; idx < 64 * cpr; idx += 512) {
+      const int r = idx / cpr, c = idx - r * cpr;
+      int m = m0 + r;
+      m = m < p.M ? m : p.M - 1;
+      const uint4 v = *reinterpret_cast<const uint4*>(p.attn16 + (int64_t)m * p.KWO + c * 8);
+      *reinterpret_cast<uint4*>(X + r * p1 + c * 16) = v;
+    }
+    for (int i = tid; i < D / 4; i += 512) {
+      reinterpret_cast<float4*>(vec1)[i] = reinterpret_cast<const float4*>(p.ln1g)[i];
+      reinterpret_cast<float4*>(vec1 + D)[i] = reinterpret_cast<const float4*>(p.ln1b)[i];
+      reinterpret_cast<float4*>(vec2)[i] = reinterpret_cast<const float4*>(p.ln2g)[i];
+      reinterpret_cast<float4*>(vec2 + D)[i] = reinterpret_cast<const float4*>(p.ln2b)[i];
+      reinterpret_cast<float4*>(vec2 + 2 * D)[i] = reinterpret_cast<const float4*>(p.b2)[i];
+    }
+    for (int i = tid; i < DH / 4; i += 512)
+      reinterpret_cast<float4*>(vec2 + 3 * D)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  }
+  int mrow[2];
+  f32x16 acc[NB][2];
+  {
+    const float* rp[2]; const float* lp[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      mrow[rb] = m0 + rb * 32 + ml;
+      const int mc = mrow[rb] < p.M ? mrow[rb] : p.M - 1;
+      if (p.res_vis) {
+        const int N = p.rv_nsrl * p.rv_nppf;
+        const int s = mc / N, j = mc - s * N;
+        const int a = j / p.rv_nppf, pp = j - a * p.rv_nppf;
+        const int v = s / p.rv_nfrm;
+        const int lv = p.rv_lpv ? v : v / p.rv_ncv;
+        rp[rb] = p.res_vis + ((int64_t)s * p.rv_nppf + pp) * p.rv_dv;
+        lp[rb] = p.res_lang + ((int64_t)lv * p.rv_nsrl + a) * p.rv_dl;
+      } else {
+        rp[rb] = p.residual + (int64_t)mc * p.ldr;
+        lp[rb] = rp[rb];
+      }
+    }
+    // the residual IS the initial accumulator: x + attn Wo^T is one MFMA chain, no epilogue add
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (w * NB + i) * 32 + 8 * g + 4 * hi;
+        const bool in_lang = p.res_vis && n >= p.rv_dv;       // wave-uniform per (i): dv % 32 == 0
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!((DBG & 4) && (p.dbgf & 1))) r = *reinterpret_cast<const float4*>(in_lang ? lp[rb] + (n - p.rv_dv) : rp[rb] + n);
+          acc[i][rb][4 * g + 0] = r.x; acc[i][rb][4 * g + 1] = r.y;
+          acc[i][rb][4 * g + 2] = r.z; acc[i][rb][4 * g + 3] = r.w;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---- stage 1: x + attn Wo^T, LayerNorm
+  tail_gemm<T16, NB, NB == 3 ? 4 : 6, false, DBG>(acc, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, p1, lane);
+  if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB>(acc, vec1, vec1 + D, red, w, lane, w * NB);
+  // x1 stays in the accumulator registers through FFN1 (which accumulates elsewhere) and becomes,
+  // with b2 added, the initial accumulator of FFN2: the fp32 residual stream never leaves registers.
+  // Its 16-bit copy = FFN1 operand (X is free: every wave is past stage 1, LayerNorm took barriers).
+  {
+  const int mlx = fresh(ml), hix = fresh(hi);
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = (w * NB + i) * 32 + 8 * g + 4 * hix;
+      const float4 b = *reinterpret_cast<const float4*>(vec2 + 2 * D + n);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        *reinterpret_cast<u16x4*>(X + (rb * 32 + mlx) * pD + n * 2) =
+            cvt4<T16>(acc[i][rb][4 * g], acc[i][rb][4 * g + 1], acc[i][rb][4 * g + 2], acc[i][rb][4 * g + 3]);
+        acc[i][rb][4 * g + 0] += b.x; acc[i][rb][4 * g + 1] += b.y;
+        acc[i][rb][4 * g + 2] += b.z; acc[i][rb][4 * g + 3] += b.w;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 2: FFN1 + bias + ReLU -> Y (16 bit). DH/32 = 8 or 12 n-blocks over 8 waves: at d = 768
+  // waves 0-3 own two blocks (w, w + 8), waves 4-7 one - a wave-uniform choice of instantiation
+  // (no per-block conditions inside the pipelined loop)
+  {
+    const float* b1l = vec2 + 3 * D;
+    auto ffn1_epi = [&](const f32x16 (&h)[2], int blk) {
+      const int mlx = fresh(ml), hix = fresh(hi);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = blk * 32 + 8 * g + 4 * hix;
+        const float4 b = *reinterpret_cast<const float4*>(b1l + n);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          *reinterpret_cast<u16x4*>(Y + (rb * 32 + mlx) * pH + n * 2) =
+              cvt4<T16>(relu_nan(h[rb][4 * g] + b.x), relu_nan(h[rb][4 * g + 1] + b.y),
+                        relu_nan(h[rb][4 * g + 2] + b.z), relu_nan(h[rb][4 * g + 3] + b.w));
+      }
+    };
+    const int rot = (xpos * (D >> 4)) >> 3;
+    // (two blocks = two passes over K with one accumulator pair: 64 fewer live registers than one
+    // pass with two pairs, which spilled x1; the extra LDS operand reads are free here)
+    f32x16 hacc[1][2];
+    tail_gemm<T16, 1, 4, true, DBG>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane);
+    ffn1_epi(hacc[0], w);
+    if (NB1 == 2 && w < 4) {
+      tail_gemm<T16, 1, 4, true, DBG>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane);
+      ffn1_epi(hacc[0], w + 8);
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 3: (x1 + b2) + W2 hidden, LayerNorm
+  tail_gemm<T16, NB, NB == 3 ? 4 : 8, false, DBG>(acc, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, pH, lane);
+  if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB>(acc, vec2, vec2 + D, red, w, lane, w * NB);
+  const int mlo = fresh(ml), hio = fresh(hi);
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (w * NB + i) * 32 + 8 * g + 4 * hio;
+        const float a0 = acc[i][rb][4 * g], a1 = acc[i][rb][4 * g + 1], a2 = acc[i][rb][4 * g + 2],
+                    a3 = acc[i][rb][4 * g + 3];
+        if (mrow[rb] < p.M && !((DBG & 4) && (p.dbgf & 8))) {
+          if (p.y32) *reinterpret_cast<float4*>(p.y32 + (int64_t)mrow[rb] * D + n) = make_float4(a0, a1, a2, a3);
+          if (p.y16)
+            *reinterpret_cast<u16x4*>(p.y16 + (int64_t)mrow[rb] * D + n) =
+                p.y16_bf16 ? cvt4<BF16>(a0, a1, a2, a3) : cvt4<F16>(a0, a1, a2, a3);
+        }
+        if constexpr (SCORE)       // lin2 operand, in the head's own 16-bit type (X was last read in stage 2)
+          *reinterpret_cast<u16x4*>(X + (rb * 32 + mlo) * pD + n * 2) = cvt4<TH>(a0, a1, a2, a3);
+      }
+  // score-head operands that are not weight streams: requested before the lin2 GEMM, used after it
+  float4 hb[4], hw[4];
+  float am = 0.f, cm = 0.f;
+  int64_t o_idx = 0;
+  if constexpr (SCORE) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = w * 32 + 8 * g + 4 * hi;
+      hb[g] = *reinterpret_cast<const float4*>(p.bl + n);
+      hw[g] = *reinterpret_cast<const float4*>(p.wl2 + n);
+    }
+    if (tid < 64) {
+      const int64_t row0 = (int64_t)m0 + tid;
+      const int64_t row = row0 < p.M ? row0 : p.M - 1;
+      const vog_score_args& a = p.sc;      // same index arithmetic as score_kernel (elementwise.hip)
+      const int N = a.nsrl * a.nppf;
+      const int s = (int)(row / N), j = (int)(row % N);
+      const int v = s / a.nfrm, f = s % a.nfrm;
+      const int arg = j / a.nppf, pp = j % a.nppf;
+      const int NP = a.nfrm * a.nppf;
+      const int r = f * a.nppf + pp;
+      o_idx = ((int64_t)v * a.nsrl + arg) * NP + r;
+      const int b = v / a.nc_v, c = v % a.nc_v;
+      int cmp;
+      if (a.conc_type == VOG_CONC_TEMP) cmp = r / (a.nfrm0 * a.nppf0);
+      else if (a.conc_type == VOG_CONC_SPAT) cmp = (r / a.nppf0) % a.ncmp;
+      else cmp = c;
+      const int lrow = a.nvl > 1 ? (b * a.nvl + c) : b;
+      am = (float)a.arg_msk[(int64_t)lrow * a.nsrl + arg];
+      cm = (float)a.cmp_msk[(int64_t)b * a.ncmp + cmp];
+    }
+  }
+  if constexpr (SCORE) {
+    __syncthreads();
+    // ---- stage 4: lin2.0 + ReLU, lin2.2 as a row dot product, inverse regroup + masks
+    f32x16 sacc[1][2];
+    tail_gemm<TH, 1, 8, true, DBG>(sacc, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, X, pD, lane);
+    float part[2] = {0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = hb[g], ww = hw[g];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        part[rb] += relu_nan(sacc[0][rb][4 * g] + b.x) * ww.x + relu_nan(sacc[0][rb][4 * g + 1] + b.y) * ww.y +
+                    relu_nan(sacc[0][rb][4 * g + 2] + b.z) * ww.z + relu_nan(sacc[0][rb][4 * g + 3] + b.w) * ww.w;
+    }
+    part[0] += __shfl_xor(part[0], 32); part[1] += __shfl_xor(part[1], 32);
+    if (hi == 0) { red[w * 64 + ml] = part[0]; red[w * 64 + 32 + ml] = part[1]; }
+    __syncthreads();
+    if (tid < 64 && (int64_t)m0 + tid < p.M) {
+      float logit = p.bl2[0];
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) logit += red[ww * 64 + tid];
+      p.sc.outs[o_idx] = logit;
+      p.sc.outs_eval[o_idx] = tail_sigmoid(logit) * am * cm;
+    }
+  }
+}
+};
+
+template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0>
+__global__ __launch_bounds__(512) void tx_tail_kernel(TailParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tt_smem[];
+  TxTailBody<T16, TH, NB, SCORE, DBG>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, tt_smem);
+}
+
+}  // namespace vog
