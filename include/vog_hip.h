@@ -325,6 +325,13 @@ typedef struct vog_lstm_layer_args {
   const float* gxs; const void* whh; void* hx; uint32_t* sync; void* out16;
   const int64_t* lens; int Bn, T, R; vog_dtype dtype;
   int out_frag;   /* 1: out16 in the A-fragment order of vog_gemm_args.a_frag (as vog_bilstm_step) */
+  /* Fused input projection (wih != NULL; gxs is then ignored): the kernel computes x W_ih^T + bias for
+   * its own gate rows in a prologue (W_ih streamed once through registers, the layer input staged in
+   * LDS) - no separate GEMM launch and no [2][T][Bn][4R] fp32 round trip. wih: vog_lstm_pack_w of
+   * (weight_ih, weight_ih_reverse) [2][4R][K]; xa: layer input [Bn*T (row b*T + t), K] t16 in the
+   * A-fragment order of vog_gemm_args.a_frag (pad rows of the last 16-row tile readable); bias: [2][4R]
+   * fp32 = b_ih + b_hh per direction. Needs Bn*T <= 64 and K % 256 == 0. */
+  const void* wih; const void* xa; const float* bias; int K;
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);
 int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream);
@@ -332,6 +339,8 @@ int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream);
 /* host: [2][4R][R] fp32 (weight_hh_l*, weight_hh_l*_reverse) -> fragment order, 16 bit.
  * dst holds 2*4R*R halfwords: [dir][unit/4][k/32][lane 64][8]. */
 int vog_lstm_pack_whh(const float* whh_fwd, const float* whh_bwd, void* dst_host, int R, vog_dtype dtype);
+/* same packing for a [4R][K] pair (weight_ih): [dir][unit/4][K/32][lane 64][8], K % 32 == 0 */
+int vog_lstm_pack_w(const float* w_fwd, const float* w_bwd, void* dst_host, int R, int K, vog_dtype dtype);
 
 /* lang[b,a,:] = relu(W [full[b,cap0] || full[b,cap1]] + bias) * msk
  * (retrieve_srl_arg_from_lang_encode mdl_vog.py:97-140). full: [Bn*T, L] fp32. */
@@ -467,8 +476,12 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * "pair_launches" (default 1): step i of the language chain (input projection / BiLSTM layer / out-projection)
  * and step i of the visual chain (encoders / obj_tx QKV, attention, tail / mul_tx QKV) - independent until
  * mul_tx's attention - share ONE launch (csrc/pair.hip: blocks [0, nA) run one kernel body, the rest the
- * other) wherever a pair kernel exists for the two shapes; 0 = every step its own launch. Same kernels
- * bodies either way: results are bit-identical (tests/test_gpu_forward.py). */
+ * other) wherever a pair kernel exists for the two shapes; 0 = every step its own launch. Same kernel
+ * bodies either way: results are bit-identical (tests/test_gpu_forward.py).
+ * "fused_ih" (default 0): 1 = the BiLSTM input projections run inside the persistent layer kernel
+ * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 64 and K % 256 == 0 (2: layer 0
+ * only, 3: layers >= 1 only). Measured on MI355X: fewer launches and 30 % less CU time, but the
+ * prologue streams W_ih through 64 CUs only (12 / 32 us per layer vs 6.4 / 9.5 us): opt-in. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 

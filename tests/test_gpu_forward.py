@@ -165,6 +165,24 @@ def test_paired_launches_equal_separate_launches(name):
         assert torch.equal(a[k], b[k]), (name, k)
 
 
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
+                                  "full/cfg1_igrnd_spat_gt5_bs2"])
+def test_fused_lstm_input_projection_matches_separate_gemm(name):
+    """fused_ih: x W_ih^T + b computed in the persistent layer kernel's prologue vs the separate GEMM
+    launch (same 16-bit operands, another fp32 summation order)."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("fused_ih", 0)
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("fused_ih", 1)
+    b = eng.forward(dev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(b["mdl_outs"]).all()
+    assert (a["mdl_outs"] - b["mdl_outs"]).abs().max().item() < 5e-4
+    ncmp = batch["new_srl_idxs"].shape[1]
+    pa, pb = eng.unpack_pred(a["pred_rec"], ncmp), eng.unpack_pred(b["pred_rec"], ncmp)
+    assert (pa["scores"] - pb["scores"]).abs().max().item() < 2e-4
+
+
 def test_forward_f16_transformers():
     """cfg 5 flavour: fp16 MFMA path with fp32 accumulate."""
     name = "full/cfg5_vog_svsq_gt5_bs16"

@@ -88,6 +88,10 @@ struct vog_ctx {
   std::vector<unsigned short*> wih_f;                   // same, fragment order (M <= 64 kernel)
   unsigned short* w_outproj_f = nullptr;
   std::vector<unsigned short*> whh;                     // [layer] [2][4R][R]
+  std::vector<unsigned short*> wih_p;                   // [layer] W_ih in the W_hh tile order (fused input projection), or null
+  int fused_ih = 0;                     // LSTM input projections inside the persistent layer kernel (opt-in: the prologue
+                                        // streams W_ih through 64 CUs only: 12 / 32 us per layer against 6.4 / 9.5 us for
+                                        // the whole-chip GEMM launches; within noise on throughput, worse on latency)
   std::vector<float*> bsum;                             // [layer] [8R]
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
@@ -571,6 +575,13 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       // LSTM outputs feed M <= 64 GEMMs (next layer's input projection, final projection): then the
       // step kernel writes them in A-fragment order and those GEMMs load contiguous fragments
       const bool ofrag = (Bn * T + Bn) <= 64;
+      // input projection inside the persistent layer kernel (no GEMM launch, no gx round trip): needs
+      // the layer input in fragment order (embedding rows from lang_prep / the previous layer's out16)
+      const int Kin = l == 0 ? g.E : 2 * R;
+      // fused_ih: 1 = every layer, 2 = layer 0 only, 3 = layers >= 1 only (experiments)
+      const bool ih_fused = (c->fused_ih == 1 || (c->fused_ih == 2 && l == 0) || (c->fused_ih == 3 && l > 0)) && c->lstm_persistent && vog_bilstm_layer_supported(Bn, R) && ofrag &&
+                            c->wih_p[l] && (Kin % 256) == 0 && Bn * T <= 64 &&
+                            (l > 0 || (c->emb16 && (g.E % 32) == 0));
       if (l == 0) {
         ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E;
         // M > 64 runs on the LDS-DMA kernel, which cannot convert in flight: same values, pre-rounded
@@ -589,7 +600,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       ga.M = Bn * T; ga.N = 8 * R; ga.rep = 1; ga.dtype = et;
       ga.out_rows = lrows; ga.out_rows_ncol = 4 * R;
       if (ga.M <= 64 && c->wih_f[l]) { ga.w = c->wih_f[l]; ga.w_frag = 1; }
-      steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
+      if (!ih_fused)
+        steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
       // final state must land in hA (adjacent to out16): after T steps it is in buf[T % 2]
       void* hA = ofrag ? ws.at<void>("lstm_hA2_" + std::to_string(l))
                        : (void*)(ws.at<unsigned short>("lstm_out16_" + std::to_string(l)) + (int64_t)Bn * T * 2 * R);
@@ -601,6 +613,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         pa.sync = ws.at<uint32_t>("lstm_sync_" + std::to_string(l));
         pa.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
         pa.lens = b->srl_arg_word_mask_len; pa.Bn = Bn; pa.T = T; pa.R = R; pa.dtype = et; pa.out_frag = ofrag ? 1 : 0;
+        if (ih_fused) {
+          pa.wih = c->wih_p[l]; pa.bias = c->bsum[l]; pa.K = Kin;
+          pa.xa = l == 0 ? ws.at<void>("emb_a0") : ws.at<void>("lstm_out16_" + std::to_string(l - 1));
+        }
         steps.push_back({"lstm_layer", [=](hipStream_t st) { return vog_bilstm_layer(&pa, st); }});
         continue;
       }
@@ -794,32 +810,35 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     // Pairs are chosen by shape: a 512-thread body next to a 512-thread body, 256 next to 256 (a
     // register-heavy 512-thread partner would cut the occupancy of a small-block streaming kernel:
     // input projection + encoders in one grid measured 29.8 us against 6.4 + 16.0 apart).
-    struct Want { const char* lang; int occ; const char* vis; const char* then; };
-    const Want want[] = {{"lstm_layer", 0, "vis_enc", nullptr}, {"lstm_ih1", 0, "obj_qkv", "obj_attn"},
-                         {"lstm_layer", 1, "obj_tail", nullptr}, {"lstm_outproj", 0, "mul_pv", nullptr}};
-    struct Plan2 { int ia, ib, ic; };
+    // The BiLSTM layers (64 CUs for ~38 us each) take the encoders and the obj_tx tail as partners; the
+    // obj_tx QKV projection and attention follow the first pair on their own (paired with the layer-1
+    // input projection they measured SLOWER than apart: 22.5 vs 9.5 + 7.4 us).
+    struct Want { const char* lang; int occ; const char* vis; const char* then0; const char* then1; };
+    const Want want[] = {{"lstm_layer", 0, "vis_enc", "obj_qkv", "obj_attn"},
+                         {"lstm_layer", 1, "obj_tail", nullptr, nullptr}, {"lstm_outproj", 0, "mul_pv", nullptr, nullptr}};
+    struct Plan2 { int ia, ib, ic, id; };
     std::vector<Plan2> plans;
     bool ok = true;
     int prev_vis = -1;
     for (auto& w : want) {
-      Plan2 q{find(w.lang, w.occ), find(w.vis, 0), w.then ? find(w.then, 0) : -1};
+      Plan2 q{find(w.lang, w.occ), find(w.vis, 0), w.then0 ? find(w.then0, 0) : -1, w.then1 ? find(w.then1, 0) : -1};
       // every visual step only moves EARLIER (its producers sit in earlier pairs) and the visual chain
       // keeps its own order; any missing piece (other model variants / shapes) leaves the rest unpaired
-      if (q.ia < 0 || q.ib < 0 || q.ib < q.ia || q.ib < prev_vis || (w.then && (q.ic < q.ib))) { ok = false; break; }
-      prev_vis = w.then ? q.ic : q.ib;
+      if (q.ia < 0 || q.ib < 0 || q.ib < q.ia || q.ib < prev_vis || (w.then0 && q.ic < q.ib) || (w.then1 && q.id < q.ic)) { ok = false; break; }
+      prev_vis = w.then1 ? q.id : (w.then0 ? q.ic : q.ib);
       plans.push_back(q);
     }
     if (ok) {
       // nothing else of the visual chain may sit between the moved steps (it would be overtaken)
       std::vector<int> moved;
-      for (auto& q : plans) { moved.push_back(q.ib); if (q.ic >= 0) moved.push_back(q.ic); }
+      for (auto& q : plans) { moved.push_back(q.ib); if (q.ic >= 0) moved.push_back(q.ic); if (q.id >= 0) moved.push_back(q.id); }
       for (int i = moved.front(); i <= moved.back() && ok; ++i)
         if (steps[i].branch == 0 && std::find(moved.begin(), moved.end(), i) == moved.end()) ok = false;
     }
     if (ok) {
       std::vector<int> role(steps.size(), 0);           // 1 = removed from its old position
       std::vector<Step> out;
-      for (auto& q : plans) { role[q.ib] = 1; if (q.ic >= 0) role[q.ic] = 1; }
+      for (auto& q : plans) { role[q.ib] = 1; if (q.ic >= 0) role[q.ic] = 1; if (q.id >= 0) role[q.id] = 1; }
       for (size_t i = 0; i < steps.size(); ++i) {
         if (role[i]) continue;
         const Plan2* q = nullptr;
@@ -831,6 +850,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
         out.push_back(m);
         if (q->ic >= 0) { Step t = steps[q->ic]; t.branch = m.branch; out.push_back(t); }
+        if (q->id >= 0) { Step t = steps[q->id]; t.branch = m.branch; out.push_back(t); }
       }
       steps.swap(out);
     }
@@ -877,6 +897,7 @@ extern "C" int vog_ctx_create(const vog_model_desc* d, vog_ctx** out) {
   // persistent BiLSTM layer kernel: 4 instances x 64 CUs): with more queues it is off by default
   if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { if (atoi(e) > 4) c->lstm_persistent = 0; }
   if (const char* e = getenv("VOG_LSTM_PERSISTENT")) c->lstm_persistent = atoi(e) ? 1 : 0;
+  if (const char* e = perf_env("VOG_FUSED_IH")) c->fused_ih = atoi(e);
   const int R = d->rnn_size, E = d->emb_dim, L = d->lang_enc;
   add_w(c, "lstm_encoder.embed_tokens.weight", (int64_t)(d->vocab_size + 1) * E);
   for (int l = 0; l < d->rnn_layers; ++l)
@@ -959,7 +980,7 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
     if (!c->host.count(n)) VOG_FAIL(-3, "missing weight '%s'", n.c_str());
   for (void* p : c->allocs) (void)hipFree(p);
   c->allocs.clear();
-  c->wih.clear(); c->wih_f.clear(); c->whh.clear(); c->bsum.clear();
+  c->wih.clear(); c->wih_f.clear(); c->whh.clear(); c->bsum.clear(); c->wih_p.clear();
   c->obj = TxWeights(); c->mul = TxWeights();
   const vog_model_desc& d = c->d;
   const int R = d.rnn_size, et = d.enc_dtype;
@@ -985,6 +1006,17 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
       std::string s0 = "_l" + std::to_string(l), s1 = s0 + "_reverse";
       VOG_TRY(vog_lstm_pack_whh(W(c, "lstm_encoder.lstm.weight_hh" + s0).data(),
                                 W(c, "lstm_encoder.lstm.weight_hh" + s1).data(), whh.data(), R, (vog_dtype)et));
+    }
+    {
+      unsigned short* pp = nullptr;
+      if (in % 256 == 0 && R % 32 == 0) {
+        std::vector<unsigned short> wp((size_t)8 * R * in);
+        std::string s0 = "_l" + std::to_string(l);
+        VOG_TRY(vog_lstm_pack_w(W(c, "lstm_encoder.lstm.weight_ih" + s0).data(),
+                                W(c, "lstm_encoder.lstm.weight_ih" + s0 + "_reverse").data(), wp.data(), R, in, (vog_dtype)et));
+        VOG_TRY(upload<unsigned short>(c, wp, &pp));
+      }
+      c->wih_p.push_back(pp);
     }
     unsigned short *pw, *ph; float* pb;
     {
@@ -1258,6 +1290,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
+  if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 
@@ -1417,12 +1450,17 @@ extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t 
   Plan plan;
   std::vector<Step> steps;
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
+  // "name#k": the k-th step of that name (the two BiLSTM layers share one)
+  std::string want(kernel);
+  int occ = 0;
+  { const size_t h = want.find('#'); if (h != std::string::npos) { occ = atoi(want.c_str() + h + 1); want.resize(h); } }
   const Step* s = nullptr;
-  for (auto& x : steps) if (x.name == kernel && x.branch >= 0) { s = &x; break; }
+  auto pick = [&]() { int k = occ; for (auto& x : steps) if (x.name == want && x.branch >= 0 && k-- == 0) { s = &x; break; } };
+  pick();
   if (!s) {     // a step that runs paired in the forward can still be timed on its own
     steps.clear();
     VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps, false, false));
-    for (auto& x : steps) if (x.name == kernel && x.branch >= 0) { s = &x; break; }
+    pick();
   }
   if (!s) VOG_FAIL(-4, "no kernel step '%s'", kernel);
   hipStream_t st = (hipStream_t)stream;

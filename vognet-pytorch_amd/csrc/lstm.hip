@@ -71,16 +71,29 @@ extern "C" int vog_bilstm_layer_supported(int Bn, int R) {
 }
 
 extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
-  VOG_CHECK_ARG(a && a->gxs && a->whh && a->hx && a->sync && a->out16 && a->lens && a->T > 0);
+  VOG_CHECK_ARG(a && (a->gxs || a->wih) && a->whh && a->hx && a->sync && a->out16 && a->lens && a->T > 0);
   if (!vog_bilstm_layer_supported(a->Bn, a->R))
     VOG_FAIL(-1, "persistent BiLSTM layer: unsupported Bn=%d R=%d (use vog_bilstm_step)", a->Bn, a->R);
   vog::LstmLayerParams p{a->gxs, (const unsigned short*)a->whh, (unsigned long long*)a->hx, a->sync,
-                         (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R, a->out_frag};
+                         (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R, a->out_frag,
+                         (const unsigned short*)a->wih, (const unsigned short*)a->xa, a->bias, a->K};
+  const bool fused = a->wih != nullptr;
+  if (fused) VOG_CHECK_ARG(a->xa && a->bias && a->K > 0 && (a->K % 256) == 0 && a->Bn * a->T <= 64);
   dim3 grid(a->R / 32, 2);
   hipStream_t st = (hipStream_t)stream;
-#define VOG_LAUNCH_LAYER(KS)                                                                     \
-  VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vog::lstm_layer_kernel<T16, KS>), grid, dim3(512),  \
-                                             vog::LstmLayerBody<T16, KS>::LDS, st, p))
+#define VOG_LAUNCH_LAYER(KS)                                                                          \
+  VOG_DISPATCH_DTYPE(a->dtype, {                                                                      \
+    auto kern = vog::lstm_layer_kernel<T16, KS>;                                                      \
+    static bool attr_set = false;                                                                     \
+    if (fused && !attr_set) {                                                                         \
+      VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,                         \
+                                  (int)vog::LstmLayerBody<T16, KS>::LDS_FUSED));                      \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    ::vog::launch(kern, grid, dim3(512),                                                              \
+                  fused ? vog::LstmLayerBody<T16, KS>::LDS_FUSED : vog::LstmLayerBody<T16, KS>::LDS, st, p); \
+  })
   switch (a->R / 32) {
     case 1: VOG_LAUNCH_LAYER(1); break;
     case 2: VOG_LAUNCH_LAYER(2); break;
@@ -102,9 +115,14 @@ extern "C" int vog_lstm_schedule(const int64_t* lens, int32_t* rows, int Bn, int
 
 extern "C" int vog_lstm_pack_whh(const float* whh_fwd, const float* whh_bwd, void* dst_host, int R,
                                  vog_dtype dtype) {
-  VOG_CHECK_ARG(whh_fwd && whh_bwd && dst_host && R > 0 && (R % 32) == 0 && (R % 4) == 0);
+  return vog_lstm_pack_w(whh_fwd, whh_bwd, dst_host, R, R, dtype);
+}
+
+extern "C" int vog_lstm_pack_w(const float* whh_fwd, const float* whh_bwd, void* dst_host, int R, int K,
+                               vog_dtype dtype) {
+  VOG_CHECK_ARG(whh_fwd && whh_bwd && dst_host && R > 0 && (R % 4) == 0 && K > 0 && (K % 32) == 0);
   unsigned short* dst = (unsigned short*)dst_host;
-  const int ksteps = R / 32;
+  const int ksteps = K / 32;
   for (int dir = 0; dir < 2; ++dir) {
     const float* w = dir == 0 ? whh_fwd : whh_bwd;
     for (int tile = 0; tile < R / 4; ++tile)
@@ -112,7 +130,7 @@ extern "C" int vog_lstm_pack_whh(const float* whh_fwd, const float* whh_bwd, voi
         for (int lane = 0; lane < 64; ++lane) {
           const int rr = lane & 15;                           // tile row = unit_local*4 + gate
           const int64_t grow = (int64_t)(rr & 3) * R + tile * 4 + (rr >> 2);
-          const float* src = w + grow * R + ks * 32 + (lane >> 4) * 8;
+          const float* src = w + grow * K + ks * 32 + (lane >> 4) * 8;
           unsigned short* d = dst + ((((int64_t)dir * (R / 4) + tile) * ksteps + ks) * 64 + lane) * 8;
           for (int j = 0; j < 8; ++j) {
             if (dtype == VOG_BF16) {

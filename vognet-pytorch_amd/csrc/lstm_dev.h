@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
 struct LstmLayerParams {
   const float* gxs; const unsigned short* whh; unsigned long long* hx; unsigned int* sync;
   unsigned short* out16; const int64_t* lens; int Bn, T, R; int out_frag;
+  // fused input projection (wih != nullptr; gxs unused): x W_ih^T + bias for THIS workgroup's gate
+  // rows is computed in the prologue. wih: [dir][unit/4][K/32][lane][8] (vog_lstm_pack_w), xa: the
+  // layer input [Bn*T rows (b*T + t), K] in A-fragment order, bias: [2][4R] (b_ih + b_hh).
+  const unsigned short* wih; const unsigned short* xa; const float* bias; int K;
 };
 
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -134,6 +138,12 @@ struct LstmLayerBody {
   static constexpr int THREADS = 512;
   static constexpr int RW = KSTEPS * 32, HS_LD = RW + 8;   // +8 halfwords: rows land on different banks
   static constexpr size_t LDS = (size_t)16 * HS_LD * 2;
+  // fused input projection: + gates of every (sentence, position) for the 128 gate rows of the
+  // workgroup ([8 waves][<= 64 columns][4 units][4 gates] fp32, 80-byte column pitch) + one K chunk
+  // (256) of the layer input in fragment order ([<= 4 column tiles][8 k-steps][64 lanes][16 B])
+  static constexpr int GX_PITCH = 20;                      // floats per column (16 + 4: spreads the banks)
+  static constexpr size_t LDS_HS = ((size_t)16 * HS_LD * 2 + 15) / 16 * 16;
+  static constexpr size_t LDS_FUSED = LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)4 * 8 * 1024;
 
   static __device__ __forceinline__ void run(const LstmLayerParams& p, const BlockCtx& cx, unsigned char* smem) {
     unsigned short* hs = reinterpret_cast<unsigned short*>(smem);
@@ -146,14 +156,81 @@ struct LstmLayerBody {
     const bool valid_b = b < p.Bn;
     const int len = valid_b ? (int)p.lens[b] : 0;
 
+    float c = 0.f, h_own = 0.f;
+    // ---- fused input projection (replaces the separate x W_ih^T GEMM launch and its [2][T][Bn][4R]
+    // fp32 round trip): every wave computes the gates of ITS 16 rows for all Bn*T (sentence, position)
+    // columns: W_ih rows stream once through registers (K in chunks of 256), the layer input is
+    // staged per chunk in LDS and shared by the 8 waves; the result stays in LDS for the recurrence.
+    const bool fused = p.wih != nullptr;
+    float* gxl = reinterpret_cast<float*>(smem + LDS_HS) + (size_t)wid * 64 * GX_PITCH;
+    if (fused) {
+      unsigned char* xch = smem + LDS_HS + (size_t)8 * 64 * GX_PITCH * 4;
+      const int ncols = p.Bn * p.T, nct = (ncols + 15) >> 4;          // <= 4 column tiles
+      const int ksteps = p.K >> 5, nchunk = ksteps >> 3;               // K % 256 == 0
+      f32x4 ga[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) ga[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const u16x8* wsrc = reinterpret_cast<const u16x8*>(p.wih) + (((int64_t)dir * (R / 4) + tile0) * ksteps) * 64 + lane;
+      const uint4* xsrc = reinterpret_cast<const uint4*>(p.xa);
+      // chunk c of column tile ct: k-steps [8c, 8c+8) = 8 KiB contiguous at ((ct*ksteps + 8c)*64) uint4.
+      auto load_w = [&](u16x8 (&wq)[8], int c) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wq[ks] = wsrc[(c * 8 + ks) * 64];
+      };
+      auto load_x = [&](uint4 (&xq)[4], int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = tid + j * THREADS;                              // uint4 index inside the chunk image
+          const int ct = idx >> 9, r = idx & 511;                         // 512 uint4 per (column tile, chunk)
+          xq[j] = xsrc[((int64_t)(ct < nct ? ct : 0) * ksteps + c * 8) * 64 + r];
+        }
+      };
+      auto consume = [&](const u16x8 (&wq)[8], const uint4 (&xq)[4]) {
+        __syncthreads();                                                  // previous chunk's LDS reads done
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reinterpret_cast<uint4*>(xch)[tid + j * THREADS] = xq[j];
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (ct < nct) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+              const u16x8 xf = *reinterpret_cast<const u16x8*>(xch + ((ct * 8 + ks) * 64 + lane) * 16);
+              ga[ct] = mfma16<T16>(wq[ks], xf, ga[ct]);
+            }
+          }
+      };
+      // one chunk of prefetch: the next chunk's weight fragments and input piece are requested right
+      // after this chunk's LDS image is complete, i.e. under its MFMAs (measured: three chunks in flight
+      // in fully unrolled code were SLOWER, 69.7 vs 57 us for the K = 2048 layer)
+      u16x8 w0[8], w1[8];
+      uint4 x0[4], x1[4];
+      load_w(w0, 0); load_x(x0, 0);
+      for (int c = 0; c < nchunk; c += 2) {
+        if (c + 1 < nchunk) { load_w(w1, c + 1); load_x(x1, c + 1); }
+        consume(w0, x0);
+        if (c + 1 < nchunk) {
+          if (c + 2 < nchunk) { load_w(w0, c + 2); load_x(x0, c + 2); }
+          consume(w1, x1);
+        }
+      }
+      // D[row = 4*ul + gate][col = lane & 15]: lane (col, ul) holds the 4 gates of unit ul: + bias, park
+      float bs[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[(int64_t)dir * 4 * R + (int64_t)r * R + tile0 * 4 + ul];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        if (ct < nct)
+          *reinterpret_cast<float4*>(gxl + (ct * 16 + b) * GX_PITCH + ul * 4) =
+              make_float4(ga[ct][0] + bs[0], ga[ct][1] + bs[1], ga[ct][2] + bs[2], ga[ct][3] + bs[3]);
+      // (gxl is wave-private: no barrier needed before this wave reads it back below)
+    }
     // this wave's 16 rows of W_hh: registers for the whole sequence
     u16x8 wf[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
       wf[ks] = *reinterpret_cast<const u16x8*>(
           p.whh + ((((int64_t)dir * (R / 4) + tile0) * KSTEPS + ks) * 64 + lane) * 8);
-
-    float c = 0.f, h_own = 0.f;
     // hand-off buffer, u64 words: [parity][dir][16 sentences][R/2]; a word = two 16-bit h values +
     // the 32-bit number of the step that produced them. The tag makes every word self-validating:
     // a consumer needs no arrival flag and no acknowledgement wait, just one (re-tried) load.
@@ -163,10 +240,18 @@ struct LstmLayerBody {
 
     for (int s = 0; s < p.T; ++s) {
       // input projections of this step (address-independent of everything else)
-      float gin[4];
+      float gin[4] = {0.f, 0.f, 0.f, 0.f};
+      if (fused) {
+        if (valid_b && s < len) {
+          const int pos_in = dir == 0 ? s : len - 1 - s;
+          const float4 g4 = *reinterpret_cast<const float4*>(gxl + (b * p.T + pos_in) * GX_PITCH + ul * 4);
+          gin[0] = g4.x; gin[1] = g4.y; gin[2] = g4.z; gin[3] = g4.w;
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        gin[r] = valid_b ? p.gxs[(((int64_t)dir * p.T + s) * p.Bn + b) * 4 * R + (int64_t)r * R + tile0 * 4 + ul] : 0.f;
+        for (int r = 0; r < 4; ++r)
+          gin[r] = valid_b ? p.gxs[(((int64_t)dir * p.T + s) * p.Bn + b) * 4 * R + (int64_t)r * R + tile0 * 4 + ul] : 0.f;
+      }
       // h_{s-1} of ALL units: written by the other workgroups with write-through atomics, read
       // with L1-bypassing atomics (agent scope on both sides: no fences needed). The eight waves need
       // the same Bn x R vector: the workgroup fetches it ONCE, 8 bytes per thread per round, into

@@ -84,13 +84,10 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
   static std::once_flag once;
   std::call_once(once, [] {
     using SkinnyIh = GemmSkinnyBody<F16, false, 8, 1, 4>;
-    using SkinnyWide = GemmSkinnyBody<F16, false, 8, 2, 8>;
     using Lstm = LstmLayerBody<F16, 32>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_f16()}] = &launch_pair<Lstm, VisEncBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<Lstm, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
-    r[{kid_gemm_skinny_wide_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<SkinnyWide, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
-    r[{kid_gemm_skinny_wide_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<SkinnyWide, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_F16)}] = &launch_pair<Lstm, TxTailBody<F16, F16, 2, false, 0>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;

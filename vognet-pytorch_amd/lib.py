@@ -89,7 +89,8 @@ class LstmStepArgs(C.Structure):
 
 class LstmLayerArgs(C.Structure):
     _fields_ = [("gxs", c_vp), ("whh", c_vp), ("hx", c_vp), ("sync", c_vp), ("out16", c_vp),
-                ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32), ("out_frag", c_i32)]
+                ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32), ("out_frag", c_i32),
+                ("wih", c_vp), ("xa", c_vp), ("bias", c_vp), ("K", c_i32)]
 
 
 class VislangArgs(C.Structure):
@@ -191,6 +192,7 @@ SYMBOLS = {
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vog_lstm_pack_whh": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32]),
+    "vog_lstm_pack_w": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32]),
     "vog_prep_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                c_vp, c_vp, c_i32, C.POINTER(VisprepArgs), c_vp]),
     "vog_lang_prep": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
