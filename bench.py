@@ -1,7 +1,9 @@
 """bench.py — queries/sec of the VOGNet forward (gt5, spat, bs=4) on N MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by
-torch.distributed.run, one rank per GPU over RCCL). A "step" = one pass of the
+Contract: `python bench.py --gpus N --steps K --warmup W`. For N>1 the driver launches it under
+torch.distributed.run (one rank per GPU over RCCL); run plainly with --gpus N > 1 and no
+WORLD_SIZE in the environment it re-executes ITSELF under torch.distributed.run on 127.0.0.1.
+A "step" = one pass of the
 whole hot path over ONE batch of 4 synthetic (query, 4-video) pairs already
 resident in HBM: language LSTM -> encoders -> obj_tx -> mul_tx -> score head ->
 per-frame arg-max / box gather (-> all-gather of the packed predictions when
@@ -48,7 +50,7 @@ WORKLOADS = {
 VOCAB = 5000
 PEAK_MFMA_TFLOPS = 2500.0       # dense bf16/f16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0           # HBM3E peak (same table; ~6300 GB/s is what streaming kernels achieve)
-PEAK_HBM_GBS = 8000.0
+N_CUS = 256
 
 
 def make_cfg(w):
@@ -130,18 +132,52 @@ def pmc_traffic(workload):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; logical count // 2 if unreadable."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if seen:
+            return len(seen)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
 def cpu_baseline(w, cfg, sd, batch, budget_s=24.0):
-    """The CPU oracle (a validated port of the reference forward, oracle/vog_oracle.py)
-    timed on this host on the same workload. The forward is a chain of small
-    GEMMs (M = 4..4000), so more threads is not faster: a few thread counts are
-    tried inside the time budget and the best one is reported, `cores` = the
-    thread count it used."""
+    """The CPU oracle (a validated port of the reference forward, oracle/vog_oracle.py: torch-CPU fp32
+    ops, manual LSTM loops; "kind": "port" - the reference itself measured 43 queries/s on cfg 2 in the
+    survey probe, this port 41-42) timed on this host on the same workload, as SURVEY.md 8(d) asks:
+    N = 8 threads AND N = all physical cores, CPU model stated. `value` is the better of the two and
+    `cores` the thread count it used (the forward is a chain of small GEMMs, M = 4..4000: more
+    threads is not faster)."""
     from oracle import vog_oracle as vo
     ncpu = os.cpu_count() or 1
+    nphys = physical_cores()
     oc = vo.OracleCfg.from_cfg(cfg, VOCAB, ec.num_prop_per_frm(cfg))
     sdt, inp = vo.to_torch(sd), vo.to_torch(batch)
     tried = {}
-    cands = [t for t in (8, 32) if t <= ncpu] or [ncpu]
+    cands = sorted({min(8, ncpu), min(nphys, ncpu)})
     with torch.no_grad():
         for nt in cands:
             torch.set_num_threads(nt)
@@ -160,10 +196,27 @@ def cpu_baseline(w, cfg, sd, batch, budget_s=24.0):
     best = min(tried, key=lambda k: tried[k][0])
     med, n = tried[best]
     return {"value": w["B"] / med, "unit": "queries/s", "cores": best, "kind": "port",
+            "cpu_model": cpu_model(), "physical_cores": nphys, "logical_cpus": ncpu,
+            "by_threads": {str(k): w["B"] / v[0] for k, v in tried.items()},
             "sample": f"{n} timed forwards of the same batch (bs={w['B']}) after 1 warm-up, median; "
-                      f"host has {ncpu} logical cpus; threads tried: "
-                      + ", ".join(f"{k}: {w['B'] / v[0]:.1f} q/s" for k, v in tried.items()),
+                      f"threads tried: " + ", ".join(f"{k}: {w['B'] / v[0]:.1f} q/s" for k, v in tried.items()),
             "ms_per_batch": med * 1e3}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run (one rank
+    per GPU, rendezvous on 127.0.0.1) and relay its exit code; rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -200,6 +253,8 @@ def main():
                     help="print '<queries/s> <us/step>' and exit (ablation experiments, scratch/ablate.sh)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,7 +276,9 @@ def main():
     eng.load_state_dict(sd)
     # the persistent layer kernel needs all its 64 workgroups co-resident: safe up to 4 of them in
     # flight (4 hardware queues x 64 workgroups = 256 CUs); a stalled hand-off poisons the output with NaN
-    persistent = not args.lstm_steps and (args.mode != "aql" or max(1, args.queues) <= 4)
+    # (AQL: a submission of K row-interleaved programs on Q queues runs Q*K instances at once)
+    persistent = not args.lstm_steps and (args.mode != "aql" or
+                                          max(1, args.queues) * max(1, args.interleave) <= 4)
     eng.set_option("lstm_persistent", int(persistent))
     cfg_id = int(args.workload[3:])
     aql = args.mode == "aql"
@@ -270,48 +327,19 @@ def main():
         # the four forward streams and drags that stream's chain behind the collective's dependencies.
         unit_rows = G * w["B"]
         per_half = max(nunits, (32 // nunits) * nunits)           # unit launches per half ring
-        ring = [torch.zeros(per_half * unit_rows, recbuf.shape[1], dtype=torch.float32, device=dev)
-                for _ in range(2)]
-        gathered = [torch.empty((world * ring[0].shape[0], ring[0].shape[1]), dtype=torch.float32, device=dev)
-                    for _ in range(2)]
+        ring = D.RecordRing(unit_rows, recbuf.shape[1], per_half, dev) if use_dist else None
         gathered_aql = torch.empty((world * recbuf.shape[0], recbuf.shape[1]), dtype=torch.float32, device=dev) \
             if (aql and use_dist) else None
-        gs = torch.cuda.Stream(device=dev)
-        ev = [torch.cuda.Event() for _ in range(nunits)]
-        work = [None, None]
-        pos = {"half": 0, "n": 0}
-
-        def exchange(h):
-            for u in range(nunits):
-                ev[u].record(streams[u])
-                gs.wait_event(ev[u])
-            with torch.cuda.stream(gs):
-                work[h] = dist.all_gather_into_tensor(gathered[h], ring[h], async_op=True)
 
         def step(i):                       # graph mode: one unit (slot, or group of G batches) per call
             u = i % nunits
             units[u].launch(streams[u])
-            if not use_dist:
-                return
-            h, n = pos["half"], pos["n"]
-            with torch.cuda.stream(streams[u]):
-                if n < nunits and work[h] is not None:
-                    work[h].wait()             # this half was gathered a whole ring ago: never stalls
-                ring[h][n * unit_rows:(n + 1) * unit_rows].copy_(recbuf[u * unit_rows:(u + 1) * unit_rows],
-                                                                 non_blocking=True)
-            pos["n"] = n + 1
-            if pos["n"] == per_half:
-                exchange(h)
-                pos["half"], pos["n"] = 1 - h, 0
+            if ring is not None:
+                ring.push(recbuf[u * unit_rows:(u + 1) * unit_rows], streams[u])
 
         def fence():
-            if use_dist and not aql:
-                if pos["n"]:
-                    exchange(pos["half"])
-                    pos["half"], pos["n"] = 1 - pos["half"], 0
-                for h in range(2):
-                    if work[h] is not None:
-                        work[h].wait()
+            if ring is not None and not aql:
+                ring.flush()
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -396,7 +424,8 @@ def main():
     value = world * args.steps * w["B"] / dt
     res = {
         "metric": "queries/sec (VOGNet forward, gt5 spat, bs=4)", "value": value, "unit": "queries/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1, "per_rank_value": value / world,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": w["tx"], "data": "synthetic",
         "config": {"workload": w["desc"], "global_batch": world * w["B"], "batch_per_gpu": w["B"],
@@ -406,6 +435,7 @@ def main():
                                   + ("" if args.no_split else ", lang/vis chains share rows")) if aql
                    else f"hipGraph on {nstreams} HIP streams",
                    "weights": "seeded default-init-like, vocab 5000",
+                   "launches_per_forward": "see kernels_usec: steps joined by '+' share one launch (csrc/pair.hip)",
                    "parallelism": f"dp{world} (replicated weights; prediction records of every batch staged in a "
                                   f"device ring, one RCCL all-gather per 32 batches)"},
     }
@@ -414,29 +444,42 @@ def main():
     # ---- roofline of the dominant kernel: HIP-event timing inside libvog_hip on this stream
     flops, total_flops = kernel_flops(w, T)
     ktimes = {}
-    for k in flops:
+    names = list(flops) + ["prep", "lstm_layer#0", "lstm_layer#1", "lstm_layer+vis_enc", "lstm_layer+obj_tail",
+                           "lstm_outproj+mul_pv", "lstm_step"]
+    for k in names:
         try:
             ktimes[k] = eng.time_kernel(slots[0], k, args.kernel_iters)
-        except Exception as e:      # a kernel name absent for this model variant
+        except Exception:           # a step name absent for this model variant / option set
             ktimes[k] = None
     lstm_us = None
-    for nm in ("lstm_layer", "lstm_step"):
-        try:
-            lstm_us = (nm, eng.time_kernel(slots[0], nm, args.kernel_iters))
+    for nm in ("lstm_layer#0", "lstm_step"):
+        if ktimes.get(nm):
+            lstm_us = (nm.split("#")[0], ktimes[nm])
             break
-        except Exception:
-            pass
-    # dominant kernel = largest share of a forward's kernel time (launches x duration). At the
-    # gt5 shapes that is the recurrent step (2 layers x T launches, HBM bound: W_hh streams once
-    # per step); at p100 it is an MFMA GEMM.
+    # dominant kernel = largest share of a forward's kernel time (launches x duration). At the gt5
+    # shapes that is the persistent BiLSTM layer (2 launches; latency bound, its roofline is HBM: W_hh
+    # streams once per launch); the largest MFMA kernel is the fused mul_tx tail.
     pmc = pmc_traffic(args.workload + ("" if persistent else "_lstm_steps")) or {}
-    mfma_dom = max((k for k in flops if ktimes[k] and flops[k] > 0), key=lambda k: ktimes[k])
+    cands = [k for k in flops if ktimes.get(k) and flops[k] > 0]
+    mfma_dom = max(cands, key=lambda k: ktimes[k])
     ach = flops[mfma_dom] / (ktimes[mfma_dom] * 1e-6) / 1e12
+    # row-block kernels occupy ceil(rows / 64) CUs, not the chip: also quote the fraction of THEIR CUs' peak
     roof_mfma = {"bound": "mfma", "kernel": mfma_dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                  "traffic": (pmc.get("kernels", {}).get(mfma_dom) or {}).get("bytes_per_launch"),
                  "usec_per_launch": ktimes[mfma_dom], "flops_per_launch": flops[mfma_dom],
                  "launches_per_forward": 1}
+    if mfma_dom in ("mul_tail", "obj_tail"):
+        nppf0 = 5 if w["exp"] == "gt5" else 100
+        ncmp = 1 if w["conc"] == "svsq" else 4
+        rows = w["B"] * ncmp * 10 * nppf0 * (5 if mfma_dom == "mul_tail" else 1)   # proposals (x nsrl argument slots)
+        wgs = (rows + 63) // 64
+        act = min(N_CUS, wgs)
+        roof_mfma["workgroups"] = wgs
+        roof_mfma["active_cus"] = act
+        roof_mfma["frac_of_active_cus_peak"] = ach / (PEAK_MFMA_TFLOPS * act / N_CUS)
+        roof_mfma["note"] = ("one 64-row block per workgroup, one workgroup per CU: the launch uses `active_cus` of "
+                             "the 256 CUs (the others serve the batches in flight on the other streams)")
     res["roofline"] = roof_mfma
     if lstm_us and lstm_us[0] == "lstm_layer" and 2 * lstm_us[1] > ktimes[mfma_dom]:
         # persistent layer kernel: W_hh is read ONCE per launch and kept in registers for all T steps
@@ -446,13 +489,18 @@ def main():
                            "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
                            "traffic": (pmc.get("kernels", {}).get("lstm_layer") or {}).get("bytes_per_launch"),
                            "usec_per_launch": lstm_us[1], "bytes_per_launch": nbytes, "launches_per_forward": 2,
-                           "share_of_forward_kernel_time": 2 * lstm_us[1] / (
-                               2 * lstm_us[1] + sum(v for v in ktimes.values() if v)),
+                           "share_of_forward_kernel_time": 2 * lstm_us[1] / max(1e-9, sum(
+                               ktimes[k] for k in ("prep", "lstm_ih0", "lstm_layer#0", "lstm_ih1", "lstm_layer#1",
+                                                   "lstm_outproj", "argvec", "mul_pl", "vis_enc", "obj_qkv", "obj_attn",
+                                                   "obj_tail", "mul_pv", "mul_attn", "mul_tail", "pred_head")
+                               if ktimes.get(k))),
+                           "usec_per_step": lstm_us[1] / T,
                            "note": "latency bound by design, not bandwidth bound: T dependent steps per launch, each "
-                                   "one fabric round trip (self-validating tagged h words of all workgroups) + LDS + "
-                                   "64 MFMAs + gates, ~3.7 us per step (scratch/ts_layer.hip); W_hh is read once and "
-                                   "stays in registers. It replaces 2T step launches that ran at 43 % of the HBM "
-                                   "peak but moved T x 16.8 MB of W_hh per layer (--lstm-steps)"}
+                                   "one fabric round trip (self-validating tagged h words of all 32 workgroups of a "
+                                   "direction, the guide's allgather primitive: 2.4-3.0 us for 8 KB from 32 CUs) + LDS "
+                                   "+ 32 MFMAs per wave + gates; W_hh is read once and stays in registers (64 CUs). "
+                                   "In the forward it shares its launch with the encoders / the obj_tx tail "
+                                   "(csrc/pair.hip), which run on the other CUs"}
         res["roofline_mfma"] = roof_mfma
     elif lstm_us and lstm_us[0] == "lstm_step" and 2 * T * lstm_us[1] > ktimes[mfma_dom]:
         nbytes = lstm_step_bytes(w, T)
@@ -461,9 +509,7 @@ def main():
                            "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
                            "traffic": (pmc.get("kernels", {}).get("lstm_step") or {}).get("bytes_per_launch"),
                            "usec_per_launch": lstm_us[1], "bytes_per_launch": nbytes,
-                           "launches_per_forward": 2 * T,
-                           "share_of_forward_kernel_time": 2 * T * lstm_us[1] / (
-                               2 * T * lstm_us[1] + sum(v for v in ktimes.values() if v))}
+                           "launches_per_forward": 2 * T}
         res["roofline_mfma"] = roof_mfma
     pmc = pmc_traffic(args.workload + ("" if persistent else "_lstm_steps")) or {}
     if pmc.get("bytes_per_forward"):
@@ -472,8 +518,6 @@ def main():
         res["forward_hbm"] = {"bytes_per_forward_pmc": pmc["bytes_per_forward"], "achieved": gbs, "unit": "GB/s",
                               "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS, "source": pmc.get("source")}
     res["kernels_usec"] = {k: (round(v, 2) if v else None) for k, v in ktimes.items()}
-    if lstm_us:
-        res["kernels_usec"][lstm_us[0]] = round(lstm_us[1], 2)
     res["forward_roofline"] = {"algorithmic_gflop_per_batch": total_flops / 1e9,
                                "achieved_tflops": total_flops / (dt / args.steps) / 1e12,
                                "frac_of_mfma_peak": total_flops / (dt / args.steps) / 1e12 / PEAK_MFMA_TFLOPS}

@@ -105,3 +105,51 @@ def test_async_gather_settled_before_slot_reuse_world2():
     for s in seen:                       # rank-major: rank 0's rows then rank 1's, same step
         st = int(s[0]) // 100
         assert s == [float(100 * st)] * 4 + [float(100 * st + 1)] * 4
+
+
+def _worker_ring(rank, world, port, q):
+    """bench.py's / Evaluator.forward's exchange code itself (dist.RecordRing), gloo + CPU tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, width, per_half = 4, 1700, 3
+    got = []
+
+    def on_half(g, n_valid):
+        got.append(D.unpack_gathered(g, world, per_half, rows, n_valid)[:, 0].clone())
+
+    ring = D.RecordRing(rows, width, per_half, "cpu", on_half=on_half)
+    for step in range(8):                              # 8 batches: two full halves + a partial one
+        ring.push(torch.full((rows, width), float(100 * step + rank)))
+    ring.flush()
+    assert ring.gathers == 3
+    if rank == 0:
+        q.put(torch.cat(got).tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_ring_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_ring, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # (batch, rank, row) order over all 8 batches: what per-batch all-gathers would have produced
+    expect = [float(100 * st + r) for st in range(8) for r in range(2) for _ in range(4)]
+    assert seen == expect
+
+
+def test_record_ring_single_process():
+    got = []
+    ring = D.RecordRing(2, 5, 2, "cpu", on_half=lambda g, n: got.append(D.unpack_gathered(g, 1, 2, 2, n).clone()))
+    for k in range(3):
+        ring.push(torch.full((2, 5), float(k)))
+    ring.flush()
+    assert torch.cat(got)[:, 0].tolist() == [0.0, 0.0, 1.0, 1.0, 2.0, 2.0]

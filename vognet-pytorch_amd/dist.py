@@ -82,3 +82,102 @@ def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
         dist.all_gather(parts, rec)
         out = torch.cat(parts, 0)
     return out
+
+
+class RecordRing:
+    """The exchange step of the N > 1 path: per-batch prediction records are staged in a ring of
+    two halves and ONE all-gather moves a half (`per_half` batches of `rows` records) at a time.
+
+    Why not a collective per batch: on one MI355X a per-batch all-gather costs 12-20 us per step (the
+    process group's stream is a 5th stream on 4 hardware queues and drags a forward stream behind the
+    collective's dependencies); one gather per 32 batches costs 4.6 us per step. Rows inside a half
+    keep the order they were pushed in; the gathered tensor is rank-major per half, i.e. rank 0's
+    concatenation order in the reference (code/eval_vsrl_corr.py:125-140) within every half.
+
+    Works for CUDA tensors (copies on the batch's own stream, collective on `gather_stream` behind
+    events, settled a whole ring later) and for CPU tensors with gloo (synchronous copies): the same
+    code path is exercised by tests/test_dist_gloo.py at world_size 2 and used by bench.py and
+    Evaluator.forward. `on_half(gathered [world*per_half*rows, width], n_valid_batches)` is called on
+    every rank when a half has been gathered (after it settled), in push order."""
+
+    def __init__(self, rows: int, width: int, per_half: int, device, dtype=torch.float32, on_half=None):
+        self.rows, self.width, self.per_half = int(rows), int(width), int(per_half)
+        self.world = get_world_size()
+        self.cuda = torch.device(device).type == "cuda"
+        n = self.per_half * self.rows
+        self.ring = [torch.zeros(n, width, dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [torch.empty(self.world * n, width, dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.count = [0, 0]                       # batches staged in the half when it was sent
+        self.half, self.n = 0, 0
+        self.on_half = on_half
+        self.gather_stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self._streams = set()
+        self.gathers = 0
+
+    def _settle(self, h: int):
+        if self.work[h] is not None:
+            self.work[h].wait()
+            self.work[h] = None
+            if self.on_half is not None:
+                self.on_half(self.gathered[h], self.count[h])
+
+    def push(self, rec: torch.Tensor, stream=None):
+        """Stage one batch's records ([rows, width]); sends the half when it is full."""
+        h, n = self.half, self.n
+        if n == 0:
+            self._settle(h)                        # this half was sent a whole ring ago: never stalls in steady state
+        dst = self.ring[h][n * self.rows:(n + 1) * self.rows]
+        if self.cuda and stream is not None:
+            with torch.cuda.stream(stream):
+                dst.copy_(rec, non_blocking=True)
+            self._streams.add(stream)
+        else:
+            dst.copy_(rec)
+        self.n = n + 1
+        if self.n == self.per_half:
+            self._send()
+
+    def _send(self):
+        h = self.half
+        self.count[h] = self.n
+        if self.world > 1 or self.on_half is not None:
+            if self.cuda:
+                for s in self._streams:            # the collective runs behind every stream that staged rows
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+                    self.gather_stream.wait_event(ev)
+                self._streams = set()
+                with torch.cuda.stream(self.gather_stream):
+                    self.work[h] = self._gather(h)
+            else:
+                self.work[h] = self._gather(h)
+            self.gathers += 1
+        self.half, self.n = 1 - h, 0
+
+    def _gather(self, h: int):
+        if self.world == 1:
+            self.gathered[h].copy_(self.ring[h])
+
+            class _Done:
+                def wait(self_inner):
+                    return True
+            return _Done()
+        return dist.all_gather_into_tensor(self.gathered[h], self.ring[h], async_op=True)
+
+    def flush(self):
+        """Send a partially filled half and settle everything (end of the loop)."""
+        if self.n:
+            self._send()
+        first = self.half                          # older half first: push order
+        for h in (first, 1 - first):
+            self._settle(h)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.gather_stream)
+
+
+def unpack_gathered(gathered: torch.Tensor, world: int, per_half: int, rows: int, n_valid: int) -> torch.Tensor:
+    """[world*per_half*rows, W] (rank-major) -> [n_valid*world*rows, W] in (batch, rank, row) order:
+    batch k of every rank back to back = the order a per-batch all-gather would have produced."""
+    w = gathered.view(world, per_half, rows, -1)[:, :n_valid]
+    return w.permute(1, 0, 2, 3).reshape(n_valid * world * rows, -1)
