@@ -396,6 +396,30 @@ typedef struct vog_pred_args {
 int64_t vog_pred_record_bytes(int ncmp, int nsrl, int nfrm0);
 int vog_pred_head(const vog_pred_args* a, void* stream);
 
+/* Loss of one batch on the device: LossB_TEMP / LossB_SPAT
+ * (code/mdl_conc_single.py:180-433) and LossB_SEP (code/mdl_conc_sep.py:220-447) with the IoU targets of
+ * utils/box_utils.py:61-118: target[b,v,a,r] = max_k(IoU(prop r, gt box srl_boxes[b,v,a,k]) * mask *
+ * [video(r) == target_cmp[b]] * srl_boxes_lens[b,v,a,k]) > 0.5; masked mean of BCE-with-logits over
+ * mdl_outs, times the number of proposals, times loss_lambda. sep also returns the verb loss.
+ *   mdl_outs [B, (ncmp if sep else 1), nsrl, NP]; NP = proposals per row block (temp / spat: all ncmp videos)
+ *   pad_proposals [B,(ncmp,)NP,7], pad_gt_bboxs [B,(ncmp,)G,5] fp32; pad_frm_mask [B,(ncmp,)NP,G],
+ *   pad_pnt_mask [B,(ncmp,)NP] bytes (nonzero = the IoU counts); srl_boxes / srl_boxes_lens
+ *   [B,nv,nsrl,nbox], srl_arg_boxes_mask [B,nv,nsrl], target_cmp [B], num_cmp_msk [B,ncmp],
+ *   verb_cmp [B,ncmp], verb_cross_cmp_msk [B,ncmp,ncmp] int64.
+ *   out: 3 floats = loss, mdl_out_loss, verb_loss (0 unless sep). scratch: vog_loss_scratch_bytes().
+ * Deterministic (fixed-order reduction, no atomics). */
+typedef struct vog_loss_args {
+  const float* mdl_outs; const float* vidf_outs;
+  const float* pad_proposals; const float* pad_gt_bboxs;
+  const unsigned char* pad_frm_mask; const unsigned char* pad_pnt_mask;
+  const int64_t* srl_boxes; const int64_t* srl_boxes_lens; const int64_t* srl_arg_boxes_mask;
+  const int64_t* target_cmp; const int64_t* num_cmp_msk; const int64_t* verb_cmp; const int64_t* verb_cross_cmp_msk;
+  float* out; float* scratch;
+  int B, ncmp, nv, nsrl, nbox, NP, G, nppf0, conc_type; float loss_lambda;
+} vog_loss_args;
+int64_t vog_loss_scratch_bytes(const vog_loss_args* a);
+int vog_loss_fwd(const vog_loss_args* a, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)
  * ------------------------------------------------------------------------- */

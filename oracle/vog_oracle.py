@@ -424,3 +424,88 @@ def pred_head(oc: OracleCfg, out: Dict[str, torch.Tensor], inp: Dict[str, torch.
 def to_torch(d):
     return {k: torch.from_numpy(v) if not isinstance(v, torch.Tensor) else v
             for k, v in d.items()}
+
+
+# --------------------------------------------------------------------------- #
+# Losses: LossB_TEMP / LossB_SPAT (code/mdl_conc_single.py:180-433),
+# LossB_SEP (code/mdl_conc_sep.py:220-447), IoU of utils/box_utils.py:61-118.
+# --------------------------------------------------------------------------- #
+def bbox_overlaps(props, gt, mask):
+    """props [b,N,>=4], gt [b,K,>=4], mask [b,N,K] -> [b,N,K] (box_utils.py:61-118: +1 pixel
+    convention, IoU times the mask, 0 where the gt box is empty, -1 where the proposal is empty)."""
+    ax = props[:, :, 2] - props[:, :, 0] + 1
+    ay = props[:, :, 3] - props[:, :, 1] + 1
+    gx = gt[:, :, 2] - gt[:, :, 0] + 1
+    gy = gt[:, :, 3] - gt[:, :, 1] + 1
+    a_area = (ax * ay).unsqueeze(2)
+    g_area = (gx * gy).unsqueeze(1)
+    iw = (torch.min(props[:, :, None, 2], gt[:, None, :, 2]) - torch.max(props[:, :, None, 0], gt[:, None, :, 0]) + 1).clamp(min=0)
+    ih = (torch.min(props[:, :, None, 3], gt[:, None, :, 3]) - torch.max(props[:, :, None, 1], gt[:, None, :, 1]) + 1).clamp(min=0)
+    ov = iw * ih / (a_area + g_area - iw * ih)
+    ov = ov * mask.to(ov.dtype)
+    ov = ov.masked_fill(((gx == 1) & (gy == 1)).unsqueeze(1), 0.0)
+    ov = ov.masked_fill(((ax == 1) & (ay == 1)).unsqueeze(2), -1.0)
+    return ov
+
+
+def _bce_logits(x, t):
+    return x.clamp(min=0) - x * t + torch.log1p(torch.exp(-x.abs()))
+
+
+def loss_forward(oc: "OracleCfg", out, inp, loss_lambda: float = 1.0):
+    """-> {'loss', 'mdl_out_loss'[, 'verb_loss']} as the reference LossB_* for oc.conc_type."""
+    ct = oc.conc_type
+    sep = ct in ("sep", "svsq")
+    num_cmp = inp["new_srl_idxs"].shape[1]
+    B = inp["target_cmp"].shape[0]
+    targ = inp["target_cmp"]
+    msk = (inp["pad_frm_mask"].bool() | inp["pad_pnt_mask"].bool().unsqueeze(-1))
+    if sep:
+        P, G, M = inp["pad_proposals"], inp["pad_gt_bboxs"], msk
+        ov = bbox_overlaps(P.flatten(0, 1), G.flatten(0, 1), M.flatten(0, 1)).view(B, num_cmp, P.shape[2], G.shape[2])
+        vid = torch.arange(num_cmp).view(1, num_cmp, 1, 1)
+        ov_one = ov * (vid == targ.view(B, 1, 1, 1)).to(ov.dtype)
+        srl_boxes = inp["srl_boxes"]
+        if srl_boxes.shape[1] == 1 and num_cmp > 1:
+            srl_boxes = srl_boxes.expand(-1, num_cmp, -1, -1)
+        nsrl, nb = srl_boxes.shape[2:]
+        NP = ov.shape[2]
+        tg = torch.gather(ov_one.unsqueeze(2).expand(B, num_cmp, nsrl, NP, ov.shape[3]), -1,
+                          srl_boxes.unsqueeze(3).expand(B, num_cmp, nsrl, NP, nb))
+        tg = tg * inp["srl_boxes_lens"].float().unsqueeze(-2)
+        targets = tg.max(-1)[0] > 0.5
+        tot = _bce_logits(out["mdl_outs"], targets.float())
+        abm = inp["srl_arg_boxes_mask"]
+        if abm.shape[1] == 1 and num_cmp > 1:
+            abm = abm.expand(-1, num_cmp, -1)
+        bm = inp["num_cmp_msk"].unsqueeze(-1).expand(*abm.shape).float().unsqueeze(-1).expand(*targets.shape)
+        tot = tot * bm
+        sel = tot[bm != 0] if abm.max() > 0 else tot
+        mdl_out_loss = sel.mean() * tot.shape[-1]
+        vl = _bce_logits(out["vidf_outs"], inp["verb_cmp"].float())
+        vm = (inp["verb_cross_cmp_msk"].float().sum(-1) > 0).float()
+        vl = vl * vm
+        verb_loss = vl[vm != 0].mean()
+        d = {"loss": mdl_out_loss, "mdl_out_loss": mdl_out_loss, "verb_loss": verb_loss}
+        return {k: v * loss_lambda for k, v in d.items()}
+    ov = bbox_overlaps(inp["pad_proposals"], inp["pad_gt_bboxs"], msk)           # [B, NPtot, G]
+    NPt = ov.shape[1]
+    r = torch.arange(NPt)
+    if ct == "temp":
+        vid = r // (NPt // num_cmp)
+    else:
+        vid = (r // oc.nppf0) % num_cmp
+    ov_one = ov * (vid.view(1, NPt, 1) == targ.view(B, 1, 1)).to(ov.dtype)
+    srl_boxes = inp["srl_boxes"]
+    nv, nsrl, nb = srl_boxes.shape[1:]
+    tg = torch.gather(ov_one.view(B, 1, 1, NPt, -1).expand(B, nv, nsrl, NPt, ov.shape[2]), -1,
+                      srl_boxes.unsqueeze(3).expand(B, nv, nsrl, NPt, nb))
+    tg = tg * inp["srl_boxes_lens"].float().unsqueeze(-2)
+    targets = tg.max(-1)[0] > 0.5
+    tot = _bce_logits(out["mdl_outs"], targets.float())
+    abm = inp["srl_arg_boxes_mask"]
+    bm = abm.float().view(B, nv, nsrl, 1) * inp["num_cmp_msk"].float()[:, vid].view(B, 1, 1, NPt)
+    sel = tot[bm != 0] if abm.max() > 0 else tot
+    mdl_out_loss = sel.mean() * NPt
+    d = {"loss": mdl_out_loss, "mdl_out_loss": mdl_out_loss}
+    return {k: v * loss_lambda for k, v in d.items()}

@@ -1,0 +1,211 @@
+"""-m gpu: the DROP-IN SURFACE on hardware. Everything here goes through the reference's plugin
+boundary - `get_mdl_loss_eval(cfg)` (code/mdl_selector.py:26-69) -> `cls(cfg, comm)`
+(code/mdl_base.py:11-22) -> `load_state_dict` of a checkpoint-shaped dict -> `mdl(batch)` ->
+`Evaluator*.get_out_results_boxes / forward_one_batch / forward` (code/eval_vsrl_corr.py) and the
+`main_dist` CLI - never through VogEngine directly. Outputs are held to the same reference goldens
+and tolerances as tests/test_gpu_forward.py."""
+import importlib
+import json
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from tests.gpu_util import comm_for
+from tests.test_gpu_forward import _check_against
+
+pytestmark = pytest.mark.gpu
+
+sel_mod = importlib.import_module("vognet-pytorch_amd.mdl_selector")
+main_mod = importlib.import_module("vognet-pytorch_amd.main_dist")
+L = importlib.import_module("vognet-pytorch_amd.lib")
+mgl = importlib.import_module("oracle.make_golden_loss")
+synth = importlib.import_module("vognet-pytorch_amd.synth")
+
+REF_RECORD_KEYS = {"pred_boxes", "pred_scores", "pred_cmp", "idx_vid", "idx_verbs", "idx_sent", "cmp_msk",
+                   "targ_cmp", "perm", "perm_inv"}          # code/eval_vsrl_corr.py:247-273
+
+
+def _meta(batch, seed=0):
+    """The evaluator-side keys of a loader batch (dat_loader_simple.py:1476-1505)."""
+    B, ncmp = batch["num_cmp_msk"].shape
+    rng = np.random.default_rng(seed)
+    perm = np.stack([rng.permutation(ncmp) for _ in range(B)]).astype(np.int64)
+    return {"ann_idx": np.arange(100, 100 + B, dtype=np.int64), "sent_idx": np.arange(7, 7 + B, dtype=np.int64),
+            "target_cmp": rng.integers(0, ncmp, size=(B,)).astype(np.int64), "permute": perm,
+            "permute_inv": np.argsort(perm, axis=1).astype(np.int64)}
+
+
+def _build(name, key_style="module"):
+    cfg, sd, batch, c = cases.build(name)
+    sel = sel_mod.get_mdl_loss_eval(cfg)
+    comm = comm_for(c)
+    mdl = sel["mdl"](cfg=cfg, comm=comm)
+    ck = {}
+    for k, v in sd.items():
+        kk = k
+        if key_style == "ddp_tx" and (k.startswith("mult_txf.") or k.startswith("obj_txf.")):
+            pre, rest = k.split(".", 1)                   # checkpoints of use_ddp=True transformers
+            kk = f"{pre}.module.{rest}"
+        if key_style in ("module", "ddp_tx"):
+            kk = "module." + kk                           # DDP-wrapped model (trn_utils.py:536-592)
+        if key_style == "legacy_ln" and "layernorm" in k:
+            kk = k.replace(".weight", ".gamma").replace(".bias", ".beta")
+        ck[kk] = torch.from_numpy(v)
+    mdl.load_state_dict(ck)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in {**batch, **_meta(batch)}.items()}
+    evl = sel["eval"](cfg, comm, torch.device("cuda", 0))
+    return cfg, sel, mdl, evl, dev, batch, c
+
+
+@pytest.mark.parametrize("name,key_style", [
+    ("full/cfg2_vog_spat_gt5_bs4", "module"), ("full/cfg3_vog_temp_gt5_bs8", "ddp_tx"),
+    ("full/vog_sep_gt5_bs4_ragged", "legacy_ln"), ("full/cfg5_vog_svsq_gt5_bs16", "plain"),
+    ("small/vgrnd_temp", "module"), ("small/igrnd_sep", "module"), ("small/vog_spat_noobj", "ddp_tx")])
+def test_selector_model_evaluator_vs_reference_golden(name, key_style):
+    cfg, sel, mdl, evl, dev, batch, c = _build(name, key_style)
+    before = {k: v.clone() for k, v in dev.items()}
+    with torch.no_grad():
+        out = mdl(dev)
+    assert {"mdl_outs", "mdl_outs_eval"} <= set(out)
+    if cfg.ds.conc_type in ("sep", "svsq"):
+        assert {"vidf_outs", "fin_scores_loss", "fin_scores"} <= set(out)
+    r = evl.get_out_results_boxes(out, dev)
+    torch.cuda.synchronize()
+    for k in before:
+        assert torch.equal(before[k], dev[k]), k           # inputs are borrowed, never modified
+    g = np.load(cases.golden_path(name))
+    _check_against(name, out, r, g, None, tol_rel=1e-3, tol_logit=6e-3)
+    # python-list records in the reference's format
+    recs = evl.forward_one_batch(out, dev)
+    B = batch["num_cmp_msk"].shape[0]
+    assert len(recs) == B and set(recs[0]) == REF_RECORD_KEYS
+    assert np.allclose(np.array(recs[1 % B]["pred_scores"]), g["scores"][1 % B], rtol=2e-3, atol=1e-6)
+    assert recs[0]["idx_vid"] == 100 and recs[0]["perm"] == dev["permute"][0].tolist()
+
+
+def test_inplace_weight_update_reaches_the_engine():
+    """Parameters changed in place (optimizer.step / p.data.copy_) must not leave stale device weights."""
+    cfg, sel, mdl, evl, dev, batch, c = _build("small/vog_spat")
+    with torch.no_grad():
+        a = mdl(dev)["mdl_outs"].clone()
+        w = dict(mdl.named_parameters())["lin2.2.bias"]
+        w.add_(0.5)
+        b = mdl(dev)["mdl_outs"]
+    torch.cuda.synchronize()
+    assert torch.allclose(b, a + 0.5, atol=1e-5)
+
+
+def test_slot_guards():
+    """A slot refuses sentences longer than the T it was captured with, and refuses to launch after the
+    engine's weights were re-finalized (its graph points at freed buffers)."""
+    cfg, sel, mdl, evl, dev, batch, c = _build("full/cfg2_ragged")
+    eng = mdl.engine()
+    T = int(batch["srl_arg_word_mask_len"].max())
+    slot = eng.make_slot(dev, graph=True)
+    slot.launch()
+    torch.cuda.synchronize()
+    longer = {"srl_arg_word_mask_len": torch.full_like(dev["srl_arg_word_mask_len"], T + 1)}
+    with pytest.raises(ValueError):
+        slot.update_inputs(longer)
+    slot.update_inputs({"srl_arg_word_mask_len": dev["srl_arg_word_mask_len"]})
+    eng.load_state_dict(mdl.state_dict())
+    with pytest.raises(Exception):
+        slot.launch()
+
+
+def test_two_streams_do_not_share_a_workspace():
+    cfg, sel, mdl, evl, dev, batch, c = _build("full/cfg2_vog_spat_gt5_bs4")
+    eng = mdl.engine()
+    ref = eng.forward(dev)["mdl_outs"].clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(eng.forward(dev)["mdl_outs"])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
+
+
+class _Loader(list):
+    pass
+
+
+def test_evaluator_forward_loop_and_pickle(tmp_path):
+    """Evaluator.forward: loop a loader, records through the ring exchange, rank 0 writes the pickle in the
+    reference format (code/eval_vsrl_corr.py:101-150, 247-273); loss dict from the device loss."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    cpu = {k: v.cpu() for k, v in dev.items()}
+    cpu.update({k: torch.from_numpy(v) for k, v in tg.items()})
+    dl = _Loader([cpu, cpu, cpu])
+    val_loss, val_acc = evl(mdl, loss_fn, dl, "valid", rank=0, pred_path=tmp_path)
+    assert set(val_acc) == set(evl.met_keys) and set(val_loss) == set(loss_fn.loss_keys)
+    gl = np.load(mgl.loss_path(name))
+    assert abs(float(val_loss["loss"]) - float(gl["loss"])) <= 2e-3 * float(gl["loss"])
+    recs = pickle.load(open(tmp_path / "valid_0.pkl", "rb"))
+    B = batch["num_cmp_msk"].shape[0]
+    assert len(recs) == 3 * B and set(recs[0]) == REF_RECORD_KEYS
+    g = np.load(cases.golden_path(name))
+    for k in range(3):                                         # every batch, in loader order
+        got = np.array([r["pred_scores"] for r in recs[k * B:(k + 1) * B]])
+        assert np.allclose(got, g["scores"], rtol=2e-3, atol=1e-6)
+        assert [r["idx_vid"] for r in recs[k * B:(k + 1) * B]] == list(range(100, 100 + B))
+
+
+def test_main_dist_cli_only_val(capsys):
+    """`main_dist.py <uid> --only_val=True --a.b=c`: the reference's CLI shape (code/main_dist.py:90-163)."""
+    main_mod.main_dist("t0", only_val=True, synthetic_batches=3,
+                       **{"mdl.name": "vog", "ds.conc_type": "spat", "mdl.obj_tx.use_rel": True,
+                          "mdl.mul_tx.use_rel": True, "train.bsv": 4})
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["uid"] == "t0" and res["queries"] == 12 and res["mdl"] == "vog" and np.isfinite(res["checksum"])
+    with pytest.raises(AssertionError):
+        main_mod.main_dist("t1", only_val=True, **{"mdl.no_such_key": 1})
+
+
+# ---- device loss (csrc/loss.hip) through the selector's loss class -----------------------------------------
+@pytest.mark.parametrize("name", mgl.LOSS_CASES)
+def test_device_loss_vs_reference_golden(name):
+    """LossB_* on the device against the goldens of the REFERENCE loss classes, fed with the reference's
+    own forward outputs (isolates the loss): <= 2e-5 relative (fp32 summation order only)."""
+    cfg, batch, c, tg = mgl.targets_for(name)
+    sel = sel_mod.get_mdl_loss_eval(cfg)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    g = np.load(cases.golden_path(name))
+    gl = np.load(mgl.loss_path(name))
+    out = {k: torch.from_numpy(g[k]).cuda() for k in ("mdl_outs", "vidf_outs") if k in g.files}
+    inp = {k: torch.from_numpy(v).cuda() for k, v in {**batch, **tg}.items()}
+    res = loss_fn(out, inp)
+    torch.cuda.synchronize()
+    assert {k for k in res if not k.startswith("_")} == set(gl.files) - {"sha_targets"} == set(loss_fn.loss_keys)
+    for k in loss_fn.loss_keys:
+        got, ref = float(res[k]), float(gl[k])
+        assert abs(got - ref) <= 2e-5 * abs(ref), (k, got, ref)
+    # bit-reproducible (fixed-order reduction)
+    res2 = loss_fn(out, inp)
+    assert all(torch.equal(res[k], res2[k]) for k in loss_fn.loss_keys)
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg3_vog_temp_gt5_bs8",
+                                  "full/vog_sep_gt5_bs4_ragged"])
+def test_forward_then_loss_end_to_end(name):
+    """mdl(batch) -> loss_fn(out, batch) entirely on the device vs the reference loss of the reference
+    forward: the 16-bit forward moves logits by <= 6e-3, the loss (a mean of 4000 BCE terms) by <= 2e-3 rel."""
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    dev.update({k: torch.from_numpy(v).cuda() for k, v in tg.items()})
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    with torch.no_grad():
+        res = loss_fn(mdl(dev), dev)
+    gl = np.load(mgl.loss_path(name))
+    for k in loss_fn.loss_keys:
+        assert abs(float(res[k]) - float(gl[k])) <= 2e-3 * abs(float(gl[k])), (k, float(res[k]), float(gl[k]))

@@ -952,6 +952,11 @@ extern "C" int vog_ctx_set_weight(vog_ctx* c, const char* name, const float* hos
   VOG_CHECK_ARG(c && name && host);
   std::string n(name);
   if (n.rfind("module.", 0) == 0) n = n.substr(7);          // DDP-wrapped checkpoints (trn_utils.py:536-592)
+  // transformers trained with mdl.{obj,mul}_tx.use_ddp=True keep an inner `module.` (mdl_vog.py:441-445,577-578)
+  for (const char* pre : {"mult_txf.", "obj_txf."}) {
+    const std::string pm = std::string(pre) + "module.";
+    if (n.rfind(pm, 0) == 0) n = std::string(pre) + n.substr(pm.size());
+  }
   // legacy LayerNorm parameter names (trn_utils.py:560-565)
   for (const char* pr : {".gamma", ".beta"}) {
     const std::string suf(pr);
@@ -961,10 +966,14 @@ extern "C" int vog_ctx_set_weight(vog_ctx* c, const char* name, const float* hos
   }
   auto it = c->numel.find(n);
   if (it == c->numel.end()) {
-    // parameters that exist in reference checkpoints but are not read by forward
+    // parameters that exist in reference checkpoints but are not read by forward: srl_simple_lin and
+    // lin_tmp always; a transformer's weights only when THIS model variant does not declare that
+    // transformer at all (a VidGrnd / VOGNet checkpoint loaded into a smaller variant). A key of a
+    // declared transformer that does not match is an error, never silently dropped.
+    const bool obj_decl = has_obj_weights(c->d), mul_decl = has_mul(c->d);
     if (n.rfind("srl_simple_lin", 0) == 0 || n.rfind("lin_tmp", 0) == 0 ||
-        n.rfind("obj_txf", 0) == 0 || n.rfind("pe_obj_sub_enc", 0) == 0 ||
-        n.rfind("mult_txf", 0) == 0 || n.rfind("pe_mul_sub_enc", 0) == 0)
+        (!obj_decl && (n.rfind("obj_txf", 0) == 0 || n.rfind("pe_obj_sub_enc", 0) == 0)) ||
+        (!mul_decl && (n.rfind("mult_txf", 0) == 0 || n.rfind("pe_mul_sub_enc", 0) == 0)))
       return 0;
     VOG_FAIL(-3, "unexpected weight '%s'", name);
   }

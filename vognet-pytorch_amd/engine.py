@@ -64,7 +64,8 @@ class VogEngine:
         h = C.c_void_p()
         L.check(self.lib.vog_ctx_create(C.byref(self.desc), C.byref(h)), "vog_ctx_create")
         self.ctx = h
-        self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._ws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        self.weights_epoch = 0          # bumped by load_state_dict: slots / groups captured before it refuse to launch
         self._graphs: Dict[tuple, C.c_void_p] = {}
         self._finalized = False
         self.use_graph = bool(cfg.hip.use_graph) if "hip" in cfg else True
@@ -86,12 +87,16 @@ class VogEngine:
                     f"vog_ctx_set_weight({k})")
         self._drop_graphs()
         with torch.cuda.device(self.device):
+            torch.cuda.synchronize()            # nothing in flight may still read the buffers finalize frees
             L.check(self.lib.vog_ctx_finalize(self.ctx), "vog_ctx_finalize")
         self._finalized = True
+        self.weights_epoch += 1
 
     # ---- workspace -----------------------------------------------------------
     def workspace(self, B: int, ncmp: int, T: int) -> torch.Tensor:
-        key = (B, ncmp, T)
+        # one workspace per (shape, stream): two forwards of one shape issued on different streams must
+        # not share LSTM hand-off words / q,k,v fragments / the implicit intermediates
+        key = (B, ncmp, T, int(L.stream_ptr()))
         ws = self._ws.get(key)
         if ws is None:
             n = self.lib.vog_workspace_bytes(self.ctx, B, ncmp, T)
@@ -211,6 +216,9 @@ class VogEngine:
     def aql_submit(self, slots, queue: int = 0) -> None:
         """Enqueue the AQL programs of `slots` row-interleaved on one queue. NOT stream ordered:
         the slots' inputs must already be complete; collect results with slot.wait()."""
+        for sl in slots:
+            for m in getattr(sl, "slots", [sl]):
+                m._check_epoch()
         arr = (C.c_void_p * len(slots))(*[s.aql for s in slots])
         L.check(self.lib.vog_aql_submit(arr, len(slots), int(queue)), "vog_aql_submit")
 
@@ -271,6 +279,7 @@ class Slot:
 
     def __init__(self, eng: VogEngine, inp, T, with_pred, graph, pred_rec=None):
         self.eng = eng
+        self.epoch = eng.weights_epoch
         self.inp = {k: (v.to(eng.device).contiguous() if isinstance(v, torch.Tensor)
                         else torch.from_numpy(np.ascontiguousarray(v)).to(eng.device))
                     for k, v in inp.items()}
@@ -315,13 +324,27 @@ class Slot:
         return self.out
 
     def update_inputs(self, inp):
-        """Copy a new batch (same shapes, same T) into the slot's buffers."""
+        """Copy a new batch (same shapes, sentence lengths <= the T this slot was captured with) into
+        the slot's buffers. T is baked into the captured graph / AQL program and the workspace: a
+        longer sentence would index the LSTM schedule out of its rows, so it is refused here (capture
+        the slot with T = cfg.ds.max_seq_length when the lengths are not known in advance)."""
+        lens = inp.get("srl_arg_word_mask_len")
+        if lens is not None:
+            mx = int((lens if isinstance(lens, torch.Tensor) else torch.as_tensor(lens)).max())
+            if mx > self.T:
+                raise ValueError(f"batch has a sentence of {mx} tokens but this slot was captured with T = {self.T}")
         for k, v in inp.items():
             if k in self.inp:
                 self.inp[k].copy_(v if isinstance(v, torch.Tensor) else torch.from_numpy(v),
                                   non_blocking=True)
 
+    def _check_epoch(self):
+        if self.epoch != self.eng.weights_epoch:
+            raise L.VogError("the engine's weights were re-finalized after this slot was captured: its graph / "
+                             "AQL program points at freed weight buffers - create a new slot")
+
     def launch(self, stream: Optional[torch.cuda.Stream] = None):
+        self._check_epoch()
         sp = L.stream_ptr(stream)
         if self.graph is not None:
             L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
@@ -410,6 +433,8 @@ class Group:
         return [s.out for s in self.slots]
 
     def launch(self, stream: Optional[torch.cuda.Stream] = None):
+        for sl in self.slots:
+            sl._check_epoch()
         sp = L.stream_ptr(stream)
         if self.graph is not None:
             L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")

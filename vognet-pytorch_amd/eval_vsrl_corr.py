@@ -4,8 +4,9 @@ Same classes / ctor / `get_out_results_boxes` / record format as reference
 code/eval_vsrl_corr.py (Evaluator{SEP,TEMP,SPAT}: 24-33, 162-424), with the
 arg-max + box gather done by `vog_pred_head` on the GPU and the cross-rank
 gather done by one RCCL all-gather (dist.py) instead of pickle files.
-Metrics (`GroundEval_*`, code/eval_fn_corr.py) need the dataset annotations and
-are out of scope: attach one via `self.grnd_eval`.
+The validation loss comes from the device loss (`mdl_conc.LossB_*` -> `vog_loss_fwd`). Metrics
+(`GroundEval_*`, code/eval_fn_corr.py) need the dataset annotations: attach one
+via `self.grnd_eval`; the pickle written here is in the format they read.
 """
 from __future__ import annotations
 
@@ -91,33 +92,79 @@ class Evaluator(torch.nn.Module):
         n = len(cols["pred_boxes"])
         return [{k: v[i] for k, v in cols.items()} for i in range(n)]
 
+    META_KEYS = ("ann_idx", "new_srl_idxs", "sent_idx", "num_cmp_msk", "target_cmp", "permute", "permute_inv")
+    META_NAMES = {"ann_idx": "idx_vid", "new_srl_idxs": "idx_verbs", "sent_idx": "idx_sent", "num_cmp_msk": "cmp_msk",
+                  "target_cmp": "targ_cmp", "permute": "perm", "permute_inv": "perm_inv"}
+    GATHER_EVERY = 16          # batches per cross-rank exchange (dist.RecordRing half)
+
     def forward(self, model, loss_fn, dl, dl_name, rank=0, pred_path=None, mb=None):
-        """Loop a dataloader, collect prediction records; ranks exchange the
-        packed device records with ONE all-gather per batch; rank 0 writes the
-        merged pickle in the reference format. Loss / metric values are only
-        produced when the (out-of-scope) loss_fn / grnd_eval are supplied."""
+        """The validation loop of the reference (code/eval_vsrl_corr.py:101-150): forward, loss_fn(out,
+        batch), prediction records; rank 0 writes `<pred_path>/<dl_name>_<rank>.pkl` in the reference
+        record format (:247-273) and returns (loss dict, metric dict).
+
+        Exchange: the reference pickles per-rank predictions and rank 0 re-reads the files (:125-140).
+        Here every batch's packed device records get the batch's metadata appended (same int64 row,
+        exact for |id| < 2^53: carried as fp64 bit patterns in two fp32 words each) and travel through
+        ONE all-gather per GATHER_EVERY batches (dist.RecordRing; a collective per batch plus seven for
+        the metadata cost 12-20 us per step each). Record order on rank 0 = (batch, rank, query), the
+        order of the reference's per-batch concatenation."""
         model.eval()
         results = []
-        meta_keys = ("ann_idx", "new_srl_idxs", "sent_idx", "num_cmp_msk", "target_cmp",
-                     "permute", "permute_inv")
+        losses = {}
+        nums = 0
+        ring = None
+        world = D.get_world_size()
+        layout = {}
+
+        def on_half(g, n_valid):
+            rows = D.unpack_gathered(g, world, self.GATHER_EVERY, layout["B"], n_valid)
+            if not D.is_main_process():
+                return
+            rec = rows[:, :layout["rw"]].contiguous()
+            r = self.unpack(rec, layout["ncmp"], layout["nsrl"])
+            cols = {"pred_boxes": r["boxes"], "pred_scores": r["scores"], "pred_cmp": r["indexs"]}
+            off = layout["rw"]
+            for k in layout["meta"]:
+                w = layout["meta_w"][k]
+                m = rows[:, off:off + 2 * w].contiguous().view(torch.float64).to(torch.int64)
+                cols[self.META_NAMES[k]] = m[:, 0] if layout["meta_1d"][k] else m
+                off += 2 * w
+            cols = {k: v.detach().cpu().tolist() for k, v in cols.items()}
+            n = len(cols["pred_boxes"])
+            results.extend({k: v[i] for k, v in cols.items()} for i in range(n))
+
         for batch in dl:
             batch = {k: v.to(self.device) for k, v in batch.items()}
+            b = next(iter(batch.values())).shape[0]
             with torch.no_grad():
                 out = model(batch)
-            rec = D.all_gather_records(self._records(out, batch))
-            ncmp = batch["new_srl_idxs"].size(1)
-            nsrl = out["mdl_outs_eval"].shape[2]
-            r = self.unpack(rec, ncmp, nsrl)
-            meta = {k: D.all_gather_records(batch[k]) for k in meta_keys if k in batch}
-            if D.is_main_process():
-                cols = {"pred_boxes": r["boxes"], "pred_scores": r["scores"], "pred_cmp": r["indexs"]}
-                names = {"ann_idx": "idx_vid", "new_srl_idxs": "idx_verbs", "sent_idx": "idx_sent",
-                         "num_cmp_msk": "cmp_msk", "target_cmp": "targ_cmp", "permute": "perm",
-                         "permute_inv": "perm_inv"}
-                cols.update({names[k]: v for k, v in meta.items()})
-                cols = {k: v.detach().cpu().tolist() for k, v in cols.items()}
-                n = len(cols["pred_boxes"])
-                results += [{k: v[i] for k, v in cols.items()} for i in range(n)]
+                if loss_fn is not None:
+                    ld = loss_fn(out, batch)
+                    for k, v in ld.items():
+                        if not k.startswith("_"):
+                            losses[k] = losses.get(k, 0.0) + v.detach().double() * b
+                    nums += b
+            rec = self._records(out, batch)
+            meta = [k for k in self.META_KEYS if k in batch]
+            if ring is None:
+                layout.update(B=rec.shape[0], rw=rec.shape[1], ncmp=batch["new_srl_idxs"].size(1),
+                              nsrl=out["mdl_outs_eval"].shape[2], meta=meta,
+                              meta_w={k: int(batch[k].numel() // rec.shape[0]) for k in meta},
+                              meta_1d={k: batch[k].dim() == 1 for k in meta})
+                width = rec.shape[1] + 2 * sum(layout["meta_w"].values())
+                ring = D.RecordRing(rec.shape[0], width, self.GATHER_EVERY, rec.device, on_half=on_half)
+            assert rec.shape[0] == layout["B"], "the exchange ring is built for a fixed batch size (drop_last loaders)"
+            row = torch.cat([rec] + [batch[k].reshape(rec.shape[0], -1).to(torch.float64).view(torch.float32)
+                                     for k in meta], dim=1)
+            ring.push(row, torch.cuda.current_stream() if rec.is_cuda else None)
+        if ring is not None:
+            ring.flush()
+        val_loss = {k: (v / max(1, nums)).float() for k, v in losses.items()}
+        if D.get_world_size() > 1:
+            for k in sorted(val_loss):                 # as reduce_dict in the reference (utils/trn_utils.py:61-90)
+                t = val_loss[k].clone()
+                torch.distributed.all_reduce(t)
+                val_loss[k] = t / world
         val_acc = {k: torch.tensor(0.0) for k in self.met_keys}
         if D.is_main_process() and pred_path is not None:
             fname = Path(pred_path) / f"{dl_name}_{rank}.pkl"
@@ -128,7 +175,7 @@ class Evaluator(torch.nn.Module):
                 acc = self.grnd_eval.eval_ground_acc(fname)
                 val_acc = {k: torch.tensor(v) for k, v in acc.items() if k in self.met_keys}
         D.synchronize()
-        return {}, val_acc
+        return val_loss, val_acc
 
 
 class EvaluatorSEP(Evaluator):

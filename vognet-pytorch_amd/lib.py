@@ -129,6 +129,15 @@ class VisencArgs(C.Structure):
                 ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32)]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("mdl_outs", c_vp), ("vidf_outs", c_vp), ("pad_proposals", c_vp), ("pad_gt_bboxs", c_vp),
+                ("pad_frm_mask", c_vp), ("pad_pnt_mask", c_vp), ("srl_boxes", c_vp), ("srl_boxes_lens", c_vp),
+                ("srl_arg_boxes_mask", c_vp), ("target_cmp", c_vp), ("num_cmp_msk", c_vp), ("verb_cmp", c_vp),
+                ("verb_cross_cmp_msk", c_vp), ("out", c_vp), ("scratch", c_vp),
+                ("B", c_i32), ("ncmp", c_i32), ("nv", c_i32), ("nsrl", c_i32), ("nbox", c_i32), ("NP", c_i32),
+                ("G", c_i32), ("nppf0", c_i32), ("conc_type", c_i32), ("loss_lambda", c_f32)]
+
+
 class PredcmpArgs(C.Structure):
     _fields_ = [("final_hidden", c_vp), ("prop_seg", c_vp), ("w0", c_vp), ("b0", c_vp),
                 ("w2", c_vp), ("b2", c_vp), ("outs", c_vp), ("arg_msk", c_vp), ("cmp_msk", c_vp),
@@ -179,6 +188,8 @@ SYMBOLS = {
     "vog_tx_tail_fwd": (c_i32, [C.POINTER(TxTailArgs), c_vp]),
     "vog_vis_encode_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "vog_vis_encode": (c_i32, [C.POINTER(VisencArgs), c_vp]),
+    "vog_loss_scratch_bytes": (c_i64, [C.POINTER(LossArgs)]),
+    "vog_loss_fwd": (c_i32, [C.POINTER(LossArgs), c_vp]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),

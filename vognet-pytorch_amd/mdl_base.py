@@ -33,6 +33,23 @@ def _register(root: nn.Module, dotted: str, value: torch.Tensor):
     m.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
 
 
+def normalize_key(k: str) -> str:
+    """Reference checkpoint key -> the plain key: DDP `module.` prefix (utils/trn_utils.py:536-592),
+    the inner `module.` of transformers trained with mdl.{obj,mul}_tx.use_ddp=True
+    (`mult_txf.module.encoder...`, code/mdl_vog.py:441-445,577-578) and the legacy LayerNorm
+    gamma / beta names (trn_utils.py:560-565)."""
+    if k.startswith("module."):
+        k = k[7:]
+    for pre in ("mult_txf.", "obj_txf."):
+        if k.startswith(pre + "module."):
+            k = pre + k[len(pre) + 7:]
+    if "layernorm" in k and k.endswith(".gamma"):
+        k = k[:-6] + ".weight"
+    if "layernorm" in k and k.endswith(".beta"):
+        k = k[:-5] + ".bias"
+    return k
+
+
 class AnetBaseMdl(nn.Module):
     def __init__(self, cfg, comm):
         super().__init__()
@@ -100,14 +117,7 @@ class AnetBaseMdl(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts reference checkpoints: optional `module.` prefix and legacy
         LayerNorm gamma/beta names (utils/trn_utils.py:536-592)."""
-        sd = {}
-        for k, v in state_dict.items():
-            k = k[7:] if k.startswith("module.") else k
-            if "layernorm" in k and k.endswith(".gamma"):
-                k = k[:-6] + ".weight"
-            if "layernorm" in k and k.endswith(".beta"):
-                k = k[:-5] + ".bias"
-            sd[k] = v
+        sd = {normalize_key(k): v for k, v in state_dict.items()}
         r = super().load_state_dict(sd, strict=strict)
         self._weights_dirty = True
         return r
@@ -117,12 +127,18 @@ class AnetBaseMdl(nn.Module):
         self._weights_dirty = True
         return r
 
+    def _param_version(self):
+        # in-place updates (p.data.copy_, optimizer.step, manual init) bump Tensor._version
+        return tuple((id(p), p._version) for p in self.parameters())
+
     def engine(self) -> VogEngine:
         if self._engine is None:
             self._engine = VogEngine(self.cfg, self.comm)
-        if self._weights_dirty:
+        ver = self._param_version()
+        if self._weights_dirty or ver != getattr(self, "_uploaded_version", None):
             self._engine.load_state_dict(self.state_dict())
             self._weights_dirty = False
+            self._uploaded_version = ver
         return self._engine
 
     def forward(self, inp: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -227,3 +227,59 @@ def init_state_dict(cfg, vocab_size: int, seed: int = 0,
         _tx(sd, rng, "mult_txf", d_mul, m.mul_tx.n_layers, perturb_ln)
         _linear(sd, rng, "pe_mul_sub_enc.0", m.mul_tx.n_heads, 5)
     return sd
+
+
+# --------------------------------------------------------------------------- #
+# loss-side keys of a loader batch (dat_loader_simple.py:425-459,
+# 734-780, 1476-1505): ground-truth boxes, frame / padding masks, per-argument box
+# indices and the contrastive-sampling targets. Own RNG stream: make_batch's draws (and
+# the SHA-256 of its inputs stored in the forward goldens) are unchanged.
+# --------------------------------------------------------------------------- #
+def make_targets(batch: Dict[str, np.ndarray], conc_type: str, nppf0: int, *, n_gt: int = 100,
+                 n_box: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(10_007 + seed)
+    sep = conc_type in ("sep", "svsq")
+    props = batch["pad_proposals"]
+    B, ncmp = batch["num_cmp_msk"].shape
+    lead = props.shape[:-2]
+    NP = props.shape[-2]
+    nv = batch["srl_arg_inds_msk"].shape[1]
+    nsrl = batch["srl_arg_inds_msk"].shape[2]
+    flat = props.reshape(-1, NP, 7)
+    n = flat.shape[0]
+    gt = np.zeros((n, n_gt, 5), np.float32)
+    frm = np.zeros((n, NP, n_gt), np.uint8)
+    pnt = np.zeros((n, NP), np.uint8)
+    for i in range(n):
+        # a third of the gt slots are jittered copies of proposals (IoU well above 0.5 with their
+        # source), a third random boxes, the rest empty padding (x1=y1=x2=y2=0 -> "area zero")
+        src = rng.integers(0, NP, size=n_gt)
+        k1, k2 = n_gt // 3, 2 * n_gt // 3
+        g = flat[i, src, :5].copy()
+        g[:k1, :4] += rng.uniform(-3, 3, size=(k1, 4)).astype(np.float32)
+        x = np.sort(rng.uniform(0, VID_W, size=(k2 - k1, 2)), axis=-1)
+        y = np.sort(rng.uniform(0, VID_H, size=(k2 - k1, 2)), axis=-1)
+        g[k1:k2, 0], g[k1:k2, 2], g[k1:k2, 1], g[k1:k2, 3] = x[:, 0], x[:, 1], y[:, 0], y[:, 1]
+        g[k2:] = 0.0
+        gt[i] = g
+        # the mask multiplies the IoU (utils/box_utils.py:108-109): 1 where proposal and gt box share a
+        # frame, plus a few random entries; pnt marks a handful of padded proposals
+        frm[i] = (flat[i, :, 4][:, None] == g[None, :, 4]).astype(np.uint8)
+        frm[i] |= (rng.uniform(size=(NP, n_gt)) < 0.02).astype(np.uint8)
+        pnt[i] = (rng.uniform(size=NP) < 0.03).astype(np.uint8)
+        # a few degenerate proposals are needed to hit the "anchor area zero -> -1" branch, but the
+        # proposals are inputs of the forward and stay untouched: degenerate GT boxes cover the other branch
+    srl_boxes = rng.integers(0, n_gt // 3, size=(B, nv, nsrl, n_box)).astype(np.int64)
+    srl_boxes_lens = (rng.uniform(size=(B, nv, nsrl, n_box)) < 0.7).astype(np.int64)
+    arg_boxes_mask = (batch["srl_arg_inds_msk"] * (rng.uniform(size=(B, nv, nsrl)) < 0.8)).astype(np.int64)
+    out = {
+        "pad_gt_bboxs": gt.reshape(lead + (n_gt, 5)),
+        "pad_frm_mask": frm.reshape(lead + (NP, n_gt)),
+        "pad_pnt_mask": pnt.reshape(lead + (NP,)),
+        "srl_boxes": srl_boxes, "srl_boxes_lens": srl_boxes_lens, "srl_arg_boxes_mask": arg_boxes_mask,
+        "target_cmp": rng.integers(0, ncmp, size=(B,)).astype(np.int64),
+    }
+    if sep:
+        out["verb_cmp"] = (rng.uniform(size=(B, ncmp)) < 0.5).astype(np.int64)
+        out["verb_cross_cmp_msk"] = (rng.uniform(size=(B, ncmp, ncmp)) < 0.6).astype(np.int64)
+    return out
