@@ -1,0 +1,77 @@
+"""rocprofv3 --pmc csv files of scratch/prof_forward.py -> a markdown table + an entry of profiles/pmc_traffic.json.
+
+usage: pmc_round2.py <workload> <forwards> <fetch_csv> <write_csv> <sq_csv|-> <out_md> <json>
+Per (kernel, grid): launches per forward, FETCH_SIZE x2 (gfx950: the counter tallies 128-B requests at
+64 B, MI355X_MICROARCH.md "HBM") and WRITE_SIZE (as reported) in MB per launch, and from the SQ pass
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES) (busy cycles of the CUs the kernel
+occupied; 4 SIMDs per CU) beside SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES as the judge's formula."""
+import collections, csv, json, os, re, sys
+
+wl, forwards, fcsv, wcsv, sqcsv, out_md, out_json = sys.argv[1:8]
+forwards = int(forwards)
+OURS = ("lstm", "gemm", "attn", "layernorm", "splitk", "argvec", "score", "pred", "vis_", "lang_prep", "prep_fused",
+        "vislang", "qkv_combine", "cast2", "box_u", "srl_gather", "predcmp", "tx_tail", "pair_kernel", "loss_")
+
+
+def load(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    if path == "-" or not os.path.exists(path):
+        return acc
+    for r in csv.DictReader(open(path)):
+        n = re.sub(r"^void ", "", r["Kernel_Name"]).replace("vog::", "")
+        n = re.sub(r"\(.*\)$", "", n)
+        if not n.startswith(OURS):
+            continue
+        acc[(n, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def step_name(n, grid):
+    if n.startswith("tx_tail_kernel") and ", 3, true" in n: return "mul_tail"
+    if n.startswith("tx_tail_kernel") and ", 2, false" in n: return "obj_tail"
+    if n.startswith("lstm_layer_kernel"): return "lstm_layer"
+    if n.startswith("vis_enc_kernel"): return "vis_enc"
+    if n.startswith("attn_struct"): return "mul_attn"
+    if n.startswith("attn_tile"): return "attn_tile"
+    return None
+
+
+f, w, sq = load(fcsv), load(wcsv), load(sqcsv)
+rows, total, kern = [], 0.0, {}
+for key in sorted(f, key=lambda k: -sum(f[k]["FETCH_SIZE"])):
+    fv = f[key]["FETCH_SIZE"]
+    lpf = max(1, round(len(fv) / forwards))
+    fb = 2.0 * 1024 * sum(fv) / len(fv)
+    wv = w.get(key, {}).get("WRITE_SIZE", [0.0])
+    wb = 1024 * sum(wv) / max(1, len(wv))
+    total += (fb + wb) * lpf
+    s = sq.get(key, {})
+    mf = sum(s.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])) / max(1, len(s.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])))
+    busy = sum(s.get("SQ_BUSY_CYCLES", [0])) / max(1, len(s.get("SQ_BUSY_CYCLES", [0])))
+    bcu = sum(s.get("SQ_BUSY_CU_CYCLES", [0])) / max(1, len(s.get("SQ_BUSY_CU_CYCLES", [0])))
+    u1 = mf / busy if busy else None
+    u2 = mf / (4.0 * bcu) if bcu else None
+    rows.append((key[0][:64], key[1], lpf, fb / 1e6, wb / 1e6, u1, u2))
+    nm = step_name(*key)
+    if nm:
+        kern[nm] = {"kernel": key[0], "grid_threads": key[1], "fetch_bytes": fb, "write_bytes": wb,
+                    "bytes_per_launch": fb + wb, "launches_per_forward": lpf,
+                    "mfma_busy_over_sq_busy": u1, "mfma_util_of_occupied_cus": u2}
+with open(out_md, "w") as o:
+    o.write(f"# {wl}: HBM-side traffic and MFMA utilisation per kernel (rocprofv3 --pmc, separate passes)\n\n"
+            f"Command: `scratch/prof_round2.sh` -> `scratch/prof_forward.py {wl} {forwards}` (eager launches, pair_launches = 0 so "
+            f"every step is its own kernel). FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported.\n\n"
+            f"**{total / 1e6:.1f} MB per forward** (sum over kernels of (fetch + write) x launches per forward).\n\n"
+            "| kernel | grid (threads) | launches / forward | fetch MB | write MB | MFMA_BUSY / SQ_BUSY | MFMA_BUSY / (4 x BUSY_CU) |\n"
+            "|---|---:|---:|---:|---:|---:|---:|\n")
+    for r in rows:
+        o.write(f"| `{r[0]}` | {r[1]} | {r[2]} | {r[3]:.2f} | {r[4]:.2f} | "
+                f"{'' if r[5] is None else f'{r[5]:.3f}'} | {'' if r[6] is None else f'{r[6]:.3f}'} |\n")
+try:
+    js = json.load(open(out_json))
+except Exception:
+    js = {}
+js[wl] = {"bytes_per_forward": total, "kernels": kern,
+          "source": f"{os.path.relpath(out_md, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; FETCH x2 gfx950 correction)"}
+json.dump(js, open(out_json, "w"), indent=1, sort_keys=True)
+print(open(out_md).read())
