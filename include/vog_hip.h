@@ -396,6 +396,26 @@ typedef struct vog_pred_args {
 int64_t vog_pred_record_bytes(int ncmp, int nsrl, int nfrm0);
 int vog_pred_head(const vog_pred_args* a, void* stream);
 
+/* SPAT / TEMP batch assembly on the device (verb_item_getter_SPAT / _TEMP,
+ * code/dat_loader_simple.py:1046-1338): per-video items of B queries ([B, ncmp, ...], what
+ * AV_CS.itemcollector stacks) -> the tensors the forward and the loss read, written straight into the
+ * caller's (slot's) input buffers. Forward part (always): props [B,ncmp,NPv,7] -> [B,ncmp*NPv,7]
+ * (spat: x1,x2 += vid_w*video, (frame,video,prop) order; temp: frame += nfrm0*video), region features
+ * [.., prop_dim] and pnt mask (bytes, optional) re-ordered the same way, seg_feature_for_frms
+ * [B,ncmp,nfrm0,seg_dim] -> [B,ncmp*nfrm0,seg_dim] (spat: (frame,video) order). Loss part (gt_in != NULL):
+ * gt boxes [B,ncmp,G,5] shifted the same way, first num_box[b,v] of every video concatenated and zero
+ * padded -> [B,G,5]; srl_boxes += boxes in front of target_cmp where srl_boxes_lens > 0; frm_mask
+ * [B,ncmp*NPv,G] bytes = frame(prop) != frame(gt) for g < total boxes else 1; num_box_out [B] int64.
+ * Bit-exact with the reference (fp32 adds, copies). */
+typedef struct vog_assemble_args {
+  const float* props_in; float* props_out; const float* region_in; float* region_out;
+  const float* seg_in; float* seg_out; const unsigned char* pnt_in; unsigned char* pnt_out;
+  const float* gt_in; float* gt_out; const int64_t* num_box; int64_t* num_box_out; const int64_t* target_cmp;
+  const int64_t* srl_boxes_in; int64_t* srl_boxes_out; const int64_t* srl_boxes_lens; unsigned char* frm_out;
+  int B, ncmp, nfrm0, nppf0, prop_dim, seg_dim, G, nv, nsrl, nbox, conc_type; float vid_w;
+} vog_assemble_args;
+int vog_assemble_batch(const vog_assemble_args* a, void* stream);
+
 /* Loss of one batch on the device: LossB_TEMP / LossB_SPAT
  * (code/mdl_conc_single.py:180-433) and LossB_SEP (code/mdl_conc_sep.py:220-447) with the IoU targets of
  * utils/box_utils.py:61-118: target[b,v,a,r] = max_k(IoU(prop r, gt box srl_boxes[b,v,a,k]) * mask *

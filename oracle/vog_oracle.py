@@ -509,3 +509,51 @@ def loss_forward(oc: "OracleCfg", out, inp, loss_lambda: float = 1.0):
     mdl_out_loss = sel.mean() * NPt
     d = {"loss": mdl_out_loss, "mdl_out_loss": mdl_out_loss}
     return {k: v * loss_lambda for k, v in d.items()}
+
+
+# --------------------------------------------------------------------------- #
+# SPAT / TEMP batch assembly: verb_item_getter_SPAT / _TEMP
+# (code/dat_loader_simple.py:1046-1338) for a whole batch, numpy. items: leading axes [B, ncmp].
+# --------------------------------------------------------------------------- #
+def assemble_batch(items, conc_type: str, nfrm0: int, nppf0: int, vid_w: float = 720.0):
+    import numpy as np
+    P = items["pad_proposals"]
+    B, ncmp, NPv, _ = P.shape
+    G = items["pad_gt_bboxs"].shape[2]
+    vid = np.arange(ncmp, dtype=np.float32).reshape(1, ncmp, 1)
+    props, gt = P.copy(), items["pad_gt_bboxs"].copy()
+    if conc_type == "spat":        # x += 720 * video (process_props :1081-1103), then (frame, video, prop) order
+        for cidx in (0, 2):
+            props[..., cidx] = props[..., cidx] + vid * np.float32(vid_w)
+            gt[..., cidx] = gt[..., cidx] + vid * np.float32(vid_w)
+
+        def reshuffle(a):           # reshuffle_boxes :1067-1078
+            sh = a.shape
+            return a.reshape(B, ncmp, nfrm0, nppf0, *sh[3:]).swapaxes(1, 2).reshape(B, ncmp * NPv, *sh[3:])
+        segs = items["seg_feature_for_frms"].swapaxes(1, 2)
+    else:                           # frame += 10 * video (process_props :1240-1262), plain concatenation
+        props[..., 4] = props[..., 4] + vid * np.float32(nfrm0)
+        gt[..., 4] = gt[..., 4] + vid * np.float32(nfrm0)
+
+        def reshuffle(a):
+            return a.reshape(B, ncmp * NPv, *a.shape[3:])
+        segs = items["seg_feature_for_frms"]
+    out = {"pad_proposals": reshuffle(props), "pad_region_feature": reshuffle(items["pad_region_feature"]),
+           "pad_pnt_mask": reshuffle(items["pad_pnt_mask"]),
+           "seg_feature_for_frms": np.ascontiguousarray(segs).reshape(B, ncmp * nfrm0, -1)}
+    gts = np.zeros((B, G, 5), np.float32)
+    frm = np.ones((B, ncmp * NPv, G), np.uint8)
+    srl = items["srl_boxes"].copy()
+    nb_tot = items["num_box"].sum(-1)
+    for b in range(B):
+        rows = [gt[b, v, k] for v in range(ncmp) for k in range(int(items["num_box"][b, v]))]
+        if not rows:
+            rows = [gt[b, 0, 0]]                              # the reference's fallback (:1106-1108)
+        gts[b, :len(rows)] = np.stack(rows)
+        nb = int(nb_tot[b])
+        frm[b, :, :nb] = (out["pad_proposals"][b, :, 4:5] != gts[b, None, :nb, 4]).astype(np.uint8)
+        cum = np.concatenate([[0], np.cumsum(items["num_box"][b])])
+        shift = int(cum[int(items["target_cmp"][b])])
+        srl[b][items["srl_boxes_lens"][b] > 0] += shift
+    out.update({"pad_gt_bboxs": gts, "pad_frm_mask": frm, "srl_boxes": srl, "num_box": nb_tot.astype(np.int64)})
+    return out

@@ -209,3 +209,50 @@ def test_forward_then_loss_end_to_end(name):
     gl = np.load(mgl.loss_path(name))
     for k in loss_fn.loss_keys:
         assert abs(float(res[k]) - float(gl[k])) <= 2e-3 * abs(float(gl[k])), (k, float(res[k]), float(gl[k]))
+
+
+# ---- device-side SPAT / TEMP batch assembly (csrc/assemble.hip) ----------------------------------------------
+mga = importlib.import_module("oracle.make_golden_assemble")
+dls = importlib.import_module("vognet-pytorch_amd.dat_loader_simple")
+ec = importlib.import_module("vognet-pytorch_amd.extended_config")
+vo = importlib.import_module("oracle.vog_oracle")
+
+
+def _asm_cfg(conc):
+    cfg = ec.get_default_cfg()
+    ec.update_from_dict(cfg, {"ds.conc_type": conc})
+    return cfg
+
+
+@pytest.mark.parametrize("conc", ["spat", "temp"])
+def test_device_assembly_vs_reference_fixture(conc):
+    """Bit-exact against the output of the reference loader methods (tests/golden/assemble__*.npz)."""
+    it = mga.items()
+    g = np.load(mga.path(conc))
+    asm = dls.DeviceBatchAssembler(_asm_cfg(conc), {"num_prop_per_frm": mga.SHAPE["nppf0"]})
+    res = asm({k: torch.from_numpy(v).cuda() for k, v in it.items()})
+    torch.cuda.synchronize()
+    for k in mga.KEYS:
+        got = res[k].cpu().numpy()
+        assert got.shape == g[k].shape, k
+        assert np.array_equal(got, g[k].astype(got.dtype)), k
+
+
+@pytest.mark.parametrize("conc", ["spat", "temp"])
+def test_device_assembly_full_size_into_slot_buffers(conc):
+    """cfg-2 / cfg-3 sized items assembled straight into a slot's input tensors == the oracle's assembly, and
+    the forward then runs on them (finite outputs)."""
+    name = {"spat": "full/cfg2_vog_spat_gt5_bs4", "temp": "full/cfg3_vog_temp_gt5_bs8"}[conc]
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    B = batch["num_cmp_msk"].shape[0]
+    it = synth.make_items(B, 4, c["nppf0"], seed=9)
+    ref = vo.assemble_batch(it, conc, 10, c["nppf0"])
+    asm = dls.DeviceBatchAssembler(cfg, comm_for(c))
+    slot = mdl.engine().make_slot(dev, graph=True)
+    asm({k: torch.from_numpy(v).cuda() for k, v in it.items()}, out={k: slot.inp[k] for k in dls.FWD_KEYS},
+        with_loss_keys=False)
+    out = slot.launch()
+    torch.cuda.synchronize()
+    for k in dls.FWD_KEYS:
+        assert np.array_equal(slot.inp[k].cpu().numpy(), ref[k]), k
+    assert torch.isfinite(out["mdl_outs"]).all()

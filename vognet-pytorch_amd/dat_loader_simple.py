@@ -1,0 +1,78 @@
+"""Device-side SPAT / TEMP batch assembly — the step in front of the forward path.
+
+The reference builds a SPAT / TEMP sample on the CPU inside the dataset
+(`AV_CS.verb_item_getter_SPAT / _TEMP`, code/dat_loader_simple.py:1046-1338): four per-video items are
+shifted (x += 720 * video / frame += 10 * video), re-ordered and concatenated, one query at a time, and
+the collated batch is copied to the GPU. Here the per-video items of a whole batch (what
+`AV_CS.itemcollector` stacks, [B, ncmp, ...]) are handed over as they are and `vog_assemble_batch`
+(csrc/assemble.hip) writes the forward's / loss's tensors straight into their device buffers - e.g. a
+`Slot`'s persistent inputs. Dataset reading itself (h5 / csv files, the 530 GB dataset) stays out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+
+FWD_KEYS = ("pad_proposals", "pad_region_feature", "seg_feature_for_frms")
+
+
+class DeviceBatchAssembler:
+    def __init__(self, cfg, comm):
+        self.conc_type = cfg.ds.conc_type
+        assert self.conc_type in ("spat", "temp"), "sep / svsq batches need no assembly (verb_item_getter_SEP)"
+        self.nfrm0 = int(cfg.ds.num_sampled_frm)
+        self.nppf0 = int(comm["num_prop_per_frm"])
+        self.vid_w = float(cfg.ds.resized_width)
+        self.lib = L.load()
+
+    def __call__(self, items: Dict[str, torch.Tensor], out: Optional[Dict[str, torch.Tensor]] = None,
+                 with_loss_keys: bool = True) -> Dict[str, torch.Tensor]:
+        """items: device tensors with leading axes [B, ncmp]. `out`: optional existing destination tensors
+        (e.g. `slot.inp`) for any of the produced keys; missing ones are allocated."""
+        P = items["pad_proposals"]
+        assert P.is_cuda and P.dtype == torch.float32 and P.dim() == 4 and P.shape[-1] == 7
+        B, ncmp, NPv, _ = P.shape
+        assert NPv == self.nfrm0 * self.nppf0
+        dev = P.device
+        R, S = items["pad_region_feature"], items["seg_feature_for_frms"]
+        out = dict(out or {})
+
+        def dst(k, shape, dtype):
+            t = out.get(k)
+            if t is None:
+                t = torch.empty(shape, dtype=dtype, device=dev)
+                out[k] = t
+            assert tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.is_cuda and t.is_contiguous(), k
+            return t
+
+        a = L.AssembleArgs()
+        keep = [P.contiguous(), R.contiguous(), S.contiguous()]
+        a.props_in, a.region_in, a.seg_in = (L.ptr(t) for t in keep)
+        a.props_out = L.ptr(dst("pad_proposals", (B, ncmp * NPv, 7), torch.float32))
+        a.region_out = L.ptr(dst("pad_region_feature", (B, ncmp * NPv, R.shape[-1]), torch.float32))
+        a.seg_out = L.ptr(dst("seg_feature_for_frms", (B, ncmp * self.nfrm0, S.shape[-1]), torch.float32))
+        if "pad_pnt_mask" in items:
+            pm = items["pad_pnt_mask"].to(torch.uint8).contiguous()
+            keep.append(pm)
+            a.pnt_in, a.pnt_out = L.ptr(pm), L.ptr(dst("pad_pnt_mask", (B, ncmp * NPv), torch.uint8))
+        if with_loss_keys and "pad_gt_bboxs" in items:
+            G = items["pad_gt_bboxs"].shape[2]
+            sb = items["srl_boxes"]
+            for k in ("pad_gt_bboxs", "num_box", "target_cmp", "srl_boxes", "srl_boxes_lens"):
+                keep.append(items[k].contiguous())
+            a.gt_in, a.num_box, a.target_cmp, a.srl_boxes_in, a.srl_boxes_lens = (L.ptr(t) for t in keep[-5:])
+            a.gt_out = L.ptr(dst("pad_gt_bboxs", (B, G, 5), torch.float32))
+            a.num_box_out = L.ptr(dst("num_box", (B,), torch.int64))
+            a.srl_boxes_out = L.ptr(dst("srl_boxes", tuple(sb.shape), torch.int64))
+            a.frm_out = L.ptr(dst("pad_frm_mask", (B, ncmp * NPv, G), torch.uint8))
+            a.G, a.nv, a.nsrl, a.nbox = G, sb.shape[1], sb.shape[2], sb.shape[3]
+        a.B, a.ncmp, a.nfrm0, a.nppf0 = B, ncmp, self.nfrm0, self.nppf0
+        a.prop_dim, a.seg_dim = R.shape[-1], S.shape[-1]
+        a.conc_type, a.vid_w = L.CONC_TYPE[self.conc_type], self.vid_w
+        L.check(self.lib.vog_assemble_batch(C.byref(a), L.stream_ptr()), "vog_assemble_batch")
+        out["_keepalive"] = keep
+        return out

@@ -138,6 +138,16 @@ class LossArgs(C.Structure):
                 ("G", c_i32), ("nppf0", c_i32), ("conc_type", c_i32), ("loss_lambda", c_f32)]
 
 
+class AssembleArgs(C.Structure):
+    _fields_ = [("props_in", c_vp), ("props_out", c_vp), ("region_in", c_vp), ("region_out", c_vp),
+                ("seg_in", c_vp), ("seg_out", c_vp), ("pnt_in", c_vp), ("pnt_out", c_vp),
+                ("gt_in", c_vp), ("gt_out", c_vp), ("num_box", c_vp), ("num_box_out", c_vp), ("target_cmp", c_vp),
+                ("srl_boxes_in", c_vp), ("srl_boxes_out", c_vp), ("srl_boxes_lens", c_vp), ("frm_out", c_vp),
+                ("B", c_i32), ("ncmp", c_i32), ("nfrm0", c_i32), ("nppf0", c_i32), ("prop_dim", c_i32),
+                ("seg_dim", c_i32), ("G", c_i32), ("nv", c_i32), ("nsrl", c_i32), ("nbox", c_i32),
+                ("conc_type", c_i32), ("vid_w", c_f32)]
+
+
 class PredcmpArgs(C.Structure):
     _fields_ = [("final_hidden", c_vp), ("prop_seg", c_vp), ("w0", c_vp), ("b0", c_vp),
                 ("w2", c_vp), ("b2", c_vp), ("outs", c_vp), ("arg_msk", c_vp), ("cmp_msk", c_vp),
@@ -190,6 +200,7 @@ SYMBOLS = {
     "vog_vis_encode": (c_i32, [C.POINTER(VisencArgs), c_vp]),
     "vog_loss_scratch_bytes": (c_i64, [C.POINTER(LossArgs)]),
     "vog_loss_fwd": (c_i32, [C.POINTER(LossArgs), c_vp]),
+    "vog_assemble_batch": (c_i32, [C.POINTER(AssembleArgs), c_vp]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),

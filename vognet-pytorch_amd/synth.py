@@ -283,3 +283,40 @@ def make_targets(batch: Dict[str, np.ndarray], conc_type: str, nppf0: int, *, n_
         out["verb_cmp"] = (rng.uniform(size=(B, ncmp)) < 0.5).astype(np.int64)
         out["verb_cross_cmp_msk"] = (rng.uniform(size=(B, ncmp, ncmp)) < 0.6).astype(np.int64)
     return out
+
+
+# --------------------------------------------------------------------------- #
+# per-video ITEMS of a query as `AV_CS.itemcollector` stacks them (dat_loader_simple.py:1405-1510,
+# SURVEY.md App. B.5): the input of the SPAT / TEMP batch assembly (verb_item_getter_SPAT / _TEMP,
+# dat_loader_simple.py:1046-1338). Leading axes [B, ncmp].
+# --------------------------------------------------------------------------- #
+def make_items(B: int, ncmp: int, nppf0: int, *, prop_dim: int = 2048, seg_dim: int = 3072, n_gt: int = 100,
+               nsrl: int = NSRL, n_box: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(20_011 + seed)
+    NPv = NFRM0 * nppf0
+    x = np.sort(rng.uniform(0, VID_W, size=(B, ncmp, NFRM0, nppf0, 2)), axis=-1)
+    y = np.sort(rng.uniform(0, VID_H, size=(B, ncmp, NFRM0, nppf0, 2)), axis=-1)
+    box = np.zeros((B, ncmp, NFRM0, nppf0, 7), np.float32)
+    box[..., 0], box[..., 2], box[..., 1], box[..., 3] = x[..., 0], x[..., 1], y[..., 0], y[..., 1]
+    box[..., 4] = np.arange(NFRM0, dtype=np.float32)[None, None, :, None]
+    box[..., 5] = rng.integers(0, 431, size=box.shape[:-1]).astype(np.float32)
+    box[..., 6] = rng.uniform(0, 1, size=box.shape[:-1]).astype(np.float32)
+    num_box = rng.integers(0, 12, size=(B, ncmp)).astype(np.int64)
+    num_box[0, 0] = 0                                      # a video without ground-truth boxes
+    if B > 1:
+        num_box[1, :] = 0                                  # a query without any (the "gt_boxs[0, 0]" fallback)
+    gt = np.zeros((B, ncmp, n_gt, 5), np.float32)
+    gx = np.sort(rng.uniform(0, VID_W, size=(B, ncmp, n_gt, 2)), axis=-1)
+    gy = np.sort(rng.uniform(0, VID_H, size=(B, ncmp, n_gt, 2)), axis=-1)
+    gt[..., 0], gt[..., 2], gt[..., 1], gt[..., 3] = gx[..., 0], gx[..., 1], gy[..., 0], gy[..., 1]
+    gt[..., 4] = rng.integers(0, NFRM0, size=(B, ncmp, n_gt)).astype(np.float32)
+    return {
+        "pad_proposals": box.reshape(B, ncmp, NPv, 7),
+        "pad_region_feature": rng.standard_normal((B, ncmp, NPv, prop_dim), dtype=np.float32),
+        "seg_feature_for_frms": rng.standard_normal((B, ncmp, NFRM0, seg_dim), dtype=np.float32),
+        "pad_pnt_mask": (rng.uniform(size=(B, ncmp, NPv)) < 0.1).astype(np.uint8),
+        "pad_gt_bboxs": gt, "num_box": num_box,
+        "target_cmp": rng.integers(0, ncmp, size=(B,)).astype(np.int64),
+        "srl_boxes": rng.integers(0, 12, size=(B, 1, nsrl, n_box)).astype(np.int64),
+        "srl_boxes_lens": (rng.uniform(size=(B, 1, nsrl, n_box)) < 0.6).astype(np.int64),
+    }
