@@ -236,6 +236,11 @@ typedef struct vog_visenc_args {
   const void* w_prop_f; const void* w_seg_f; const float* b_prop; const float* b_seg;
   float* c32; void* c16; int64_t ldc; int c16_dtype;
   int n_prop_rows, nppf0, prop_dim, seg_dim, prop_enc, seg_enc; vog_dtype dtype;
+  /* lean = 1: 64-row x 128-column workgroups (32 of them at cfg 2) that read the fp32 rows once per column
+   * half and stage them in LDS: ~2x the latency of the wide form but ~5x less busy-CU time - the form used
+   * when the encoders share the launch of a persistent BiLSTM layer (csrc/pair.hip). Same results up to
+   * fp32 summation order. */
+  int lean;
 } vog_visenc_args;
 int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
 int vog_vis_encode(const vog_visenc_args* a, void* stream);
@@ -517,15 +522,17 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * last mul_tx layer, lin2 + the score head) as ONE vog_tx_tail_fwd launch where
  * vog_tx_tail_supported; 0 = the separate GEMM / LayerNorm / score launches (always used for other shapes).
  * "fused_enc" (default 1): vog_vis_encode instead of cast + two split-K GEMMs + finish where supported.
+ * "enc_lean" (default -1 = lean exactly when the encoders will share a BiLSTM layer's launch; 0 / 1 force).
  * "pair_launches" (default 1): step i of the language chain (input projection / BiLSTM layer / out-projection)
  * and step i of the visual chain (encoders / obj_tx QKV, attention, tail / mul_tx QKV) - independent until
  * mul_tx's attention - share ONE launch (csrc/pair.hip: blocks [0, nA) run one kernel body, the rest the
  * other) wherever a pair kernel exists for the two shapes; 0 = every step its own launch. Same kernel
  * bodies either way: results are bit-identical (tests/test_gpu_forward.py).
- * "fused_ih" (default 0): 1 = the BiLSTM input projections run inside the persistent layer kernel
- * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 64 and K % 256 == 0 (2: layer 0
- * only, 3: layers >= 1 only). Measured on MI355X: fewer launches and 30 % less CU time, but the
- * prologue streams W_ih through 64 CUs only (12 / 32 us per layer vs 6.4 / 9.5 us): opt-in. */
+ * "fused_ih" (default 1): the BiLSTM input projections run inside the persistent layer kernel
+ * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 64 and K % 256 == 0 (0: never,
+ * 2: layer 0 only, 3: layers >= 1 only). Measured on MI355X (cfg 2): two launches fewer, W_ih streamed
+ * by the layer's 64 CUs (+7 / +17 us per layer against 6.4 / 9.7 us for the whole-chip GEMMs):
+ * 43.1 k vs 40.9 k queries/s with 4 batches in flight, 10 us more single-batch latency. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
 int vog_graph_destroy(vog_graph* g);
 

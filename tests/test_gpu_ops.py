@@ -620,9 +620,10 @@ def test_tx_tail_matches_torch_chain(M, d, kwo, mode, dtype):
     assert torch.all(outs_eval[ref_eval == 0] == 0)
 
 
+@pytest.mark.parametrize("lean", [0, 1])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("rows,nppf0", [(800, 5), (75, 5), (1600, 100)])
-def test_vis_encode_fused(rows, nppf0, dtype):
+def test_vis_encode_fused(rows, nppf0, dtype, lean):
     """Both feature encoders + the prop||seg concat in one launch, from the fp32 features, against
     relu(Linear) on the same 16-bit-rounded operands (mdl_vog.py:291-314, mdl_conc_single.py:51-66)."""
     torch.manual_seed(rows)
@@ -647,6 +648,7 @@ def test_vis_encode_fused(rows, nppf0, dtype):
                                                                 L.ptr(bp), L.ptr(bs))
     a.c32, a.c16, a.ldc, a.c16_dtype = L.ptr(c32), L.ptr(c16), Np + Ns, L.VOG_BF16
     a.n_prop_rows, a.nppf0, a.prop_dim, a.seg_dim, a.prop_enc, a.seg_enc, a.dtype = rows, nppf0, Kp, Ks, Np, Ns, DT[dtype]
+    a.lean = lean
     assert lib.vog_vis_encode_supported(Kp, Ks, Np, Ns) == 1
     L.check(lib.vog_vis_encode(C.byref(a), _sp()), "vis_encode")
     torch.cuda.synchronize()

@@ -89,14 +89,16 @@ struct vog_ctx {
   unsigned short* w_outproj_f = nullptr;
   std::vector<unsigned short*> whh;                     // [layer] [2][4R][R]
   std::vector<unsigned short*> wih_p;                   // [layer] W_ih in the W_hh tile order (fused input projection), or null
-  int fused_ih = 0;                     // LSTM input projections inside the persistent layer kernel (opt-in: the prologue
-                                        // streams W_ih through 64 CUs only: 12 / 32 us per layer against 6.4 / 9.5 us for
-                                        // the whole-chip GEMM launches; within noise on throughput, worse on latency)
+  int fused_ih = 1;                     // LSTM input projections inside the persistent layer kernel where supported (no GEMM
+                                        // launches, no gx round trip; W_ih streams through the layer's 64 CUs: +7 / +17 us per
+                                        // layer against 6.4 / 9.7 us whole-chip launches -> 5 % more throughput with 4 batches
+                                        // in flight, 10 us more single-batch latency)
   std::vector<float*> bsum;                             // [layer] [8R]
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
+  int enc_lean = -1;                    // -1: lean form exactly when the encoders share a BiLSTM layer's launch
   int pair_launches = 1;                // step i of the language chain shares a launch with step i of the visual chain (pair.hip)
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
   float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
@@ -703,6 +705,9 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       ve.c32 = ps32; ve.c16 = ps16; ve.ldc = g.d_obj; ve.c16_dtype = d.tx_dtype;
       ve.n_prop_rows = Mp; ve.nppf0 = d.nppf0; ve.prop_dim = d.prop_dim; ve.seg_dim = d.seg_dim;
       ve.prop_enc = d.prop_enc; ve.seg_enc = d.seg_enc; ve.dtype = et;
+      const bool will_pair = c->pair_launches && !c->graph_dag && !shared && c->lstm_persistent &&
+                             vog_bilstm_layer_supported(Bn, R) && allow_pairs;
+      ve.lean = c->enc_lean < 0 ? (will_pair ? 1 : 0) : c->enc_lean;
       steps.push_back({"vis_enc", [=](hipStream_t st) { return vog_vis_encode(&ve, st); }});
     }
     const bool can_split = !enc_fused && (d.prop_dim % 64) == 0 && (d.seg_dim % 64) == 0 && Mp > 64 && Ms > 64 &&
@@ -1300,6 +1305,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
+  if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 

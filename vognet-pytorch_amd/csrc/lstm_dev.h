@@ -140,10 +140,10 @@ struct LstmLayerBody {
   static constexpr size_t LDS = (size_t)16 * HS_LD * 2;
   // fused input projection: + gates of every (sentence, position) for the 128 gate rows of the
   // workgroup ([8 waves][<= 64 columns][4 units][4 gates] fp32, 80-byte column pitch) + one K chunk
-  // (256) of the layer input in fragment order ([<= 4 column tiles][8 k-steps][64 lanes][16 B])
+  // (256) of the layer input in fragment order ([<= 4 column tiles][8 k-steps][64 lanes][16 B]), double buffered
   static constexpr int GX_PITCH = 20;                      // floats per column (16 + 4: spreads the banks)
   static constexpr size_t LDS_HS = ((size_t)16 * HS_LD * 2 + 15) / 16 * 16;
-  static constexpr size_t LDS_FUSED = LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)4 * 8 * 1024;
+  static constexpr size_t LDS_FUSED = LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)2 * 4 * 8 * 1024;
 
   static __device__ __forceinline__ void run(const LstmLayerParams& p, const BlockCtx& cx, unsigned char* smem) {
     unsigned short* hs = reinterpret_cast<unsigned short*>(smem);
@@ -173,45 +173,56 @@ struct LstmLayerBody {
       const u16x8* wsrc = reinterpret_cast<const u16x8*>(p.wih) + (((int64_t)dir * (R / 4) + tile0) * ksteps) * 64 + lane;
       const uint4* xsrc = reinterpret_cast<const uint4*>(p.xa);
       // chunk c of column tile ct: k-steps [8c, 8c+8) = 8 KiB contiguous at ((ct*ksteps + 8c)*64) uint4.
+      // Pipeline: the layer input goes global -> LDS by LDS-DMA (global_load_lds: no VGPR round trip, so
+      // the compiler cannot serialise it behind the weight loads; first form, through registers: every
+      // chunk waited vmcnt(0), 4 us per chunk), double buffered; the weight fragments of the NEXT
+      // chunk are in flight in a second register set. Two chunks = 80 KB per workgroup are always
+      // outstanding; per chunk: one counted wait, barrier, 8 x nct MFMAs, barrier.
+      unsigned char* xbuf[2] = {xch, xch + 4 * 8 * 1024};
       auto load_w = [&](u16x8 (&wq)[8], int c) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) wq[ks] = wsrc[(c * 8 + ks) * 64];
       };
-      auto load_x = [&](uint4 (&xq)[4], int c) {
+      auto dma_x = [&](int c) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int idx = tid + j * THREADS;                              // uint4 index inside the chunk image
-          const int ct = idx >> 9, r = idx & 511;                         // 512 uint4 per (column tile, chunk)
-          xq[j] = xsrc[((int64_t)(ct < nct ? ct : 0) * ksteps + c * 8) * 64 + r];
+          const int piece = j * 8 + wid;                                  // 1 KiB = 64 lanes x 16 B
+          const int ct = piece >> 3, r = ((piece & 7) << 6) + lane;       // 8 pieces per (column tile, chunk)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(xsrc + ((int64_t)(ct < nct ? ct : 0) * ksteps + c * 8) * 64 + r),
+              (__attribute__((address_space(3))) void*)(xbuf[c & 1] + piece * 1024), 16, 0, 0);
         }
       };
-      auto consume = [&](const u16x8 (&wq)[8], const uint4 (&xq)[4]) {
-        __syncthreads();                                                  // previous chunk's LDS reads done
-#pragma unroll
-        for (int j = 0; j < 4; ++j) reinterpret_cast<uint4*>(xch)[tid + j * THREADS] = xq[j];
-        __syncthreads();
+      auto mfmas = [&](const u16x8 (&wq)[8], int c) {
+        const unsigned char* xb = xbuf[c & 1];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
           if (ct < nct) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-              const u16x8 xf = *reinterpret_cast<const u16x8*>(xch + ((ct * 8 + ks) * 64 + lane) * 16);
+              const u16x8 xf = *reinterpret_cast<const u16x8*>(xb + ((ct * 8 + ks) * 64 + lane) * 16);
               ga[ct] = mfma16<T16>(wq[ks], xf, ga[ct]);
             }
           }
       };
-      // one chunk of prefetch: the next chunk's weight fragments and input piece are requested right
-      // after this chunk's LDS image is complete, i.e. under its MFMAs (measured: three chunks in flight
-      // in fully unrolled code were SLOWER, 69.7 vs 57 us for the K = 2048 layer)
       u16x8 w0[8], w1[8];
-      uint4 x0[4], x1[4];
-      load_w(w0, 0); load_x(x0, 0);
+      dma_x(0); load_w(w0, 0);
+      if (nchunk > 1) { dma_x(1); load_w(w1, 1); }
       for (int c = 0; c < nchunk; c += 2) {
-        if (c + 1 < nchunk) { load_w(w1, c + 1); load_x(x1, c + 1); }
-        consume(w0, x0);
+        // chunk c (even): everything issued before the 12 most recent VMEM ops has landed
+        if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mfmas(w0, c);
+        __syncthreads();                                                  // xbuf[0] free again
+        if (c + 2 < nchunk) { dma_x(c + 2); load_w(w0, c + 2); }
         if (c + 1 < nchunk) {
-          if (c + 2 < nchunk) { load_w(w0, c + 2); load_x(x0, c + 2); }
-          consume(w1, x1);
+          if (c + 2 < nchunk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          mfmas(w1, c + 1);
+          __syncthreads();
+          if (c + 3 < nchunk) { dma_x(c + 3); load_w(w1, c + 3); }
         }
       }
       // D[row = 4*ul + gate][col = lane & 15]: lane (col, ul) holds the 4 gates of unit ul: + bias, park

@@ -86,6 +86,7 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     using SkinnyIh = GemmSkinnyBody<F16, false, 8, 1, 4>;
     using Lstm = LstmLayerBody<F16, 32>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_f16()}] = &launch_pair<Lstm, VisEncBody<F16>>;
+    r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16()}] = &launch_pair<Lstm, VisEncLeanBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<Lstm, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;

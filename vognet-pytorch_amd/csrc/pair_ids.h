@@ -9,4 +9,5 @@ const void* kid_gemm_pipe_qkv(int dtype);   // gemm_pipe<T16, 64, 64, 2, EPI_QKV
 const void* kid_lstm_layer_f16();           // lstm_layer_kernel<F16, 32>
 const void* kid_tx_tail_512(int dtype);     // tx_tail_kernel<T16, F16, 2, false, 0>
 const void* kid_vis_enc_f16();              // vis_enc_kernel<F16>
+const void* kid_vis_enc_lean_f16();         // vis_enc_lean_kernel<F16>
 }  // namespace vog

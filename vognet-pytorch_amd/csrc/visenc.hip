@@ -22,6 +22,7 @@
 namespace vog {
 
 const void* kid_vis_enc_f16() { return reinterpret_cast<const void*>(vis_enc_kernel<F16>); }
+const void* kid_vis_enc_lean_f16() { return reinterpret_cast<const void*>(vis_enc_lean_kernel<F16>); }
 
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
   return (prop_dim % 256) == 0 && (seg_dim % 256) == 0 && (prop_enc % 32) == 0 && (seg_enc % 32) == 0 &&
@@ -42,6 +43,13 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
   p.tiles_all = p.tiles0 + ceil_div(p.p[1].M, 16);
   p.c32 = a->c32; p.c16 = (unsigned short*)a->c16; p.ldc = a->ldc;
   p.c16_bf16 = a->c16_dtype == VOG_BF16;
+  if (a->lean) {
+    const int nb = ceil_div(p.tiles0, 4) + ceil_div(p.tiles_all - p.tiles0, 4);
+    VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(nb * 2), dim3(512),
+                                               VisEncLeanBody<T16>::LDS, st, p));
+    VOG_LAUNCH_CHECK();
+    return 0;
+  }
   const int groups = ceil_div(p.tiles_all, 8);
   VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_kernel<T16>), dim3(groups * 8 * 8), dim3(512), VisEncBody<T16>::LDS, st, p));
   VOG_LAUNCH_CHECK();

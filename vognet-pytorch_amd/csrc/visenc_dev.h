@@ -108,4 +108,122 @@ __global__ __launch_bounds__(512) void vis_enc_kernel(VisEncParams a) {
   VisEncBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, ve_smem);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Lean" form for the launch it shares with the persistent BiLSTM layer (pair.hip): there the encoders
+// have ~40 us to finish and only the CUs the BiLSTM leaves free, and what they cost the OTHER batches in
+// flight is busy-CU time. The wide form above keeps 480 workgroups busy (~4600 CU*us per cfg-2 forward,
+// most of it re-reading the fp32 rows 8x and the weights 60x out of L2); this one gives a workgroup 64
+// rows x 128 columns: the fp32 rows are read ONCE per column half, converted and staged in LDS (fragment
+// order) per K chunk of 256, the 8 waves own 16 columns each and stream their weight fragments once.
+// 32 workgroups, ~1 MB through each CU: ~25 us (proposals) / ~37 us (segments), ~900 CU*us.
+// ---------------------------------------------------------------------------------------------------
+template <typename T16>
+struct VisEncLeanBody {
+  using Params = VisEncParams;
+  static constexpr int THREADS = 512;
+  static constexpr int RB = 64, KC = 256;
+  static constexpr size_t LDS = (size_t)2 * (RB / 16) * (KC / 32) * 1024;       // two A-chunk images (fragment order)
+
+  static __device__ __forceinline__ void run(const VisEncParams& a, const BlockCtx& cx, unsigned char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // item = (row block of 64, column half); tiles0 / tiles_all count 16-row tiles: 4 per block
+    const int nb0 = (a.tiles0 + 3) >> 2, nb_all = nb0 + ((a.tiles_all - a.tiles0 + 3) >> 2);
+    const int blk = cx.bx >> 1, half = cx.bx & 1;
+    if (blk >= nb_all) return;
+    const bool second = blk >= nb0;
+    const float* qx = second ? a.p[1].x : a.p[0].x;
+    const unsigned short* qw = second ? a.p[1].w : a.p[0].w;
+    const float* qb = second ? a.p[1].bias : a.p[0].bias;
+    const int qM = second ? a.p[1].M : a.p[0].M, qN = second ? a.p[1].N : a.p[0].N;
+    const int qK = second ? a.p[1].K : a.p[0].K, qrep = second ? a.p[1].rep : a.p[0].rep;
+    const int qcol0 = second ? a.p[1].col0 : a.p[0].col0;
+    const int m0 = (second ? blk - nb0 : blk) * RB;
+    const int n0 = half * 128 + w * 16;                      // this wave's 16 columns
+    if (half * 128 >= qN) return;
+    const bool n_ok = n0 < qN;
+    const int ksteps = qK >> 5, nchunk = qK / KC;            // K % 256 == 0
+    const u16x8* wf = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok ? n0 : 0) >> 4) * ksteps) * 64 + lane;
+    // A staging: thread -> (row, 8-column piece): 32 pieces per row and chunk, 16 rows per pass, 4 passes
+    const int pr = tid >> 5, pc = tid & 31;
+    f32x4 acc[RB / 16];
+#pragma unroll
+    for (int mt = 0; mt < RB / 16; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 xa[4][2];
+    u16x8 wq[2][8];
+    auto load_a = [&](int c) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        int m = m0 + ps * 16 + pr;
+        m = m < qM ? m : qM - 1;
+        const float* src = qx + (int64_t)m * qK + c * KC + pc * 8;
+        xa[ps][0] = *reinterpret_cast<const float4*>(src);
+        xa[ps][1] = *reinterpret_cast<const float4*>(src + 4);
+      }
+    };
+    auto store_a = [&](int c) {      // -> fragment order [m tile][k-step][lane = kgroup*16 + m%16][8 halfwords]
+      unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const u16x8 h = {to16<T16>(xa[ps][0].x), to16<T16>(xa[ps][0].y), to16<T16>(xa[ps][0].z), to16<T16>(xa[ps][0].w),
+                         to16<T16>(xa[ps][1].x), to16<T16>(xa[ps][1].y), to16<T16>(xa[ps][1].z), to16<T16>(xa[ps][1].w)};
+        const int ks = pc >> 2, kgp = pc & 3;
+        *reinterpret_cast<u16x8*>(img + ((ps * (KC / 32) + ks) * 64 + kgp * 16 + pr) * 16) = h;
+      }
+    };
+    auto load_w = [&](u16x8 (&q)[8], int c) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) q[ks] = wf[(c * 8 + ks) * 64];
+    };
+    auto mfmas = [&](const u16x8 (&q)[8], int c) {
+      const unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
+#pragma unroll
+      for (int mt = 0; mt < RB / 16; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const u16x8 af = *reinterpret_cast<const u16x8*>(img + ((mt * (KC / 32) + ks) * 64 + lane) * 16);
+          acc[mt] = mfma16<T16>(af, q[ks], acc[mt]);
+        }
+    };
+    load_a(0); load_w(wq[0], 0);
+    for (int c = 0; c < nchunk; c += 2) {
+      store_a(c);                                            // image (c & 1) was last read two chunks ago
+      if (c + 1 < nchunk) { load_a(c + 1); load_w(wq[1], c + 1); }
+      __syncthreads();
+      mfmas(wq[0], c);
+      if (c + 1 < nchunk) {
+        store_a(c + 1);
+        if (c + 2 < nchunk) { load_a(c + 2); load_w(wq[0], c + 2); }
+        __syncthreads();
+        mfmas(wq[1], c + 1);
+      }
+    }
+    // D[row = 4*(lane>>4) + reg][col = lane & 15]
+    if (!n_ok) return;
+    const int col = n0 + (lane & 15);
+    if (col >= qN) return;
+    const float b = qb[col];
+#pragma unroll
+    for (int mt = 0; mt < RB / 16; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + mt * 16 + (lane >> 4) * 4 + r;
+        if (row >= qM) continue;
+        const float o = fmaxf(acc[mt][r] + b, 0.f);
+        const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+        for (int j = 0; j < qrep; ++j) {
+          const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
+          if (a.c32) a.c32[off] = o;
+          if (a.c16) a.c16[off] = h;
+        }
+      }
+  }
+};
+
+template <typename T16>
+__global__ __launch_bounds__(512) void vis_enc_lean_kernel(VisEncParams a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vl_smem[];
+  VisEncLeanBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vl_smem);
+}
+
 }  // namespace vog
