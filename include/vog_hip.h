@@ -122,8 +122,15 @@ typedef struct vog_qkv_args {
    * VISUAL tokens of every sequence only ([S,H,npad_kv*dp], no language part): the operands of
    * vog_rel_attention_struct_fwd. */
   int kv_visual_only, npad_kv;
+  /* wqkv_p32 != NULL: row-block form (csrc/qkvrb_dev.h). The same [3*H*dp, K] weights in
+   * vog_pack_w_frag32 order; a workgroup owns 64 rows x 512 output columns, stages its rows in LDS
+   * once and streams each weight fragment once: ~1/3 of the busy-CU time of the tiled GEMM at
+   * M = 800, at twice its latency (the right trade with several forwards in flight). Needs
+   * vog_qkv_rowblock_supported(3*H*dp, K); wqkv / ldw are not read. */
+  const void* wqkv_p32;
 } vog_qkv_args;
 int vog_qkv_proj(const vog_qkv_args* a, void* stream);
+int vog_qkv_rowblock_supported(int n_out, int K);
 
 /* Layer-0 QKV of mul_tx through the token structure: every token is
  * [vis[v, f*nppf+p] || lang[l, a]], so x Wqkv^T = PV[vis row] + PL[lang row] with

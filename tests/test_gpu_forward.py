@@ -14,6 +14,8 @@ reference fp32 CPU forward):
 Budget: bf16 operands in the two transformers, f16 elsewhere, fp32 accumulate
 — oracle-simulated at 4.5e-4 (tests/test_quant_budget.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -115,11 +117,15 @@ def test_forward_persistent_lstm_layer(name):
     eng.set_option("lstm_persistent", 1)
     b = eng.forward(dev)
     torch.cuda.synchronize()
-    # same arithmetic, different fp32 summation order of the recurrent dot products
-    assert (a["mdl_outs"] - b["mdl_outs"]).abs().max().item() < 5e-4
+    # same arithmetic, different fp32 summation order of the recurrent dot products and (fused_ih, on
+    # by default with the persistent kernel) of the input projections; logits are O(1..10), the golden
+    # tests allow 6e-3 on them
+    dl = (a["mdl_outs"] - b["mdl_outs"]).abs().max().item()
+    assert dl < 1.5e-3, dl
     ncmp = batch["new_srl_idxs"].shape[1]
     pa, pb = eng.unpack_pred(a["pred_rec"], ncmp), eng.unpack_pred(b["pred_rec"], ncmp)
-    assert (pa["scores"] - pb["scores"]).abs().max().item() < 2e-4
+    ds = (pa["scores"] - pb["scores"]).abs().max().item()
+    assert ds < 4e-4, ds
 
 
 @pytest.mark.parametrize("name", FULL + ["small/vog_spat", "small/vgrnd_sep", "small/edge_temp_len1",
@@ -178,10 +184,28 @@ def test_fused_lstm_input_projection_matches_separate_gemm(name):
     b = eng.forward(dev)
     torch.cuda.synchronize()
     assert torch.isfinite(b["mdl_outs"]).all()
-    assert (a["mdl_outs"] - b["mdl_outs"]).abs().max().item() < 5e-4
+    dl = (a["mdl_outs"] - b["mdl_outs"]).abs().max().item()
+    assert dl < 1.5e-3, dl
     ncmp = batch["new_srl_idxs"].shape[1]
     pa, pb = eng.unpack_pred(a["pred_rec"], ncmp), eng.unpack_pred(b["pred_rec"], ncmp)
-    assert (pa["scores"] - pb["scores"]).abs().max().item() < 2e-4
+    ds = (pa["scores"] - pb["scores"]).abs().max().item()
+    assert ds < 4e-4, ds
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
+                                  "full/cfg4_vog_spat_p100_bs4", "small/vog_spat"])
+def test_forward_rowblock_qkv_vs_reference_golden(name):
+    """qkv_lean = 1: the row-block QKV projections (csrc/qkvrb_dev.h; off by default) against the same
+    goldens as the tiled GEMM they replace (shapes they do not cover keep the tiled kernel)."""
+    if not os.path.exists(cases.golden_path(name)):
+        pytest.skip("no golden for " + name)
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("qkv_lean", 1)
+    out = eng.forward(dev)
+    torch.cuda.synchronize()
+    pred = eng.unpack_pred(out["pred_rec"], batch["new_srl_idxs"].shape[1])
+    g = np.load(cases.golden_path(name))
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
 def test_forward_f16_transformers():
@@ -268,6 +292,7 @@ def _aql_outputs(eng, dev, split, n_slots=1, queue=0, reps=2):
 def test_aql_program_equals_stream_forward(name, split):
     """Raw AQL dispatch of the recorded forward == the HIP-stream forward, bit for bit."""
     eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("enc_lean", 1)            # (the encoder form otherwise follows the pairing decision)
     ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
     torch.cuda.synchronize()
     eng.aql_open(1)

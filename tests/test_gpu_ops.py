@@ -346,6 +346,62 @@ def test_qkv_proj_structured_fused():
         assert (got - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item()), which
 
 
+def _pack32_cols(lib, w32, K, dtype):
+    """vog_pack_w_frag32 of the first K columns of the fp32 matrix w32 -> device halfwords."""
+    wc = w32.detach().cpu().contiguous()
+    N = wc.shape[0]
+    dst = torch.empty(N * K, dtype=torch.int16)
+    L.check(lib.vog_pack_w_frag32(L.ptr(wc), wc.shape[1], N, K, L.ptr(dst), DT[dtype]), "pack32")
+    return dst.cuda()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", ["obj", "mul", "vis"])
+def test_qkv_rowblock_equals_tiled(dtype, case):
+    """vog_qkv_proj with wqkv_p32 (row-block kernel, csrc/qkvrb_dev.h) writes the same Q/K/V^T fragment
+    images as the tiled LDS-DMA GEMM (to the rounding of a different fp32 summation order) and touches
+    no pad slot: ragged row counts, K = 512 / 768, and the visual-rows form of mul_tx layer 0 (first
+    d_vis columns of a wider weight matrix, 20 tokens per sequence)."""
+    lib = _lib()
+    torch.manual_seed(23)
+    td = t16(dtype)
+    S, N, H, dp, K, ld = {"obj": (3, 203, 3, 192, 512, 512), "mul": (7, 100, 3, 256, 768, 768),
+                          "vis": (13, 20, 3, 256, 512, 768)}[case]
+    npad = (N + 31) // 32 * 32
+    ncol = 3 * H * dp
+    assert lib.vog_qkv_rowblock_supported(ncol, K) == 1
+    w32 = (torch.randn(ncol, ld) / math.sqrt(ld)).to(td).float()
+    w16 = w32.cuda().to(td)
+    wp = _pack32_cols(lib, w32, K, dtype)
+    x = torch.randn(S * N, K, device="cuda").to(td)
+    outs = []
+    for lean in (0, 1):
+        q = torch.zeros(S, H, npad * dp, device="cuda").to(td)
+        k = torch.zeros_like(q)
+        vt = torch.zeros_like(q)
+        a = L.QkvArgs()
+        a.x16, a.ldx, a.wqkv, a.ldw = L.ptr(x), K, L.ptr(w16), ld
+        a.q, a.k, a.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
+        a.S, a.N, a.H, a.dp, a.npad, a.K, a.dtype = S, N, H, dp, npad, K, DT[dtype]
+        a.wqkv_p32 = L.ptr(wp) if lean else None
+        L.check(lib.vog_qkv_proj(C.byref(a), _sp()), "qkv")
+        torch.cuda.synchronize()
+        outs.append((q, k, vt))
+    for name, kind, t, r in zip("qkv", ("qk", "qk", "v"), outs[0], outs[1]):
+        d = (t.float() - r.float()).abs().max().item()
+        scale = max(1.0, t.float().abs().max().item())
+        assert d <= (2e-2 if dtype == "bf16" else 3e-3) * scale, (name, d)
+        msk = torch.ones(npad * dp, dtype=torch.bool, device="cuda")
+        msk[frag_index(N, dp, kind).reshape(-1).cuda()] = False
+        assert (r[:, :, msk] == 0).all(), name
+    # and against the dense product
+    full = (x.float() @ w16[:, :K].float().t()).view(S, N, 3, H, dp)
+    for which, (buf, kind) in enumerate(zip(outs[1], ("qk", "qk", "v"))):
+        got = from_frag(buf.float(), N, dp, kind)
+        ref = full[:, :, which].permute(0, 2, 1, 3)
+        assert (got - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item()), which
+
+
 def test_layernorm():
     lib = _lib()
     torch.manual_seed(1)

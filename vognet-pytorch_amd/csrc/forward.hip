@@ -56,6 +56,7 @@ struct TxLayer {
   unsigned short *wqkv, *wo, *w1, *w2;     // 16-bit, padded
   unsigned short* wqkv_lang_f;             // Wqkv[:, d_vis:] in fragment order (structured layer 0)
   unsigned short *wo_p, *w1_p, *w2_p;      // 32x16 fragment order (fused encoder tail, txtail.hip), or null
+  unsigned short *wqkv_p, *wqkv_pv;        // padded Wqkv in the same order (row-block QKV, qkvrb_dev.h): all d columns / the first d_vis
   float *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 struct TxWeights {
@@ -98,6 +99,9 @@ struct vog_ctx {
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
+  int qkv_lean = 0;                     // 1: row-block QKV projections (qkvrb_dev.h) where the shape allows: ~1/3 of the
+                                        // busy-CU time of the tiled GEMM at twice its latency; measured neutral at cfg 2
+                                        // (47.9 k vs 49.1 k queries/s with 4 forwards in flight), so off by default
   int enc_lean = -1;                    // -1: lean form exactly when the encoders share a BiLSTM layer's launch
   int pair_launches = 1;                // step i of the language chain shares a launch with step i of the visual chain (pair.hip)
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
@@ -196,6 +200,20 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
     }
     VOG_TRY(upload<unsigned short>(c, wqkv, &L.wqkv));
     L.wqkv_lang_f = nullptr;
+    L.wqkv_p = L.wqkv_pv = nullptr;
+    {
+      std::vector<float> wqf((size_t)3 * H * dp * d, 0.f);
+      for (int which = 0; which < 3; ++which) {
+        const auto& w = W(c, p + ".selfattn.layer." + nm[which] + ".weight");
+        for (int h = 0; h < H; ++h)
+          for (int dd = 0; dd < tw->head_dim[h]; ++dd)
+            memcpy(&wqf[((size_t)(which * H + h) * dp + dd) * d], &w[(size_t)(tw->head_off[h] + dd) * d], d * sizeof(float));
+      }
+      if (vog_qkv_rowblock_supported(3 * H * dp, d)) VOG_TRY(up_frag32(c, wqf.data(), d, 3 * H * dp, d, dt, &L.wqkv_p));
+      const int dv = d - c->d.lang_enc;
+      if (l == 0 && std::string(prefix) == "mult_txf" && dv > 0 && vog_qkv_rowblock_supported(3 * H * dp, dv))
+        VOG_TRY(up_frag32(c, wqf.data(), d, 3 * H * dp, dv, dt, &L.wqkv_pv));
+    }
     {
       const int dl = c->d.lang_enc, dv = d - dl;
       if (l == 0 && std::string(prefix) == "mult_txf" && dv > 0 && dl % 32 == 0) {
@@ -399,6 +417,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     qa.x16 = cur16; qa.ldx = tw.d; qa.wqkv = L.wqkv; qa.ldw = tw.d;
     qa.q = ws.at<void>(n + "_q"); qa.k = ws.at<void>(n + "_k"); qa.vt = ws.at<void>(n + "_vt");
     qa.S = S; qa.N = N; qa.H = tw.H; qa.dp = tw.dp; qa.npad = npad; qa.K = tw.d; qa.dtype = dt;
+    qa.wqkv_p32 = c->qkv_lean ? L.wqkv_p : nullptr;
     const bool fact = structured && l == 0;
     if (fact) {
       // layer 0 of mul_tx: tokens are [vis[p] || lang[a]] -> project the two parts once each
@@ -410,6 +429,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       const float* plang = ws.at<float>(n + "_pl");
       const int npad_kv = (int)round_up64(sv.nppf, 32);
       qs.N = sv.nppf; qs.npad = npad_kv;
+      qs.wqkv_p32 = c->qkv_lean ? L.wqkv_pv : nullptr;
       steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_qkv_proj(&qs, st); }});
       vog_attn_struct_args sa{};
       sa.q_visual = 1;
@@ -707,7 +727,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       ve.prop_enc = d.prop_enc; ve.seg_enc = d.seg_enc; ve.dtype = et;
       const bool will_pair = c->pair_launches && !c->graph_dag && !shared && c->lstm_persistent &&
                              vog_bilstm_layer_supported(Bn, R) && allow_pairs;
-      ve.lean = c->enc_lean < 0 ? (will_pair ? 1 : 0) : c->enc_lean;
+      // lean form (64-row x 128-column workgroups, every fp32 row read once per column half): when the
+      // encoders share the launch of a BiLSTM layer (busy-CU time matters, latency is hidden), and for
+      // the p100 shapes where the wide form's 8 column slices per row tile re-stream the features
+      ve.lean = c->enc_lean < 0 ? ((will_pair || Mp >= 4096) ? 1 : 0) : c->enc_lean;
       steps.push_back({"vis_enc", [=](hipStream_t st) { return vog_vis_encode(&ve, st); }});
     }
     const bool can_split = !enc_fused && (d.prop_dim % 64) == 0 && (d.seg_dim % 64) == 0 && Mp > 64 && Ms > 64 &&
@@ -903,6 +926,7 @@ extern "C" int vog_ctx_create(const vog_model_desc* d, vog_ctx** out) {
   if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { if (atoi(e) > 4) c->lstm_persistent = 0; }
   if (const char* e = getenv("VOG_LSTM_PERSISTENT")) c->lstm_persistent = atoi(e) ? 1 : 0;
   if (const char* e = perf_env("VOG_FUSED_IH")) c->fused_ih = atoi(e);
+  if (const char* e = perf_env("VOG_QKV_LEAN")) c->qkv_lean = atoi(e);
   const int R = d->rnn_size, E = d->emb_dim, L = d->lang_enc;
   add_w(c, "lstm_encoder.embed_tokens.weight", (int64_t)(d->vocab_size + 1) * E);
   for (int l = 0; l < d->rnn_layers; ++l)
@@ -1306,6 +1330,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }
+  if (strcmp(name, "qkv_lean") == 0) { c->qkv_lean = value ? 1 : 0; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 

@@ -15,6 +15,7 @@
 // MFMA B-operand fragment order (8 consecutive k per lane): no transposes.
 #include <stdlib.h>
 #include "gemm_dev.h"
+#include "qkvrb_dev.h"
 #include "pair_ids.h"
 
 namespace vog {
@@ -188,6 +189,8 @@ int gemm_run(const vog_gemm_args* g, hipStream_t st) {
   return 0;
 }
 
+int qkv_rowblock_supported(int n_out, int K);
+
 int qkv_run(const vog_qkv_args* a, hipStream_t st) {
   VOG_CHECK_ARG(a && a->x16 && a->wqkv && a->q && a->k && a->vt);
   VOG_CHECK_ARG(a->K % 8 == 0 && a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->npad >= a->N && (a->npad % 32) == 0 && (a->dp % 32) == 0);
@@ -215,8 +218,35 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
     p.fdT_mul = d <= 1 ? 0u : (unsigned)((((1ull << 32) * ((1ull << sh) - (unsigned long long)d)) / (unsigned long long)d) + 1ull);
   }
   p.debug = gemm_debug_flags();
+  if (a->wqkv_p32) {
+    if (!qkv_rowblock_supported(p.N, p.K))
+      VOG_FAIL(-1, "row-block QKV: unsupported shape (K %% 128 == 0, 256 <= K <= 1024, (3*H*dp / 32) even)");
+    p.w_p32 = (const unsigned short*)a->wqkv_p32;
+    static const int narrow = perf_env("VOG_QKV_NARROW") ? atoi(perf_env("VOG_QKV_NARROW")) : 0;
+    const int nrb = ceil_div(p.M, 64);
+    const size_t lds = QkvRowBlockBody<F16, 2>::lds_bytes(p.K);
+#define VOG_QKVRB(NBWV)                                                                                        \
+    VOG_DISPATCH_DTYPE(a->dtype, {                                                                              \
+      auto kern = qkv_rowblock_kernel<T16, NBWV>;                                                               \
+      static bool attr_set = false;                                                                             \
+      if (!attr_set) {                                                                                          \
+        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        attr_set = true;                                                                                        \
+      }                                                                                                         \
+      const int per = ceil_div(nrb * ceil_div(p.N, QkvRowBlockBody<T16, NBWV>::WG_COLS), 8);                    \
+      ::vog::launch(kern, dim3(per * 8), dim3(512), lds, st, p);                                                \
+    })
+    if (narrow) VOG_QKVRB(1); else VOG_QKVRB(2);
+#undef VOG_QKVRB
+    VOG_LAUNCH_CHECK();
+    return 0;
+  }
   VOG_DISPATCH_DTYPE(a->dtype, return (launch_tiled<T16, false, EPI_QKV>(p, st)));
   return 0;
+}
+
+int qkv_rowblock_supported(int n_out, int K) {
+  return (K % 128) == 0 && K >= 256 && K <= 1024 && (n_out % 64) == 0;
 }
 
 }  // namespace vog
@@ -247,6 +277,7 @@ extern "C" int vog_pack_w_frag(const float* w, int64_t ld, int N, int K, void* d
 extern "C" int vog_gemm_bias_act(const vog_gemm_args* g, void* stream) {
   return vog::gemm_run(g, (hipStream_t)stream);
 }
+extern "C" int vog_qkv_rowblock_supported(int n_out, int K) { return vog::qkv_rowblock_supported(n_out, K); }
 extern "C" int vog_qkv_proj(const vog_qkv_args* a, void* stream) {
   return vog::qkv_run(a, (hipStream_t)stream);
 }

@@ -18,6 +18,7 @@ static int gemm_debug_flags() {
 struct GemmParams {
   const void* a; const int32_t* a_rows; int64_t lda;
   const unsigned short* w; int64_t ldw;
+  const unsigned short* w_p32;         // row-block QKV (qkvrb_dev.h): weights in vog_pack_w_frag32 order
   const float* bias; const float* residual; int64_t ldr;
   float* c32; unsigned short* c16; int64_t ldc; int64_t ldc16;
   int M, N, K; int relu; int rep; int c16_bf16; int debug;
@@ -230,6 +231,130 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmParams p) {
     }
 }
 
+// QKV epilogue of one wave tile parked in LDS (ep[row][EP_LD], WTM rows x WTN columns, origin (mw, nw)):
+// writes the Q / K / V^T MFMA-fragment images the attention kernels read. Shared by the LDS-DMA GEMM
+// below and the row-block kernel of qkvrb_dev.h.
+template <typename T16, int WTM, int WTN>
+__device__ __forceinline__ void qkv_epilogue_tile(const GemmParams& p, const float* ep, int mw, int nw, int lane) {
+  constexpr int EP_LD = WTN + 4;
+  // QKV: handle the wave tile in 32-column groups; (which, head) is uniform per group
+  const int hd = p.H * p.dp;
+#pragma unroll
+  for (int cg = 0; cg < WTN / 32; ++cg) {
+    const int nb = __builtin_amdgcn_readfirstlane(nw + cg * 32);
+    if (nb >= p.N) continue;
+    const int which = nb / hd;
+    const int h = (nb - which * hd) / p.dp;
+    const int dd0 = nb % p.dp;
+    // (token count per sequence, padded count) of the plain fragment writers below
+    const bool kv_vis = p.pl && p.st_kv_vis && which >= 1;
+    const int ntok_w = kv_vis ? p.st_nppf : p.ntok, npad_w = kv_vis ? p.npad_kv : p.npad;
+    if (p.pl && !kv_vis) {
+      // structured layer 0: row m = visual row (v, f, p'); token(arg) = arg*nppf + p'
+      const int ldp = 3 * hd;
+      if (which < 2) {
+        // one lane = 8 consecutive head columns of one visual row = ONE 16-byte fragment chunk per
+        // argument (vs two 8-byte halves from adjacent lanes: same 13.9 us at cfg 2 - the epilogue's
+        // 8.5 us are the 18 MB of fan-out writes themselves, not their granularity)
+        unsigned short* base = which == 0 ? p.q : p.k;
+        const int c = lane & 3, rsub = lane >> 2;
+#pragma unroll 2
+        for (int ps = 0; ps < WTM / 16; ++ps) {
+          const int rl = ps * 16 + rsub;
+          const int m = mw + rl;
+          if (m >= p.M) continue;
+          const float4 v0 = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c]);
+          const float4 v1 = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c + 4]);
+          const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
+          const int vid = sq / p.st_nfrm;
+          const int lv = p.st_lpv ? vid : vid / p.st_ncv;
+          const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + 8 * c;
+          unsigned short* dst = base + ((int64_t)sq * p.H + h) * p.npad * p.dp;
+          for (int ar = 0; ar < p.st_nsrl; ++ar) {
+            const float4 l0 = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp);
+            const float4 l1 = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp + 4);
+            const u16x8 o = {to16<T16>(v0.x + l0.x), to16<T16>(v0.y + l0.y), to16<T16>(v0.z + l0.z), to16<T16>(v0.w + l0.w),
+                             to16<T16>(v1.x + l1.x), to16<T16>(v1.y + l1.y), to16<T16>(v1.z + l1.z), to16<T16>(v1.w + l1.w)};
+            *reinterpret_cast<u16x8*>(dst + frag_qk(ar * p.st_nppf + pp, dd0 + 8 * c, p.dp)) = o;
+          }
+        }
+      } else if ((p.st_nppf & 3) == 0) {
+        // V fragments, vector form: an aligned group of 4 visual rows = 4 consecutive tokens of
+        // every argument = 4 consecutive j of one fragment lane -> one 8-byte store. Lanes run
+        // along dd: conflict-free LDS column reads, 16-byte-strided global stores.
+        const int dd = lane & 31, gsub = lane >> 5;
+        for (int rg = gsub; rg < WTM / 4; rg += 2) {
+          const int rl = rg * 4;
+          const int m = mw + rl;
+          if (m >= p.M) continue;                    // M % 4 == 0 here (nppf % 4 == 0)
+          const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
+          const int vid = sq / p.st_nfrm;
+          const int lv = p.st_lpv ? vid : vid / p.st_ncv;
+          const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + dd;
+          unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp;
+          float x[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = ep[(rl + e) * EP_LD + cg * 32 + dd];
+          for (int ar = 0; ar < p.st_nsrl; ++ar) {
+            const float l = plr[(int64_t)ar * ldp];
+            const u16x4 o = {to16<T16>(x[0] + l), to16<T16>(x[1] + l), to16<T16>(x[2] + l), to16<T16>(x[3] + l)};
+            *reinterpret_cast<u16x4*>(dst + frag_v(ar * p.st_nppf + pp, dd0 + dd, p.dp)) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
+          const int rl = th * 64 + lane;
+          const int m = mw + rl;
+          if (rl < WTM && m < p.M) {
+            const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
+            const int vid = sq / p.st_nfrm;
+            const int lv = p.st_lpv ? vid : vid / p.st_ncv;
+            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb;
+            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp;
+            for (int ar = 0; ar < p.st_nsrl; ++ar) {
+              unsigned short* d2 = dst + frag_v(ar * p.st_nppf + pp, dd0, p.dp);
+              const float* l = plr + (int64_t)ar * ldp;
+#pragma unroll 8
+              for (int dd = 0; dd < 32; ++dd)
+                d2[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd] + l[dd]);
+            }
+          }
+        }
+      }
+    } else if (which < 2) {
+      unsigned short* base = which == 0 ? p.q : p.k;
+      const int c = lane & 7, rsub = lane >> 3;     // 8 chunks of 4 columns per row, 8 rows per pass
+#pragma unroll 4
+      for (int ps = 0; ps < WTM / 8; ++ps) {
+        const int rl = ps * 8 + rsub;
+        const int m = mw + rl;
+        if (m >= p.M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
+        const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
+        const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
+        *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * npad_w * p.dp +
+                                  frag_qk(tok, dd0 + 4 * c, p.dp)) = o;
+      }
+    } else {
+      // V fragments: lane = token; 2-byte stores inside this token's fragment block
+#pragma unroll
+      for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
+        const int rl = th * 64 + lane;
+        const int m = mw + rl;
+        if (rl < WTM && m < p.M) {
+          const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
+          // dd0 % 32 == 0: the 32 columns of this group are one d-block of the V fragment
+          unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_v(tok, dd0, p.dp);
+#pragma unroll 8
+          for (int dd = 0; dd < 32; ++dd)
+            dst[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd]);
+        }
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------
 // pipelined kernel: K % 64 == 0, 16-bit A. Global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), STAGES-deep
@@ -421,122 +546,7 @@ struct GemmPipeBody {
       }
     }
   } else {
-    // QKV: handle the wave tile in 32-column groups; (which, head) is uniform per group
-    const int hd = p.H * p.dp;
-#pragma unroll
-    for (int cg = 0; cg < WTN / 32; ++cg) {
-      const int nb = __builtin_amdgcn_readfirstlane(nw + cg * 32);
-      if (nb >= p.N) continue;
-      const int which = nb / hd;
-      const int h = (nb - which * hd) / p.dp;
-      const int dd0 = nb % p.dp;
-      // (token count per sequence, padded count) of the plain fragment writers below
-      const bool kv_vis = p.pl && p.st_kv_vis && which >= 1;
-      const int ntok_w = kv_vis ? p.st_nppf : p.ntok, npad_w = kv_vis ? p.npad_kv : p.npad;
-      if (p.pl && !kv_vis) {
-        // structured layer 0: row m = visual row (v, f, p'); token(arg) = arg*nppf + p'
-        const int ldp = 3 * hd;
-        if (which < 2) {
-          // one lane = 8 consecutive head columns of one visual row = ONE 16-byte fragment chunk per
-          // argument (vs two 8-byte halves from adjacent lanes: same 13.9 us at cfg 2 - the epilogue's
-          // 8.5 us are the 18 MB of fan-out writes themselves, not their granularity)
-          unsigned short* base = which == 0 ? p.q : p.k;
-          const int c = lane & 3, rsub = lane >> 2;
-#pragma unroll 2
-          for (int ps = 0; ps < WTM / 16; ++ps) {
-            const int rl = ps * 16 + rsub;
-            const int m = mw + rl;
-            if (m >= p.M) continue;
-            const float4 v0 = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c]);
-            const float4 v1 = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c + 4]);
-            const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
-            const int vid = sq / p.st_nfrm;
-            const int lv = p.st_lpv ? vid : vid / p.st_ncv;
-            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + 8 * c;
-            unsigned short* dst = base + ((int64_t)sq * p.H + h) * p.npad * p.dp;
-            for (int ar = 0; ar < p.st_nsrl; ++ar) {
-              const float4 l0 = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp);
-              const float4 l1 = *reinterpret_cast<const float4*>(plr + (int64_t)ar * ldp + 4);
-              const u16x8 o = {to16<T16>(v0.x + l0.x), to16<T16>(v0.y + l0.y), to16<T16>(v0.z + l0.z), to16<T16>(v0.w + l0.w),
-                               to16<T16>(v1.x + l1.x), to16<T16>(v1.y + l1.y), to16<T16>(v1.z + l1.z), to16<T16>(v1.w + l1.w)};
-              *reinterpret_cast<u16x8*>(dst + frag_qk(ar * p.st_nppf + pp, dd0 + 8 * c, p.dp)) = o;
-            }
-          }
-        } else if ((p.st_nppf & 3) == 0) {
-          // V fragments, vector form: an aligned group of 4 visual rows = 4 consecutive tokens of
-          // every argument = 4 consecutive j of one fragment lane -> one 8-byte store. Lanes run
-          // along dd: conflict-free LDS column reads, 16-byte-strided global stores.
-          const int dd = lane & 31, gsub = lane >> 5;
-          for (int rg = gsub; rg < WTM / 4; rg += 2) {
-            const int rl = rg * 4;
-            const int m = mw + rl;
-            if (m >= p.M) continue;                    // M % 4 == 0 here (nppf % 4 == 0)
-            const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
-            const int vid = sq / p.st_nfrm;
-            const int lv = p.st_lpv ? vid : vid / p.st_ncv;
-            const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb + dd;
-            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp;
-            float x[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = ep[(rl + e) * EP_LD + cg * 32 + dd];
-            for (int ar = 0; ar < p.st_nsrl; ++ar) {
-              const float l = plr[(int64_t)ar * ldp];
-              const u16x4 o = {to16<T16>(x[0] + l), to16<T16>(x[1] + l), to16<T16>(x[2] + l), to16<T16>(x[3] + l)};
-              *reinterpret_cast<u16x4*>(dst + frag_v(ar * p.st_nppf + pp, dd0 + dd, p.dp)) = o;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
-            const int rl = th * 64 + lane;
-            const int m = mw + rl;
-            if (rl < WTM && m < p.M) {
-              const int sq = m / p.st_nppf, pp = m - sq * p.st_nppf;
-              const int vid = sq / p.st_nfrm;
-              const int lv = p.st_lpv ? vid : vid / p.st_ncv;
-              const float* plr = p.pl + (int64_t)lv * p.st_nsrl * ldp + nb;
-              unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * p.npad * p.dp;
-              for (int ar = 0; ar < p.st_nsrl; ++ar) {
-                unsigned short* d2 = dst + frag_v(ar * p.st_nppf + pp, dd0, p.dp);
-                const float* l = plr + (int64_t)ar * ldp;
-#pragma unroll 8
-                for (int dd = 0; dd < 32; ++dd)
-                  d2[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd] + l[dd]);
-              }
-            }
-          }
-        }
-      } else if (which < 2) {
-        unsigned short* base = which == 0 ? p.q : p.k;
-        const int c = lane & 7, rsub = lane >> 3;     // 8 chunks of 4 columns per row, 8 rows per pass
-#pragma unroll 4
-        for (int ps = 0; ps < WTM / 8; ++ps) {
-          const int rl = ps * 8 + rsub;
-          const int m = mw + rl;
-          if (m >= p.M) continue;
-          const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
-          const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
-          const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
-          *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * npad_w * p.dp +
-                                    frag_qk(tok, dd0 + 4 * c, p.dp)) = o;
-        }
-      } else {
-        // V fragments: lane = token; 2-byte stores inside this token's fragment block
-#pragma unroll
-        for (int th = 0; th < WTM / 64 + (WTM % 64 ? 1 : 0); ++th) {
-          const int rl = th * 64 + lane;
-          const int m = mw + rl;
-          if (rl < WTM && m < p.M) {
-            const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
-            // dd0 % 32 == 0: the 32 columns of this group are one d-block of the V fragment
-            unsigned short* dst = p.vt + ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_v(tok, dd0, p.dp);
-#pragma unroll 8
-            for (int dd = 0; dd < 32; ++dd)
-              dst[dd * 8] = to16<T16>(ep[rl * EP_LD + cg * 32 + dd]);
-          }
-        }
-      }
-    }
+    qkv_epilogue_tile<T16, WTM, WTN>(p, ep, mw, nw, lane);
   }
 }
 };

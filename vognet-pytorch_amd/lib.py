@@ -56,7 +56,7 @@ class QkvArgs(C.Structure):
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
                 ("K", c_i32), ("dtype", c_i32),
                 ("pl", c_vp), ("nsrl", c_i32), ("nppf", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32),
-                ("nc_v", c_i32), ("kv_visual_only", c_i32), ("npad_kv", c_i32)]
+                ("nc_v", c_i32), ("kv_visual_only", c_i32), ("npad_kv", c_i32), ("wqkv_p32", c_vp)]
 
 
 class AttnStructArgs(C.Structure):
@@ -203,6 +203,7 @@ SYMBOLS = {
     "vog_assemble_batch": (c_i32, [C.POINTER(AssembleArgs), c_vp]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),
+    "vog_qkv_rowblock_supported": (c_i32, [c_i32, c_i32]),
     "vog_qkv_combine": (c_i32, [C.POINTER(QkvCombArgs), c_vp]),
     "vog_rel_attention_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
     "vog_rel_attention_struct_fwd": (c_i32, [C.POINTER(AttnStructArgs), c_vp]),
