@@ -160,6 +160,12 @@ typedef struct vog_attn_args {
   const float* u; const float* pe_b;
   int S, N, H, dp, npad; int use_rel; int n_box, seq_per_vid, NP;
   float inv_scale; vog_dtype dtype;
+  /* optional: 4 device bytes owned by the caller. With it, bf16 sequences of >= 1024 tokens and head
+   * dims <= 192 run attn_tile2_kernel (64 queries per wave, softmax against a fixed per-row reference
+   * overlapped with the MFMAs; csrc/attn_tile2_dev.h); the flag is cleared, raised by the kernel if a
+   * row left the safe range of that formulation, and a second (normally empty) launch of the
+   * running-maximum kernel redoes the call when it was raised. NULL: running-maximum kernel only. */
+  int* guard_flag;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
 

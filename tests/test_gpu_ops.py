@@ -244,6 +244,64 @@ def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
     assert (got[..., dh:] == 0).all()                           # padded head columns stay zero
 
 
+@pytest.mark.parametrize("S,N,H,dh,dp,nsrl,use_rel", [
+    (1, 2011, 3, 171, 192, 1, 1), (2, 1100, 3, 128, 128, 5, 1), (1, 4000, 1, 171, 192, 1, 1),
+    (3, 1024, 2, 64, 64, 1, 0), (2, 1057, 1, 32, 32, 1, 1)])
+@pytest.mark.parametrize("hostile", [0, 1])
+def test_rel_attention_long_fixed_reference(S, N, H, dh, dp, nsrl, use_rel, hostile):
+    """Long bf16 sequences with a guard flag -> attn_tile2_kernel (csrc/attn_tile2_dev.h): softmax against
+    the row maximum of key block 0. hostile = 1 plants keys far above anything in block 0 (logits +60
+    and more): the kernel must raise the flag and the running-maximum pass must produce the result."""
+    lib = _lib()
+    torch.manual_seed(S * 1000 + N + hostile)
+    td = torch.bfloat16
+    npad = (N + 31) // 32 * 32
+    q = torch.zeros(S, H, N, dp, device="cuda")
+    k = torch.zeros(S, H, N, dp, device="cuda")
+    v = torch.zeros(S, H, N, dp, device="cuda")
+    q[..., :dh] = torch.randn(S, H, N, dh, device="cuda") * 2
+    k[..., :dh] = torch.randn(S, H, N, dh, device="cuda") * 2
+    v[..., :dh] = torch.randn(S, H, N, dh, device="cuda")
+    inv_scale = 1.0 / math.sqrt(H * dh)
+    if hostile:
+        # a few late keys aligned with a few queries: q.k * inv_scale ~ +100 nats above block 0's logits
+        for j, i in ((N - 5, 3), (N // 2 + 1, 40), (700, N - 1)):
+            k[:, :, j, :dh] = q[:, :, i, :dh] * (100.0 / inv_scale) / (q[:, :, i, :dh] ** 2).sum(-1, keepdim=True)
+    q16, k16, v16 = q.to(td), k.to(td), v.to(td)
+    qf, kf, vf = to_frag(q16, "qk"), to_frag(k16, "qk"), to_frag(v16, "v")
+    n_box = N // nsrl
+    u_box = torch.randn(S, n_box, H, device="cuda") * 3
+    peb = torch.randn(H, device="cuda")
+    u_tok = u_box.repeat(1, nsrl, 1)
+    if N % nsrl:
+        u_tok = torch.cat([u_tok, u_box[:, : N - n_box * nsrl]], 1)
+    ref = _attn_ref(q16.float(), k16.float(), v16.float(), u_tok, peb, n_box, inv_scale, use_rel)
+    flag = torch.full((4,), 7, dtype=torch.int32, device="cuda")
+    outs = []
+    for guard in (None, flag):
+        out = torch.full((S * N, H * dp), float("nan"), device="cuda").to(td)
+        a = L.AttnArgs()
+        a.q, a.k, a.vt, a.out16 = L.ptr(qf), L.ptr(kf), L.ptr(vf), L.ptr(out)
+        a.u, a.pe_b = L.ptr(u_box.contiguous()), L.ptr(peb)
+        a.S, a.N, a.H, a.dp, a.npad = S, N, H, dp, npad
+        a.use_rel, a.n_box, a.seq_per_vid, a.NP = use_rel, n_box, 1, n_box
+        a.inv_scale, a.dtype = inv_scale, DT["bf16"]
+        a.guard_flag = L.ptr(guard) if guard is not None else None
+        L.check(lib.vog_rel_attention_fwd(C.byref(a), _sp()), "attn")
+        torch.cuda.synchronize()
+        got = out.float().view(S, N, H, dp).permute(0, 2, 1, 3)
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item()
+        tol = 2.5e-2 * max(1.0, ref.abs().max().item())
+        assert err <= tol, (guard is not None, err, tol)
+        assert (got[..., dh:] == 0).all()
+        outs.append(got)
+    assert int(flag[0].item()) == (1 if hostile else 0)          # raised exactly when the reference moved too far
+    assert (flag[1:] == 7).all()
+    if hostile:
+        assert torch.equal(outs[0], outs[1])                     # the fallback pass is the running-maximum kernel
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_qkv_layout(dtype):
     lib = _lib()

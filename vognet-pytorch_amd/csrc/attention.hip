@@ -27,7 +27,9 @@
 //     epilogue / vog_qkv_combine): every operand fragment is one contiguous KiB,
 //     loaded straight into registers (or, for attn_tile, into LDS by global_load_lds) with
 //     16-byte-per-lane coalesced accesses: no transposes, no swizzles.
+#include <type_traits>
 #include "attention_dev.h"
+#include "attn_tile2_dev.h"
 
 namespace vog {
 
@@ -70,6 +72,8 @@ int attn_struct_run(const vog_attn_struct_args* a, hipStream_t st) {
   return 0;
 }
 
+__global__ void attn_guard_clear_kernel(int* g) { if (threadIdx.x == 0) *g = 0; }
+
 template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   static int force_general = -2;      // VOG_ATTN_GENERAL=1: perf experiments only
@@ -92,6 +96,30 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
   // long sequences: enough 128-query groups to fill the chip -> shared K/V tiles through LDS
   static int tile_min = -2;           // VOG_ATTN_TILE_MIN (perf experiments): N threshold, 0 = never
   if (tile_min == -2) { const char* e = perf_env("VOG_ATTN_TILE_MIN"); tile_min = e ? atoi(e) : 512; }
+  // very long bf16 sequences: two waves per SIMD, fixed-reference softmax (attn_tile2_dev.h)
+  static int tile2_min = -2;          // VOG_ATTN_TILE2_MIN (perf experiments): N threshold, 0 = never
+  if (tile2_min == -2) { const char* e = perf_env("VOG_ATTN_TILE2_MIN"); tile2_min = e ? atoi(e) : 1024; }
+  bool fallback_pass = false;         // tile2 ran: attn_tile_kernel below runs only if the guard was raised
+  if constexpr (NDB <= 6 && std::is_same<T16, BF16>::value) {   // (head dim 256 would spill at 2 waves per SIMD)
+    constexpr int NF2 = (NDB * 32) / 16 + 2 * NDB;
+    const size_t lds2 = (size_t)4 * NF2 * 1024 + (size_t)p.npad * sizeof(float);
+    if (tile2_min > 0 && p.N >= tile2_min && p.guard && !force_general && lds2 <= 160 * 1024) {
+      auto kern = attn_tile2_kernel<T16, NDB>;
+      static bool attr_t2 = false;
+      if (!attr_t2) {
+        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_t2 = true;
+      }
+      ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: recorded by the AQL path too)
+      dim3 grid(ceil_div(p.N, 256) * p.H * p.S);
+      ::vog::launch(kern, grid, dim3(512), lds2, st, p);
+      VOG_LAUNCH_CHECK();
+      fallback_pass = true;
+    }
+  }
+  AttnParams pt = p;
+  if (!fallback_pass) pt.guard = nullptr;
   if (tile_min > 0 && p.N >= tile_min && !force_general) {
     constexpr int NF = (NDB * 32) / 16 + 2 * NDB;
     const size_t lds = (size_t)2 * NF * 1024 + (size_t)p.npad * sizeof(float);
@@ -104,7 +132,7 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
       attr_tile = true;
     }
     dim3 grid(ceil_div(p.N, 128) * p.H * p.S);
-    ::vog::launch(kern, grid, dim3(256), lds, st, p);
+    ::vog::launch(kern, grid, dim3(256), lds, st, pt);
     VOG_LAUNCH_CHECK();
     return 0;
   }
@@ -151,6 +179,7 @@ int attn_run(const vog_attn_args* a, hipStream_t st) {
   p.u = a->u; p.pe_b = a->pe_b;
   p.S = a->S; p.N = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad; p.use_rel = a->use_rel;
   p.n_box = a->n_box; p.seq_per_vid = a->seq_per_vid; p.NP = a->NP; p.inv_scale = a->inv_scale;
+  p.guard = a->guard_flag;
   VOG_DISPATCH_DTYPE(a->dtype, return attn_dispatch<T16>(p, st));
   return 0;
 }

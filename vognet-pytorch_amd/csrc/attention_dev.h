@@ -11,6 +11,8 @@ struct AttnParams {
   const float* u; const float* pe_b;
   int S, N, H, dp, npad, use_rel, n_box, seq_per_vid, NP;
   float inv_scale;
+  int* guard;       // attn_tile2_kernel: set to 1 when its fixed-reference softmax left its safe range;
+                    // attn_tile_kernel: when non-null, run only if *guard != 0 (fallback pass)
 };
 
 template <typename T16, int NDB>
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char tsm[];
   unsigned char* kv = tsm;                           // [2][NF][1024]
   float* us = reinterpret_cast<float*>(tsm + 2 * NF * 1024);   // [npad] bias precursor of every key
+  if (p.guard && *reinterpret_cast<volatile const int*>(p.guard) == 0) return;   // fallback pass of attn_tile2_kernel: not needed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ql = lane & 31;

@@ -48,6 +48,34 @@ template <> __device__ __forceinline__ float from16<F16>(unsigned short v) {
   return (float)__builtin_bit_cast(_Float16, v);
 }
 
+// ---- LDS reads the compiler does not see -------------------------------------------
+// hipcc's waitcnt pass cannot tell which LDS bytes an in-flight LDS-DMA (global_load_lds) will write,
+// so it puts s_waitcnt vmcnt(0) in front of EVERY LDS load that follows one: a prefetch ring fed by
+// LDS-DMA degenerates into issue -> wait -> compute (measured: one full L2 round trip per key block /
+// K tile). Kernels that keep DMA in flight across LDS reads therefore read through these wrappers
+// (the asm hides the address space) and do the bookkeeping themselves: lds_wait<N>() before the first
+// use of a fragment (in/out operands tie the consumer to the wait).
+__device__ __forceinline__ u16x8 lds_read128(const void* p) {
+  u16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ u16x8 lds_read128(const void* p) {
+  u16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(uintptr_t)p), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ f32x4 lds_read_f4(const void* p) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p));
+  return v;
+}
+template <int N, typename A>
+__device__ __forceinline__ void lds_wait(A& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N, typename A, typename B>
+__device__ __forceinline__ void lds_wait(A& a, B& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
 // ---- MFMA wrappers (fp32 accumulate) ----------------------------------------------
 // 32x32x16: A lane l holds row (l&31), k = (l>>5)*8+j; B lane l holds col (l&31),
 // same k; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).

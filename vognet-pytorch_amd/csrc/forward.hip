@@ -351,6 +351,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
     const std::string n(nm);
     p.add(n + "_u", g.rows_obj * tw.H * 4);
+    p.add(n + "_guard", 256);                 // vog_attn_args.guard_flag (long-sequence attention)
     p.add(n + "_q", (int64_t)S * tw.H * tw.dp * npad * 2);      // fragment order, npad = N up to 32
     p.add(n + "_k", (int64_t)S * tw.H * tw.dp * npad * 2);
     p.add(n + "_vt", (int64_t)S * tw.H * tw.dp * npad * 2);
@@ -447,6 +448,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.u = u; aa.pe_b = tw.pe_b; aa.S = S; aa.N = N; aa.H = tw.H; aa.dp = tw.dp; aa.npad = npad;
     aa.use_rel = tw.use_rel; aa.n_box = n_box; aa.seq_per_vid = spv; aa.NP = g.NP;
     aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
+    aa.guard_flag = ws.at<int>(n + "_guard");
     if (!fact)
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
     const bool last = l == tw.n_layers - 1;

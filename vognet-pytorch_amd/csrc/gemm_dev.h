@@ -460,21 +460,25 @@ struct GemmPipeBody {
     if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
     const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
     if (p.debug & 2) continue;
+    // all fragments of the tile are requested before its first MFMA (the waits then step down with the
+    // arrivals): read-then-multiply per k-step exposed one LDS round trip per MFMA group
+    u16x8 fa[4][FM], fb[4][FN];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      u16x8 fa[FM], fb[FN];
       const int g = ks * 2 + hi;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
-        fa[i] = *reinterpret_cast<const u16x8*>(st + a_row[i] * 128 + ((g ^ ((a_row[i] >> 1) & 7)) << 4));
+        fa[ks][i] = *reinterpret_cast<const u16x8*>(st + a_row[i] * 128 + ((g ^ ((a_row[i] >> 1) & 7)) << 4));
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        fb[j] = *reinterpret_cast<const u16x8*>(st + b_row[j] * 128 + ((g ^ ((b_row[j] >> 1) & 7)) << 4));
+        fb[ks][j] = *reinterpret_cast<const u16x8*>(st + b_row[j] * 128 + ((g ^ ((b_row[j] >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma32<T16>(fb[j], fa[i], acc[i][j]);   // C^T: D[n][m]
-    }
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma32<T16>(fb[ks][j], fa[ks][i], acc[i][j]);   // C^T: D[n][m]
   }
   if (p.debug & 4) { if (acc[0][0][0] != 123.456f) return; }
   // ---- epilogue through LDS -------------------------------------------------------
