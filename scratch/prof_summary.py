@@ -35,12 +35,31 @@ for r in rows:
 ev = c.execute("select start, end, queue_id from kernels order by start").fetchall()
 queues = sorted({e[2] for e in ev})
 if len(queues) > 1:
-    pts = sorted([(s, 1) for s, _, _ in ev] + [(e, -1) for _, e, _ in ev])
-    hist, cur, last = {}, 0, pts[0][0]
-    for t, d in pts:
-        hist[cur] = hist.get(cur, 0) + (t - last)
-        cur += d
-        last = t
-    win = pts[-1][0] - pts[0][0]
+    def histogram(evs):
+        pts = sorted([(s, 1) for s, _, _ in evs] + [(e, -1) for _, e, _ in evs])
+        hist, cur, last = {}, 0, pts[0][0]
+        for t, d in pts:
+            hist[cur] = hist.get(cur, 0) + (t - last)
+            cur += d
+            last = t
+        return hist, pts[-1][0] - pts[0][0]
+    hist, win = histogram(ev)
     print(f"\nqueues {queues}; window {win/1e3:.1f} us; sum(durations)/window = {tot/win:.3f}")
-    print("kernels executing at once: " + ", ".join(f"{k}: {100*v/win:.1f}%" for k, v in sorted(hist.items())))
+    print("kernels executing at once (whole trace, incl. start-up, warm-up and the per-kernel timing passes): "
+          + ", ".join(f"{k}: {100*v/win:.1f}%" for k, v in sorted(hist.items())))
+    # the timed region: the densest contiguous stretch of dispatches (no gap longer than 1 ms), i.e.
+    # the K steps issued round-robin over the streams
+    best, lo = (0, 0, 0), 0
+    for i in range(1, len(ev) + 1):
+        if i == len(ev) or ev[i][0] - max(e[1] for e in ev[max(lo, i - 8):i]) > 1_000_000:
+            if i - lo > best[0]:
+                best = (i - lo, lo, i)
+            lo = i
+    _, a, b = best
+    core = ev[a:b]
+    k = len(core) // 10                      # drop the ramp at both ends
+    core = core[k:len(core) - k] if len(core) > 50 else core
+    hist, win = histogram(core)
+    dur = sum(e - s for s, e, _ in core)
+    print(f"steady state ({len(core)} dispatches, {win/1e3:.1f} us): sum(durations)/window = {dur/win:.3f}; kernels executing at once: "
+          + ", ".join(f"{k}: {100*v/win:.1f}%" for k, v in sorted(hist.items())))

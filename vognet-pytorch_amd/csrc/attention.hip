@@ -8,11 +8,14 @@
 // the Linear is affine in the box, so pe[i,j,h] = relu(u[i,h] - u[j,h] + b[h])
 // with u = W_pe . box — three VALU ops per (i,j), nothing stored.
 //
-// Four kernels share the math below and differ in how K / V reach the MFMA (csrc/attention_dev.h):
+// Five kernels share the math below and differ in how K / V reach the MFMA (csrc/attention_dev.h,
+// attn_tile2_dev.h):
 // attn_sb (N <= 128: one workgroup per (sequence, head), keys split over the 4 waves, global softmax
 // statistics exchanged through LDS before P.V), attn_frag (128 < N < 512: per-wave running softmax,
 // LDS tree merge), attn_tile (N >= 512: K / V^T blocks staged once per workgroup by LDS-DMA, double
-// buffered) and attn_struct / attn_struct1 (mul_tx layer 0: separable softmax over visual + language keys).
+// buffered), attn_tile2 (bf16, N >= 1024, head dim <= 192: two waves per SIMD, fixed-reference softmax
+// with a guard flag + attn_tile as the fallback pass) and attn_struct / attn_struct1 (mul_tx layer 0:
+// separable softmax over visual + language keys).
 // Common mapping (wave64, v_mfma_f32_32x32x16): a wave owns 32 queries;
 //   * "swapped" products so a query's softmax row lives in one lane:
 //       S^T[key][q] = K_blk . Q^T        (A = K fragment, B = Q fragment)

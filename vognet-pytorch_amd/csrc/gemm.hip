@@ -1,18 +1,23 @@
 // K2: C = act(A * W^T + bias) (+residual)  — the nn.Linear of the reference
 // (transformer_code.py:58-61,77-81,169-172; mdl_vog.py:182-188,202-207,224-230)
-// as MFMA kernels for gfx950. Two shapes of kernel:
+// as MFMA kernels for gfx950 (device code: gemm_dev.h, qkvrb_dev.h). Since the encoder-layer tails
+// (txtail.hip) and the feature encoders (visenc.hip) have their own fused kernels, what runs here in a
+// forward are the QKV projections and the M <= 64 language-path GEMMs:
 //
-//  * gemm_tiled:  BMxBNx64 LDS-staged tiles, 4 waves (2x2), v_mfma_f32_32x32x16
-//    with fp32 accumulators, register prefetch of the next K tile. Used when
-//    M is large (token matrices: 800..80000 rows).
-//  * gemm_skinny: M <= 64 (language path: B*T rows). Weight-streaming regime:
-//    one workgroup owns 16 output columns, its 4 waves split K, every wave
-//    keeps its slice of the W panel in registers (deep load queue, no LDS
-//    round trip for an operand that is read exactly once) and loops over the
-//    16-row tiles of A with v_mfma_f32_16x16x32; partial sums meet in LDS.
+//  * gemm_pipe:   BMxBNx64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16, operands by LDS-DMA
+//    (global_load_lds) through a 2-4 stage ring, one raw s_barrier per K tile, epilogue through LDS
+//    (plain rows, or the Q / K / V^T MFMA-fragment images the attention kernels read). K % 64 == 0.
+//  * qkv_rowblock (vog_qkv_args.wqkv_p32): 64 rows x 512 columns per workgroup, rows in LDS once,
+//    weights streamed once in fragment order (the tail kernel's machinery); optional.
+//  * gemm_skinny: M <= 64. Weight-streaming regime: one workgroup owns 16 output columns, its 4
+//    waves split K, weights and activations in fragment order go straight to registers (no LDS
+//    round trip for an operand that is read exactly once), v_mfma_f32_16x16x32, partial sums meet
+//    in LDS.
+//  * gemm_tiled:  register-staged fallback for shapes the DMA kernel does not take (K % 64 != 0,
+//    fp32 A operand with M > 64).
 //
-// Both read W as [N,K] row-major 16-bit (K contiguous), which is exactly the
-// MFMA B-operand fragment order (8 consecutive k per lane): no transposes.
+// W is [N,K] row-major 16-bit (K contiguous) = the MFMA B-operand fragment order (8 consecutive k
+// per lane), or pre-packed per 16x32 / 32x16 fragment (vog_pack_w_frag / vog_pack_w_frag32).
 #include <stdlib.h>
 #include "gemm_dev.h"
 #include "qkvrb_dev.h"

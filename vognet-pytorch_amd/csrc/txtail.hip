@@ -21,8 +21,8 @@
 //   * products are "swapped" (D[n][m] = W[n][:] . X[m][:]): a lane holds ONE row m and 4-column
 //     strips of n, so the LayerNorm statistics are in-register sums + one cross-half shuffle + one
 //     8-way LDS exchange, and the next stage's LDS operand is written with 8-byte stores.
-//   * the fp32 residual stream stays in registers (d = 512) or in a workgroup-private, thread-major
-//     scratch slab (d = 768: 96 more registers would not fit beside the accumulators).
+//   * the fp32 residual stream stays in registers for both widths (d = 512, 768): the residual is the
+//     initial accumulator of the Wo chain, x1 (+ b2) the initial accumulator of FFN2.
 // Bound: the workgroup streams 2.75 MB (mul_tx incl. lin2) / 1.05 MB (obj_tx) of weights through
 // one CU's L2 port (~64 B/clk) and issues 5376 / 1536 32x32x16 MFMAs: both ~18 us at cfg 2 -> the
 // kernel sits at the CU's own MFMA/ingest balance point; what it removes is six dependent launches,
