@@ -4,9 +4,11 @@ Same classes / ctor / `get_out_results_boxes` / record format as reference
 code/eval_vsrl_corr.py (Evaluator{SEP,TEMP,SPAT}: 24-33, 162-424), with the
 arg-max + box gather done by `vog_pred_head` on the GPU and the cross-rank
 gather done by one RCCL all-gather (dist.py) instead of pickle files.
-The validation loss comes from the device loss (`mdl_conc.LossB_*` -> `vog_loss_fwd`). Metrics
-(`GroundEval_*`, code/eval_fn_corr.py) need the dataset annotations: attach one
-via `self.grnd_eval`; the pickle written here is in the format they read.
+The validation loss comes from the device loss (`mdl_conc.LossB_*` -> `vog_loss_fwd`). Metrics: when the
+annotation files of `cfg.ds` (`val_ds4_inds`, `anet_ent_annot_file`) exist, `after_init` builds the
+`GroundEval_*` of the concatenation type (eval_fn_corr.py in this package, pinned against the reference's)
+as the reference's `after_init` does (eval_vsrl_corr.py:154-158, 277-283, 349-351) and rank 0 scores the
+merged pickle at the end of `forward`; without the files `val_acc` is zeros.
 """
 from __future__ import annotations
 
@@ -38,6 +40,17 @@ class Evaluator(torch.nn.Module):
     def after_init(self):
         self.met_keys = ["avg1", "avg1_cons", "avg1_vidf", "avg1_strict"]
         self.num_sampled_frm = self.num_frms
+        self.grnd_eval = self._make_grnd_eval()
+
+    def _make_grnd_eval(self):
+        import os
+        from . import eval_fn_corr as M
+        ds = self.cfg.ds
+        files = [getattr(ds, k, None) if not isinstance(ds, dict) else ds.get(k) for k in ("val_ds4_inds", "anet_ent_annot_file")]
+        if self.conc_type is None or not all(isinstance(f, str) and os.path.isfile(f) for f in files):
+            return None
+        cls = {"sep": M.GroundEval_SEP, "temp": M.GroundEval_TEMP, "spat": M.GroundEval_SPAT}[self.conc_type]
+        return cls(self.cfg, self.comm)
 
     # ---- device head -----------------------------------------------------------
     def _records(self, out, inp):
