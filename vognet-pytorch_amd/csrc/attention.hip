@@ -33,6 +33,7 @@
 #include <type_traits>
 #include "attention_dev.h"
 #include "attn_tile2_dev.h"
+#include "attn_struct_lds_dev.h"
 
 namespace vog {
 
@@ -43,6 +44,22 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
                                      : (size_t)p.npad_kv * sizeof(float);
   if (lds > 64 * 1024) VOG_FAIL(-1, "struct attention: %d visual keys exceed the LDS budget", p.nppf);
   dim3 grid(p.S * p.H * ((nqb + 3) / 4));
+  // several visual key blocks: K / V^T through an LDS ring shared by the workgroup (attn_struct_lds_dev.h)
+  static int lds_form = -2;           // VOG_ATTN_STRUCT_LDS=0 (perf experiments): per-wave L2 loads instead
+  if (lds_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_LDS"); lds_form = e ? atoi(e) : 1; }
+  constexpr int NF = (NDB * 32) / 16 + 2 * NDB;
+  const size_t lds_res = (size_t)4 * NF * 1024 + ((size_t)p.npad_kv + (size_t)p.nsrl * 3 * NDB * 32) * sizeof(float);
+  if (p.npad_kv > 32 && lds_form && lds_res <= 150 * 1024) {
+    auto kern = attn_struct_lds_kernel<T16, NDB>;
+    static bool attr_sl = false;
+    if (!attr_sl) {
+      VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_sl = true;
+    }
+    ::vog::launch(kern, grid, dim3(256), lds_res, st, p);
+    VOG_LAUNCH_CHECK();
+    return 0;
+  }
   if (p.npad_kv == 32) ::vog::launch((attn_struct1_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
   else ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
@@ -70,7 +87,8 @@ int attn_struct_run(const vog_attn_struct_args* a, hipStream_t st) {
   AttnStructParams p{(const unsigned short*)a->q, (const unsigned short*)a->kv, (const unsigned short*)a->vv, a->pl,
                      (unsigned short*)a->out16, a->u, a->pe_b, a->S, a->H, a->dp, a->nsrl, a->nppf, a->npad_q,
                      a->npad_kv, a->nfrm, a->lang_per_vid, a->nc_v, a->use_rel, a->seq_per_vid, a->NP, a->inv_scale,
-                     a->q_visual ? 1 : 0};
+                     a->q_visual ? 1 : 0, 0};
+  { static const int dbg = perf_env("VOG_ATTN_STRUCT_DEBUG") ? atoi(perf_env("VOG_ATTN_STRUCT_DEBUG")) : 0; p.dbg = dbg; }
   VOG_DISPATCH_DTYPE(a->dtype, return (attn_struct_dispatch<T16>(p, st)));
   return 0;
 }

@@ -537,6 +537,8 @@ struct AttnStructParams {
   unsigned short* out; const float* u; const float* pe_b;
   int S, H, dp, nsrl, nppf, npad_q, npad_kv, nfrm, lpv, ncv, use_rel, seq_per_vid, NP;
   float inv_scale; int q_visual;
+  int dbg;          // perf experiments only (VOG_ATTN_STRUCT_DEBUG; wrong results): 1 no output stores, 2 no language block,
+                    // 4 no visual key blocks
 };
 
 #ifdef VOG_TS_ATTN   // scratch/ts_attn.hip: wall-clock stamps (100 MHz) per wave
