@@ -232,6 +232,19 @@ typedef struct vog_tx_tail_args {
 int vog_tx_tail_supported(int d, int dh, int kwo);
 int64_t vog_tx_tail_scratch_bytes(int M, int d);
 int vog_tx_tail_fwd(const vog_tx_tail_args* a, void* stream);
+/* One whole (Rel)EncoderLayer.forward (transformer_code.py:189-203 = RelMultiHead :176-186 + the two
+ * ResidualBlocks :21-31 + FeedForward :73-81) as ONE entry - SURVEY.md 8(b)'s `vog_encoder_layer_fwd`:
+ * QKV projection -> RelAttention -> tail, three launches, nothing but Q/K/V^T fragments and the 16-bit
+ * attention rows in HBM between them. The three argument blocks are the ones of the stand-alone entries
+ * and must be consistent (qkv.q/k/vt = attn.q/k/vt, attn.out16 = tail.attn16, tail.M = qkv.S * qkv.N,
+ * tail.kwo = qkv.H * qkv.dp); the call checks that. */
+typedef struct vog_encoder_layer_args {
+  vog_qkv_args qkv;
+  vog_attn_args attn;
+  vog_tx_tail_args tail;
+} vog_encoder_layer_args;
+int vog_encoder_layer_fwd(const vog_encoder_layer_args* a, void* stream);
+
 /* host: fp32 [N, ld] (first K columns) -> 16-bit 32x16 fragment order, N*K halfwords:
  * [N/32][K/16][lane = ((k%16)/8)*32 + n%32][k%8]  (N % 32 == 0, K % 16 == 0). */
 int vog_pack_w_frag32(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);

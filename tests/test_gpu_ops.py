@@ -772,3 +772,90 @@ def test_vis_encode_fused(rows, nppf0, dtype, lean):
     err = (c32 - ref).abs().max().item()
     assert err <= 2e-3, err
     assert (c16.float() - ref).abs().max().item() <= 3e-2
+
+
+@pytest.mark.parametrize("S,N,H,d,use_rel", [(4, 200, 3, 512, 1), (6, 100, 3, 768, 1), (3, 67, 3, 512, 0)])
+def test_encoder_layer_fwd_matches_plain_torch_layer(S, N, H, d, use_rel):
+    """vog_encoder_layer_fwd (one call = QKV projection -> RelAttention -> Wo/LN/FFN/LN tail) against a
+    plain fp32 torch (Rel)EncoderLayer on the same 16-bit-rounded operands (transformer_code.py:128-203:
+    torch.chunk heads, scale sqrt(d_model), bias relu(u_i - u_j + b_h) added before the scaling)."""
+    lib = _lib()
+    torch.manual_seed(S * 7 + N)
+    dtype, T = "bf16", torch.bfloat16
+    heads = vo.chunk_sizes(d, H)
+    dp = (max(heads) + 31) // 32 * 32
+    npad = (N + 31) // 32 * 32
+    dh = d // 2
+    M = S * N
+    x = torch.randn(M, d, device="cuda")
+    x16 = x.to(T)
+    wq, wk, wv = (torch.randn(d, d) / math.sqrt(d) for _ in range(3))
+    wo = torch.randn(d, d) / math.sqrt(d)
+    w1 = torch.randn(dh, d) / math.sqrt(d)
+    w2 = torch.randn(d, dh) / math.sqrt(dh)
+    b1, b2 = torch.randn(dh, device="cuda") * 0.1, torch.randn(d, device="cuda") * 0.1
+    g1, be1 = 1 + 0.1 * torch.randn(d, device="cuda"), 0.1 * torch.randn(d, device="cuda")
+    g2, be2 = 1 + 0.1 * torch.randn(d, device="cuda"), 0.1 * torch.randn(d, device="cuda")
+    # padded weights (heads padded to dp with zero rows / columns)
+    wqkv_pad = torch.zeros(3 * H * dp, d)
+    wo_pad = torch.zeros(d, H * dp)
+    off = 0
+    for h, hd_ in enumerate(heads):
+        for which, w in enumerate((wq, wk, wv)):
+            wqkv_pad[(which * H + h) * dp:(which * H + h) * dp + hd_] = w[off:off + hd_]
+        wo_pad[:, h * dp:h * dp + hd_] = wo[:, off:off + hd_]
+        off += hd_
+    wqkv16 = wqkv_pad.cuda().to(T)
+    u_box = torch.randn(S, N, H, device="cuda") * 2
+    peb = torch.randn(H, device="cuda")
+    q = torch.zeros(S, H, npad * dp, device="cuda").to(T)
+    k, vt = torch.zeros_like(q), torch.zeros_like(q)
+    attn16 = torch.zeros(M, H * dp, device="cuda").to(T)
+    y32 = torch.full((M, d), float("nan"), device="cuda")
+    flag = torch.zeros(4, dtype=torch.int32, device="cuda")
+    wo_p, w1_p, w2_p = _pack32(wo_pad, dtype), _pack32(w1, dtype), _pack32(w2, dtype)
+    a = L.EncoderLayerArgs()
+    a.qkv.x16, a.qkv.ldx, a.qkv.wqkv, a.qkv.ldw = L.ptr(x16), d, L.ptr(wqkv16), d
+    a.qkv.q, a.qkv.k, a.qkv.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
+    a.qkv.S, a.qkv.N, a.qkv.H, a.qkv.dp, a.qkv.npad, a.qkv.K, a.qkv.dtype = S, N, H, dp, npad, d, DT[dtype]
+    a.attn.q, a.attn.k, a.attn.vt, a.attn.out16 = L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(attn16)
+    a.attn.u, a.attn.pe_b = L.ptr(u_box), L.ptr(peb)
+    a.attn.S, a.attn.N, a.attn.H, a.attn.dp, a.attn.npad = S, N, H, dp, npad
+    a.attn.use_rel, a.attn.n_box, a.attn.seq_per_vid, a.attn.NP = use_rel, N, 1, N
+    a.attn.inv_scale, a.attn.dtype, a.attn.guard_flag = 1.0 / math.sqrt(d), DT[dtype], L.ptr(flag)
+    a.tail.attn16, a.tail.kwo = L.ptr(attn16), H * dp
+    a.tail.wo_p, a.tail.w1_p, a.tail.w2_p = L.ptr(wo_p), L.ptr(w1_p), L.ptr(w2_p)
+    a.tail.residual, a.tail.ldr = L.ptr(x), d
+    a.tail.ln1g, a.tail.ln1b, a.tail.b1, a.tail.b2, a.tail.ln2g, a.tail.ln2b = (
+        L.ptr(g1), L.ptr(be1), L.ptr(b1), L.ptr(b2), L.ptr(g2), L.ptr(be2))
+    a.tail.y32, a.tail.y16_dtype, a.tail.head_dtype = L.ptr(y32), -1, L.VOG_F16
+    a.tail.M, a.tail.d, a.tail.dh, a.tail.dtype = M, d, dh, DT[dtype]
+    L.check(lib.vog_encoder_layer_fwd(C.byref(a), _sp()), "encoder layer")
+    torch.cuda.synchronize()
+    # plain torch layer on the operands the kernels see
+    r16 = lambda w: w.cuda().to(T).float()                                    # noqa: E731
+    xs = x16.float().view(S, N, d)
+    qh = (xs @ r16(wq).t()).to(T).float()
+    kh = (xs @ r16(wk).t()).to(T).float()
+    vh = (xs @ r16(wv).t()).to(T).float()
+    outs, off = [], 0
+    for h, hd_ in enumerate(heads):
+        logits = qh[..., off:off + hd_] @ kh[..., off:off + hd_].transpose(-1, -2)
+        if use_rel:
+            uh = u_box[..., h]
+            logits = logits + torch.relu(uh.unsqueeze(-1) - uh.unsqueeze(-2) + peb[h])
+        pa = torch.softmax(logits / math.sqrt(d), dim=-1)
+        outs.append(pa @ vh[..., off:off + hd_])
+        off += hd_
+    att = torch.cat(outs, -1).reshape(M, d).to(T).float()
+    x1 = _ln(att @ r16(wo).t() + x, g1, be1)
+    hid = torch.relu(x1.to(T).float() @ r16(w1).t() + b1).to(T).float()
+    y = _ln(x1 + hid @ r16(w2).t() + b2, g2, be2)
+    err = (y32 - y).abs().max().item()
+    print("encoder layer max abs err", err)
+    assert torch.isfinite(y32).all()
+    assert err <= 2.5e-2, err                       # P is rounded to bf16 inside the attention (LayerNorm outputs are O(1))
+    assert (y32 - y).abs().mean().item() <= 1.5e-3
+    # inconsistent argument blocks are refused
+    a.tail.M = M - 1
+    assert lib.vog_encoder_layer_fwd(C.byref(a), _sp()) != 0

@@ -134,6 +134,20 @@ extern "C" int vog_tx_tail_fwd(const vog_tx_tail_args* a, void* stream) {
   return vog::tx_tail_run(a, (hipStream_t)stream);
 }
 
+extern "C" int vog_encoder_layer_fwd(const vog_encoder_layer_args* a, void* stream) {
+  VOG_CHECK_ARG(a != nullptr);
+  VOG_CHECK_ARG(a->qkv.q == a->attn.q && a->qkv.k == a->attn.k && a->qkv.vt == a->attn.vt);
+  VOG_CHECK_ARG(a->attn.out16 == a->tail.attn16 && a->tail.M == a->qkv.S * a->qkv.N &&
+                a->tail.kwo == a->qkv.H * a->qkv.dp && a->attn.S == a->qkv.S && a->attn.N == a->qkv.N &&
+                a->attn.H == a->qkv.H && a->attn.dp == a->qkv.dp && a->attn.npad == a->qkv.npad &&
+                a->qkv.pl == nullptr);
+  int rc = vog_qkv_proj(&a->qkv, stream);
+  if (rc != 0) return rc;
+  rc = vog_rel_attention_fwd(&a->attn, stream);
+  if (rc != 0) return rc;
+  return vog_tx_tail_fwd(&a->tail, stream);
+}
+
 extern "C" int vog_pack_w_frag32(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype) {
   VOG_CHECK_ARG(w && dst_host && N > 0 && K > 0 && (N % 32) == 0 && (K % 16) == 0 && ld >= K);
   unsigned short* dst = (unsigned short*)dst_host;

@@ -122,6 +122,10 @@ class TxTailArgs(C.Structure):
         self.head_dtype = VOG_F16
 
 
+class EncoderLayerArgs(C.Structure):
+    _fields_ = [("qkv", QkvArgs), ("attn", AttnArgs), ("tail", TxTailArgs)]
+
+
 class VisencArgs(C.Structure):
     _fields_ = [("prop", c_vp), ("seg", c_vp), ("w_prop_f", c_vp), ("w_seg_f", c_vp), ("b_prop", c_vp),
                 ("b_seg", c_vp), ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("c16_dtype", c_i32),
@@ -196,6 +200,7 @@ SYMBOLS = {
     "vog_tx_tail_supported": (c_i32, [c_i32, c_i32, c_i32]),
     "vog_tx_tail_scratch_bytes": (c_i64, [c_i32, c_i32]),
     "vog_tx_tail_fwd": (c_i32, [C.POINTER(TxTailArgs), c_vp]),
+    "vog_encoder_layer_fwd": (c_i32, [C.POINTER(EncoderLayerArgs), c_vp]),
     "vog_vis_encode_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "vog_vis_encode": (c_i32, [C.POINTER(VisencArgs), c_vp]),
     "vog_loss_scratch_bytes": (c_i64, [C.POINTER(LossArgs)]),
