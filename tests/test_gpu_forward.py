@@ -310,6 +310,20 @@ def test_aql_program_equals_stream_forward(name, split):
             assert torch.equal(ref[k], s2.out[k]), (name, k, "unpaired")
 
 
+def test_aql_program_p100_long_sequence_kernels():
+    """The p100 forward through AQL packets: the long-sequence attention (guard clear + attn_tile2 + the
+    conditional running-maximum pass) and the LDS-ring separable attention are recorded like any other
+    kernel; outputs equal the stream forward bit for bit."""
+    name = "full/cfg4_vog_spat_p100_bs4"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    eng.aql_open(1)
+    (slot,) = _aql_outputs(eng, dev, False)
+    for k in ref:
+        assert torch.equal(ref[k], slot.out[k]), k
+
+
 def test_aql_interleaved_programs_and_queues():
     """Two forwards row-interleaved behind shared barrier packets on each of two queues at once."""
     name = "full/cfg2_vog_spat_gt5_bs4"
