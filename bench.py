@@ -246,7 +246,6 @@ def main():
                          "beside the strict per-batch figure")
     ap.add_argument("--no-split", action="store_true", help="aql: one kernel per row (no lang/vis row sharing)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--dag", action="store_true", help="capture the language chain as a parallel graph branch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=100)
     ap.add_argument("--throughput-only", action="store_true",
@@ -305,7 +304,7 @@ def main():
         if G == 1:
             for s_, b in enumerate(batches):
                 slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
-                                           graph=(not args.no_graph) and not aql, dag=args.dag,
+                                           graph=(not args.no_graph) and not aql, 
                                            pred_rec=recbuf[s_ * w["B"]:(s_ + 1) * w["B"]]))
             units = slots
         else:

@@ -536,10 +536,8 @@ typedef struct vog_graph vog_graph;
 int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
                       void* stream, vog_graph** out);
 int vog_graph_launch(vog_graph* g, void* stream);
-/* Integer options of a context. "graph_dag" (default 0): capture the language chain as a
- * parallel branch of the graph (forked beside the encoders + obj_tx, joined before mul_tx).
- * Measured on MI355X: lower single-batch latency (381 -> 332 us at cfg 2, step-launch LSTM) but
- * lower throughput with several batches in flight (18.2k vs 20.3k queries/s), so it is opt-in.
+/* Integer options of a context. ("graph_dag", the language chain as a parallel graph branch, was
+ * removed: lower throughput with batches in flight and unstable in the runtime; setting it to 1 fails.)
  * "lstm_persistent" (default 1; env VOG_LSTM_PERSISTENT presets it): use vog_bilstm_layer instead
  * of T step launches where vog_bilstm_layer_supported. Its co-residency limit (4 instances) is met
  * automatically on HIP streams (4 hardware queues execute at most 4 kernels at once); set it to 0

@@ -77,11 +77,8 @@ struct vog_ctx {
   std::map<std::string, std::vector<float>> host;
   std::vector<void*> allocs;
   bool finalized = false;
-  int graph_dag = 0;                    // capture the language chain as a parallel branch
   int lstm_persistent = 1;              // one launch per BiLSTM layer where supported (W_hh resident on chip; vog_hip.h)
   int fused_tail = 1;                   // Wo..LN2 (+ lin2 + score) of an encoder layer as one launch where supported
-  hipStream_t side = nullptr;           // language branch during graph capture
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // device weights
   float* emb = nullptr;
   unsigned short* emb16 = nullptr;                      // 16-bit copy: A operand when the LSTM input GEMM has M > 64
@@ -553,7 +550,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // the language and the visual prologue are independent: one launch for both (not when the language
   // chain is captured as its own graph branch, and not in the group forms, where they live in
   // different programs)
-  const bool fuse_prep = !shared && !lang_only && !c->graph_dag;
+  const bool fuse_prep = !shared && !lang_only;
   // one launch for both encoders + the concat, straight from the fp32 features (visenc.hip)
   const bool enc_fused = c->fused_enc && c->w_prop_f && c->w_seg_f && !lang_only;
   auto make_visprep = [&]() {
@@ -727,7 +724,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       ve.c32 = ps32; ve.c16 = ps16; ve.ldc = g.d_obj; ve.c16_dtype = d.tx_dtype;
       ve.n_prop_rows = Mp; ve.nppf0 = d.nppf0; ve.prop_dim = d.prop_dim; ve.seg_dim = d.seg_dim;
       ve.prop_enc = d.prop_enc; ve.seg_enc = d.seg_enc; ve.dtype = et;
-      const bool will_pair = c->pair_launches && !c->graph_dag && !shared && c->lstm_persistent &&
+      const bool will_pair = c->pair_launches && !shared && c->lstm_persistent &&
                              vog_bilstm_layer_supported(Bn, R) && allow_pairs;
       // lean form (64-row x 128-column workgroups, every fp32 row read once per column half): when the
       // encoders share the launch of a BiLSTM layer (busy-CU time matters, latency is hidden), and for
@@ -830,7 +827,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // ~46 us): step i of one shares a launch with step i of the other. The visual step moves up to the
   // language step's position (its own inputs are produced by earlier pairs); combinations without a
   // registered pair kernel fall back to two launches inside pair_launch.
-  if (allow_pairs && c->pair_launches && !c->graph_dag && !shared && c->lstm_persistent) {
+  if (allow_pairs && c->pair_launches && !shared && c->lstm_persistent) {
     auto find = [&](const char* nm, int occurrence) {
       for (size_t i = 0; i < steps.size(); ++i)
         if (steps[i].name == nm && steps[i].branch >= 0 && occurrence-- == 0) return (int)i;
@@ -1128,7 +1125,6 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
 
 extern "C" int vog_ctx_destroy(vog_ctx* c) {
   if (!c) return 0;
-  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
   return 0;
@@ -1256,37 +1252,16 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
   std::vector<Step> steps;
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
   hipStream_t st = (hipStream_t)stream;
-  if (!c->side) {
-    VOG_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    VOG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    VOG_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  }
-  // The graph is a DAG: the language chain (prep -> 2 x (input GEMM + T steps) -> projections)
-  // is captured on a side stream forked from `st` and joined before the first kernel that
-  // needs the argument vectors, so it runs beside the encoders + obj_tx instead of ahead of them.
+  // One linear chain. (A DAG form - the language chain captured as a parallel branch - was measured and
+  // removed: graph branches of 4 forwards in flight oversubscribe the 4 hardware queues, 33 k instead of
+  // 48 k queries/s, and replaying two such graphs on 2 streams crashed inside hipGraphLaunch on ROCm 7.2.
+  // Steps that can run side by side share a launch instead: csrc/pair.hip.)
   VOG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  hipError_t fe = hipEventRecord(c->ev_fork, st);
-  if (fe == hipSuccess) fe = hipStreamWaitEvent(c->side, c->ev_fork, 0);
-  bool joined = false;
-  if (fe != hipSuccess) rc = -(int)fe - 1000;
   for (auto& s : steps) {
+    if (s.branch < 0) continue;          // join marker (AQL row bookkeeping)
+    rc = s.fn(st);
     if (rc != 0) break;
-    if (s.branch < 0) {
-      if (!joined) {
-        fe = hipEventRecord(c->ev_join, c->side);
-        if (fe == hipSuccess) fe = hipStreamWaitEvent(st, c->ev_join, 0);
-        if (fe != hipSuccess) rc = -(int)fe - 1000;
-        joined = true;
-      }
-      continue;
-    }
-    rc = s.fn(c->graph_dag && s.branch == 1 && !joined ? c->side : st);
-  }
-  if (rc == 0 && !joined) {             // no join marker (cannot happen today): join at the end
-    fe = hipEventRecord(c->ev_join, c->side);
-    if (fe == hipSuccess) fe = hipStreamWaitEvent(st, c->ev_join, 0);
-    if (fe != hipSuccess) rc = -(int)fe - 1000;
   }
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(st, &g);
@@ -1325,7 +1300,10 @@ extern "C" int vog_group_graph_capture(vog_ctx* c, const vog_batch* lb, void* lw
 
 extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   VOG_CHECK_ARG(c && name);
-  if (strcmp(name, "graph_dag") == 0) { c->graph_dag = value ? 1 : 0; return 0; }
+  if (strcmp(name, "graph_dag") == 0) {
+    if (value) VOG_FAIL(-4, "graph_dag was removed (parallel graph branches: slower with batches in flight, unstable in the runtime)");
+    return 0;
+  }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }

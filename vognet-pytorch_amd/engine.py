@@ -201,11 +201,8 @@ class VogEngine:
 
     # ---- persistent slots (graph replay; what bench.py and the evaluator use) ----
     def make_slot(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
-                  with_pred: bool = True, graph: Optional[bool] = None, dag: bool = False,
+                  with_pred: bool = True, graph: Optional[bool] = None,
                   pred_rec: Optional[torch.Tensor] = None) -> "Slot":
-        """dag=True captures the language chain as a parallel graph branch (lower latency of a
-        single batch, lower throughput with several slots in flight)."""
-        L.check(self.lib.vog_ctx_set_int(self.ctx, b"graph_dag", int(dag)), "vog_ctx_set_int")
         return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph, pred_rec)
 
     def aql_open(self, n_queues: int = 1) -> None:
@@ -234,7 +231,7 @@ class VogEngine:
         return Group(self, inps, with_pred, graph, pred_rec)
 
     def set_option(self, name: str, value: int) -> None:
-        """Integer options of the context: 'graph_dag', 'lstm_persistent', 'fused_tail' (include/vog_hip.h)."""
+        """Integer options of the context: 'lstm_persistent', 'fused_tail', 'pair_launches', ... (include/vog_hip.h)."""
         L.check(self.lib.vog_ctx_set_int(self.ctx, name.encode(), int(value)), f"vog_ctx_set_int({name})")
 
     def time_kernel(self, slot: "Slot", name: str, iters: int = 50) -> float:
