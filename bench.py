@@ -260,7 +260,17 @@ def main():
     torch.cuda.set_device(local_rank)
     # VOG_BENCH_FORCE_DIST=1: run the N > 1 exchange path (RCCL all-gather per step) with one rank too
     use_dist = world > 1 or bool(os.environ.get("VOG_BENCH_FORCE_DIST"))
+    out = sys.stdout
     if use_dist:
+        # RCCL prints a version banner through C stdio (it surfaced AFTER the JSON line at exit): keep the
+        # process's stdout for the one JSON line, send everything else written to fd 1 to stderr
+        sys.stdout.flush()
+        out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        if "RANK" not in os.environ:                     # forced single-rank group: fill in the rendezvous
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", init_method="env://")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
@@ -409,7 +419,7 @@ def main():
         del slots4
     if args.throughput_only:
         if rank == 0:
-            print(f"{world * args.steps * w['B'] / dt:.1f} {dt / args.steps * 1e6:.2f}")
+            print(f"{world * args.steps * w['B'] / dt:.1f} {dt / args.steps * 1e6:.2f}", file=out, flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -581,7 +591,7 @@ def main():
             res["batch_assembly"] = {"error": str(e)}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(w, cfg, sd, batches[0])
-    print(json.dumps(res))
+    print(json.dumps(res), file=out, flush=True)
     if use_dist:
         dist.destroy_process_group()
 
