@@ -6,7 +6,7 @@ python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 for wl in cfg3 cfg4 cfg5; do timeout 300 python bench.py --workload $wl --no-cobatch-extra --no-cpu-baseline --steps 200 --warmup 20 > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 export TMPDIR=/tmp; cd /tmp
 for s in 4 1; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_s$s -o r -- python $R/bench.py --no-cpu-baseline --no-cobatch-extra --streams $s --steps 200 --warmup 20 --kernel-iters 20 > $O/kt_s$s.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_s$s -o r -- python $R/bench.py --throughput-only --streams $s --steps 400 --warmup 40 > $O/kt_s$s.log 2>&1
   db=$(find $O/kt_s$s -name "*.db" | head -1); [ -n "$db" ] && python $R/scratch/prof_summary.py $db > $O/kernel_stats_${s}streams.md 2>&1
 done
 for wl in cfg2 cfg4; do
@@ -19,6 +19,9 @@ for wl in cfg2 cfg4; do
 done
 cd $R
 rm -rf $O/pmc_*_f $O/pmc_*_w $O/pmc_*_sq $O/kt_s4 $O/kt_s1
+bash scratch/traffic_total.sh > $O/traffic_default_forward.txt 2>&1
+bash scratch/kt_forward.sh cfg4 6 0 > $O/kernel_times_cfg4.txt 2>&1
+bash scratch/prof_cu.sh 1 fin > $O/busy_cu_cfg2.txt 2>&1
 ls -la $O; head -c 600 $O/bench_cfg2.json; for wl in cfg3 cfg4 cfg5; do python - <<PY
 import json
 try:
