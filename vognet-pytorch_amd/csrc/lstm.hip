@@ -92,7 +92,7 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
       attr_set = true;                                                                                \
     }                                                                                                 \
     ::vog::launch(kern, grid, dim3(512),                                                              \
-                  fused ? vog::LstmLayerBody<T16, KS>::LDS_FUSED : vog::LstmLayerBody<T16, KS>::LDS, st, p); \
+                  fused ? vog::LstmLayerBody<T16, KS>::lds_fused(a->Bn * a->T) : vog::LstmLayerBody<T16, KS>::LDS, st, p); \
   })
   switch (a->R / 32) {
     case 1: VOG_LAUNCH_LAYER(1); break;

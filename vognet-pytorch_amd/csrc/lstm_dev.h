@@ -143,7 +143,8 @@ struct LstmLayerBody {
   // (256) of the layer input in fragment order ([<= 4 column tiles][8 k-steps][64 lanes][16 B]), double buffered
   static constexpr int GX_PITCH = 20;                      // floats per column (16 + 4: spreads the banks)
   static constexpr size_t LDS_HS = ((size_t)16 * HS_LD * 2 + 15) / 16 * 16;
-  static constexpr size_t LDS_FUSED = LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)2 * 4 * 8 * 1024;
+  static constexpr size_t LDS_FUSED = LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)2 * 4 * 8 * 1024;   // upper bound (4 column tiles)
+  static constexpr size_t lds_fused(int ncols) { return LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)2 * ((ncols + 15) / 16) * 8 * 1024; }
 
   static __device__ __forceinline__ void run(const LstmLayerParams& p, const BlockCtx& cx, unsigned char* smem) {
     unsigned short* hs = reinterpret_cast<unsigned short*>(smem);
@@ -178,7 +179,10 @@ struct LstmLayerBody {
       // chunk waited vmcnt(0), 4 us per chunk), double buffered; the weight fragments of the NEXT
       // chunk are in flight in a second register set. Two chunks = 80 KB per workgroup are always
       // outstanding; per chunk: one counted wait, barrier, 8 x nct MFMAs, barrier.
-      unsigned char* xbuf[2] = {xch, xch + 4 * 8 * 1024};
+      // (two images of nct x 8 KiB: the launcher sizes the LDS for the column tiles that exist, so that
+      // 38 KB of the CU stay free at cfg 2 - enough for a workgroup of the LDS-DMA GEMM to share the CU
+      // with this one, which spends most of its life waiting for hand-offs)
+      unsigned char* xbuf[2] = {xch, xch + nct * 8 * 1024};
       auto load_w = [&](u16x8 (&wq)[8], int c) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) wq[ks] = wsrc[(c * 8 + ks) * 64];
@@ -190,7 +194,8 @@ struct LstmLayerBody {
           const int ct = piece >> 3, r = ((piece & 7) << 6) + lane;       // 8 pieces per (column tile, chunk)
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)(xsrc + ((int64_t)(ct < nct ? ct : 0) * ksteps + c * 8) * 64 + r),
-              (__attribute__((address_space(3))) void*)(xbuf[c & 1] + piece * 1024), 16, 0, 0);
+              // (tiles past nct re-write tile 0's piece with tile 0's data: no LDS of their own)
+              (__attribute__((address_space(3))) void*)(xbuf[c & 1] + (ct < nct ? piece : (piece & 7)) * 1024), 16, 0, 0);
         }
       };
       auto mfmas = [&](const u16x8 (&wq)[8], int c) {
