@@ -493,18 +493,32 @@ def main():
     if lstm_us and lstm_us[0] == "lstm_layer" and 2 * lstm_us[1] > ktimes[mfma_dom]:
         # persistent layer kernel: W_hh is read ONCE per launch and kept in registers for all T steps
         nbytes = lstm_step_bytes(w, T) + (T - 1) * (lstm_step_bytes(w, T) - 2 * 4 * 1024 * 1024 * 2)
-        ach_b = nbytes / (lstm_us[1] * 1e-6) / 1e9
+        us_launch = lstm_us[1]
+        fused_ih = not ktimes.get("lstm_ih0") and ktimes.get("lstm_layer#0") and ktimes.get("lstm_layer#1")
+        if fused_ih:
+            # the layer kernel also computes x W_ih^T + b in its prologue (no separate GEMM launch): W_ih is
+            # read once per launch too - 2 dirs x 4R x K 16-bit, K = 512 (embedding) for layer 0, 2R for
+            # layer 1 - plus the 16-bit layer input; figures are the average of the two launches
+            R, E = 1024, 512
+            Bn = w["B"] * ((1 if w["conc"] == "svsq" else 4) if w["conc"] in ("sep", "svsq") else 1)
+            wih = [2 * 4 * R * E * 2, 2 * 4 * R * 2 * R * 2]
+            xin = [Bn * T * E * 2, Bn * T * 2 * R * 2]
+            nbytes = nbytes + (sum(wih) + sum(xin)) // 2
+            us_launch = 0.5 * (ktimes["lstm_layer#0"] + ktimes["lstm_layer#1"])
+        ach_b = nbytes / (us_launch * 1e-6) / 1e9
         res["roofline"] = {"bound": "hbm", "kernel": "lstm_layer", "achieved": ach_b, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
                            "traffic": (pmc.get("kernels", {}).get("lstm_layer") or {}).get("bytes_per_launch"),
-                           "usec_per_launch": lstm_us[1], "bytes_per_launch": nbytes, "launches_per_forward": 2,
-                           "share_of_forward_kernel_time": 2 * lstm_us[1] / max(1e-9, sum(
+                           "usec_per_launch": us_launch, "bytes_per_launch": nbytes, "launches_per_forward": 2,
+                           "input_projection_in_kernel": bool(fused_ih),
+                           "share_of_forward_kernel_time": 2 * us_launch / max(1e-9, sum(
                                ktimes[k] for k in ("prep", "lstm_ih0", "lstm_layer#0", "lstm_ih1", "lstm_layer#1",
                                                    "lstm_outproj", "argvec", "mul_pl", "vis_enc", "obj_qkv", "obj_attn",
                                                    "obj_tail", "mul_pv", "mul_attn", "mul_tail", "pred_head")
                                if ktimes.get(k))),
-                           "usec_per_step": lstm_us[1] / T,
-                           "note": "latency bound by design, not bandwidth bound: T dependent steps per launch, each "
+                           "usec_per_step": (ktimes.get("lstm_layer#0") or lstm_us[1]) / T if not fused_ih else None,
+                           "note": "(bytes: W_hh + W_ih + layer input + gates / state, each read once per launch) "
+                                   "latency bound by design, not bandwidth bound: T dependent steps per launch, each "
                                    "one fabric round trip (self-validating tagged h words of all 32 workgroups of a "
                                    "direction, the guide's allgather primitive: 2.4-3.0 us for 8 KB from 32 CUs) + LDS "
                                    "+ 32 MFMAs per wave + gates; W_hh is read once and stays in registers (64 CUs). "
