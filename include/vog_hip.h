@@ -457,8 +457,12 @@ int vog_assemble_batch(const vog_assemble_args* a, void* stream);
  *   pad_pnt_mask [B,(ncmp,)NP] bytes (nonzero = the IoU counts); srl_boxes / srl_boxes_lens
  *   [B,nv,nsrl,nbox], srl_arg_boxes_mask [B,nv,nsrl], target_cmp [B], num_cmp_msk [B,ncmp],
  *   verb_cmp [B,ncmp], verb_cross_cmp_msk [B,ncmp,ncmp] int64.
- *   out: 3 floats = loss, mdl_out_loss, verb_loss (0 unless sep). scratch: vog_loss_scratch_bytes().
- * Deterministic (fixed-order reduction, no atomics). */
+ *   out: 6 floats = loss, mdl_out_loss, verb_loss (0 unless sep), number of elements in the mean, 1 if the
+ *   mean is the masked one (0: no argument has boxes -> plain mean), rows in the verb-loss mean.
+ *   scratch: vog_loss_scratch_bytes(). Deterministic (fixed-order reduction, no atomics).
+ * vog_loss_bwd: d loss / d mdl_outs [same shape] = (sigmoid(x) - target) [* video mask for sep] * NP * lambda / n
+ *   for the elements in the mean, 0 elsewhere, and (optional, sep) d verb_loss / d vidf_outs [B, ncmp]; call after
+ *   vog_loss_fwd with the same args (it reads out[3..5]). First link of the training path. */
 typedef struct vog_loss_args {
   const float* mdl_outs; const float* vidf_outs;
   const float* pad_proposals; const float* pad_gt_bboxs;
@@ -470,6 +474,7 @@ typedef struct vog_loss_args {
 } vog_loss_args;
 int64_t vog_loss_scratch_bytes(const vog_loss_args* a);
 int vog_loss_fwd(const vog_loss_args* a, void* stream);
+int vog_loss_bwd(const vog_loss_args* a, float* grad_mdl_outs, float* grad_vidf_outs, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)

@@ -55,6 +55,43 @@ def reference_loss(cfg, c, out, full_batch):
         torch.masked_select = orig
 
 
+def grad_path(name: str) -> str:
+    return os.path.join(os.path.dirname(cases.golden_path(name)), "lossgrad__" + name.replace("/", "__") + ".npz")
+
+
+def reference_loss_grad(cfg, c, out, full_batch):
+    """autograd through the reference loss: d loss / d mdl_outs and (sep) d verb_loss / d vidf_outs."""
+    ref_import.install_stubs()
+    import mdl_conc_single as mcs  # noqa: reference modules
+    import mdl_conc_sep as mcp
+    ct = cfg.ds.conc_type
+    cls = {"temp": mcs.LossB_TEMP, "spat": mcs.LossB_SPAT, "sep": mcp.LossB_SEP, "svsq": mcp.LossB_SEP}[ct]
+    lf = cls(ref_import.ref_cfg(cfg), ref_import.Munch(num_prop_per_frm=c["nppf0"]))
+    inp = {k: torch.from_numpy(v).clone() for k, v in full_batch.items()}
+    for k in ("pad_frm_mask", "pad_pnt_mask"):
+        inp[k] = inp[k].to(torch.uint8)
+    out = {k: v.clone().requires_grad_(k in ("mdl_outs", "vidf_outs")) for k, v in out.items()}
+    orig = torch.masked_select
+    torch.masked_select = lambda x, m, *a, **k: orig(x, m.bool() if m.dtype == torch.uint8 else m, *a, **k)
+    try:
+        res = lf(out, inp)
+        g = {"grad_mdl_outs": torch.autograd.grad(res["loss"], out["mdl_outs"], retain_graph=True)[0]}
+        if "verb_loss" in res and "vidf_outs" in out:
+            g["grad_vidf_outs"] = torch.autograd.grad(res["verb_loss"], out["vidf_outs"])[0]
+        return {k: v.detach().numpy().astype(np.float32) for k, v in g.items()}
+    finally:
+        torch.masked_select = orig
+
+
+def make_grad(name: str):
+    cfg, batch, c, tg = targets_for(name)
+    g = np.load(cases.golden_path(name))
+    out = {k: torch.from_numpy(g[k]) for k in ("mdl_outs", "vidf_outs") if k in g.files}
+    rec = reference_loss_grad(cfg, c, out, {**batch, **tg})
+    np.savez_compressed(grad_path(name), **rec)
+    print(f"{name:40s} grads", {k: (v.shape, float(np.abs(v).max())) for k, v in rec.items()})
+
+
 def make(name: str):
     cfg, batch, c, tg = targets_for(name)
     g = np.load(cases.golden_path(name))
@@ -71,3 +108,4 @@ if __name__ == "__main__":
         raise SystemExit("reference tree not present; goldens are generated in the build container")
     for n in LOSS_CASES:
         make(n)
+        make_grad(n)

@@ -236,6 +236,32 @@ def test_device_loss_vs_reference_golden(name):
     assert all(torch.equal(res[k], res2[k]) for k in loss_fn.loss_keys)
 
 
+@pytest.mark.parametrize("name", mgl.LOSS_CASES)
+def test_device_loss_gradient_vs_reference_autograd(name):
+    """LossB_*.backward (vog_loss_bwd): d loss / d mdl_outs - and d verb_loss / d vidf_outs for sep - against
+    torch autograd through the REFERENCE loss classes (oracle/make_golden_loss.py::make_grad), fed with the
+    reference's own forward outputs: <= 1e-6 abs (gradients are O(1e-2)), exactly 0 where the reference's is."""
+    cfg, batch, c, tg = mgl.targets_for(name)
+    sel = sel_mod.get_mdl_loss_eval(cfg)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    g = np.load(cases.golden_path(name))
+    gg = np.load(mgl.grad_path(name))
+    out = {k: torch.from_numpy(g[k]).cuda() for k in ("mdl_outs", "vidf_outs") if k in g.files}
+    inp = {k: torch.from_numpy(v).cuda() for k, v in {**batch, **tg}.items()}
+    res = loss_fn(out, inp)
+    sep = "grad_vidf_outs" in gg.files
+    got = loss_fn.backward(res, with_verb=sep)
+    torch.cuda.synchronize()
+    gm = (got[0] if sep else got).cpu().numpy()
+    ref = gg["grad_mdl_outs"]
+    assert gm.shape == ref.shape
+    assert np.abs(gm - ref).max() <= 1e-6 + 2e-5 * np.abs(ref).max(), np.abs(gm - ref).max()
+    assert np.all(gm[ref == 0] == 0)
+    if sep:
+        gv = got[1].cpu().numpy()
+        assert np.abs(gv - gg["grad_vidf_outs"]).max() <= 1e-6 + 2e-5 * np.abs(gg["grad_vidf_outs"]).max()
+
+
 @pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg3_vog_temp_gt5_bs8",
                                   "full/vog_sep_gt5_bs4_ragged"])
 def test_forward_then_loss_end_to_end(name):

@@ -205,6 +205,7 @@ SYMBOLS = {
     "vog_vis_encode": (c_i32, [C.POINTER(VisencArgs), c_vp]),
     "vog_loss_scratch_bytes": (c_i64, [C.POINTER(LossArgs)]),
     "vog_loss_fwd": (c_i32, [C.POINTER(LossArgs), c_vp]),
+    "vog_loss_bwd": (c_i32, [C.POINTER(LossArgs), c_vp, c_vp, c_vp]),
     "vog_assemble_batch": (c_i32, [C.POINTER(AssembleArgs), c_vp]),
     "vog_splitk_finish": (c_i32, [C.POINTER(SplitkProb), C.POINTER(SplitkProb), c_vp]),
     "vog_qkv_proj": (c_i32, [C.POINTER(QkvArgs), c_vp]),

@@ -44,7 +44,8 @@ class _LossB(nn.Module):
     the evaluator calls it for every validation batch, code/eval_vsrl_corr.py:119). The IoU targets
     (utils/box_utils.py:61-118), the target selection and the masked BCE run on the device in
     `vog_loss_fwd` (csrc/loss.hip); the returned values are 0-dim device tensors (no sync here).
-    Forward only: the training backward is SURVEY.md 8(f) rank 4."""
+    `backward(loss_dict)` returns d loss / d mdl_outs (`vog_loss_bwd`): the first link of the training path
+    (SURVEY.md 8(f) rank 4); nothing behind it (score head, transformers, BiLSTM) has a backward yet."""
     loss_keys = ["loss", "mdl_out_loss"]
     conc_types = ()
 
@@ -94,7 +95,7 @@ class _LossB(nn.Module):
         a.nbox, a.NP, a.G, a.nppf0 = inp["srl_boxes"].shape[3], NP, inp["pad_gt_bboxs"].shape[-2], self.nppf0
         a.conc_type, a.loss_lambda = L.CONC_TYPE[self.cfg.ds.conc_type], self.loss_lambda
         assert inp["pad_proposals"].shape[-2] == NP and inp["pad_gt_bboxs"].shape[-1] == 5
-        res = torch.empty(3, dtype=torch.float32, device=mo.device)
+        res = torch.empty(6, dtype=torch.float32, device=mo.device)
         scr = torch.empty(max(16, int(lib.vog_loss_scratch_bytes(C.byref(a)))), dtype=torch.uint8, device=mo.device)
         a.out, a.scratch = L.ptr(res), L.ptr(scr)
         L.check(lib.vog_loss_fwd(C.byref(a), L.stream_ptr()), "vog_loss_fwd")
@@ -102,7 +103,25 @@ class _LossB(nn.Module):
         if sep:
             d["verb_loss"] = res[2]
         d["_keepalive"] = (keep, scr)
+        d["_args"] = a
         return d
+
+    def backward(self, loss_dict, with_verb: bool = False):
+        """d loss / d mdl_outs (and, `with_verb`, d verb_loss / d vidf_outs) for the dict `forward` returned:
+        `vog_loss_bwd`, the first link of the training path (the reference gets it from autograd)."""
+        import ctypes as C
+        from . import lib as L
+        lib = L.load()
+        a = loss_dict["_args"]
+        mo = loss_dict["_keepalive"][0][0]
+        g = torch.empty_like(mo)
+        gv = None
+        if with_verb:
+            assert self.cfg.ds.conc_type in ("sep", "svsq")
+            gv = torch.empty((a.B, a.ncmp), dtype=torch.float32, device=mo.device)
+        L.check(lib.vog_loss_bwd(C.byref(a), L.ptr(g), L.ptr(gv) if gv is not None else None, L.stream_ptr()),
+                "vog_loss_bwd")
+        return (g, gv) if with_verb else g
 
 
 class LossB_TEMP(_LossB):
