@@ -25,8 +25,12 @@ constexpr int LS_CH = 8;      // k-steps per wave kept in registers per chunk
 __device__ unsigned long long g_ts[64][2048][4];
 __device__ int g_ts_launch;
 #define VOG_TS(slot) do { if (lane == 0) g_ts[p.step][(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid][slot] = wall_clock64(); } while (0)
+// persistent layer kernel: shader-clock stamps of wave 0 of every workgroup, [wg][step (T = kernel-level row)][slot]
+__device__ unsigned long long g_tsl[64][24][8];
+#define VOG_TSL(step, slot) do { if (tid == 0) g_tsl[cx.by * cx.gx + cx.bx][step][slot] = wall_clock64(); } while (0)
 #else
 #define VOG_TS(slot) do { } while (0)
+#define VOG_TSL(step, slot) do { } while (0)
 #endif
 
 template <typename T16>
@@ -158,6 +162,7 @@ struct LstmLayerBody {
     const int len = valid_b ? (int)p.lens[b] : 0;
 
     float c = 0.f, h_own = 0.f;
+    VOG_TSL(p.T, 0);
     // ---- fused input projection (replaces the separate x W_ih^T GEMM launch and its [2][T][Bn][4R]
     // fp32 round trip): every wave computes the gates of ITS 16 rows for all Bn*T (sentence, position)
     // columns: W_ih rows stream once through registers (K in chunks of 256), the layer input is
@@ -241,6 +246,7 @@ struct LstmLayerBody {
               make_float4(ga[ct][0] + bs[0], ga[ct][1] + bs[1], ga[ct][2] + bs[2], ga[ct][3] + bs[3]);
       // (gxl is wave-private: no barrier needed before this wave reads it back below)
     }
+    VOG_TSL(p.T, 1);
     // this wave's 16 rows of W_hh: registers for the whole sequence
     u16x8 wf[KSTEPS];
 #pragma unroll
@@ -255,6 +261,7 @@ struct LstmLayerBody {
     bool dead = false;
 
     for (int s = 0; s < p.T; ++s) {
+      VOG_TSL(s, 0);
       // input projections of this step (address-independent of everything else)
       float gin[4] = {0.f, 0.f, 0.f, 0.f};
       if (fused) {
@@ -311,7 +318,9 @@ struct LstmLayerBody {
           }
         }
       }
+      VOG_TSL(s, 1);
       dead = __syncthreads_or(dead ? 1 : 0) != 0;
+      VOG_TSL(s, 2);
       // two accumulation chains (even / odd k-steps): a dependent MFMA issues every ~2x its issue slot
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -324,6 +333,10 @@ struct LstmLayerBody {
         acc0 = mfma16<T16>(wf[ks], fh0, acc0);
         if (ks + 1 < KSTEPS) acc1 = mfma16<T16>(wf[ks + 1], fh1, acc1);
       }
+#ifdef VOG_TS_DEBUG
+      asm volatile("" :: "v"(acc0), "v"(acc1));
+#endif
+      VOG_TSL(s, 3);
       const bool active = s < len;
       const int pos = dir == 0 ? s : len - 1 - s;
       const int unit = tile0 * 4 + ul;
@@ -348,6 +361,7 @@ struct LstmLayerBody {
           __hip_atomic_store(dst + 1, tag | x2 | ((unsigned long long)x3 << 16), VOG_RLX_AGENT);
         }
       }
+      VOG_TSL(s, 4);
       if (s + 1 == p.T) break;                             // nothing reads h_T through hx
       __syncthreads();                                     // hs is rewritten at the top of the next step
     }

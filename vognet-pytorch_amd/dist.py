@@ -107,7 +107,8 @@ class RecordRing:
         n = self.per_half * self.rows
         self.ring = [torch.zeros(n, width, dtype=dtype, device=device) for _ in range(2)]
         self.gathered = [torch.empty(self.world * n, width, dtype=dtype, device=device) for _ in range(2)]
-        self.work = [None, None]
+        self.work = [None, None]                  # pending gather of a half: True (CPU, done) or a CUDA event
+        self.read_done = [None, None]             # CUDA event: the last gather that READ ring[h] has finished
         self.count = [0, 0]                       # batches staged in the half when it was sent
         self.half, self.n = 0, 0
         self.on_half = on_half
@@ -116,8 +117,12 @@ class RecordRing:
         self.gathers = 0
 
     def _settle(self, h: int):
+        """The gather of half h has to be complete before `on_half` reads `gathered[h]`: on CUDA the
+        CURRENT stream waits for the event recorded behind the gather on `gather_stream` (the
+        single-rank copy and the RCCL collective alike), so the reads `on_half` enqueues are ordered."""
         if self.work[h] is not None:
-            self.work[h].wait()
+            if self.cuda:
+                torch.cuda.current_stream().wait_event(self.work[h])
             self.work[h] = None
             if self.on_half is not None:
                 self.on_half(self.gathered[h], self.count[h])
@@ -128,10 +133,13 @@ class RecordRing:
         if n == 0:
             self._settle(h)                        # this half was sent a whole ring ago: never stalls in steady state
         dst = self.ring[h][n * self.rows:(n + 1) * self.rows]
-        if self.cuda and stream is not None:
-            with torch.cuda.stream(stream):
+        if self.cuda:
+            st = stream if stream is not None else torch.cuda.current_stream()
+            if self.read_done[h] is not None:      # the previous gather of this half may still be reading ring[h]
+                st.wait_event(self.read_done[h])
+            with torch.cuda.stream(st):
                 dst.copy_(rec, non_blocking=True)
-            self._streams.add(stream)
+            self._streams.add(st)
         else:
             dst.copy_(rec)
         self.n = n + 1
@@ -149,31 +157,37 @@ class RecordRing:
                     self.gather_stream.wait_event(ev)
                 self._streams = set()
                 with torch.cuda.stream(self.gather_stream):
-                    self.work[h] = self._gather(h)
+                    self._gather(h)
+                    done = torch.cuda.Event()
+                    done.record(self.gather_stream)
+                self.work[h] = done
+                self.read_done[h] = done
             else:
-                self.work[h] = self._gather(h)
+                self._gather(h)
+                self.work[h] = True
             self.gathers += 1
+        elif self.cuda:
+            self._streams = set()
         self.half, self.n = 1 - h, 0
 
     def _gather(self, h: int):
+        """Enqueued on `gather_stream` (CUDA) or run synchronously (CPU / gloo). The RCCL call is the
+        stream-ordered form: it returns at once and `gather_stream` does not pass it before the collective
+        has finished, so the event recorded behind it covers the collective."""
         if self.world == 1:
             self.gathered[h].copy_(self.ring[h])
-
-            class _Done:
-                def wait(self_inner):
-                    return True
-            return _Done()
-        return dist.all_gather_into_tensor(self.gathered[h], self.ring[h], async_op=True)
+        else:
+            dist.all_gather_into_tensor(self.gathered[h], self.ring[h])
 
     def flush(self):
         """Send a partially filled half and settle everything (end of the loop)."""
         if self.n:
             self._send()
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.gather_stream)
         first = self.half                          # older half first: push order
         for h in (first, 1 - first):
             self._settle(h)
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.gather_stream)
 
 
 def unpack_gathered(gathered: torch.Tensor, world: int, per_half: int, rows: int, n_valid: int) -> torch.Tensor:

@@ -142,7 +142,10 @@ class Evaluator(torch.nn.Module):
                 m = rows[:, off:off + 2 * w].contiguous().view(torch.float64).to(torch.int64)
                 cols[self.META_NAMES[k]] = m[:, 0] if layout["meta_1d"][k] else m
                 off += 2 * w
-            cols = {k: v.detach().cpu().tolist() for k, v in cols.items()}
+            # the last column marks real rows: a short batch (validation loaders keep the tail,
+            # drop_last=is_train, utils/trn_utils.py:200-203) is padded to the ring's row count
+            keep = (rows[:, off] > 0.5).cpu()
+            cols = {k: v.detach().cpu()[keep].tolist() for k, v in cols.items()}
             n = len(cols["pred_boxes"])
             results.extend({k: v[i] for k, v in cols.items()} for i in range(n))
 
@@ -164,11 +167,15 @@ class Evaluator(torch.nn.Module):
                               nsrl=out["mdl_outs_eval"].shape[2], meta=meta,
                               meta_w={k: int(batch[k].numel() // rec.shape[0]) for k in meta},
                               meta_1d={k: batch[k].dim() == 1 for k in meta})
-                width = rec.shape[1] + 2 * sum(layout["meta_w"].values())
+                width = rec.shape[1] + 2 * sum(layout["meta_w"].values()) + 1
                 ring = D.RecordRing(rec.shape[0], width, self.GATHER_EVERY, rec.device, on_half=on_half)
-            assert rec.shape[0] == layout["B"], "the exchange ring is built for a fixed batch size (drop_last loaders)"
-            row = torch.cat([rec] + [batch[k].reshape(rec.shape[0], -1).to(torch.float64).view(torch.float32)
-                                     for k in meta], dim=1)
+            nb = rec.shape[0]
+            assert nb <= layout["B"], (f"batch of {nb} queries after a first batch of {layout['B']}: the exchange "
+                                       "ring is sized by the first batch (only the tail batch may be shorter)")
+            row = torch.cat([rec] + [batch[k].reshape(nb, -1).to(torch.float64).view(torch.float32) for k in meta]
+                            + [torch.ones(nb, 1, dtype=torch.float32, device=rec.device)], dim=1)
+            if nb < layout["B"]:
+                row = torch.cat([row, row.new_zeros(layout["B"] - nb, row.shape[1])], dim=0)
             ring.push(row, torch.cuda.current_stream() if rec.is_cuda else None)
         if ring is not None:
             ring.flush()
