@@ -295,9 +295,10 @@ int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask, int32_t* 
 int vog_lstm_schedule(const int64_t* lens, int32_t* rows, int Bn, int T, void* stream);
 
 /* Fused prologue of the language path (one launch instead of memset + vog_srl_gather +
- * vog_lstm_schedule): zero `zero_bytes` at `zero` (multiple of 16), token re-index and the
- * packed-sequence schedule. */
-int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+ * vog_lstm_schedule): zero `zero_bytes` at `zero` (multiple of 16), fill the `ones_bytes` (multiple of
+ * 16) that follow them with 0xff (the "not written yet" pattern of the persistent BiLSTM's hand-off
+ * slots), token re-index and the packed-sequence schedule. */
+int vog_lang_prep(void* zero, int64_t zero_bytes, int64_t ones_bytes, const int64_t* words_ind, const int64_t* word_mask,
                   const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
                   int seq_len, int vocab_size,
                   /* optional (a0_frag != NULL): also gather the tokens' 16-bit embedding rows
@@ -316,7 +317,7 @@ typedef struct vog_visprep_args {
 int vog_vis_prep(const vog_visprep_args* a, void* stream);
 /* vog_lang_prep + vog_vis_prep in ONE launch (the two prologues are independent of each other;
  * one launch less on the forward's dependent chain). Arguments as for the two entries. */
-int vog_prep_fused(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+int vog_prep_fused(void* zero, int64_t zero_bytes, int64_t ones_bytes, const int64_t* words_ind, const int64_t* word_mask,
                    const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
                    int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
                    const vog_visprep_args* vis, void* stream);
@@ -337,19 +338,21 @@ typedef struct vog_lstm_step_args {
   int out_frag; int final_row0;
 } vog_lstm_step_args;
 int vog_bilstm_step(const vog_lstm_step_args* a, void* stream);
-/* ALL T steps of one BiLSTM layer in ONE launch (persistent workgroups): 2 x R/32
- * workgroups of 4 waves, every wave keeps its 32 rows of W_hh in registers for the whole
- * sequence (W_hh is read once per layer instead of once per step). Between steps the hidden
- * state goes through `hx` as SELF-VALIDATING 8-byte words (two 16-bit h values + the 32-bit
- * number of the producing step), stored with write-through agent-scope atomics and fetched
- * (L1-bypassing) once per workgroup into LDS; stale words are re-fetched as a batch. No flags,
- * no fences: one fabric round trip per step. Measured on MI355X (cfg 2, Bn = 4, R = 1024):
- * 3.7 us per step, 45.9 us per layer, against 12 x 4.95 us for vog_bilstm_step launches that
- * each re-stream 16.8 MB of W_hh; single-batch latency 336 vs 365 us, 27.0k vs 21.6k queries/s
- * with 4 batches in flight. Requires Bn <= 16 and R/32 in {1,2,4,32} (vog_bilstm_layer_supported);
- * hx ([2 parities][2 dirs][16][R/2] u64) and sync (256 x u32) must be zero at launch (vog_lang_prep
- * does it); every wait is bounded (~1 s): on timeout sync[2] is set, the kernel drains and writes
- * NaN into the final-state rows so that a stalled run cannot pass for a result.
+/* ALL T steps of one BiLSTM layer in ONE launch (persistent workgroups): 2 x R/32 workgroups of 8 waves,
+ * every wave keeps its 16 rows of W_hh in registers for the whole sequence (W_hh is read once per
+ * layer instead of once per step). Between steps the hidden state goes through `hx` =
+ * [T slots][2 dirs][Bn][R] 16-bit values, one slot per step, which must hold 0xffff in every halfword
+ * at launch (vog_lang_prep / vog_prep_fused `ones_bytes` arm it; vog_bilstm_hx_bytes gives the size):
+ * every value validates itself - 0xffff is a NaN pattern no h can take - so a consumer needs no tag,
+ * flag or fence, just one (re-tried) 16-byte L1-bypassing load per thread and step; the workgroup
+ * stages the vector in LDS (double buffered) and every wave reads its MFMA B fragments from there.
+ * Publishing: if all workgroups of a direction run on ONE XCD (they report their XCC id in `sync` at
+ * start; small layers) every lane stores its value with a store that stays in that XCD's L2; otherwise
+ * the workgroup's 64 bytes per sentence are written through by one wave (0.75 / 1.33 us per exchange,
+ * scratch/ubench/handoff_v3.hip). Measured (cfg 2, Bn = 4, R = 1024): 2.5 us per step (3.0 in round 2).
+ * Requires Bn <= 16 and R/32 in {1,2,4,32} (vog_bilstm_layer_supported); sync (256 x u32) must be zero
+ * at launch (vog_lang_prep does it); every wait is bounded (~1 s): on timeout sync[2] is set, the
+ * kernel drains and writes NaN into ALL its output rows so that a stalled run cannot pass for a result.
  * CO-RESIDENCY: all 2 x R/32 workgroups (one per CU) must be resident at once; launch at most 4
  * instances concurrently on a 256-CU part (HIP's 4 hardware queues guarantee that for streams). */
 typedef struct vog_lstm_layer_args {
@@ -365,6 +368,7 @@ typedef struct vog_lstm_layer_args {
   const void* wih; const void* xa; const float* bias; int K;
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);
+int64_t vog_bilstm_hx_bytes(int Bn, int T, int R);   /* size of vog_lstm_layer_args.hx */
 int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream);
 
 /* host: [2][4R][R] fp32 (weight_hh_l*, weight_hh_l*_reverse) -> fragment order, 16 bit.

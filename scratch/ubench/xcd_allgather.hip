@@ -41,7 +41,7 @@ struct Res { u64 t0, t1; unsigned bad, spins, xcc, dead; };
 // NW words per sentence (= R/2), NS sentences; every participant owns NW/32 consecutive words of each sentence
 template <int ST, int LD>
 __global__ __launch_bounds__(512) void k(u64* hx, Res* res, unsigned* done, const uint4* bg, size_t bg_n, int place, int xsel,
-                                         int steps, int warm, int NS, int NW, int load_bg) {
+                                         int steps, int warm, int NS, int NW, int load_bg, int fresh) {
   extern __shared__ unsigned lds[];
   const int tid = threadIdx.x;
   unsigned xcc;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512) void k(u64* hx, Res* res, unsigned* done, cons
     // publish step s+1 tags into parity (s+1)&1 ... like the layer kernel: step s reads parity s&1 (tag s), writes (s+1)&1 (tag s+1)
     // gather tag s (step 0: zero-initialised buffer = tag 0 payload 0)
     for (int base = tid; base < items; base += 512 * 4) {
-      const u64* src = hx + (size_t)(s & 1) * par;
+      const u64* src = hx + (size_t)(fresh ? s : (s & 1)) * par;
       u64 v[4];
       int it[4];
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void k(u64* hx, Res* res, unsigned* done, cons
       for (;;) {
         bool stale = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) stale |= (unsigned)(v[j] >> 32) != (unsigned)s;
+        for (int j = 0; j < 4; ++j) stale |= (unsigned)(v[j] >> 32) != (unsigned)s && !(fresh && s == 0);
         if (!stale) break;
         load8x4<LD>(src + it[0], src + it[1], src + it[2], src + it[3], v[0], v[1], v[2], v[3]);
         if (++sp > (1u << 18)) { dead = true; break; }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512) void k(u64* hx, Res* res, unsigned* done, cons
       const int sen = tid / per, j = tid % per;
       const int itw = sen * NW + pi * per + j;
       const u64 val = ((u64)(unsigned)(s + 1) << 32) | payload(s + 1, itw);
-      store8<ST>(hx + (size_t)((s + 1) & 1) * par + itw, val);
+      store8<ST>(hx + (size_t)(fresh ? s + 1 : ((s + 1) & 1)) * par + itw, val);
     }
     __syncthreads();
   }
@@ -115,15 +115,15 @@ __global__ __launch_bounds__(512) void k(u64* hx, Res* res, unsigned* done, cons
 }
 
 template <int ST, int LD>
-static void run(const char* name, int place, int xsel, int load_bg, u64* hx, Res* res, unsigned* done, uint4* bg, size_t bg_n,
+static void run(const char* name, int place, int xsel, int load_bg, int fresh, u64* hx, Res* res, unsigned* done, uint4* bg, size_t bg_n,
                 int NS, int NW) {
   const int steps = 400, warm = 50;
   for (int rep = 0; rep < 2; ++rep) {
-    CHECK(hipMemset(hx, 0, (size_t)2 * NS * NW * 8));
+    CHECK(hipMemset(hx, 0, (size_t)402 * NS * NW * 8));
     CHECK(hipMemset(res, 0, sizeof(Res) * 32));
     CHECK(hipMemset(done, 0, 4));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<ST, LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    hipLaunchKernelGGL((k<ST, LD>), dim3(256), dim3(512), 100 * 1024, 0, hx, res, done, bg, bg_n, place, xsel, steps, warm, NS, NW, load_bg);
+    hipLaunchKernelGGL((k<ST, LD>), dim3(256), dim3(512), 100 * 1024, 0, hx, res, done, bg, bg_n, place, xsel, steps, warm, NS, NW, load_bg, fresh);
     CHECK(hipDeviceSynchronize());
   }
   std::vector<Res> h(32);
@@ -134,30 +134,22 @@ static void run(const char* name, int place, int xsel, int load_bg, u64* hx, Res
     const double us = (double)(r.t1 - r.t0) / 100.0 / (steps - warm);
     mn = std::min(mn, us); mx = std::max(mx, us); av += us / 32; bad += r.bad; dead += r.dead; spins += r.spins; xmask |= 1u << r.xcc;
   }
-  printf("%-34s place %d bg %d NS %d NW %4d: %.3f us/step (min %.3f max %.3f)  bad %u dead %u  retries/step/WG %.1f  xcc mask 0x%02x\n",
-         name, place, load_bg, NS, NW, av, mn, mx, bad, dead, (double)spins / 32 / steps, xmask);
+  printf("%-34s fresh %d place %d bg %d NS %d NW %4d: %.3f us/step (min %.3f max %.3f)  bad %u dead %u  retries/step/WG %.1f  xcc mask 0x%02x\n",
+         name, fresh, place, load_bg, NS, NW, av, mn, mx, bad, dead, (double)spins / 32 / steps, xmask);
 }
 
 int main() {
   u64* hx; Res* res; unsigned* done; uint4* bg;
   const size_t bg_n = (size_t)512 * 1024 * 1024 / 16;
-  CHECK(hipMalloc(&hx, (size_t)2 * 16 * 1024 * 8));
+  CHECK(hipMalloc(&hx, (size_t)402 * 16 * 512 * 8));
   CHECK(hipMalloc(&res, sizeof(Res) * 32));
   CHECK(hipMalloc(&done, 4));
   CHECK(hipMalloc(&bg, bg_n * 16));
   CHECK(hipMemset(bg, 1, bg_n * 16));
-  for (int NS : {4, 16})
-    for (int bgl = 0; bgl < 2; ++bgl) {
-      const int NW = 512;
-      run<0, 0>("store sc1      load sc1", 0, 0, bgl, hx, res, done, bg, bg_n, NS, NW);
-      run<0, 0>("store sc1      load sc1", 1, 3, bgl, hx, res, done, bg, bg_n, NS, NW);
-      run<1, 0>("store plain    load sc1", 1, 3, bgl, hx, res, done, bg, bg_n, NS, NW);
-      run<2, 0>("store sc0      load sc1", 1, 3, bgl, hx, res, done, bg, bg_n, NS, NW);
-      run<1, 1>("store plain    load sc0sc1", 1, 3, bgl, hx, res, done, bg, bg_n, NS, NW);
-      run<3, 1>("store sc0sc1   load sc0sc1", 1, 3, bgl, hx, res, done, bg, bg_n, NS, NW);
-      run<3, 1>("store sc0sc1   load sc0sc1", 0, 0, bgl, hx, res, done, bg, bg_n, NS, NW);
-    }
-  // the plain-store form across XCDs must FAIL (stale forever -> dead): shows the check has teeth
-  run<1, 0>("store plain    load sc1 (x-XCD)", 0, 0, 0, hx, res, done, bg, bg_n, 4, 512);
+  for (int fresh = 0; fresh < 2; ++fresh) {
+    run<0, 0>("store sc1      load sc1", 0, 0, 0, fresh, hx, res, done, bg, bg_n, 4, 512);
+    run<0, 0>("store sc1      load sc1", 1, 3, 0, fresh, hx, res, done, bg, bg_n, 4, 512);
+    run<1, 0>("store plain    load sc1", 1, 3, 0, fresh, hx, res, done, bg, bg_n, 4, 512);
+  }
   return 0;
 }

@@ -461,7 +461,7 @@ __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
 // fused prologues (one graph node each instead of 3)
 // ---------------------------------------------------------------------------
 struct LangPrepArgs {
-  uint4* zero; int64_t zero16; const int64_t* words; const int64_t* mask; const int64_t* lens;
+  uint4* zero; int64_t zero16; int64_t ones16; const int64_t* words; const int64_t* mask; const int64_t* lens;
   int32_t* tok; int32_t* rows; int Bn, T, nsrl, seq_len, vocab;
   const unsigned short* emb16; unsigned short* a0; int E;
 };
@@ -474,7 +474,12 @@ __device__ __forceinline__ void lang_prep_body(const LangPrepArgs& a, int bid, i
   const unsigned short* __restrict__ emb16 = a.emb16; unsigned short* __restrict__ a0 = a.a0; const int E = a.E;
   const int64_t gid = (int64_t)bid * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)nblocks * blockDim.x;
-  for (int64_t i = gid; i < zero16; i += stride) zero[i] = make_uint4(0, 0, 0, 0);
+  // [zero16 x 16 B of zeros][ones16 x 16 B of 0xff: the hand-off slots of the persistent BiLSTM, lstm_dev.h]
+  const int64_t fill16 = zero16 + a.ones16;
+  for (int64_t i = gid; i < fill16; i += stride) {
+    const unsigned v = i < zero16 ? 0u : 0xffffffffu;
+    zero[i] = make_uint4(v, v, v, v);
+  }
   if (a0) {
     // embedding rows of the Bn*T tokens, 16 bit, in the A-fragment order of the M <= 64 GEMM:
     // one 16-byte chunk (8 consecutive k of one token) per thread
@@ -547,21 +552,22 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(LangPrepArgs la, int la
   else vis_prep_body<T16>(va, cast_blocks, (int)blockIdx.x - lang_blocks);
 }
 
-static int lang_prep_setup(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+static int lang_prep_setup(void* zero, int64_t zero_bytes, int64_t ones_bytes, const int64_t* words_ind, const int64_t* word_mask,
                            const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
                            int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
                            LangPrepArgs* la, int* blocks_out) {
   VOG_CHECK_ARG(words_ind && word_mask && lens && tok && rows && Bn > 0 && T > 0 && T <= seq_len);
   VOG_CHECK_ARG(!a0_frag || (emb16 && emb_dim > 0 && (emb_dim % 32) == 0));
   VOG_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && (zero_bytes == 0 || zero));
-  const int64_t z16 = zero_bytes / 16;
-  int64_t blocks = (z16 + 255) / 256;
+  VOG_CHECK_ARG(ones_bytes >= 0 && (ones_bytes % 16) == 0 && (ones_bytes == 0 || zero));
+  const int64_t z16 = zero_bytes / 16, o16 = ones_bytes / 16;
+  int64_t blocks = (z16 + o16 + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   int64_t need = ((int64_t)Bn * T + 255) / 256;
   if (a0_frag) { const int64_t n2 = ((int64_t)Bn * T * (emb_dim / 8) + 255) / 256; need = n2 > need ? n2 : need; }
   if (need > 1024) need = 1024;
   if (blocks < need) blocks = need;
-  *la = LangPrepArgs{(uint4*)zero, z16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size,
+  *la = LangPrepArgs{(uint4*)zero, z16, o16, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len, vocab_size,
                      (const unsigned short*)emb16, (unsigned short*)a0_frag, emb_dim};
   *blocks_out = (int)blocks;
   return 0;
@@ -604,24 +610,24 @@ extern "C" int vog_cast_f32_to_t16(const float* src0, void* dst0, int64_t n0, co
   return 0;
 }
 
-extern "C" int vog_lang_prep(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+extern "C" int vog_lang_prep(void* zero, int64_t zero_bytes, int64_t ones_bytes, const int64_t* words_ind, const int64_t* word_mask,
                              const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
                              int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
                              void* stream) {
   LangPrepArgs la; int blocks = 0;
-  VOG_TRY(lang_prep_setup(zero, zero_bytes, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len,
+  VOG_TRY(lang_prep_setup(zero, zero_bytes, ones_bytes, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len,
                           vocab_size, emb16, a0_frag, emb_dim, &la, &blocks));
   ::vog::launch(lang_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, la);
   VOG_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int vog_prep_fused(void* zero, int64_t zero_bytes, const int64_t* words_ind, const int64_t* word_mask,
+extern "C" int vog_prep_fused(void* zero, int64_t zero_bytes, int64_t ones_bytes, const int64_t* words_ind, const int64_t* word_mask,
                               const int64_t* lens, int32_t* tok, int32_t* rows, int Bn, int T, int nsrl,
                               int seq_len, int vocab_size, const void* emb16, void* a0_frag, int emb_dim,
                               const vog_visprep_args* vis, void* stream) {
   LangPrepArgs la; int lblocks = 0, cast_blocks = 0, u_blocks = 0;
-  VOG_TRY(lang_prep_setup(zero, zero_bytes, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len,
+  VOG_TRY(lang_prep_setup(zero, zero_bytes, ones_bytes, words_ind, word_mask, lens, tok, rows, Bn, T, nsrl, seq_len,
                           vocab_size, emb16, a0_frag, emb_dim, &la, &lblocks));
   VOG_TRY(vis_prep_setup(vis, &cast_blocks, &u_blocks));
   VOG_DISPATCH_DTYPE(vis->dtype, ::vog::launch((prep_fused_kernel<T16>), dim3(lblocks + cast_blocks + u_blocks),

@@ -305,7 +305,7 @@ static Geo make_geo(const vog_model_desc& d, int B, int ncmp, int T) {
 struct Plan {
   std::map<std::string, std::pair<int64_t, int64_t>> buf;   // name -> (offset, bytes)
   int64_t total = 0;
-  int64_t zero_off = 0, zero_bytes = 0;
+  int64_t zero_off = 0, zero_bytes = 0, ones_off = 0, ones_bytes = 0;
   int64_t add(const std::string& n, int64_t bytes) {
     const int64_t off = total;
     buf[n] = {off, bytes};
@@ -328,10 +328,14 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_hB_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);
     p.add("lstm_hA2_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);   // ping buffer when out16 is fragment-ordered
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
-    p.add("lstm_hx_" + std::to_string(l), (int64_t)2 * 2 * 16 * (g.R / 2) * 8);   // tagged hand-off words
-    p.add("lstm_sync_" + std::to_string(l), 1024);   // [0..3] status words, [4 + dir*64 + g] arrival flags
+    p.add("lstm_sync_" + std::to_string(l), 1024);   // [2] timeout, [4 + dir] workgroups arrived, [8 + dir] XCC ids seen
   }
   p.zero_bytes = p.total - p.zero_off;
+  // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
+  // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
+  p.ones_off = p.total;
+  for (int l = 0; l < nl; ++l) p.add("lstm_hx_" + std::to_string(l), vog_bilstm_hx_bytes(g.Bn, g.T, g.R));
+  p.ones_bytes = p.total - p.ones_off;
   p.add("emb_a0", round_up64(g.Bn * g.T, 16) * g.E * 2);   // layer-0 A operand in fragment order (M <= 64)
   p.add("tok", (int64_t)g.Bn * g.T * 4);
   p.add("lstm_rows", (int64_t)2 * g.Bn * g.T * 4);
@@ -570,7 +574,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   };
   if (!shared) {
     char* z = ws.base + plan.zero_off;
-    const int64_t zb = plan.zero_bytes;
+    const int64_t zb = plan.zero_bytes, ob = plan.ones_bytes;   // (the 0xff region starts where the zeros end)
     int32_t* tok = ws.at<int32_t>("tok");
     const int64_t *wi = b->srl_arg_words_ind, *wm = b->srl_arg_word_mask;
     const int nsrl = d.nsrl, sl = d.seq_len, V = d.vocab_size;
@@ -585,10 +589,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       if (fuse_prep) {
         const vog_visprep_args vp = make_visprep();
         steps.push_back({"prep", [=](hipStream_t st) {
-          return vog_prep_fused(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, &vp, st); }});
+          return vog_prep_fused(z, zb, ob, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, &vp, st); }});
       } else {
         steps.push_back({"lang_prep", [=](hipStream_t st) {
-          return vog_lang_prep(z, zb, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, st); }});
+          return vog_lang_prep(z, zb, ob, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, st); }});
       }
     }
     for (int l = 0; l < d.rnn_layers; ++l) {

@@ -70,11 +70,16 @@ extern "C" int vog_bilstm_layer_supported(int Bn, int R) {
   return Bn >= 1 && Bn <= 16 && R % 32 == 0 && R / 32 <= 64 && (ks == 1 || ks == 2 || ks == 4 || ks == 32);
 }
 
+extern "C" int64_t vog_bilstm_hx_bytes(int Bn, int T, int R) {
+  if (Bn <= 0 || T <= 0 || R <= 0) return -1;
+  return (int64_t)T * 2 * Bn * R * 2;
+}
+
 extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
   VOG_CHECK_ARG(a && (a->gxs || a->wih) && a->whh && a->hx && a->sync && a->out16 && a->lens && a->T > 0);
   if (!vog_bilstm_layer_supported(a->Bn, a->R))
     VOG_FAIL(-1, "persistent BiLSTM layer: unsupported Bn=%d R=%d (use vog_bilstm_step)", a->Bn, a->R);
-  vog::LstmLayerParams p{a->gxs, (const unsigned short*)a->whh, (unsigned long long*)a->hx, a->sync,
+  vog::LstmLayerParams p{a->gxs, (const unsigned short*)a->whh, (unsigned short*)a->hx, a->sync,
                          (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R, a->out_frag,
                          (const unsigned short*)a->wih, (const unsigned short*)a->xa, a->bias, a->K};
   const bool fused = a->wih != nullptr;
@@ -84,15 +89,15 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
 #define VOG_LAUNCH_LAYER(KS)                                                                          \
   VOG_DISPATCH_DTYPE(a->dtype, {                                                                      \
     auto kern = vog::lstm_layer_kernel<T16, KS>;                                                      \
+    using Body = vog::LstmLayerBody<T16, KS>;                                                         \
     static bool attr_set = false;                                                                     \
-    if (fused && !attr_set) {                                                                         \
+    if (!attr_set) {                                                                                  \
       VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,                         \
-                                  (int)vog::LstmLayerBody<T16, KS>::LDS_FUSED));                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Body::LDS_MAX));   \
       attr_set = true;                                                                                \
     }                                                                                                 \
     ::vog::launch(kern, grid, dim3(512),                                                              \
-                  fused ? vog::LstmLayerBody<T16, KS>::lds_fused(a->Bn * a->T) : vog::LstmLayerBody<T16, KS>::LDS, st, p); \
+                  fused ? Body::lds_fused(a->Bn, a->Bn * a->T) : Body::lds_plain(a->Bn), st, p);      \
   })
   switch (a->R / 32) {
     case 1: VOG_LAUNCH_LAYER(1); break;

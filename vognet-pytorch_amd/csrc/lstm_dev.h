@@ -11,6 +11,15 @@ struct LstmParams {
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// the persistent layer kernel's forms: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (12
+// instructions per quotient, 5 quotients on the dependent chain of every step)
+__device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float a = fabsf(x);
+  const float e = __expf(-2.0f * a);
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return x < 0.f ? -t : t;
+}
 __device__ __forceinline__ float tanh_(float x) {
   // tanh via exp of -2|x| : accurate to ~1e-7 rel, no overflow
   const float a = fabsf(x);
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmParams p) {
 // persistent layer kernel: all T steps, both directions, one launch
 // ----------------------------------------------------------------------------
 struct LstmLayerParams {
-  const float* gxs; const unsigned short* whh; unsigned long long* hx; unsigned int* sync;
+  const float* gxs; const unsigned short* whh; unsigned short* hx; unsigned int* sync;
   unsigned short* out16; const int64_t* lens; int Bn, T, R; int out_frag;
   // fused input projection (wih != nullptr; gxs unused): x W_ih^T + bias for THIS workgroup's gate
   // rows is computed in the prologue. wih: [dir][unit/4][K/32][lane][8] (vog_lstm_pack_w), xa: the
@@ -131,27 +140,68 @@ struct LstmLayerParams {
 };
 
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define VOG_RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// 16 bytes straight from the L2 (sc1: the CU's own L1 is bypassed - it is never refreshed by another
+// CU's stores). A compiler-visible buffer load (not inline asm): hipcc keeps its own vmcnt books.
+__device__ __forceinline__ u32x4 load16_l2(const void* base, unsigned byte_off, unsigned bytes) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */);
+}
+// any of the 8 halfwords == 0xffff (the "not written yet" pattern; as f16 / bf16 it is a NaN no h can be)
+__device__ __forceinline__ bool has_unwritten(u32x4 v) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const unsigned y = ~v[i]; m |= (y - 0x00010001u) & v[i] & 0x80008000u; }
+  return m != 0;
+}
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 15u;
+}
 
 // Body form (common.h): 512 threads = 8 waves, ONE 16-row tile (4 units x 4 gates) of W_hh per wave,
 // i.e. 128 registers of weights per lane - the kernel fits the 256-register budget of a 512-thread
-// workgroup and can therefore share a launch with the other 512-thread bodies (pair.hip). (The first
-// form, 4 waves x 2 tiles, held 256 registers of weights per lane: nothing else could live beside it.)
+// workgroup and can therefore share a launch with the other 512-thread bodies (pair.hip).
+//
+// Hand-off (round 3). h_s of ALL units travels through `hx` = [step][dir][sentence][R] 16-bit values,
+// one slot per step (nothing is ever rewritten inside a forward), armed with 0xffff by the forward's
+// prologue (vog_lang_prep `ones_bytes`). Every VALUE validates itself: a consumer needs no tag, no flag
+// and no ordering between words - a 16-byte load whose 8 halfwords hold no 0xffff is complete, whatever
+// the granularity at which the stores became visible. Per step a workgroup fetches the Bn x R vector
+// ONCE (one 16-byte L1-bypassing load per thread at Bn = 4), re-fetches chunks that still hold the
+// pattern, stages it in LDS (two buffers: ONE barrier per step) and every wave reads its MFMA B
+// fragments from there.
+// Where the workgroups of a direction sit decides the store flavour: every workgroup reports its XCC id
+// at kernel start, and only if all of a direction report the same one (small layers: one or two
+// workgroups per direction) the direction uses stores that stay in that XCD's L2 - correctness never
+// depends on the placement. (A forced placement - the 32 workgroups of a direction on ONE XCD, the other
+// blocks of the launch on the remaining six - was built and measured in round 3: 1.9 instead of 2.5 us per
+// step, but W_ih / W_hh then enter through one XCD's fabric port (+7 us per layer) and every other kernel's
+// blocks dealt to the two occupied XCDs wait for the layer: 31 k instead of 56 k queries/s with 4 forwards
+// in flight. Removed; scratch/ubench/{xcd_allgather,handoff_v3}.hip keep the exchange measurements.)
 template <typename T16, int KSTEPS>
 struct LstmLayerBody {
   using Params = LstmLayerParams;
   static constexpr int THREADS = 512;
-  static constexpr int RW = KSTEPS * 32, HS_LD = RW + 8;   // +8 halfwords: rows land on different banks
-  static constexpr size_t LDS = (size_t)16 * HS_LD * 2;
-  // fused input projection: + gates of every (sentence, position) for the 128 gate rows of the
-  // workgroup ([8 waves][<= 64 columns][4 units][4 gates] fp32, 80-byte column pitch) + one K chunk
-  // (256) of the layer input in fragment order ([<= 4 column tiles][8 k-steps][64 lanes][16 B]), double buffered
+  static constexpr int RW = KSTEPS * 32, HS_LD = RW + 32;  // +32 halfwords: sentence rows 16 banks apart
+  // LDS: [gates of the fused input projection, kept for the whole recurrence]
+  //      [union: layer-input chunks of the projection (2 x nct x 8 KiB) | h staging (2 x Bn x HS_LD x 2 B)] [16 B flags] [publish buffer]
   static constexpr int GX_PITCH = 20;                      // floats per column (16 + 4: spreads the banks)
-  static constexpr size_t LDS_HS = ((size_t)16 * HS_LD * 2 + 15) / 16 * 16;
-  static constexpr size_t LDS_FUSED = LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)2 * 4 * 8 * 1024;   // upper bound (4 column tiles)
-  static constexpr size_t lds_fused(int ncols) { return LDS_HS + (size_t)8 * 64 * GX_PITCH * 4 + (size_t)2 * ((ncols + 15) / 16) * 8 * 1024; }
+  static constexpr size_t GX_BYTES = (size_t)8 * 64 * GX_PITCH * 4;
+  static constexpr size_t hs_bytes(int Bn) { return ((size_t)2 * Bn * HS_LD * 2 + 15) / 16 * 16; }
+  static constexpr size_t xbuf_bytes(int ncols) { return (size_t)2 * ((ncols + 15) / 16) * 8 * 1024; }
+  static constexpr size_t TAIL = 16 + 16 * 32 * 2;          // flags + the publish buffer [<= 16 sentences][32 units]
+  static constexpr size_t lds_plain(int Bn) { return hs_bytes(Bn) + TAIL; }
+  static constexpr size_t lds_fused(int Bn, int ncols) {
+    return GX_BYTES + (hs_bytes(Bn) > xbuf_bytes(ncols) ? hs_bytes(Bn) : xbuf_bytes(ncols)) + TAIL;
+  }
+  static constexpr size_t LDS_MAX = GX_BYTES + ((size_t)2 * 16 * HS_LD * 2 > (size_t)2 * 4 * 8 * 1024 ? (size_t)2 * 16 * HS_LD * 2 : (size_t)2 * 4 * 8 * 1024) + TAIL;
 
   static __device__ __forceinline__ void run(const LstmLayerParams& p, const BlockCtx& cx, unsigned char* smem) {
-    unsigned short* hs = reinterpret_cast<unsigned short*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = cx.by;
@@ -160,6 +210,21 @@ struct LstmLayerBody {
     const int b = lane & 15, ul = lane >> 4, kg = (lane >> 4) * 8;
     const bool valid_b = b < p.Bn;
     const int len = valid_b ? (int)p.lens[b] : 0;
+    const bool fused = p.wih != nullptr;
+    unsigned char* uni = smem + (fused ? GX_BYTES : 0);
+    unsigned short* hs = reinterpret_cast<unsigned short*>(uni);
+    const int ncols = p.Bn * p.T;
+    const size_t uni_bytes = fused ? (hs_bytes(p.Bn) > xbuf_bytes(ncols) ? hs_bytes(p.Bn) : xbuf_bytes(ncols)) : hs_bytes(p.Bn);
+    unsigned int* flags = reinterpret_cast<unsigned int*>(uni + uni_bytes);   // [0] timeout seen, [1] direction shares an XCD
+    unsigned short* pub = reinterpret_cast<unsigned short*>(uni + uni_bytes + 16);
+
+    // where am I: one report per workgroup, read back before the first publish (after the prologue)
+    if (tid == 0) {
+      flags[0] = 0;
+      // ONE atomic per workgroup: a counter per (direction, XCC id). (A mask word + an arrival counter
+      // would be two relaxed atomics whose order another workgroup need not observe.)
+      __hip_atomic_fetch_add(p.sync + 16 + dir * 16 + xcc_id(), 1u, VOG_RLX_AGENT);
+    }
 
     float c = 0.f, h_own = 0.f;
     VOG_TSL(p.T, 0);
@@ -167,11 +232,10 @@ struct LstmLayerBody {
     // fp32 round trip): every wave computes the gates of ITS 16 rows for all Bn*T (sentence, position)
     // columns: W_ih rows stream once through registers (K in chunks of 256), the layer input is
     // staged per chunk in LDS and shared by the 8 waves; the result stays in LDS for the recurrence.
-    const bool fused = p.wih != nullptr;
-    float* gxl = reinterpret_cast<float*>(smem + LDS_HS) + (size_t)wid * 64 * GX_PITCH;
+    float* gxl = reinterpret_cast<float*>(smem) + (size_t)wid * 64 * GX_PITCH;
     if (fused) {
-      unsigned char* xch = smem + LDS_HS + (size_t)8 * 64 * GX_PITCH * 4;
-      const int ncols = p.Bn * p.T, nct = (ncols + 15) >> 4;          // <= 4 column tiles
+      unsigned char* xch = uni;
+      const int nct = (ncols + 15) >> 4;                                // <= 4 column tiles
       const int ksteps = p.K >> 5, nchunk = ksteps >> 3;               // K % 256 == 0
       f32x4 ga[4];
 #pragma unroll
@@ -184,9 +248,6 @@ struct LstmLayerBody {
       // chunk waited vmcnt(0), 4 us per chunk), double buffered; the weight fragments of the NEXT
       // chunk are in flight in a second register set. Two chunks = 80 KB per workgroup are always
       // outstanding; per chunk: one counted wait, barrier, 8 x nct MFMAs, barrier.
-      // (two images of nct x 8 KiB: the launcher sizes the LDS for the column tiles that exist, so that
-      // 38 KB of the CU stay free at cfg 2 - enough for a workgroup of the LDS-DMA GEMM to share the CU
-      // with this one, which spends most of its life waiting for hand-offs)
       unsigned char* xbuf[2] = {xch, xch + nct * 8 * 1024};
       auto load_w = [&](u16x8 (&wq)[8], int c) {
 #pragma unroll
@@ -244,7 +305,9 @@ struct LstmLayerBody {
         if (ct < nct)
           *reinterpret_cast<float4*>(gxl + (ct * 16 + b) * GX_PITCH + ul * 4) =
               make_float4(ga[ct][0] + bs[0], ga[ct][1] + bs[1], ga[ct][2] + bs[2], ga[ct][3] + bs[3]);
-      // (gxl is wave-private: no barrier needed before this wave reads it back below)
+      // (gxl is wave-private: no barrier needed before this wave reads it back below; the layer-input
+      // chunks share their LDS with the h staging buffers, which are first written in step 1 - behind
+      // the barrier below)
     }
     VOG_TSL(p.T, 1);
     // this wave's 16 rows of W_hh: registers for the whole sequence
@@ -253,12 +316,38 @@ struct LstmLayerBody {
     for (int ks = 0; ks < KSTEPS; ++ks)
       wf[ks] = *reinterpret_cast<const u16x8*>(
           p.whh + ((((int64_t)dir * (R / 4) + tile0) * KSTEPS + ks) * 64 + lane) * 8);
-    // hand-off buffer, u64 words: [parity][dir][16 sentences][R/2]; a word = two 16-bit h values +
-    // the 32-bit number of the step that produced them. The tag makes every word self-validating:
-    // a consumer needs no arrival flag and no acknowledgement wait, just one (re-tried) load.
-    const int64_t hx_dir = (int64_t)dir * 16 * (R / 2);
-    const int64_t hx_par = (int64_t)2 * 16 * (R / 2);
     bool dead = false;
+    // do all workgroups of this direction share one XCD? (every one has reported by now, or will)
+    if (tid == 0) {
+      unsigned spins = 0, nz = 0;
+      for (;;) {
+        unsigned sum = 0;
+        nz = 0;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const unsigned v = __hip_atomic_load(p.sync + 16 + dir * 16 + x, VOG_RLX_AGENT);
+          sum += v;
+          nz += v != 0 ? 1u : 0u;
+        }
+        if (sum >= cx.gx) break;                           // counters only grow: every report is in
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 20) || __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0) {   // ~1 s: give up
+          __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
+          flags[0] = 1;
+          nz = 2;
+          break;
+        }
+      }
+      flags[1] = nz == 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool same_xcd = flags[1] != 0;
+    dead = flags[0] != 0;
+
+    const unsigned hx_bytes = (unsigned)((size_t)p.T * 2 * p.Bn * R * 2);
+    const int cps = RW / 8;                                // 16-byte chunks per sentence
+    const int nchunks = p.Bn * cps;
+    const int hs_buf = p.Bn * HS_LD;                       // halfwords per staging buffer
 
     for (int s = 0; s < p.T; ++s) {
       VOG_TSL(s, 0);
@@ -275,63 +364,70 @@ struct LstmLayerBody {
         for (int r = 0; r < 4; ++r)
           gin[r] = valid_b ? p.gxs[(((int64_t)dir * p.T + s) * p.Bn + b) * 4 * R + (int64_t)r * R + tile0 * 4 + ul] : 0.f;
       }
-      // h_{s-1} of ALL units: written by the other workgroups with write-through atomics, read
-      // with L1-bypassing atomics (agent scope on both sides: no fences needed). The eight waves need
-      // the same Bn x R vector: the workgroup fetches it ONCE, 8 bytes per thread per round, into
-      // LDS and every wave reads its MFMA B fragments from there.
-      {
-        const unsigned long long* hsrc = p.hx + (s & 1) * hx_par + hx_dir;
-        const int items = p.Bn * (RW / 2);                   // words to fetch: sentence-major
-        for (int base = tid; base < items; base += THREADS * 4) {
-          unsigned long long v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int it = base + j * THREADS;
-            v[j] = it < items ? __hip_atomic_load(hsrc + (int64_t)(it / (RW / 2)) * (R / 2) + it % (RW / 2), VOG_RLX_AGENT)
-                              : ((unsigned long long)(unsigned)s << 32);
-          }
-          // re-fetch, as ONE batch per round, the words whose producer had not stored yet
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s > 0) {                                         // h_{-1} = 0: step 0 has no matrix part
+        // h_{s-1} of ALL units: slot s-1. One 16-byte chunk (8 units of one sentence) per thread and round.
+        unsigned short* hsb = hs + (s & 1) * hs_buf;
+        const unsigned slot_off = (unsigned)(((size_t)(s - 1) * 2 + dir) * p.Bn * R * 2);
+        for (int base = tid; base < nchunks; base += THREADS) {
+          const int sb = base / cps, j = base - sb * cps;
+          const unsigned off = slot_off + (unsigned)(sb * R + j * 8) * 2;
+          u32x4 v = load16_l2(p.hx, off, hx_bytes);
           unsigned int spins = 0;
-          for (;;) {
-            bool stale = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              stale |= (base + j * THREADS < items) && (unsigned int)(v[j] >> 32) != (unsigned int)s;
-            if (!stale || dead) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int it = base + j * THREADS;
-              if (it < items && (unsigned int)(v[j] >> 32) != (unsigned int)s)
-                v[j] = __hip_atomic_load(hsrc + (int64_t)(it / (RW / 2)) * (R / 2) + it % (RW / 2), VOG_RLX_AGENT);
-            }
+          while (has_unwritten(v) && !dead) {
+            asm volatile("" ::: "memory");
+            v = load16_l2(p.hx, off, hx_bytes);
             if ((++spins & 255u) == 0 &&
                 (spins > (1u << 20) || __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0)) {   // ~1 s: give up
               __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
               dead = true;
             }
           }
+          *reinterpret_cast<u32x4*>(&hsb[sb * HS_LD + j * 8]) = v;
+        }
+        if (dead) flags[0] = 1;
+        VOG_TSL(s, 1);
+        __syncthreads();
+        VOG_TSL(s, 2);
+        const unsigned int dead_wg = flags[0];
+        // lanes of the unused MFMA columns read sentence 0 (their results are never looked at)
+        const unsigned short* hrow = hsb + (valid_b ? b : 0) * HS_LD + kg;
+        // two accumulation chains (even / odd k-steps). The B fragments come from LDS 8 at a time, one
+        // group AHEAD of the MFMAs that use them (two register sets; the scheduling fences keep hipcc from
+        // folding the groups back into read-2 / wait / MFMA-2, which exposes the LDS latency 16 times per
+        // step: 0.95 us of a 3 us step in round 2)
+        constexpr int G = KSTEPS < 8 ? KSTEPS : 8;
+        u16x8 fa[G], fb[G];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int it = base + j * THREADS;
-            if (it < items)
-              *reinterpret_cast<unsigned int*>(&hs[(it / (RW / 2)) * HS_LD + (it % (RW / 2)) * 2]) = (unsigned int)v[j];
+        for (int j = 0; j < G; ++j) fa[j] = *reinterpret_cast<const u16x8*>(hrow + j * 32);
+#pragma unroll
+        for (int k0 = 0; k0 < KSTEPS; k0 += 2 * G) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (k0 + G < KSTEPS) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) fb[j] = *reinterpret_cast<const u16x8*>(hrow + (k0 + G + j) * 32);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            if (j & 1) acc1 = mfma16<T16>(wf[k0 + j], fa[j], acc1);
+            else acc0 = mfma16<T16>(wf[k0 + j], fa[j], acc0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (k0 + 2 * G < KSTEPS) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) fa[j] = *reinterpret_cast<const u16x8*>(hrow + (k0 + 2 * G + j) * 32);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (k0 + G < KSTEPS) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+              if (j & 1) acc1 = mfma16<T16>(wf[k0 + G + j], fb[j], acc1);
+              else acc0 = mfma16<T16>(wf[k0 + G + j], fb[j], acc0);
+            }
           }
         }
-      }
-      VOG_TSL(s, 1);
-      dead = __syncthreads_or(dead ? 1 : 0) != 0;
-      VOG_TSL(s, 2);
-      // two accumulation chains (even / odd k-steps): a dependent MFMA issues every ~2x its issue slot
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks += 2) {
-        u16x8 fh0 = {0, 0, 0, 0, 0, 0, 0, 0}, fh1 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid_b) {
-          fh0 = *reinterpret_cast<const u16x8*>(&hs[b * HS_LD + ks * 32 + kg]);
-          if (ks + 1 < KSTEPS) fh1 = *reinterpret_cast<const u16x8*>(&hs[b * HS_LD + (ks + 1) * 32 + kg]);
-        }
-        acc0 = mfma16<T16>(wf[ks], fh0, acc0);
-        if (ks + 1 < KSTEPS) acc1 = mfma16<T16>(wf[ks + 1], fh1, acc1);
+        dead = dead || dead_wg != 0;
       }
 #ifdef VOG_TS_DEBUG
       asm volatile("" :: "v"(acc0), "v"(acc1));
@@ -343,27 +439,41 @@ struct LstmLayerBody {
       if (active) {
         const float gi = acc0[0] + acc1[0] + gin[0], gf = acc0[1] + acc1[1] + gin[1];
         const float gg = acc0[2] + acc1[2] + gin[2], go = acc0[3] + acc1[3] + gin[3];
-        c = sigm(gf) * c + sigm(gi) * tanh_(gg);
-        const float hn = sigm(go) * tanh_(c);
-        const unsigned short h16 = to16<T16>(hn);
+        c = sigm_fast(gf) * c + sigm_fast(gi) * tanh_fast(gg);
+        const float hn = sigm_fast(go) * tanh_fast(c);
+        unsigned short h16 = to16<T16>(hn);
+        if (h16 == 0xffffu) h16 = 0xfe00u;                 // a NaN, but never the "not written yet" pattern
         h_own = from16<T16>(h16);
         if (p.out_frag) p.out16[frag_a(b * p.T + pos, dir * R + unit, 2 * R)] = h16;
         else p.out16[((int64_t)b * p.T + pos) * 2 * R + (int64_t)dir * R + unit] = h16;
       }
-      // publish h_s of this tile: 4 units of one sentence = two 8-byte write-through stores
-      {
-        const unsigned int x0 = to16<T16>(h_own);
-        const unsigned int x1 = __shfl(x0, b + 16), x2 = __shfl(x0, b + 32), x3 = __shfl(x0, b + 48);
-        if (lane < 16 && valid_b) {
-          const unsigned long long tag = (unsigned long long)(unsigned int)(s + 1) << 32;
-          unsigned long long* dst = p.hx + ((s + 1) & 1) * hx_par + hx_dir + (int64_t)b * (R / 2) + tile0 * 2;
-          __hip_atomic_store(dst, tag | x0 | ((unsigned long long)x1 << 16), VOG_RLX_AGENT);
-          __hip_atomic_store(dst + 1, tag | x2 | ((unsigned long long)x3 << 16), VOG_RLX_AGENT);
+      // publish h_s of this tile into slot s (nothing reads h_{T-1} through hx).
+      // One XCD: every lane stores its own 16-bit value with a store that stays in the shared L2, where
+      // the readers' sc1 loads are served (0.75 us per exchange in scratch/ubench/handoff_v3.hip).
+      // Several XCDs: the stores are written through to memory, and there the NUMBER of write
+      // transactions decides (1.75-2.0 us with a store per wave and sentence, 1.33 us with 16-byte
+      // stores of one wave): the 8 waves park their values in LDS and 4 lanes per sentence store the
+      // workgroup's 64 bytes - one more barrier per step, half a microsecond less on the fabric.
+      // (No cross-lane packing with ds_bpermute: hipcc puts s_waitcnt vmcnt(0) in front of it here, i.e.
+      // the publish would wait for the write acknowledge of the previous step's stores.)
+      if (s + 1 < p.T) {
+        unsigned short x0 = to16<T16>(h_own);
+        if (x0 == 0xffffu) x0 = 0xfe00u;
+        unsigned short* slot = p.hx + ((size_t)s * 2 + dir) * p.Bn * R;
+        if (same_xcd) {
+          if (valid_b) __hip_atomic_store(slot + (size_t)b * R + tile0 * 4 + ul, x0, VOG_RLX_WG);
+        } else {
+          if (valid_b) pub[b * 32 + wid * 4 + ul] = x0;
+          __syncthreads();
+          if (tid < p.Bn * 4) {
+            const int sb = tid >> 2, q = tid & 3;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(pub + sb * 32 + q * 8);
+            u32x4* dst = reinterpret_cast<u32x4*>(slot + (size_t)sb * R + cx.bx * 32 + q * 8);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+          }
         }
       }
       VOG_TSL(s, 4);
-      if (s + 1 == p.T) break;                             // nothing reads h_T through hx
-      __syncthreads();                                     // hs is rewritten at the top of the next step
     }
     // final hidden state rows (h of the last ACTIVE step of every sentence). A stalled hand-off
     // (a producer workgroup never became resident: more of these kernels in flight than the chip

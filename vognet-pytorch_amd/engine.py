@@ -50,6 +50,53 @@ def model_desc_from_cfg(cfg, comm) -> L.ModelDesc:
     return d
 
 
+# ---- persistent BiLSTM: how many forwards may be in flight ---------------------------------------------
+# The layer kernel needs its 64 workgroups (one CU each) resident at the same time; they wait for each
+# other's hidden states. Four such kernels fill the chip exactly; a fifth one (or another long-lived
+# resident kernel, e.g. an RCCL collective waiting for its peers) can leave every one of them short of CUs
+# until the hand-off times out and poisons the output with NaN. The engine therefore keeps a per-device
+# BOOK: every forward it issues (slot / group launch, eager call) belongs to one of N lanes - a stream
+# gets the next lane the first time it is seen - and a lane remembers the stream that used it last: a
+# launch from another stream first waits for that stream (`wait_stream`), so the forwards of a lane are
+# serialised on the GPU whatever the caller does and at most N layer kernels are ever resident. N = 4, or 3
+# while a process group with more than one rank exists (one kernel's worth of CUs stays free for the
+# collective). Streams that keep to themselves (bench.py: one slot per stream; the evaluator: one stream)
+# never wait. (AQL programs run on the library's own queues: aql.hip has its own guard.)
+_LANE_BOOK: Dict[int, Dict[int, "torch.cuda.Stream"]] = {}
+_STREAM_LANE: Dict[int, Dict[int, int]] = {}
+
+
+def _dev_index(device: torch.device) -> int:
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def _max_inflight() -> int:
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return 3
+    except Exception:
+        pass
+    return 4
+
+
+def _lane_enter(device: torch.device, stream: Optional["torch.cuda.Stream"]) -> int:
+    """Call before enqueuing a forward on `stream` (None = the current stream). Returns its lane."""
+    st = stream if stream is not None else torch.cuda.current_stream(device)
+    i = _dev_index(device)
+    m = _STREAM_LANE.setdefault(i, {})
+    key = int(st.cuda_stream)
+    if key not in m:
+        m[key] = len(m)                     # first come, first served; later streams share round-robin
+    lane = m[key] % _max_inflight()
+    book = _LANE_BOOK.setdefault(i, {})
+    prev = book.get(lane)
+    if prev is not None and prev.cuda_stream != st.cuda_stream:
+        st.wait_stream(prev)
+    book[lane] = st
+    return lane
+
+
 class VogEngine:
     def __init__(self, cfg, comm, device: Optional[torch.device] = None):
         self.lib = L.load()
@@ -193,6 +240,7 @@ class VogEngine:
         assert self._finalized, "load_state_dict first"
         with torch.cuda.device(self.device):
             b, out, (B, ncmp, T) = self.make_batch(inp, T, with_pred)
+            _lane_enter(self.device, None)
             ws = self.workspace(B, ncmp, T)
             L.check(self.lib.vog_forward(self.ctx, C.byref(b), ws.data_ptr(), ws.numel(),
                                          L.stream_ptr()), "vog_forward")
@@ -233,6 +281,7 @@ class VogEngine:
     def set_option(self, name: str, value: int) -> None:
         """Integer options of the context: 'lstm_persistent', 'fused_tail', 'pair_launches', ... (include/vog_hip.h)."""
         L.check(self.lib.vog_ctx_set_int(self.ctx, name.encode(), int(value)), f"vog_ctx_set_int({name})")
+
 
     def time_kernel(self, slot: "Slot", name: str, iters: int = 50) -> float:
         us = C.c_float()
@@ -342,6 +391,7 @@ class Slot:
 
     def launch(self, stream: Optional[torch.cuda.Stream] = None):
         self._check_epoch()
+        _lane_enter(self.eng.device, stream)
         sp = L.stream_ptr(stream)
         if self.graph is not None:
             L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
@@ -432,6 +482,7 @@ class Group:
     def launch(self, stream: Optional[torch.cuda.Stream] = None):
         for sl in self.slots:
             sl._check_epoch()
+        _lane_enter(self.eng.device, stream)
         sp = L.stream_ptr(stream)
         if self.graph is not None:
             L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
@@ -464,3 +515,4 @@ class Group:
                 self.eng.lib.vog_graph_destroy(self.graph)
         except Exception:
             pass
+

@@ -218,13 +218,14 @@ SYMBOLS = {
     "vog_box_u": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp]),
     "vog_srl_gather": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vog_bilstm_layer_supported": (c_i32, [c_i32, c_i32]),
+    "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vog_lstm_pack_whh": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32]),
     "vog_lstm_pack_w": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32]),
-    "vog_prep_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+    "vog_prep_fused": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                c_vp, c_vp, c_i32, C.POINTER(VisprepArgs), c_vp]),
-    "vog_lang_prep": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+    "vog_lang_prep": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                               c_vp, c_vp, c_i32, c_vp]),
     "vog_vis_prep": (c_i32, [C.POINTER(VisprepArgs), c_vp]),
     "vog_bilstm_step": (c_i32, [C.POINTER(LstmStepArgs), c_vp]),
