@@ -428,36 +428,126 @@ def test_group_language_encoder_matches_standalone_forwards(name, n, mode):
     _check_against(name, outs[0], pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
 
 
+class _OracleGolden(dict):
+    """An oracle result in the shape `_check_against` expects from a golden .npz."""
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+def _oracle_golden(cfg, sd, batch, c):
+    o = oracle_run(cfg, sd, batch, c)
+    keys = ("mdl_outs", "mdl_outs_eval", "scores", "boxes", "indexs", "vidf_outs", "fin_scores", "fin_scores_loss")
+    return _OracleGolden({k: o[k].numpy() for k in keys if k in o})
+
+
+def _variant(name, dseed_shift):
+    """The inputs of case `name` re-drawn with another data seed (same weights, same shapes)."""
+    key = f"{name}#v{dseed_shift}"
+    cc = dict(cases.CASES[name])
+    cc["dseed"] = cc["dseed"] + dseed_shift
+    cases.CASES[key] = cc
+    try:
+        _, _, b, _ = cases.build(key)
+    finally:
+        del cases.CASES[key]
+    return b
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8"])
+def test_slot_replay_with_new_inputs(name):
+    """A captured slot replayed on CHANGED inputs: `update_inputs(B)` + launch, then a batch assembled on the
+    device straight into the slot's buffers + launch, then A again. Every replay must equal the eager forward
+    on the same data bit for bit (a stale hand-off slot, workspace stage or graph-baked pointer surviving from
+    the previous replay would show here, not in replays of identical inputs) and the CPU oracle within the
+    golden tolerances."""
+    import importlib
+    dls = importlib.import_module("vognet-pytorch_amd.dat_loader_simple")
+    synth = importlib.import_module("vognet-pytorch_amd.synth")
+    from oracle import vog_oracle as vo
+    eng, cfg, sd, batch_a, c, dev_a = build_engine(name)
+    batch_b = _variant(name, 41)
+    T = int(max(batch_a["srl_arg_word_mask_len"].max(), batch_b["srl_arg_word_mask_len"].max()))
+    ncmp = batch_a["new_srl_idxs"].shape[1]
+    slot = eng.make_slot(dev_a, T=T, graph=True)
+    keys = ("mdl_outs", "mdl_outs_eval", "pred_rec")
+
+    def check(batch, tag):
+        out = slot.launch()
+        torch.cuda.synchronize()
+        got = {k: out[k].clone() for k in keys}
+        ref = eng.forward({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in batch.items()}, T=T)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), (tag, k)
+        g = _oracle_golden(cfg, sd, batch, c)
+        _check_against(f"{name}/{tag}", got, eng.unpack_pred(got["pred_rec"], ncmp), g, None, tol_rel=1e-3, tol_logit=6e-3)
+        return got
+
+    first = check(batch_a, "A")
+    slot.update_inputs({k: torch.from_numpy(v) for k, v in batch_b.items()})
+    second = check(batch_b, "B")
+    assert not torch.equal(first["mdl_outs"], second["mdl_outs"])
+    # device-side batch assembly (csrc/assemble.hip) into the slot's input buffers
+    conc = cfg.ds.conc_type
+    B = batch_a["num_cmp_msk"].shape[0]
+    it = synth.make_items(B, 4, c["nppf0"], seed=23)
+    asm = dls.DeviceBatchAssembler(cfg, {"num_prop_per_frm": c["nppf0"]})
+    asm({k: torch.from_numpy(v).cuda() for k, v in it.items()}, out={k: slot.inp[k] for k in dls.FWD_KEYS},
+        with_loss_keys=False)
+    torch.cuda.synchronize()
+    batch_c = dict(batch_b)
+    batch_c.update({k: slot.inp[k].cpu().numpy() for k in dls.FWD_KEYS})
+    ref_asm = vo.assemble_batch(it, conc, 10, c["nppf0"])
+    for k in dls.FWD_KEYS:
+        assert np.array_equal(batch_c[k], ref_asm[k]), k
+    third = check(batch_c, "assembled")
+    assert not torch.equal(third["mdl_outs"], second["mdl_outs"])
+    slot.update_inputs({k: torch.from_numpy(v) for k, v in batch_a.items()})
+    again = check(batch_a, "A again")
+    for k in keys:
+        assert torch.equal(again[k], first[k]), k
+
+
 def test_persistent_lstm_handoff_is_deterministic_under_load():
-    """Four graphs in flight for 3000 launches: every output stays bit-identical to the slot's
-    first result. The persistent BiLSTM hands h between 64 workgroups through self-validating
-    words; a stale, torn or timed-out hand-off would show up here as a difference or a NaN
-    (scratch/stress_lstm.py is the long version: 76k forwards without a mismatch)."""
+    """Four graphs in flight for 3000 launches, every slot ALTERNATING between two input batches
+    (A / B / A ..., copied into its buffers on its own stream before each launch): every output stays
+    bit-identical to the first result for the same inputs. The persistent BiLSTM hands h between 64
+    workgroups through self-validating values in per-step slots that the forward's prologue re-arms; a
+    stale, torn or timed-out hand-off - or anything left over from the previous replay's DIFFERENT data -
+    would show up here as a difference or a NaN (scratch/stress_lstm.py is the long version)."""
     name = "full/cfg2_ragged"
     eng, cfg, sd, batch, c, dev = build_engine(name)
-    from tests.gpu_util import cases as _cases
-    slots, streams = [], []
+    slots, streams, inputs = [], [], []
     for s in range(4):
-        key = f"{name}#stress{s}"
-        cc = dict(_cases.CASES[name])
-        cc["dseed"] = cc["dseed"] + 17 * s
-        _cases.CASES[key] = cc
-        try:
-            _, _, b, _ = _cases.build(key)
-        finally:
-            del _cases.CASES[key]
-        slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()}, graph=True))
+        ab = [_variant(name, 17 * s + 1), _variant(name, 17 * s + 9)]
+        T = int(max(b["srl_arg_word_mask_len"].max() for b in ab))
+        inputs.append([{k: torch.from_numpy(v).cuda() for k, v in b.items()} for b in ab])
+        slots.append(eng.make_slot(inputs[s][0], T=T, graph=True))
         streams.append(torch.cuda.Stream())
-    for sl, st in zip(slots, streams):
-        sl.launch(st)
     torch.cuda.synchronize()
-    refs = [{k: v.clone() for k, v in sl.out.items() if isinstance(v, torch.Tensor)} for sl in slots]
-    for r in refs:
-        assert torch.isfinite(r["mdl_outs"]).all()
+    refs = []
+    for sl, st, ab in zip(slots, streams, inputs):
+        r = []
+        for which in (0, 1):
+            with torch.cuda.stream(st):
+                sl.update_inputs(ab[which])
+            sl.launch(st)
+            torch.cuda.synchronize()
+            r.append({k: v.clone() for k, v in sl.out.items() if isinstance(v, torch.Tensor)})
+            assert torch.isfinite(r[-1]["mdl_outs"]).all()
+        assert not torch.equal(r[0]["mdl_outs"], r[1]["mdl_outs"])
+        refs.append(r)
+    last = [1] * 4
     for i in range(3000):
-        slots[i % 4].launch(streams[i % 4])
+        s = i % 4
+        which = (i // 4) % 2
+        with torch.cuda.stream(streams[s]):
+            slots[s].update_inputs(inputs[s][which], check_lengths=False)       # (no host sync in the loop)
+        slots[s].launch(streams[s])
+        last[s] = which
         if (i + 1) % 500 == 0:
             torch.cuda.synchronize()
-            for sl, ref in zip(slots, refs):
-                for k in ref:
-                    assert torch.equal(sl.out[k], ref[k]), (i, k)
+            for sl, ref, w in zip(slots, refs, last):
+                for k in ref[w]:
+                    assert torch.equal(sl.out[k], ref[w][k]), (i, k)

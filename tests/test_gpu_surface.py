@@ -201,16 +201,47 @@ def test_evaluator_forward_scores_its_pickle_with_the_grounding_metrics(tmp_path
     assert again["num_queries"] == B                           # every validation sentence was scored
 
 
-def test_main_dist_cli_only_val(capsys):
-    """`main_dist.py <uid> --only_val=True --a.b=c`: the reference's CLI shape (code/main_dist.py:90-163)."""
+def test_main_dist_cli_only_val(capsys, tmp_path):
+    """`main_dist.py <uid> --only_val=True --a.b=c`: the reference's CLI shape AND flow (code/main_dist.py:90-163
+    -> Learner.validate, utils/trn_utils.py:443-468): the evaluator is called with (mdl, loss_fn, dl, dl_name,
+    rank, pred_path), prints val_loss / val_acc and leaves `<tmp_path>/predictions/<uid>/valid_0.pkl` behind -
+    with a short tail batch, as a drop_last=False validation loader produces."""
     main_mod.main_dist("t0", only_val=True, synthetic_batches=3,
                        **{"mdl.name": "vog", "ds.conc_type": "spat", "mdl.obj_tx.use_rel": True,
-                          "mdl.mul_tx.use_rel": True, "train.bsv": 4})
-    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["uid"] == "t0" and res["queries"] == 12 and res["mdl"] == "vog" and np.isfinite(res["checksum"])
+                          "mdl.mul_tx.use_rel": True, "train.bsv": 4, "misc.tmp_path": str(tmp_path)})
+    lines = capsys.readouterr().out.splitlines()
+    res = json.loads([l for l in lines if l.startswith("{\"uid\"")][-1])
+    assert res["uid"] == "t0" and res["queries"] == 11 and res["mdl"] == "vog" and res["dl_name"] == "valid"
+    assert set(res["val_loss"]) == {"loss", "mdl_out_loss"} and all(np.isfinite(v) and v > 0 for v in res["val_loss"].values())
+    assert set(res["val_acc"]) == {"avg1", "avg1_cons", "avg1_vidf", "avg1_strict"}
+    pk = tmp_path / "predictions" / "t0" / "valid_0.pkl"
+    assert res["pred_file"] == str(pk) and pk.is_file()
+    recs = pickle.load(open(pk, "rb"))
+    assert len(recs) == 11 and set(recs[0]) == REF_RECORD_KEYS             # 4 + 4 + 3: the tail batch is short
+    assert [r["idx_vid"] for r in recs] == list(range(11))                  # loader order, padding rows dropped
     with pytest.raises(AssertionError):
         main_mod.main_dist("t1", only_val=True, **{"mdl.no_such_key": 1})
+
+
+def test_evaluator_forward_short_tail_batch(tmp_path):
+    """The last batch of a validation loader is usually smaller (drop_last=False, utils/trn_utils.py:200-203):
+    its records are padded to the exchange ring's row count and the padding is dropped again on rank 0."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    cpu = {k: v.cpu() for k, v in dev.items()}
+    cpu.update({k: torch.from_numpy(v) for k, v in tg.items()})
+    B = batch["num_cmp_msk"].shape[0]
+    tail = {k: v[: B - 1] for k, v in cpu.items()}
+    val_loss, val_acc = evl(mdl, loss_fn, _Loader([cpu, cpu, tail]), "valid", rank=0, pred_path=tmp_path)
+    recs = pickle.load(open(tmp_path / "valid_0.pkl", "rb"))
+    assert len(recs) == 3 * B - 1
+    g = np.load(cases.golden_path(name))
+    got = np.array([r["pred_scores"] for r in recs[2 * B:]])
+    assert np.allclose(got, g["scores"][: B - 1], rtol=2e-3, atol=1e-6)
+    assert [r["idx_vid"] for r in recs[2 * B:]] == list(range(100, 100 + B - 1))
+    assert set(val_loss) == set(loss_fn.loss_keys) and all(torch.isfinite(v) for v in val_loss.values())
 
 
 # ---- device loss (csrc/loss.hip) through the selector's loss class -----------------------------------------

@@ -141,7 +141,10 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
   }
   AttnParams pt = p;
   if (!fallback_pass) pt.guard = nullptr;
-  if (tile_min > 0 && p.N >= tile_min && !force_general) {
+  // (after attn_tile2 the running-maximum tile kernel is ALWAYS the second pass, whatever the experiment
+  // knobs say: it is the only kernel that honours the guard flag - anything else would redo the whole
+  // attention unconditionally)
+  if (fallback_pass || (tile_min > 0 && p.N >= tile_min && !force_general)) {
     constexpr int NF = (NDB * 32) / 16 + 2 * NDB;
     const size_t lds = (size_t)2 * NF * 1024 + (size_t)p.npad * sizeof(float);
     if (lds > 150 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the LDS budget", p.N);

@@ -326,9 +326,13 @@ class Slot:
     def __init__(self, eng: VogEngine, inp, T, with_pred, graph, pred_rec=None):
         self.eng = eng
         self.epoch = eng.weights_epoch
-        self.inp = {k: (v.to(eng.device).contiguous() if isinstance(v, torch.Tensor)
-                        else torch.from_numpy(np.ascontiguousarray(v)).to(eng.device))
-                    for k, v in inp.items()}
+        # the slot OWNS its input buffers (update_inputs / the device batch assembly write into them): a
+        # tensor that already lives on the device is copied, never aliased
+        def own(v):
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+            d = t.to(eng.device).contiguous()
+            return d.clone() if d.data_ptr() == t.data_ptr() else d
+        self.inp = {k: own(v) for k, v in inp.items()}
         with torch.cuda.device(eng.device):
             self.batch, self.out, (self.B, self.ncmp, self.T) = eng.make_batch(self.inp, T, with_pred, pred_rec)
             n = eng.lib.vog_workspace_bytes(eng.ctx, self.B, self.ncmp, self.T)
@@ -369,12 +373,12 @@ class Slot:
         L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
         return self.out
 
-    def update_inputs(self, inp):
+    def update_inputs(self, inp, check_lengths: bool = True):
         """Copy a new batch (same shapes, sentence lengths <= the T this slot was captured with) into
         the slot's buffers. T is baked into the captured graph / AQL program and the workspace: a
         longer sentence would index the LSTM schedule out of its rows, so it is refused here (capture
         the slot with T = cfg.ds.max_seq_length when the lengths are not known in advance)."""
-        lens = inp.get("srl_arg_word_mask_len")
+        lens = inp.get("srl_arg_word_mask_len") if check_lengths else None      # (the check reads the lengths: a host sync)
         if lens is not None:
             mx = int((lens if isinstance(lens, torch.Tensor) else torch.as_tensor(lens)).max())
             if mx > self.T:

@@ -157,8 +157,7 @@ class Evaluator(torch.nn.Module):
                 if loss_fn is not None:
                     ld = loss_fn(out, batch)
                     for k, v in ld.items():
-                        if not k.startswith("_"):
-                            losses[k] = losses.get(k, 0.0) + v.detach().double() * b
+                        losses[k] = losses.get(k, 0.0) + v.detach().double() * b
                     nums += b
             rec = self._records(out, batch)
             meta = [k for k in self.META_KEYS if k in batch]

@@ -4,17 +4,22 @@
 
 `fire` is not installed, so the `uid --a.b=c` syntax is parsed here; overrides go
 through `update_from_dict` (unknown key / type mismatch -> AssertionError, as
-code/extended_config.py:69-78). The trainer (`Learner`, utils/trn_utils.py) and
-the dataset loaders are out of scope (SURVEY.md 2.1 #11,#14): without the 530 GB
-dataset the driver runs the selected model on synthetic batches
-(`--only_val=True` semantics: forward + prediction head + cross-rank gather) and
-prints one JSON line with throughput and output checksums.
+code/extended_config.py:69-78). `--only_val=True` / `--only_test=True` run the reference's validation flow
+(code/main_dist.py:143-157 -> `Learner.validate`, utils/trn_utils.py:443-468): the selected evaluator is
+called as `eval_fn(mdl, loss_fn, dl, dl_name, rank=..., pred_path=<tmp_path>/predictions/<uid>)`, i.e.
+forward -> device loss -> prediction records -> ONE cross-rank exchange per 16 batches (dist.RecordRing) ->
+rank 0 writes `<pred_path>/<dl_name>_0.pkl` and scores it when the annotation files of cfg.ds exist; the
+loss and metric dicts are printed like the reference prints them, followed by one JSON line.
+The trainer (`Learner.fit`) and the dataset readers are out of scope: without the
+530 GB dataset the loader is a list of synthetic batches (`--synthetic_batches=N`, the last one a query
+short like the tail batch of a `drop_last=False` validation loader).
 """
 from __future__ import annotations
 
 import json
 import sys
 import time
+from pathlib import Path
 from typing import Any, Dict, List, Tuple
 
 import torch
@@ -50,15 +55,39 @@ def parse_argv(argv: List[str]) -> Tuple[str, Dict[str, Any]]:
 
 
 def learner_init(uid: str, cfg):
-    """Builds comm -> model -> eval like reference main_dist.py:31-87 (data and
-    Learner replaced by the synthetic driver)."""
+    """Builds comm -> model / loss / eval like reference main_dist.py:31-87 (the data side and the trainer
+    replaced by the synthetic loader below)."""
     sel = get_mdl_loss_eval(cfg)
     comm = {"vocab_size": 5000, "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1},
             "num_prop_per_frm": num_prop_per_frm(cfg)}
     mdl = sel["mdl"](cfg=cfg, comm=comm)
+    loss_fn = sel["loss"](cfg, comm)
     device = torch.device("cuda", torch.cuda.current_device())
     evl = sel["eval"](cfg, comm, device)
-    return mdl, evl, comm
+    return mdl, loss_fn, evl, comm
+
+
+def synthetic_loader(cfg, comm, n_batches: int, rank: int, world: int):
+    """Validation batches with every key the forward, the loss and the evaluator read,
+    this rank's contiguous share (dist.shard_indices = NewDistributedSampler, utils/trn_utils.py:127-156);
+    the last batch is one query short (validation loaders keep the tail, trn_utils.py:200-203)."""
+    import numpy as np
+    bs = int(cfg.train.bsv)
+    ct = cfg.ds.conc_type
+    out = []
+    for i in D.shard_indices(n_batches, rank, world):
+        b = synth.make_batch(ct, bs, comm["num_prop_per_frm"], vocab_size=comm["vocab_size"], seed=1000 * i)
+        b.update(synth.make_targets(b, ct, comm["num_prop_per_frm"], seed=i))
+        ncmp = b["num_cmp_msk"].shape[1]
+        rng = np.random.default_rng(77 + i)
+        perm = np.stack([rng.permutation(ncmp) for _ in range(bs)]).astype(np.int64)
+        b.update({"ann_idx": np.arange(i * bs, (i + 1) * bs, dtype=np.int64),
+                  "sent_idx": np.arange(i * bs, (i + 1) * bs, dtype=np.int64),
+                  "permute": perm, "permute_inv": np.argsort(perm, axis=1).astype(np.int64)})
+        if i == n_batches - 1 and bs > 1:
+            b = {k: v[: bs - 1] for k, v in b.items()}
+        out.append({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()})
+    return out
 
 
 def main_dist(uid: str, **kwargs):
@@ -75,36 +104,32 @@ def main_dist(uid: str, **kwargs):
     cfg = update_from_dict(cfg, kwargs, key_maps)
     cfg = post_proc_config(cfg)
     cfg.freeze()
-    mdl, evl, comm = learner_init(uid, cfg)
+    mdl, loss_fn, evl, comm = learner_init(uid, cfg)
     if not (cfg.only_val or cfg.only_test):
         raise NotImplementedError(
             "training (Learner.fit) is outside the forward hot path; run with --only_val=True")
     rank, world = D.get_rank(), D.get_world_size()
-    bs = cfg.train.bsv
-    device = torch.device("cuda", torch.cuda.current_device())
-    batches = []
-    for i in range(n_batches):
-        b = synth.make_batch(cfg.ds.conc_type, bs, comm["num_prop_per_frm"], vocab_size=comm["vocab_size"],
-                             seed=1000 * i + rank)
-        batches.append({k: torch.from_numpy(v) for k, v in b.items()})
+    # Learner.init_log_dirs (utils/trn_utils.py:341-368): <data.path = cfg.misc.tmp_path>/predictions/<uid>
+    pred_path = Path(cfg.misc.tmp_path) / "predictions" / uid
+    dl_name = "valid" if cfg.only_val else "test"
+    dl = synthetic_loader(cfg, comm, n_batches, rank, world)
+    nq_local = sum(int(b["num_cmp_msk"].shape[0]) for b in dl)
     torch.cuda.synchronize()
     t0 = time.time()
-    chk = 0.0
-    nq = 0
-    for b in batches:
-        b = {k: v.to(device) for k, v in b.items()}
-        with torch.no_grad():
-            out = mdl(b)
-        rec = D.all_gather_records(out["_pred_rec"])
-        nq += rec.shape[0]
-        chk += float(out["mdl_outs_eval"].sum())
+    with torch.no_grad():
+        val_loss, val_acc = evl(mdl, loss_fn, dl, dl_name, rank=rank, pred_path=pred_path)
     torch.cuda.synchronize()
     dt = time.time() - t0
     if D.is_main_process():
-        print(json.dumps({"uid": uid, "world": world, "queries": nq, "seconds": dt,
-                          "queries_per_s": nq / dt, "checksum": chk,
-                          "mdl": cfg.mdl.name, "conc_type": cfg.ds.conc_type}))
-    return
+        print(val_loss)                               # as the reference (main_dist.py:147-148)
+        print(val_acc)
+        fname = pred_path / f"{dl_name}_0.pkl"
+        print(json.dumps({"uid": uid, "world": world, "queries": nq_local * world, "seconds": dt,
+                          "queries_per_s": nq_local * world / dt, "mdl": cfg.mdl.name,
+                          "conc_type": cfg.ds.conc_type, "dl_name": dl_name, "pred_file": str(fname),
+                          "val_loss": {k: float(v) for k, v in val_loss.items()},
+                          "val_acc": {k: float(v) for k, v in val_acc.items()}}))
+    return val_loss, val_acc
 
 
 if __name__ == "__main__":

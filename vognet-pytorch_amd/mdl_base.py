@@ -128,8 +128,20 @@ class AnetBaseMdl(nn.Module):
         return r
 
     def _param_version(self):
-        # in-place updates (p.data.copy_, optimizer.step, manual init) bump Tensor._version
-        return tuple((id(p), p._version) for p in self.parameters())
+        # In-place updates of a parameter (optimizer.step, p.copy_ / p.add_ under no_grad, nn.init.*) bump
+        # Tensor._version; re-assigning p.data moves data_ptr. NOT seen: writes through `p.data` (p.data.copy_,
+        # p.data.fill_ - `.data` is a detached alias with its own version counter): call `mark_dirty()` (or
+        # `refresh_weights()`) after weight surgery of that kind.
+        return tuple((id(p), p._version, p.data_ptr()) for p in self.parameters())
+
+    def mark_dirty(self):
+        """The parameters were edited in a way `_param_version` cannot see: re-upload at the next forward."""
+        self._weights_dirty = True
+
+    def refresh_weights(self) -> VogEngine:
+        """Re-register every parameter with the engine now (invalidates captured slots: new weights_epoch)."""
+        self._weights_dirty = True
+        return self.engine()
 
     def engine(self) -> VogEngine:
         if self._engine is None:

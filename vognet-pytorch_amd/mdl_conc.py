@@ -44,7 +44,8 @@ class _LossB(nn.Module):
     the evaluator calls it for every validation batch, code/eval_vsrl_corr.py:119). The IoU targets
     (utils/box_utils.py:61-118), the target selection and the masked BCE run on the device in
     `vog_loss_fwd` (csrc/loss.hip); the returned values are 0-dim device tensors (no sync here).
-    `backward(loss_dict)` returns d loss / d mdl_outs (`vog_loss_bwd`): the first link of the training path
+    `backward(loss_dict)` (the dict `forward` returned, or any dict after it: the last call's context is kept
+    on the module) returns d loss / d mdl_outs (`vog_loss_bwd`): the first link of the training path
     (SURVEY.md 8(f) rank 4); nothing behind it (score head, transformers, BiLSTM) has a backward yet."""
     loss_keys = ["loss", "mdl_out_loss"]
     conc_types = ()
@@ -102,8 +103,11 @@ class _LossB(nn.Module):
         d = {"loss": res[0], "mdl_out_loss": res[1]}
         if sep:
             d["verb_loss"] = res[2]
-        d["_keepalive"] = (keep, scr)
-        d["_args"] = a
+        # exactly the `loss_keys` tensors, as the reference (consumers iterate the dict and call .detach() /
+        # reduce_dict on every value, code/eval_vsrl_corr.py:119-122). What `backward` needs - the argument
+        # block and the tensors it points into - stays on the module and rides on the `loss` tensor.
+        self._last = (a, keep, scr)
+        d["loss"]._vog_loss_ctx = self._last
         return d
 
     def backward(self, loss_dict, with_verb: bool = False):
@@ -112,8 +116,9 @@ class _LossB(nn.Module):
         import ctypes as C
         from . import lib as L
         lib = L.load()
-        a = loss_dict["_args"]
-        mo = loss_dict["_keepalive"][0][0]
+        ctx = getattr(loss_dict["loss"], "_vog_loss_ctx", None) or self._last
+        a, keep = ctx[0], ctx[1]
+        mo = keep[0]
         g = torch.empty_like(mo)
         gv = None
         if with_verb:
