@@ -8,6 +8,7 @@ occupied; 4 SIMDs per CU) beside SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES as th
 import collections, csv, json, os, re, sys
 
 wl, forwards, fcsv, wcsv, sqcsv, out_md, out_json = sys.argv[1:8]
+src_label = sys.argv[8] if len(sys.argv) > 8 else None      # the tracked copy of out_md (profiles/...)
 forwards = int(forwards)
 OURS = ("lstm", "gemm", "attn", "layernorm", "splitk", "argvec", "score", "pred", "vis_", "lang_prep", "prep_fused",
         "vislang", "qkv_combine", "cast2", "box_u", "srl_gather", "predcmp", "tx_tail", "pair_kernel", "loss_")
@@ -59,7 +60,7 @@ for key in sorted(f, key=lambda k: -sum(f[k]["FETCH_SIZE"])):
                     "mfma_busy_over_sq_busy": u1, "mfma_util_of_occupied_cus": u2}
 with open(out_md, "w") as o:
     o.write(f"# {wl}: HBM-side traffic and MFMA utilisation per kernel (rocprofv3 --pmc, separate passes)\n\n"
-            f"Command: `scratch/prof_round2.sh` -> `scratch/prof_forward.py {wl} {forwards}` (eager launches, pair_launches = 0 so "
+            f"Command: `scratch/prof_round3.sh` -> `scratch/prof_forward.py {wl} {forwards}` (eager launches, pair_launches = 0 so "
             f"every step is its own kernel). FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported.\n\n"
             f"**{total / 1e6:.1f} MB per forward** (sum over kernels of (fetch + write) x launches per forward).\n\n"
             "| kernel | grid (threads) | launches / forward | fetch MB | write MB | MFMA_BUSY / SQ_BUSY | MFMA_BUSY / (4 x BUSY_CU) |\n"
@@ -72,6 +73,6 @@ try:
 except Exception:
     js = {}
 js[wl] = {"bytes_per_forward": total, "kernels": kern,
-          "source": f"{os.path.relpath(out_md, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; FETCH x2 gfx950 correction)"}
+          "source": f"{src_label or os.path.relpath(out_md, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; FETCH x2 gfx950 correction)"}
 json.dump(js, open(out_json, "w"), indent=1, sort_keys=True)
 print(open(out_md).read())
