@@ -55,6 +55,17 @@ const char* vog_last_error(void);
  * (rep > 1 broadcasts a frame's segment feature onto its proposals,
  * mdl_conc_single.py:51-66). */
 struct vog_vislang_args;
+/* Optional tail of the M <= 64 GEMM kernel: the argument vectors of vog_srl_argvec computed in the SAME
+ * launch from the GEMM's fp32 output (c32 = `full` [Bn*T + .., L], ldc = L = N): every workgroup publishes
+ * its tile, waits for the others of the launch (`counter`, zero at launch) and computes its share of
+ * lang[b,a,:] - bit-identical to vog_srl_argvec. One launch and one dependent boundary less on the
+ * language chain (the out-projection's workgroups are few and co-resident; the wait is bounded). */
+typedef struct vog_argvec_tail {
+  unsigned int* counter;
+  const int64_t* capture; const int64_t* inds_msk; const float* w; const float* bias; float* lang;
+  int Bn, T, nsrl, L;
+} vog_argvec_tail;
+
 typedef struct vog_gemm_args {
   const void* a; int a_is_f32; int64_t lda; const int32_t* a_rows;
   const void* w; int64_t ldw;
@@ -85,6 +96,7 @@ typedef struct vog_gemm_args {
    * [m/16][K/32][lane = ((k%32)/8)*16 + m%16][k%8] — written that way by vog_bilstm_step
    * (out_frag) so that the LSTM -> projection hand-off needs no strided fragment loads. */
   int a_frag;
+  const vog_argvec_tail* argvec_tail;   /* NULL, or see above (M <= 64, c32 set, N == ldc == tail->L) */
 } vog_gemm_args;
 /* host: fp32 [N, ld] (first K columns) -> 16-bit fragment order, N*K halfwords. */
 int vog_pack_w_frag(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);

@@ -173,6 +173,25 @@ def test_paired_launches_equal_separate_launches(name):
 
 
 @pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
+                                  "full/cfg1_igrnd_spat_gt5_bs2", "small/vog_spat", "small/vog_sep_r64"])
+@pytest.mark.parametrize("pair", [0, 1])
+def test_argvec_tail_equals_separate_launch(name, pair):
+    """fused_argvec: the argument vectors computed by the out-projection's own workgroups after an in-launch
+    arrival barrier (vog_argvec_tail, csrc/gemm_dev.h) vs the stand-alone vog_srl_argvec launch: the same
+    device function on the same fp32 rows -> bit-identical outputs, alone and inside the pair launch."""
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("pair_launches", pair)
+    eng.set_option("fused_argvec", 0)
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("fused_argvec", 1)
+    for _ in range(3):                                   # (replays: the arrival counter is re-zeroed by the prologue)
+        b = eng.forward(dev)
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (name, k)
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
                                   "full/cfg1_igrnd_spat_gt5_bs2"])
 def test_fused_lstm_input_projection_matches_separate_gemm(name):
     """fused_ih: x W_ih^T + b computed in the persistent layer kernel's prologue vs the separate GEMM

@@ -3,14 +3,10 @@
 // pred_cmp head, prediction head. fp32 arithmetic throughout (these are exact
 // restatements; only the MFMA contractions run in 16 bit).
 #include "common.h"
+#include "argvec_dev.h"
 
 namespace vog {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------------------
@@ -161,45 +157,10 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
                                                      const float* __restrict__ bias,
                                                      float* __restrict__ lang, int T, int nsrl, int L) {
   // grid (sentence*arg, L/16): each wave owns 4 outputs with 4 independent
-  // accumulators, so all of its weight-row loads are in flight together
-  const int ba = blockIdx.x;                   // b*nsrl + a
-  const int b = ba / nsrl;
-  int64_t c0 = capture[(int64_t)ba * 2], c1 = capture[(int64_t)ba * 2 + 1];
-  c0 = c0 < 0 ? 0 : (c0 >= T ? T - 1 : c0);
-  c1 = c1 < 0 ? 0 : (c1 >= T ? T - 1 : c1);
-  const float* x0 = full + ((int64_t)b * T + c0) * L;
-  const float* x1 = full + ((int64_t)b * T + c1) * L;
-  const float mk = (float)msk[ba];
+  // accumulators, so all of its weight-row loads are in flight together (argvec_dev.h)
+  const int ba[1] = {(int)blockIdx.x};                 // b*nsrl + a
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int o0 = blockIdx.y * 16 + wid * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  // 2L <= 1024, L % 4 == 0: 16 bytes per lane per access (4 x fewer load instructions than one
-  // float per lane: the kernel is latency bound and every load instruction costs issue time),
-  // all loads issued before the FMAs
-  constexpr int MAXQ = 4;
-  const int nq = (2 * L) >> 2, lq = L >> 2;
-  float4 xv[MAXQ], wv[4][MAXQ];
-#pragma unroll
-  for (int it = 0; it < MAXQ; ++it) {
-    const int i = lane + it * 64;
-    const bool ok = i < nq;
-    xv[it] = ok ? (i < lq ? reinterpret_cast<const float4*>(x0)[i] : reinterpret_cast<const float4*>(x1)[i - lq])
-                : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      wv[k][it] = (ok && o0 + k < L) ? reinterpret_cast<const float4*>(w + (int64_t)(o0 + k) * 2 * L)[i]
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int it = 0; it < MAXQ; ++it)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      acc[k] += (wv[k][it].x * xv[it].x + wv[k][it].y * xv[it].y) + (wv[k][it].z * xv[it].z + wv[k][it].w * xv[it].w);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float v = wave_sum(acc[k]);
-    if (lane == 0 && o0 + k < L) lang[(int64_t)ba * L + o0 + k] = relu_nan(v + bias[o0 + k]) * mk;
-  }
+  argvec_rows<1>(full, capture, msk, w, bias, lang, T, nsrl, L, blockIdx.y * 16 + wid * 4, ba, lane, false);
 }
 
 // ---------------------------------------------------------------------------

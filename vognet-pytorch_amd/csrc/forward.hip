@@ -95,6 +95,9 @@ struct vog_ctx {
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
+  int fused_argvec = 0;                 // 1: argument vectors inside the language out-projection's launch (vog_argvec_tail): one
+                                        // launch less, but the in-launch arrival wait costs more than the boundary it removes
+                                        // (210.6 vs 205.2 us per forward, 72.6 vs 70.6 us per batch with 4 in flight): off
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
   int qkv_lean = 0;                     // 1: row-block QKV projections (qkvrb_dev.h) where the shape allows: ~1/3 of the
                                         // busy-CU time of the tiled GEMM at twice its latency; measured neutral at cfg 2
@@ -328,8 +331,9 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_hB_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);
     p.add("lstm_hA2_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 2);   // ping buffer when out16 is fragment-ordered
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
-    p.add("lstm_sync_" + std::to_string(l), 1024);   // [2] timeout, [4 + dir] workgroups arrived, [8 + dir] XCC ids seen
+    p.add("lstm_sync_" + std::to_string(l), 1024);   // [2] timeout, [16 + 16 dir + xcc] workgroups arrived per XCC id
   }
+  p.add("argvec_sync", 256);                          // arrival counter of the out-projection's argument-vector tail
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -655,6 +659,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         steps.push_back({"lstm_step", [=](hipStream_t st) { return vog_bilstm_step(&la, st); }});
       }
     }
+    bool argvec_done = false;
     vog_gemm_args po{}; po.c16_dtype = -1;
     po.a = ws.at<void>("lstm_out16_" + std::to_string(d.rnn_layers - 1)); po.lda = 2 * R;
     po.w = c->w_outproj; po.ldw = 2 * R; po.bias = c->b_outproj; po.relu = 1;
@@ -672,6 +677,15 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       f0.slabs = ps.c32; f0.splits = 8; f0.M = po.M; f0.N = g.L; f0.bias = c->b_outproj; f0.relu = 1; f0.rep = 1;
       f0.c32 = full32; f0.ldc = g.L;
       steps.push_back({"lstm_outproj_finish", [=](hipStream_t st) { return vog_splitk_finish(&f0, nullptr, st); }});
+    } else if (c->fused_argvec && po.M <= 64 && (po.K % 32) == 0 && (g.L % 16) == 0 && g.L <= 512 && g.L / 16 < 128) {
+      // the argument vectors ride in the out-projection's launch (vog_argvec_tail): no argvec launch
+      vog_argvec_tail av{};
+      av.counter = ws.at<unsigned int>("argvec_sync"); av.capture = b->srl_arg_words_capture;
+      av.inds_msk = b->srl_arg_inds_msk; av.w = c->w_arg; av.bias = c->b_arg; av.lang = lang_vec;
+      av.Bn = Bn; av.T = T; av.nsrl = nsrl; av.L = g.L;
+      steps.push_back({"lstm_outproj", [=](hipStream_t st) {
+        vog_gemm_args p2 = po; p2.argvec_tail = &av; return vog_gemm_bias_act(&p2, st); }});
+      argvec_done = true;
     } else {
       steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
     }
@@ -680,8 +694,9 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     const int64_t *cap = b->srl_arg_words_capture, *im = b->srl_arg_inds_msk;
     const float *wa = c->w_arg, *ba = c->b_arg;
     const int L = g.L;
-    steps.push_back({"argvec", [=](hipStream_t st) {
-      return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
+    if (!argvec_done)
+      steps.push_back({"argvec", [=](hipStream_t st) {
+        return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
   }
   if (structured && !lang_only) {
     {
@@ -1311,6 +1326,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
+  if (strcmp(name, "fused_argvec") == 0) { c->fused_argvec = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }

@@ -130,6 +130,14 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
     return launch_pipe<T16, EPI_PLAIN>(p, st);
   }
   p.w_frag = g->w_frag; p.a_frag = g->a_frag;
+  if (g->argvec_tail) {
+    const vog_argvec_tail* t = g->argvec_tail;
+    VOG_CHECK_ARG(t->counter && t->capture && t->inds_msk && t->w && t->bias && t->lang && t->Bn > 0 && t->nsrl > 0);
+    VOG_CHECK_ARG(p.M <= 64 && (p.K % 32) == 0 && p.c32 && p.N == t->L && p.ldc == t->L && t->L <= 512 && (t->L % 16) == 0 &&
+                  p.rep == 1 && !p.out_rows && ceil_div(p.N, 16) < 128);
+    p.av_counter = t->counter; p.av_capture = t->capture; p.av_msk = t->inds_msk; p.av_w = t->w; p.av_b = t->bias;
+    p.av_lang = t->lang; p.av_rows = t->Bn * t->nsrl; p.av_T = t->T; p.av_nsrl = t->nsrl; p.av_L = t->L;
+  }
   if (p.a_frag && !(p.M <= 64 && (p.K % 32) == 0 && !g->a_is_f32 && !g->a_rows))
     VOG_FAIL(-1, "a_frag activations are only valid for the M <= 64 kernel with a 16-bit A (M=%d K=%d)", p.M, p.K);
   if (p.w_frag && !(p.M <= 64 && (p.K % 32) == 0 && (p.N % 16) == 0))

@@ -1,6 +1,7 @@
 // Device side of gemm.hip (kernel bodies; also included by pair.hip, which fuses two bodies into one launch).
 #pragma once
 #include "common.h"
+#include "argvec_dev.h"
 
 namespace vog {
 
@@ -37,6 +38,9 @@ struct GemmParams {
   // st_kv_vis: K and V fragments only for the VISUAL rows (ntok = nppf per sequence, npad_kv), no
   // language part added: the separable attention (attention.hip, attn_struct_kernel) adds it itself
   int st_kv_vis, npad_kv;
+  // tail of the M <= 64 kernel (av_counter != nullptr; vog_argvec_tail): the argument vectors in the same launch
+  unsigned int* av_counter; const int64_t* av_capture; const int64_t* av_msk; const float* av_w; const float* av_b;
+  float* av_lang; int av_rows, av_T, av_nsrl, av_L;
 };
 
 template <typename T16, bool A_F32>
@@ -84,6 +88,10 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
       if (orow < 0) return;
       if (p.c32) p.c32[(int64_t)orow * p.ldc + col] = v;
       if (p.c16) p.c16[(int64_t)orow * p.ldc16 + col] = p.c16_bf16 ? to16<BF16>(v) : to16<F16>(v);
+      return;
+    }
+    if (p.av_counter) {   // argument-vector tail: other workgroups read this tile in the same launch -> write through
+      __hip_atomic_store(p.c32 + (int64_t)row * p.ldc + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
     for (int j = 0; j < p.rep; ++j) {
@@ -667,6 +675,40 @@ struct GemmSkinnyBody {
         for (int w = 0; w < KW; ++w) v += red[w][t][mt][lane][r];
         const int row = mt * 16 + (lane >> 4) * 4 + r;
         epilogue_store<T16>(p, row, (ct0 + t) * 16 + (lane & 15), v);
+      }
+    }
+  }
+  // ---- tail (vog_argvec_tail): the argument vectors need rows of the WHOLE product (c32 = `full`): every
+  // workgroup writes its tile THROUGH to memory (sc1 stores, epilogue_store), counts itself in once the
+  // stores are acknowledged and waits for the other gx * gy workgroups of this launch (they are few - 16 x 4
+  // for the language out-projection - small, and dispatched first: all co-resident), then computes ITS
+  // share of the vectors - the 16 output columns bx, the rows by, by + gy, ... - reading `full` with
+  // L1-bypassing loads. No fences: a release / acquire pair per workgroup (buffer_wbl2 / buffer_inv)
+  // was measured first and cost more than the launch it removes - inside a pair launch the L2 write-back
+  // also flushes the Q / K / V fragments the partner GEMM is writing (212 vs 205 us per forward).
+  // The wait is bounded: on a timeout the share is written as NaN.
+  if (p.av_counter) {
+    __syncthreads();
+    __shared__ unsigned int av_flag;
+    if (tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(p.av_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int want = cx.gx * cx.gy;
+      unsigned int spins = 0, bad = 0;
+      while (__hip_atomic_load(p.av_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) { bad = 1; break; }
+      }
+      av_flag = bad;
+    }
+    __syncthreads();
+    const bool poison = av_flag != 0;
+    const int o0 = (int)cx.bx * 16 * NT + wid * 4;
+    if (wid < 4 * NT) {
+      for (int r0 = (int)cx.by; r0 < p.av_rows; r0 += 2 * (int)cx.gy) {
+        const int r1 = r0 + (int)cx.gy;
+        const int ba[2] = {r0, r1 < p.av_rows ? r1 : -1};
+        argvec_rows<2, true>(p.c32, p.av_capture, p.av_msk, p.av_w, p.av_b, p.av_lang, p.av_T, p.av_nsrl, p.av_L, o0, ba, lane, poison);
       }
     }
   }

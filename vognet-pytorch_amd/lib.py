@@ -25,12 +25,17 @@ class VogError(RuntimeError):
     pass
 
 
+class ArgvecTail(C.Structure):
+    _fields_ = [("counter", c_vp), ("capture", c_vp), ("inds_msk", c_vp), ("w", c_vp), ("bias", c_vp), ("lang", c_vp),
+                ("Bn", c_i32), ("T", c_i32), ("nsrl", c_i32), ("L", c_i32)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("a", c_vp), ("a_is_f32", c_i32), ("lda", c_i64), ("a_rows", c_vp),
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32), ("a_frag", c_i32)]
+                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32), ("a_frag", c_i32), ("argvec_tail", c_vp)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
