@@ -314,6 +314,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", init_method="env://")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1 and args.mode == "graph":
+        # with a live multi-rank process group the engine keeps at most 3 forwards in flight (its lane book
+        # leaves one persistent-BiLSTM kernel's worth of CUs to the RCCL collective): one stream per lane
+        args.streams = min(args.streams, eng_mod._max_inflight())
     dev = torch.device("cuda", local_rank)
 
     w = WORKLOADS[args.workload]
