@@ -492,6 +492,28 @@ int64_t vog_loss_scratch_bytes(const vog_loss_args* a);
 int vog_loss_fwd(const vog_loss_args* a, void* stream);
 int vog_loss_bwd(const vog_loss_args* a, float* grad_mdl_outs, float* grad_vidf_outs, void* stream);
 
+/* SURVEY.md 8(f)-4, first slice of the backward: from d loss / d mdl_outs (vog_loss_bwd) through the score
+ * head (lin2.0 -> ReLU -> lin2.2, code/mdl_vog.py:224-230, 675-677) and the tail of the LAST mul_tx encoder
+ * layer (Wo + residual + LayerNorm + FFN + residual + LayerNorm, code/transformer_code.py:21-31, 73-81,
+ * 189-203) to the gradients of every parameter on that path and of the tail's two inputs. fp32 on the
+ * fp32 matrix pipe; the forward tail keeps nothing, so the activations are recomputed from `attn` and `x`.
+ * All pointers are device fp32. attn: [M, d] the concatenated heads (input of Wo); x: [M, d] the layer
+ * input (residual); rows m = (sequence s = (video, frame), token j = arg*nppf + p), M = n_vid*nfrm*nsrl*nppf;
+ * d_mdl_outs: [n_vid, nsrl, nfrm*nppf] as vog_loss_bwd writes it. Weights in the reference's own shapes
+ * (wo [d,d], w1 [dh,d], w2 [d,dh], wl = lin2.0.weight [dhead,d], wl2 = lin2.2.weight [dhead]); g_*: the
+ * gradients, same shapes (g_bl2: 1 value); d_attn / d_x: [M, d] or NULL. Pinned against autograd through
+ * the reference modules (tests/golden/bwd__*.npz, oracle/make_golden_bwd.py). */
+typedef struct vog_tail_bwd_args {
+  const float* attn; const float* x; const float* d_mdl_outs;
+  float* d_attn; float* d_x;
+  const float *wo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wl, *bl, *wl2;
+  float *g_wo, *g_ln1g, *g_ln1b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2g, *g_ln2b, *g_wl, *g_bl, *g_wl2, *g_bl2;
+  void* scratch; size_t scratch_bytes;
+  int M, d, dh, dhead, n_vid, nfrm, nppf, nsrl;
+} vog_tail_bwd_args;
+int64_t vog_mul_tail_bwd_scratch_bytes(int M, int d, int dh, int dhead);
+int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)
  * ------------------------------------------------------------------------- */

@@ -215,7 +215,7 @@ def layer_norm(x, g, b, eps=1e-5):
 
 
 def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
-                  quant=None, scope="tx"):
+                  quant=None, scope="tx", stash=None):
     """One (Rel)EncoderLayer (transformer_code.py:84-95,189-203,136-186,
     21-31,73-81). x [S,N,d]; boxes [S,n,5] normalised, N = nsrl*n, token index
     = arg*n + p; the bias on (n x n) is tiled over the nsrl x nsrl arg blocks
@@ -243,8 +243,15 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
         attn = torch.softmax(logits / scale, dim=-1)
         attn, vh = _q(quant, scope, attn, vh)
         heads.append(attn @ vh)
-    a = _q(quant, scope, torch.cat(heads, dim=-1)) @ _q(quant, scope, sd[p + "wo.weight"]).t()
-    x1 = layer_norm(x + a, sd[f"{prefix}.selfattn.layernorm.weight"],
+    cat = torch.cat(heads, dim=-1)
+    if stash is not None:            # the two inputs of the layer's tail (backward fixtures, oracle/make_golden_bwd.py)
+        stash["tail_attn"] = cat
+        stash["tail_x"] = x
+    a = _q(quant, scope, cat) @ _q(quant, scope, sd[p + "wo.weight"]).t()
+    t = x + a
+    if stash is not None:
+        stash["tail_t"] = t          # its gradient = the gradient of the layer input THROUGH THE TAIL (residual path)
+    x1 = layer_norm(t, sd[f"{prefix}.selfattn.layernorm.weight"],
                     sd[f"{prefix}.selfattn.layernorm.bias"])
     f = f"{prefix}.feedforward.layer."
     hdn = torch.relu(_q(quant, scope, x1) @ _q(quant, scope, sd[f + "linear1.weight"]).t()
@@ -255,12 +262,12 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
 
 
 def transformer(x, boxes, nsrl, sd, name, pe_name, n_layers, n_heads, use_rel,
-                quant=None):
+                quant=None, stash=None):
     """(Rel)Transformer: stack, return last layer output
     (transformer_code.py:227-241,244-279)."""
     for l in range(n_layers):
         x = encoder_layer(x, boxes, nsrl, sd, f"{name}.encoder.layers.{l}",
-                          pe_name, n_heads, use_rel, quant)
+                          pe_name, n_heads, use_rel, quant, stash=stash if l == n_layers - 1 else None)
     return x
 
 
@@ -340,10 +347,11 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
             B * nc_v * nfrm, nsrl * nppf, vld)
         bx = normalise_boxes(props5, oc.vid_w, oc.vid_h, float(nfrm)).reshape(
             B * nc_v * nfrm, nppf, 5)
+        mul_stash = {} if keep_stages else None
         x = transformer(x, bx, nsrl, sd, "mult_txf", "pe_mul_sub_enc.0",
-                        oc.mul_layers, oc.mul_heads, oc.mul_use_rel, quant)
+                        oc.mul_layers, oc.mul_heads, oc.mul_use_rel, quant, stash=mul_stash)
         if keep_stages:
-            st.update(mul_out=x)
+            st.update(mul_out=x, mul_tail_attn=mul_stash["tail_attn"], mul_tail_x=mul_stash["tail_x"], mul_tail_t=mul_stash["tail_t"])
         conc = x.reshape(B * nc_v, nfrm, nsrl, nppf, vld).transpose(1, 2).reshape(
             B, nc_v, nsrl, NP, vld)
 

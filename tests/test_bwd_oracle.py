@@ -1,0 +1,56 @@
+"""CPU: the backward fixtures (autograd through the REFERENCE modules, oracle/make_golden_bwd.py) against
+autograd through the oracle restatement (oracle/vog_oracle.py forward + loss_forward): pins the fixtures'
+meaning - which tensors, which order, which loss - where the GPU box has no reference."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from oracle import make_golden_bwd as mgb
+from oracle import vog_oracle as vo
+from oracle.make_golden_loss import targets_for
+
+CASES = [n for n in mgb.BWD_CASES if n.startswith("small/")] + ["full/cfg2_vog_spat_gt5_bs4"]
+
+
+def check_fixture(g, key, got, tol=1e-3):
+    """got (numpy) against the stored samples / norm of tensor `key`: max abs error <= tol * max |reference|."""
+    flat = np.asarray(got, np.float32).reshape(-1)
+    assert tuple(g[key + "__shape"]) == tuple(np.asarray(got).shape), key
+    idx = mgb.sample_index(flat.size)
+    ref = g[key + "__val"]
+    scale = max(float(np.abs(ref).max()), 1e-12)
+    err = float(np.abs(flat[idx] - ref).max())
+    assert err <= tol * scale, (key, err, scale)
+    nrm = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+    assert abs(nrm - float(g[key + "__norm"])) <= tol * float(g[key + "__norm"]), (key, nrm)
+    return err / scale
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_autograd_equals_reference_autograd(name):
+    cfg, batch, c, tg = targets_for(name)
+    _, sd, _, _ = cases.build(name)
+    g = np.load(mgb.bwd_path(name))
+    layer = int(g["layer"])
+    oc = vo.OracleCfg.from_cfg(cfg, c["vocab"], c["nppf0"])
+    sdt = {k: v.clone().requires_grad_(True) for k, v in vo.to_torch(sd).items()}
+    inp = vo.to_torch({**batch, **tg})
+    torch.set_num_threads(8)
+    out = vo.forward(oc, sdt, inp, keep_stages=True)
+    st = out["stages"]
+    st["mul_tail_attn"].retain_grad()
+    st["mul_tail_t"].retain_grad()
+    res = vo.loss_forward(oc, out, inp, loss_lambda=float(cfg.loss.loss_lambda))
+    assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    res["loss"].backward()
+    worst = 0.0
+    for k, n in mgb.param_names(layer).items():
+        worst = max(worst, check_fixture(g, k, sdt[n].grad.numpy(), tol=2e-4))
+    d = st["mul_tail_attn"].shape[-1]
+    worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=2e-4))
+    worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=2e-4))
+    print(name, "worst relative error", worst)

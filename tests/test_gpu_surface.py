@@ -354,3 +354,57 @@ def test_device_assembly_full_size_into_slot_buffers(conc):
     for k in dls.FWD_KEYS:
         assert np.array_equal(slot.inp[k].cpu().numpy(), ref[k]), k
     assert torch.isfinite(out["mdl_outs"]).all()
+
+
+# ---- backward, first slice (csrc/backward.hip): score head + the last mul_tx layer's tail ---------------------------
+mgb = importlib.import_module("oracle.make_golden_bwd")
+bwd = importlib.import_module("vognet-pytorch_amd.backward")
+
+
+@pytest.mark.parametrize("name", ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4"])
+def test_device_tail_backward_vs_reference_autograd(name):
+    """loss -> d mdl_outs (`LossB_*.backward`, vog_loss_bwd) -> `vog_mul_tail_bwd`: the gradients of lin2 and of
+    the last mul_tx layer's Wo / LayerNorm / FFN parameters and of the tail's two inputs, against AUTOGRAD THROUGH
+    THE REFERENCE model + loss (tests/golden/bwd__*.npz). The tail's inputs (concatenated heads, layer input) come
+    from the CPU oracle's fp32 forward (the 16-bit forward kernels keep no activations); the logits the loss
+    gradient starts from are the reference's. Bound: 1e-3 of the largest reference entry per tensor (fp32 math on
+    the fp32 matrix pipe: measured ~1e-5)."""
+    from tests.test_bwd_oracle import check_fixture
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    dev.update({k: torch.from_numpy(v).cuda() for k, v in tg.items()})
+    g = np.load(mgb.bwd_path(name))
+    layer = int(g["layer"])
+    # the tail's inputs: oracle forward (CPU fp32, == reference to 4e-7)
+    _, sd, _, _ = cases.build(name)
+    oc = vo.OracleCfg.from_cfg(cfg, c["vocab"], c["nppf0"])
+    with torch.no_grad():
+        o = vo.forward(oc, vo.to_torch(sd), vo.to_torch(batch), keep_stages=True)
+    st = o["stages"]
+    d = st["mul_tail_attn"].shape[-1]
+    attn = st["mul_tail_attn"].reshape(-1, d).contiguous().cuda()
+    x = st["mul_tail_x"].reshape(-1, d).contiguous().cuda()
+    # d loss / d mdl_outs from the device loss on the reference's logits
+    ref = np.load(cases.golden_path(name))
+    out = {"mdl_outs": torch.from_numpy(ref["mdl_outs"]).cuda()}
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    with torch.no_grad():
+        ld = loss_fn(out, dev)
+        assert abs(float(ld["loss"]) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+        d_outs = loss_fn.backward(ld)
+    B, nc_v, nsrl, NP = ref["mdl_outs"].shape
+    nfrm = 40 if cfg.ds.conc_type == "temp" else 10
+    nppf = NP // nfrm
+    res = bwd.mul_tail_backward(sd_torch(sd), layer, attn, x, d_outs, B * nc_v, nfrm, nppf, nsrl)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, n in mgb.param_names(layer).items():
+        worst = max(worst, check_fixture(g, k, res[n].cpu().numpy(), tol=1e-3))
+    worst = max(worst, check_fixture(g, "d_attn", res["_d_attn"].cpu().numpy(), tol=1e-3))
+    worst = max(worst, check_fixture(g, "d_x", res["_d_x"].cpu().numpy(), tol=1e-3))
+    print(name, "worst relative gradient error", worst)
+    assert worst <= 1e-3
+
+
+def sd_torch(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}

@@ -1,0 +1,248 @@
+// SURVEY.md 8(f)-4, first slice of the backward: from d loss / d mdl_outs (vog_loss_bwd) through the score head
+// (lin2: code/mdl_vog.py:224-230) and the tail of the LAST mul_tx encoder layer - Wo, residual, LayerNorm,
+// FFN, residual, LayerNorm (code/transformer_code.py:21-31, 73-81, 189-203) - to the gradients of every
+// parameter on that path and of the tail's two inputs (the concatenated attention heads and the layer
+// input). What the reference gets from autograd in Learner.train_epoch (utils/trn_utils.py:485-532).
+//
+// fp32 throughout, on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products and sums, 1/16 of
+// the 16-bit MFMA rate): this slice pins the MATH against autograd through the reference modules
+// (tests/golden/bwd__*.npz); the 16-bit operand path of the forward kernels is the next step. The forward
+// tail keeps its fp32 stream in registers and writes nothing back, so the backward recomputes the
+// activations it needs from the tail's inputs (activation recomputation, fp32).
+//
+//   t = a Wo^T + x            x1 = LN1(t)
+//   f = relu(x1 W1^T + b1)    u = f W2^T + b2 + x1      y = LN2(u)
+//   h = relu(y Wl^T + bl)     logit = h . w2 + b2'      mdl_outs[v, arg, frame*nppf + p] = logit(row)
+#include <map>
+#include <string>
+#include "common.h"
+
+namespace vog {
+
+// ---- C[M,N] = A . B (+ bias[n]) (relu), generic strides: A(m,k) = a[m*am + k*ak], B(k,n) = b[k*bk + n*bn] --------
+// 64 x 64 tile per workgroup, 4 waves of 32 x 32 (2 x 2 MFMA tiles of 16 x 16), K in chunks of 16 through LDS.
+struct GemmF32 {
+  const float* a; int64_t am, ak; const float* b; int64_t bk, bn; float* c; int64_t ldc;
+  const float* bias; int relu; int M, N, K;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
+  __shared__ float As[16][64 + 4];      // [k][m]
+  __shared__ float Bs[16][64 + 4];      // [k][n]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // tile loads: 1024 elements each, 4 per thread; the fast index follows the unit stride of the operand
+  const bool a_kfast = p.ak == 1, b_nfast = p.bn == 1;
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      const int mm = a_kfast ? idx >> 4 : idx & 63, kk = a_kfast ? idx & 15 : idx >> 6;
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < p.M && gk < p.K) ? p.a[(int64_t)gm * p.am + (int64_t)gk * p.ak] : 0.f;
+      const int nn = b_nfast ? idx & 63 : idx >> 4, kb = b_nfast ? idx >> 6 : idx & 15;
+      const int gn = n0 + nn, gkb = k0 + kb;
+      Bs[kb][nn] = (gn < p.N && gkb < p.K) ? p.b[(int64_t)gkb * p.bk + (int64_t)gn * p.bn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      const int kq = ks + (lane >> 4);
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = As[kq][wm + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = Bs[kq][wn + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + r, n = n0 + wn + j * 16 + (lane & 15);
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[n];
+          if (p.relu) v = v < 0.f ? 0.f : v;
+          p.c[(int64_t)m * p.ldc + n] = v;
+        }
+      }
+}
+
+static int gemm_f32(const float* a, int64_t am, int64_t ak, const float* b, int64_t bk, int64_t bn, float* c, int64_t ldc,
+                    const float* bias, int relu, int M, int N, int K, hipStream_t st) {
+  GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K};
+  ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- row-wise pieces -----------------------------------------------------------------------------
+// t = t + x (optional), stats[m] = (mean, rstd), y = (t - mean) * rstd * g + b      one wave per row
+__global__ __launch_bounds__(256) void ln_fwd_kernel(float* t, const float* x, const float* g, const float* b, float* y,
+                                                     float2* stats, int M, int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float* tr = t + (int64_t)row * d;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) { float v = tr[i]; if (x) { v += x[(int64_t)row * d + i]; tr[i] = v; } s += v; }
+  const float mean = wsum(s) / (float)d;
+  float q = 0.f;
+  for (int i = lane; i < d; i += 64) { const float c = tr[i] - mean; q += c * c; }
+  const float rstd = 1.0f / sqrtf(wsum(q) / (float)d + 1e-5f);
+  for (int i = lane; i < d; i += 64) y[(int64_t)row * d + i] = (tr[i] - mean) * rstd * g[i] + b[i];
+  if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
+// dt = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = dy * g, xh = (t - mean) * rstd; also writes
+// dyxh = dy * xh (the summand of d gamma). `add` (optional) is added to dy first (a second gradient path).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* add, const float* t, const float2* stats,
+                                                     const float* g, float* dt, float* dyxh, float* dysum, int M, int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float2 st = stats[row];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const int64_t o = (int64_t)row * d + i;
+    const float dv = dy[o] + (add ? add[o] : 0.f);
+    const float xh = (t[o] - st.x) * st.y, dxh = dv * g[i];
+    s1 += dxh; s2 += dxh * xh;
+    dyxh[o] = dv * xh;
+    if (dysum) dysum[o] = dv;
+  }
+  s1 = wsum(s1) / (float)d; s2 = wsum(s2) / (float)d;
+  for (int i = lane; i < d; i += 64) {
+    const int64_t o = (int64_t)row * d + i;
+    const float dv = dy[o] + (add ? add[o] : 0.f);
+    const float xh = (t[o] - st.x) * st.y;
+    dt[o] = st.y * (dv * g[i] - s1 - xh * s2);
+  }
+}
+
+// out[n] = sum_m in[m, n]: one workgroup per 64 columns, 4 waves stride the rows, fixed order (reproducible)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* in, float* out, int M, int d) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (n < d) for (int m = wid; m < M; m += 4) s += in[(int64_t)m * d + n];
+  red[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && n < d) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// y = dy where pre > 0 else 0
+__global__ void relu_bwd_kernel(const float* dy, const float* act, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = act[i] > 0.f ? dy[i] : 0.f;
+}
+
+// score head: dlog[m] gathered from d mdl_outs [n_vid, nsrl, nfrm*nppf] (row m = (s = (v, f), j = arg*nppf + p),
+// the inverse regroup of code/mdl_vog.py:724-737), dh[m, :] = dlog * w2 (h > 0), hw[m, :] = dlog * h (summand of d w2)
+struct ScoreBwd { const float* d_outs; const float* h; const float* w2; float* dh; float* hw; float* dlog; int M, nfrm, nppf, nsrl, dh_dim; };
+__global__ __launch_bounds__(256) void score_bwd_kernel(ScoreBwd a) {
+  const int row = blockIdx.x, N = a.nsrl * a.nppf;
+  const int s = row / N, j = row % N, v = s / a.nfrm, f = s % a.nfrm, arg = j / a.nppf, pp = j % a.nppf;
+  const float dl = a.d_outs[((int64_t)v * a.nsrl + arg) * ((int64_t)a.nfrm * a.nppf) + (int64_t)f * a.nppf + pp];
+  if (threadIdx.x == 0) a.dlog[row] = dl;
+  for (int i = threadIdx.x; i < a.dh_dim; i += blockDim.x) {
+    const float hv = a.h[(int64_t)row * a.dh_dim + i];
+    a.dh[(int64_t)row * a.dh_dim + i] = hv > 0.f ? dl * a.w2[i] : 0.f;
+    a.hw[(int64_t)row * a.dh_dim + i] = dl * hv;
+  }
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
+}  // namespace vog
+
+using namespace vog;
+
+extern "C" int64_t vog_mul_tail_bwd_scratch_bytes(int M, int d, int dh, int dhead) {
+  if (M <= 0 || d <= 0 || dh <= 0 || dhead <= 0) return -1;
+  // t, x1, u, y, dy, du, dx1, dt, tmp_d (9 x [M,d]); pre1, f?, dpre1 (3 x [M,dh]); h, dh_, hw (3 x [M,dhead]); stats, dlog
+  return ((int64_t)9 * M * d + (int64_t)3 * M * dh + (int64_t)3 * M * dhead + (int64_t)5 * M + 1024) * 4;
+}
+
+extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->attn && a->x && a->d_mdl_outs && a->scratch && a->M > 0 && a->d > 0 && a->dh > 0 && a->dhead > 0);
+  VOG_CHECK_ARG(a->wo && a->ln1g && a->ln1b && a->w1 && a->b1 && a->w2 && a->b2 && a->ln2g && a->ln2b && a->wl && a->bl && a->wl2);
+  VOG_CHECK_ARG(a->M == a->n_vid * a->nfrm * a->nsrl * a->nppf);
+  if ((int64_t)a->scratch_bytes < vog_mul_tail_bwd_scratch_bytes(a->M, a->d, a->dh, a->dhead))
+    VOG_FAIL(-2, "vog_mul_tail_bwd: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = a->M, d = a->d, H1 = a->dh, HD = a->dhead;
+  float* s = (float*)a->scratch;
+  auto take = [&](int64_t n) { float* r = s; s += n; return r; };
+  float *t = take((int64_t)M * d), *x1 = take((int64_t)M * d), *u = take((int64_t)M * d), *y = take((int64_t)M * d);
+  float *dy = take((int64_t)M * d), *du = take((int64_t)M * d), *dx1 = take((int64_t)M * d), *dt = take((int64_t)M * d);
+  float* tmp = take((int64_t)M * d);
+  float *pre1 = take((int64_t)M * H1), *dpre1 = take((int64_t)M * H1), *df = take((int64_t)M * H1);
+  float *h = take((int64_t)M * HD), *dh = take((int64_t)M * HD), *hw = take((int64_t)M * HD);
+  float2* st1 = (float2*)take((int64_t)2 * M); float2* st2 = (float2*)take((int64_t)2 * M);
+  float* dlog = take(M);
+  const int64_t nd = (int64_t)M * d, n1 = (int64_t)M * H1;
+  auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  // ---- recompute the forward in fp32
+  VOG_TRY(gemm_f32(a->attn, d, 1, a->wo, 1, d, t, d, nullptr, 0, M, d, d, st));                    // a Wo^T   (Wo [d_out, d_in])
+  ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, t, a->x, a->ln1g, a->ln1b, x1, st1, M, d);   // t += x
+  VOG_TRY(gemm_f32(x1, d, 1, a->w1, 1, d, pre1, H1, a->b1, 0, M, H1, d, st));                       // pre1 (relu applied on use)
+  ::vog::launch(relu_bwd_kernel, blocks(n1), dim3(256), 0, st, pre1, pre1, df, n1);                  // df = relu(pre1) (reused as f)
+  VOG_TRY(gemm_f32(df, H1, 1, a->w2, 1, H1, u, d, a->b2, 0, M, d, H1, st));                          // f W2^T + b2
+  ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, u, (const float*)x1, a->ln2g, a->ln2b, y, st2, M, d);   // u += x1
+  VOG_TRY(gemm_f32(y, d, 1, a->wl, 1, d, h, HD, a->bl, 1, M, HD, d, st));                            // h = relu(y Wl^T + bl)
+  // ---- score head
+  ScoreBwd sb{a->d_mdl_outs, h, a->wl2, dh, hw, dlog, M, a->nfrm, a->nppf, a->nsrl, HD};
+  ::vog::launch(score_bwd_kernel, dim3(M), dim3(256), 0, st, sb);
+  ::vog::launch(colsum_kernel, dim3(ceil_div(HD, 64)), dim3(256), 0, st, (const float*)hw, a->g_wl2, M, HD);   // d lin2.2.weight
+  ::vog::launch(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dlog, a->g_bl2, M, 1);                 // d lin2.2.bias
+  VOG_TRY(gemm_f32(dh, 1, HD, y, d, 1, a->g_wl, d, nullptr, 0, HD, d, M, st));                       // d lin2.0.weight = dh^T y
+  ::vog::launch(colsum_kernel, dim3(ceil_div(HD, 64)), dim3(256), 0, st, (const float*)dh, a->g_bl, M, HD);
+  VOG_TRY(gemm_f32(dh, HD, 1, a->wl, d, 1, dy, d, nullptr, 0, M, d, HD, st));                        // dy = dh Wl
+  // ---- LayerNorm 2
+  ::vog::launch(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)u,
+                (const float2*)st2, a->ln2g, du, tmp, (float*)nullptr, M, d);
+  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)tmp, a->g_ln2g, M, d);
+  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)dy, a->g_ln2b, M, d);
+  // ---- FFN
+  VOG_TRY(gemm_f32(du, 1, d, df, H1, 1, a->g_w2, H1, nullptr, 0, d, H1, M, st));                     // d W2 = du^T f
+  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)du, a->g_b2, M, d);
+  VOG_TRY(gemm_f32(du, d, 1, a->w2, H1, 1, dpre1, H1, nullptr, 0, M, H1, d, st));                    // df = du W2
+  ::vog::launch(relu_bwd_kernel, blocks(n1), dim3(256), 0, st, (const float*)dpre1, (const float*)pre1, dpre1, n1);
+  VOG_TRY(gemm_f32(dpre1, 1, H1, x1, d, 1, a->g_w1, d, nullptr, 0, H1, d, M, st));                   // d W1 = dpre1^T x1
+  ::vog::launch(colsum_kernel, dim3(ceil_div(H1, 64)), dim3(256), 0, st, (const float*)dpre1, a->g_b1, M, H1);
+  VOG_TRY(gemm_f32(dpre1, H1, 1, a->w1, d, 1, dx1, d, nullptr, 0, M, d, H1, st));                    // dpre1 W1
+  // ---- LayerNorm 1 (dx1 = du + dpre1 W1)
+  ::vog::launch(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const float*)dx1, (const float*)du, (const float*)t,
+                (const float2*)st1, a->ln1g, dt, tmp, dy, M, d);                                       // dy := dx1 + du (summand of d beta)
+  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)tmp, a->g_ln1g, M, d);
+  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)dy, a->g_ln1b, M, d);
+  // ---- Wo and the two inputs
+  VOG_TRY(gemm_f32(dt, 1, d, a->attn, d, 1, a->g_wo, d, nullptr, 0, d, d, M, st));                   // d Wo = dt^T a
+  if (a->d_attn) VOG_TRY(gemm_f32(dt, d, 1, a->wo, d, 1, a->d_attn, d, nullptr, 0, M, d, d, st));    // da = dt Wo
+  if (a->d_x) VOG_HIP(hipMemcpyAsync(a->d_x, dt, (size_t)nd * 4, hipMemcpyDeviceToDevice, st));      // dx = dt
+  VOG_LAUNCH_CHECK();
+  return 0;
+}

@@ -14,9 +14,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRCS = ["forward.hip", "gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip", "aql.hip"]
+SRCS = ["forward.hip", "gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip", "backward.hip", "aql.hip"]
 # translation units that hold kernels: also built device-only into libvog_hip.<tu>.co for the AQL path
-KERNEL_SRCS = ["gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip"]
+KERNEL_SRCS = ["gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip", "backward.hip"]
 HDRS = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join(ROOT, "include", "vog_hip.h")]
 OUT = os.path.join(HERE, "libvog_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

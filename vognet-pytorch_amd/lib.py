@@ -184,6 +184,15 @@ class ModelDesc(C.Structure):
                 ("vid_w", c_f32), ("vid_h", c_f32), ("tx_dtype", c_i32), ("enc_dtype", c_i32)]
 
 
+class TailBwdArgs(C.Structure):
+    _fields_ = ([(n, c_vp) for n in ("attn", "x", "d_mdl_outs", "d_attn", "d_x",
+                                      "wo", "ln1g", "ln1b", "w1", "b1", "w2", "b2", "ln2g", "ln2b", "wl", "bl", "wl2",
+                                      "g_wo", "g_ln1g", "g_ln1b", "g_w1", "g_b1", "g_w2", "g_b2", "g_ln2g", "g_ln2b",
+                                      "g_wl", "g_bl", "g_wl2", "g_bl2", "scratch")]
+                + [("scratch_bytes", C.c_size_t)]
+                + [(n, c_i32) for n in ("M", "d", "dh", "dhead", "n_vid", "nfrm", "nppf", "nsrl")])
+
+
 class Batch(C.Structure):
     _fields_ = [("B", c_i32), ("ncmp", c_i32), ("T", c_i32),
                 ("srl_arg_words_ind", c_vp), ("srl_arg_word_mask", c_vp),
@@ -223,6 +232,8 @@ SYMBOLS = {
     "vog_box_u": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp]),
     "vog_srl_gather": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vog_bilstm_layer_supported": (c_i32, [c_i32, c_i32]),
+    "vog_mul_tail_bwd_scratch_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "vog_mul_tail_bwd": (c_i32, [C.POINTER(TailBwdArgs), c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
