@@ -153,3 +153,42 @@ def test_record_ring_single_process():
         ring.push(torch.full((2, 5), float(k)))
     ring.flush()
     assert torch.cat(got)[:, 0].tolist() == [0.0, 0.0, 1.0, 1.0, 2.0, 2.0]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {"lin2.0.weight": torch.randn(8, 12, generator=g), "lin2.0.bias": torch.randn(8, generator=g),
+             "mult_txf.encoder.layers.0.selfattn.layer.wo.weight": torch.randn(12, 12, generator=g),
+             "_d_x": torch.full((3,), float(rank))}
+    n = D.all_reduce_grads(grads, bucket_bytes=400)          # small buckets: more than one collective
+    if rank == 0:
+        q.put((n, {k: v.clone() for k, v in grads.items()}))
+    D.synchronize()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    """dist.all_reduce_grads (the DDP exchange of the training path): bucketed, averaged, '_' keys untouched."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    n, got = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert n >= 2
+    ref = {}
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        for k, shape in (("lin2.0.weight", (8, 12)), ("lin2.0.bias", (8,)),
+                         ("mult_txf.encoder.layers.0.selfattn.layer.wo.weight", (12, 12))):
+            ref[k] = ref.get(k, 0) + torch.randn(*shape, generator=g) / world
+    for k in ref:
+        assert torch.allclose(got[k], ref[k], atol=1e-6), k
+    assert torch.equal(got["_d_x"], torch.zeros(3))                      # rank 0's own, not reduced
