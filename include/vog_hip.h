@@ -279,9 +279,18 @@ typedef struct vog_visenc_args {
    * when the encoders share the launch of a persistent BiLSTM layer (csrc/pair.hip). Same results up to
    * fp32 summation order. */
   int lean;
+  /* Replication of the segment rows over the nppf0 proposals of their frame (lean form only). 0: done by
+   * vog_vis_encode - inside the encoder kernel for nppf0 <= 16, otherwise by a copy kernel it launches
+   * behind it (at 100 proposals per frame the 25 MB of replica stores took the 6 workgroups owning the
+   * segment rows 100 us longer than everybody else). 1: vog_vis_encode writes replica 0 only and the caller
+   * runs vog_seg_replicate (the forward does, so that the encoder kernel stays ONE launch and can share
+   * the launch of a BiLSTM layer). */
+  int defer_replicas;
 } vog_visenc_args;
 int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
 int vog_vis_encode(const vog_visenc_args* a, void* stream);
+/* rows r*nppf0 + j (j = 1 .. nppf0-1), columns [prop_enc, prop_enc + seg_enc) of c32 / c16 := row r*nppf0 */
+int vog_seg_replicate(const vog_visenc_args* a, void* stream);
 
 /* dst[i] = (t16) src[i] for two arrays in one launch (raw proposal / segment
  * features -> the encoders' MFMA operand type; replaces the implicit fp32 read

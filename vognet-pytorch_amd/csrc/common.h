@@ -76,6 +76,15 @@ __device__ __forceinline__ void lds_wait(A& a) { asm volatile("s_waitcnt lgkmcnt
 template <int N, typename A, typename B>
 __device__ __forceinline__ void lds_wait(A& a, B& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 
+// Workgroup barrier WITHOUT the release / acquire fences of __syncthreads(): hipcc lowers those to
+// s_waitcnt vmcnt(0) lgkmcnt(0), i.e. every barrier also waits for ALL outstanding global loads (a prefetch
+// issued before the barrier is drained at it) and for the write acknowledge of every store issued so far.
+// The caller's own LDS writes are waited for here; anything else the barrier has to cover is the caller's.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // ---- MFMA wrappers (fp32 accumulate) ----------------------------------------------
 // 32x32x16: A lane l holds row (l&31), k = (l>>5)*8+j; B lane l holds col (l&31),
 // same k; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).

@@ -749,7 +749,12 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       // encoders share the launch of a BiLSTM layer (busy-CU time matters, latency is hidden), and for
       // the p100 shapes where the wide form's 8 column slices per row tile re-stream the features
       ve.lean = c->enc_lean < 0 ? ((will_pair || Mp >= 4096) ? 1 : 0) : c->enc_lean;
+      // many proposals per frame: the replication of the segment rows is its own (chip-wide) copy launch,
+      // so the encoder kernel stays one launch and can still share the BiLSTM layer's
+      const bool rep_step = ve.lean && d.nppf0 > 16 && (d.seg_enc % 4) == 0 && (d.prop_enc % 4) == 0 && (g.d_obj % 4) == 0;
+      ve.defer_replicas = rep_step ? 1 : 0;
       steps.push_back({"vis_enc", [=](hipStream_t st) { return vog_vis_encode(&ve, st); }});
+      if (rep_step) steps.push_back({"seg_rep", [=](hipStream_t st) { return vog_seg_replicate(&ve, st); }});
     }
     const bool can_split = !enc_fused && (d.prop_dim % 64) == 0 && (d.seg_dim % 64) == 0 && Mp > 64 && Ms > 64 &&
                            (d.prop_enc % 4) == 0 && (d.seg_enc % 4) == 0;
@@ -859,32 +864,42 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     // The BiLSTM layers (64 CUs for ~38 us each) take the encoders and the obj_tx tail as partners; the
     // obj_tx QKV projection and attention follow the first pair on their own (paired with the layer-1
     // input projection they measured SLOWER than apart: 22.5 vs 9.5 + 7.4 us).
-    struct Want { const char* lang; int occ; const char* vis; const char* then0; const char* then1; };
-    const Want want[] = {{"lstm_layer", 0, "vis_enc", "obj_qkv", "obj_attn"},
-                         {"lstm_layer", 1, "obj_tail", nullptr, nullptr}, {"lstm_outproj", 0, "mul_pv", nullptr, nullptr}};
-    struct Plan2 { int ia, ib, ic, id; };
+    struct Want { const char* lang; int occ; const char* vis; const char* then[3]; };
+    const bool has_rep = find("seg_rep", 0) >= 0;
+    const Want want[] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
+                                 : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}},
+                         {"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}},
+                         {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
+    struct Plan2 { int ia, ib; int it[3]; };
     std::vector<Plan2> plans;
     bool ok = true;
     int prev_vis = -1;
     for (auto& w : want) {
-      Plan2 q{find(w.lang, w.occ), find(w.vis, 0), w.then0 ? find(w.then0, 0) : -1, w.then1 ? find(w.then1, 0) : -1};
+      Plan2 q{find(w.lang, w.occ), find(w.vis, 0), {-1, -1, -1}};
       // every visual step only moves EARLIER (its producers sit in earlier pairs) and the visual chain
       // keeps its own order; any missing piece (other model variants / shapes) leaves the rest unpaired
-      if (q.ia < 0 || q.ib < 0 || q.ib < q.ia || q.ib < prev_vis || (w.then0 && q.ic < q.ib) || (w.then1 && q.id < q.ic)) { ok = false; break; }
-      prev_vis = w.then1 ? q.id : (w.then0 ? q.ic : q.ib);
+      if (q.ia < 0 || q.ib < 0 || q.ib < q.ia || q.ib < prev_vis) { ok = false; break; }
+      int last = q.ib;
+      for (int k = 0; k < 3 && w.then[k]; ++k) {
+        q.it[k] = find(w.then[k], 0);
+        if (q.it[k] < last) { ok = false; break; }
+        last = q.it[k];
+      }
+      if (!ok) break;
+      prev_vis = last;
       plans.push_back(q);
     }
     if (ok) {
       // nothing else of the visual chain may sit between the moved steps (it would be overtaken)
       std::vector<int> moved;
-      for (auto& q : plans) { moved.push_back(q.ib); if (q.ic >= 0) moved.push_back(q.ic); if (q.id >= 0) moved.push_back(q.id); }
+      for (auto& q : plans) { moved.push_back(q.ib); for (int k = 0; k < 3; ++k) if (q.it[k] >= 0) moved.push_back(q.it[k]); }
       for (int i = moved.front(); i <= moved.back() && ok; ++i)
         if (steps[i].branch == 0 && std::find(moved.begin(), moved.end(), i) == moved.end()) ok = false;
     }
     if (ok) {
       std::vector<int> role(steps.size(), 0);           // 1 = removed from its old position
       std::vector<Step> out;
-      for (auto& q : plans) { role[q.ib] = 1; if (q.ic >= 0) role[q.ic] = 1; if (q.id >= 0) role[q.id] = 1; }
+      for (auto& q : plans) { role[q.ib] = 1; for (int k = 0; k < 3; ++k) if (q.it[k] >= 0) role[q.it[k]] = 1; }
       for (size_t i = 0; i < steps.size(); ++i) {
         if (role[i]) continue;
         const Plan2* q = nullptr;
@@ -895,8 +910,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         m.name = steps[q->ia].name + "+" + steps[q->ib].name;
         m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
         out.push_back(m);
-        if (q->ic >= 0) { Step t = steps[q->ic]; t.branch = m.branch; out.push_back(t); }
-        if (q->id >= 0) { Step t = steps[q->id]; t.branch = m.branch; out.push_back(t); }
+        for (int k = 0; k < 3; ++k)
+          if (q->it[k] >= 0) { Step t = steps[q->it[k]]; t.branch = m.branch; out.push_back(t); }
       }
       steps.swap(out);
     }

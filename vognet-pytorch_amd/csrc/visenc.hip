@@ -21,6 +21,26 @@
 
 namespace vog {
 
+// Segment rows are replicated over the nppf0 proposals of their frame (concat_prop_seg_feats,
+// mdl_conc_single.py:51-66). With 100 proposals per frame the replication is 25 MB of stores that the lean
+// form left to the 6 workgroups owning the segment rows, one 2- or 4-byte store per lane and replica:
+// ~100 us after every other workgroup had finished (157 us for the whole kernel at p100). Those
+// workgroups now write replica 0 only and this kernel copies it to the other nppf0 - 1 rows, 16 bytes per
+// lane, on the whole chip.
+__global__ __launch_bounds__(256) void seg_replicate_kernel(float* c32, unsigned short* c16, int64_t ldc, int col0, int ncol,
+                                                            int rows, int rep) {
+  const int per_row = ncol >> 2;                              // 4 columns per thread
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)rows * (rep - 1) * per_row;
+  if (i >= total) return;
+  const int c4 = (int)(i % per_row);
+  const int64_t rj = i / per_row;
+  const int j = (int)(rj % (rep - 1)) + 1, r = (int)(rj / (rep - 1));
+  const int64_t src = (int64_t)r * rep * ldc + col0 + c4 * 4, dst = ((int64_t)r * rep + j) * ldc + col0 + c4 * 4;
+  if (c32) *reinterpret_cast<float4*>(c32 + dst) = *reinterpret_cast<const float4*>(c32 + src);
+  if (c16) *reinterpret_cast<u16x4*>(c16 + dst) = *reinterpret_cast<const u16x4*>(c16 + src);
+}
+
 const void* kid_vis_enc_f16() { return reinterpret_cast<const void*>(vis_enc_kernel<F16>); }
 const void* kid_vis_enc_lean_f16() { return reinterpret_cast<const void*>(vis_enc_lean_kernel<F16>); }
 
@@ -45,9 +65,20 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
   p.c16_bf16 = a->c16_dtype == VOG_BF16;
   if (a->lean) {
     const int nb = ceil_div(p.tiles0, 4) + ceil_div(p.tiles_all - p.tiles0, 4);
+    // many replicas per segment row (p100: 100): the encoder kernel writes replica 0, a copy kernel the rest
+    const bool can_copy = (p.p[1].N % 4) == 0 && (p.p[1].col0 % 4) == 0 && (p.ldc % 4) == 0;
+    if (a->defer_replicas && !can_copy) VOG_FAIL(-1, "vog_vis_encode: defer_replicas needs encode sizes and ldc %% 4 == 0");
+    const bool split_rep = !a->defer_replicas && p.p[1].rep > 16 && can_copy;
+    p.rep_first_only = (split_rep || a->defer_replicas) ? 1 : 0;
     VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(nb * 2), dim3(512),
                                                VisEncLeanBody<T16>::LDS, st, p));
     VOG_LAUNCH_CHECK();
+    if (split_rep) {
+      const int64_t total = (int64_t)p.p[1].M * (p.p[1].rep - 1) * (p.p[1].N / 4);
+      ::vog::launch(seg_replicate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.c32, p.c16, p.ldc,
+                    p.p[1].col0, p.p[1].N, p.p[1].M, p.p[1].rep);
+      VOG_LAUNCH_CHECK();
+    }
     return 0;
   }
   const int groups = ceil_div(p.tiles_all, 8);
@@ -60,6 +91,17 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
 
 extern "C" int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
   return vog::vis_encode_supported(prop_dim, seg_dim, prop_enc, seg_enc);
+}
+extern "C" int vog_seg_replicate(const vog_visenc_args* a, void* stream) {
+  VOG_CHECK_ARG(a && (a->c32 || a->c16) && a->n_prop_rows > 0 && a->nppf0 > 0 && (a->n_prop_rows % a->nppf0) == 0);
+  VOG_CHECK_ARG((a->seg_enc % 4) == 0 && (a->prop_enc % 4) == 0 && (a->ldc % 4) == 0);
+  if (a->nppf0 == 1) return 0;
+  const int rows = a->n_prop_rows / a->nppf0;
+  const int64_t total = (int64_t)rows * (a->nppf0 - 1) * (a->seg_enc / 4);
+  ::vog::launch(vog::seg_replicate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->c32,
+                (unsigned short*)a->c16, a->ldc, a->prop_enc, a->seg_enc, rows, a->nppf0);
+  VOG_LAUNCH_CHECK();
+  return 0;
 }
 extern "C" int vog_vis_encode(const vog_visenc_args* a, void* stream) {
   return vog::vis_encode_run(a, (hipStream_t)stream);

@@ -12,6 +12,7 @@ struct VisEncParams {
   VisEncProb p[2];
   int tiles0, tiles_all;         // 16-row tiles of problem 0, of both
   float* c32; unsigned short* c16; int64_t ldc; int c16_bf16;
+  int rep_first_only;            // 1: only replica j = 0 of every row is written here (seg_replicate_kernel writes the rest)
 };
 
 template <typename T16>
@@ -176,25 +177,42 @@ struct VisEncLeanBody {
       for (int ks = 0; ks < 8; ++ks) q[ks] = wf[(c * 8 + ks) * 64];
     };
     auto mfmas = [&](const u16x8 (&q)[8], int c) {
+      // A fragments of a row tile (8 k-steps) are requested together, one tile AHEAD of the MFMAs that use
+      // them (the scheduling fences keep hipcc from folding this into read-2 / wait / MFMA-2, which exposes
+      // the LDS latency 16 times per chunk)
       const unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
+      u16x8 fa[8], fb[8];
 #pragma unroll
-      for (int mt = 0; mt < RB / 16; ++mt)
+      for (int ks = 0; ks < 8; ++ks) fa[ks] = *reinterpret_cast<const u16x8*>(img + ((0 * (KC / 32) + ks) * 64 + lane) * 16);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const u16x8 af = *reinterpret_cast<const u16x8*>(img + ((mt * (KC / 32) + ks) * 64 + lane) * 16);
-          acc[mt] = mfma16<T16>(af, q[ks], acc[mt]);
+      for (int mt = 0; mt < RB / 16; mt += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) fb[ks] = *reinterpret_cast<const u16x8*>(img + (((mt + 1) * (KC / 32) + ks) * 64 + lane) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc[mt] = mfma16<T16>(fa[ks], q[ks], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt + 2 < RB / 16) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) fa[ks] = *reinterpret_cast<const u16x8*>(img + (((mt + 2) * (KC / 32) + ks) * 64 + lane) * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc[mt + 1] = mfma16<T16>(fb[ks], q[ks], acc[mt + 1]);
+      }
     };
+    // (fence-free barriers: __syncthreads() would wait for the next chunk's loads, issued just above it)
     load_a(0); load_w(wq[0], 0);
     for (int c = 0; c < nchunk; c += 2) {
       store_a(c);                                            // image (c & 1) was last read two chunks ago
       if (c + 1 < nchunk) { load_a(c + 1); load_w(wq[1], c + 1); }
-      __syncthreads();
+      lds_barrier();
       mfmas(wq[0], c);
       if (c + 1 < nchunk) {
         store_a(c + 1);
         if (c + 2 < nchunk) { load_a(c + 2); load_w(wq[0], c + 2); }
-        __syncthreads();
+        lds_barrier();
         mfmas(wq[1], c + 1);
       }
     }
@@ -211,7 +229,8 @@ struct VisEncLeanBody {
         if (row >= qM) continue;
         const float o = fmaxf(acc[mt][r] + b, 0.f);
         const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
-        for (int j = 0; j < qrep; ++j) {
+        const int nrep = a.rep_first_only ? 1 : qrep;
+        for (int j = 0; j < nrep; ++j) {
           const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
           if (a.c32) a.c32[off] = o;
           if (a.c16) a.c16[off] = h;

@@ -135,7 +135,7 @@ class VisencArgs(C.Structure):
     _fields_ = [("prop", c_vp), ("seg", c_vp), ("w_prop_f", c_vp), ("w_seg_f", c_vp), ("b_prop", c_vp),
                 ("b_seg", c_vp), ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("c16_dtype", c_i32),
                 ("n_prop_rows", c_i32), ("nppf0", c_i32), ("prop_dim", c_i32), ("seg_dim", c_i32),
-                ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32), ("lean", c_i32)]
+                ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32), ("lean", c_i32), ("defer_replicas", c_i32)]
 
 
 class LossArgs(C.Structure):
@@ -217,6 +217,7 @@ SYMBOLS = {
     "vog_encoder_layer_fwd": (c_i32, [C.POINTER(EncoderLayerArgs), c_vp]),
     "vog_vis_encode_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "vog_vis_encode": (c_i32, [C.POINTER(VisencArgs), c_vp]),
+    "vog_seg_replicate": (c_i32, [C.POINTER(VisencArgs), c_vp]),
     "vog_loss_scratch_bytes": (c_i64, [C.POINTER(LossArgs)]),
     "vog_loss_fwd": (c_i32, [C.POINTER(LossArgs), c_vp]),
     "vog_loss_bwd": (c_i32, [C.POINTER(LossArgs), c_vp, c_vp, c_vp]),
