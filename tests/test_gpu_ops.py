@@ -526,11 +526,13 @@ def test_srl_gather_and_argvec():
 
 
 @pytest.mark.parametrize("conc", ["spat", "temp", "sep"])
-def test_pred_head_exact(conc):
-    """Integer/index work: bit-exact against the oracle head, ties included."""
+@pytest.mark.parametrize("np0", [5, 100])
+def test_pred_head_exact(conc, np0):
+    """Integer/index work: bit-exact against the oracle head, ties included (np0 = 100: the wave-per-item
+    form of the p100 shapes, ties across more than one lane round)."""
     lib = _lib()
     torch.manual_seed(4)
-    B, ncmp, nsrl, nf, np0 = 3, 4, 5, 10, 5
+    B, ncmp, nsrl, nf = 3, 4, 5, 10
     oc = vo.OracleCfg(conc_type=conc, nppf0=np0)
     if conc == "sep":
         ev = torch.rand(B, ncmp, nsrl, nf * np0)
@@ -540,6 +542,9 @@ def test_pred_head_exact(conc):
         props = torch.rand(B, ncmp * nf * np0, 7)
     ev[0, 0, 4] = 0.0                         # masked argument: all ties -> first index
     ev[1, 0, 1, :7] = 0.5                     # exact ties inside a frame
+    if np0 > 64:
+        ev[2, 0, 2, :np0] = 0.25                # a whole frame of ties (more than one round of lanes)
+        ev[2, 0, 2, 70] = 0.75; ev[2, 0, 2, 3] = 0.75   # the maximum twice: lane 6 (second round) and lane 3
     fin = torch.rand(B, ncmp)
     out = {"mdl_outs_eval": ev, "fin_scores": fin}
     inp = {"pad_proposals": props, "new_srl_idxs": torch.zeros(B, ncmp, dtype=torch.int64)}

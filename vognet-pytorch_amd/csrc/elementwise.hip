@@ -355,6 +355,82 @@ __global__ __launch_bounds__(256) void predcmp_kernel(vog_predcmp_args a) {
 // prediction head (eval_vsrl_corr.py:162-220, 289-345, 357-424): one thread per
 // (query, arg, video, frame); packed record per query.
 // ---------------------------------------------------------------------------
+// Many proposals per frame (p100: 100): one WAVE per (query, arg, frame, video): the lanes split the
+// proposals, the arg-max is a wave reduction that keeps torch.max's rule (first maximum wins: larger value,
+// then smaller index). The thread-per-item form below walks the proposals in a dependent loop: 33.7 us at
+// nppf0 = 100 for 832 threads.
+__device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(i, o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+__global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t rec_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int per_q = a.nsrl * a.nfrm0 * a.ncmp;
+  if (i >= a.B * per_q) return;
+  const int b = i / per_q, r = i % per_q;
+  const int arg = r / (a.nfrm0 * a.ncmp), f = (r / a.ncmp) % a.nfrm0, c = r % a.ncmp;
+  const int npv = a.nfrm0 * a.nppf0;
+  unsigned char* rec = reinterpret_cast<unsigned char*>(a.rec) + (int64_t)b * rec_bytes;
+  float* boxes = reinterpret_cast<float*>(rec);
+  float* scores = boxes + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
+  int64_t* idx = reinterpret_cast<int64_t*>(rec + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 8 * 4);
+  auto first_prop = [&](int cc, int64_t* e0, int64_t* p0) {   // in outs_eval / in props
+    if (a.conc_type == VOG_CONC_SPAT) {
+      const int r0 = (f * a.ncmp + cc) * a.nppf0;
+      *e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
+      *p0 = (int64_t)b * a.ncmp * npv + r0;
+    } else if (a.conc_type == VOG_CONC_TEMP) {
+      const int r0 = (cc * a.nfrm0 + f) * a.nppf0;
+      *e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
+      *p0 = (int64_t)b * a.ncmp * npv + r0;
+    } else {
+      *e0 = (((int64_t)b * a.ncmp + cc) * a.nsrl + arg) * npv + (int64_t)f * a.nppf0;
+      *p0 = ((int64_t)b * a.ncmp + cc) * npv + (int64_t)f * a.nppf0;
+    }
+  };
+  auto frame_max = [&](int cc, float* best, int* bi) {      // every lane returns the frame's (max, first index)
+    int64_t e0, p0;
+    first_prop(cc, &e0, &p0);
+    float v = -INFINITY; int k0 = 0x7fffffff;
+    for (int k = lane; k < a.nppf0; k += 64) {
+      const float x = a.outs_eval[e0 + k];
+      if (x > v) { v = x; k0 = k; }                          // ascending k per lane: the first maximum stays
+    }
+    wave_argmax_first(v, k0);
+    *best = v; *bi = k0;
+  };
+  float best; int bi;
+  frame_max(c, &best, &bi);
+  int64_t e0, p0;
+  first_prop(c, &e0, &p0);
+  const int64_t o = ((int64_t)arg * a.ncmp + c) * a.nfrm0 + f;
+  if (lane < 7) boxes[o * 7 + lane] = a.props[(p0 + bi) * 7 + lane];
+  if (lane == 0) scores[o] = best;
+  if (c != 0) return;
+  int64_t out = 0;
+  if (a.conc_type == VOG_CONC_SPAT) {
+    float best_c = best;                           // video 0; first maximum over the videos
+    for (int cc = 1; cc < a.ncmp; ++cc) {
+      float bc; int dummy;
+      frame_max(cc, &bc, &dummy);
+      if (bc > best_c) { best_c = bc; out = cc; }
+    }
+  } else if (a.conc_type == VOG_CONC_SEP) {
+    float bf = a.fin_scores[(int64_t)b * a.ncmp];
+    for (int cc = 1; cc < a.ncmp; ++cc) {
+      const float v = a.fin_scores[(int64_t)b * a.ncmp + cc];
+      if (v > bf) { bf = v; out = cc; }
+    }
+  }
+  if (lane == 0) idx[(int64_t)arg * a.nfrm0 + f] = out;
+}
+
 __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
   // one thread per (query, arg, frame, video): arg-max over the proposals of that video's frame
   // and the box gather; the thread of video 0 also does the pred_cmp arg-max over the videos
@@ -696,7 +772,8 @@ extern "C" int vog_pred_head(const vog_pred_args* a, void* stream) {
   VOG_CHECK_ARG(a->conc_type != VOG_CONC_SEP || a->fin_scores);
   const int64_t rb = vog_pred_record_bytes(a->ncmp, a->nsrl, a->nfrm0);
   const int n1 = a->B * a->nsrl * a->nfrm0 * a->ncmp;
-  ::vog::launch(pred_kernel, dim3(ceil_div(n1, 64)), dim3(64), 0, (hipStream_t)stream, *a, rb);
+  if (a->nppf0 >= 32) ::vog::launch(pred_wave_kernel, dim3(ceil_div(n1, 4)), dim3(256), 0, (hipStream_t)stream, *a, rb);
+  else ::vog::launch(pred_kernel, dim3(ceil_div(n1, 64)), dim3(64), 0, (hipStream_t)stream, *a, rb);
   VOG_LAUNCH_CHECK();
   return 0;
 }
