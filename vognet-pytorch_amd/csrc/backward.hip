@@ -20,47 +20,80 @@
 namespace vog {
 
 // ---- C[M,N] = A . B (+ bias[n]) (relu), generic strides: A(m,k) = a[m*am + k*ak], B(k,n) = b[k*bk + n*bn] --------
-// 64 x 64 tile per workgroup, 4 waves of 32 x 32 (2 x 2 MFMA tiles of 16 x 16), K in chunks of 16 through LDS.
+// One of (am, ak) and one of (bk, bn) is 1 (row- or column-major operands; the launcher checks it), every
+// dimension is a multiple of 4 and the pointers are 16-byte aligned: tiles are fetched with 16-byte loads
+// along the unit stride, one chunk ahead of the MFMAs (registers), and parked in LDS as [k][m] / [k][n].
+// 128 x 64 tile per workgroup, 4 waves of 64 x 32 (4 x 2 MFMA tiles of 16 x 16), K in chunks of 16.
 struct GemmF32 {
   const float* a; int64_t am, ak; const float* b; int64_t bk, bn; float* c; int64_t ldc;
   const float* bias; int relu; int M, N, K;
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
-  __shared__ float As[16][64 + 4];      // [k][m]
-  __shared__ float Bs[16][64 + 4];      // [k][n]
+  constexpr int TM = 128, TN = 64, TK = 16;
+  __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];      // [k][m]
+  __shared__ __attribute__((aligned(16))) float Bs[TK][TN + 4];      // [k][n]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
-  f32x4 acc[2][2];
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 32;
+  f32x4 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // tile loads: 1024 elements each, 4 per thread; the fast index follows the unit stride of the operand
   const bool a_kfast = p.ak == 1, b_nfast = p.bn == 1;
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
+  float4 ra[2], rb;
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
       const int idx = tid + e * 256;
-      const int mm = a_kfast ? idx >> 4 : idx & 63, kk = a_kfast ? idx & 15 : idx >> 6;
-      const int gm = m0 + mm, gk = k0 + kk;
-      As[kk][mm] = (gm < p.M && gk < p.K) ? p.a[(int64_t)gm * p.am + (int64_t)gk * p.ak] : 0.f;
-      const int nn = b_nfast ? idx & 63 : idx >> 4, kb = b_nfast ? idx >> 6 : idx & 15;
-      const int gn = n0 + nn, gkb = k0 + kb;
-      Bs[kb][nn] = (gn < p.N && gkb < p.K) ? p.b[(int64_t)gkb * p.bk + (int64_t)gn * p.bn] : 0.f;
+      int m, k;
+      if (a_kfast) { m = idx >> 2; k = (idx & 3) * 4; } else { k = idx >> 5; m = (idx & 31) * 4; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[e] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const float4*>(p.a + (int64_t)gm * p.am + (int64_t)gk * p.ak)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    int n, k;
+    if (b_nfast) { k = tid >> 4; n = (tid & 15) * 4; } else { n = tid >> 2; k = (tid & 3) * 4; }
+    const int gn = n0 + n, gk = k0 + k;
+    rb = (gn < p.N && gk < p.K) ? *reinterpret_cast<const float4*>(p.b + (int64_t)gk * p.bk + (int64_t)gn * p.bn)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + e * 256;
+      if (a_kfast) {
+        const int m = idx >> 2, k = (idx & 3) * 4;
+        As[k][m] = ra[e].x; As[k + 1][m] = ra[e].y; As[k + 2][m] = ra[e].z; As[k + 3][m] = ra[e].w;
+      } else {
+        const int k = idx >> 5, m = (idx & 31) * 4;
+        *reinterpret_cast<float4*>(&As[k][m]) = ra[e];
+      }
+    }
+    if (b_nfast) {
+      const int k = tid >> 4, n = (tid & 15) * 4;
+      *reinterpret_cast<float4*>(&Bs[k][n]) = rb;
+    } else {
+      const int n = tid >> 2, k = (tid & 3) * 4;
+      Bs[k][n] = rb.x; Bs[k + 1][n] = rb.y; Bs[k + 2][n] = rb.z; Bs[k + 3][n] = rb.w;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += TK) {
+    park();
     __syncthreads();
+    if (k0 + TK < p.K) fetch(k0 + TK);
 #pragma unroll
-    for (int ks = 0; ks < 16; ks += 4) {
+    for (int ks = 0; ks < TK; ks += 4) {
       const int kq = ks + (lane >> 4);
-      float fa[2], fb[2];
+      float fa[4], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = As[kq][wm + i * 16 + (lane & 15)];
+      for (int i = 0; i < 4; ++i) fa[i] = As[kq][wm + i * 16 + (lane & 15)];
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = Bs[kq][wn + j * 16 + (lane & 15)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
@@ -68,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
   }
   // D: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -85,8 +118,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
 
 static int gemm_f32(const float* a, int64_t am, int64_t ak, const float* b, int64_t bk, int64_t bn, float* c, int64_t ldc,
                     const float* bias, int relu, int M, int N, int K, hipStream_t st) {
+  VOG_CHECK_ARG((am == 1 || ak == 1) && (bk == 1 || bn == 1) && (M % 4) == 0 && (N % 4) == 0 && (K % 4) == 0);
+  VOG_CHECK_ARG((am % 4 == 0 || am == 1) && (ak % 4 == 0 || ak == 1) && (bk % 4 == 0 || bk == 1) && (bn % 4 == 0 || bn == 1));
   GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K};
-  ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128)), dim3(256), 0, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -139,15 +174,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
   }
 }
 
-// out[n] = sum_m in[m, n]: one workgroup per 64 columns, 4 waves stride the rows, fixed order (reproducible)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* in, float* out, int M, int d) {
+// out[n] = sum_m in[m, n] in two fixed-order levels (reproducible): CS_CHUNKS row chunks x 64-column blocks write
+// partial sums, then one thread per column adds the chunks in order.
+constexpr int CS_CHUNKS = 64;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* in, float* part, int M, int d) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = blockIdx.x * 64 + lane;
+  const int rows = (M + CS_CHUNKS - 1) / CS_CHUNKS, r0 = blockIdx.y * rows, r1 = min(M, r0 + rows);
   float s = 0.f;
-  if (n < d) for (int m = wid; m < M; m += 4) s += in[(int64_t)m * d + n];
+  if (n < d) for (int m = r0 + wid; m < r1; m += 4) s += in[(int64_t)m * d + n];
   red[wid][lane] = s;
   __syncthreads();
-  if (wid == 0 && n < d) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wid == 0 && n < d) part[(int64_t)blockIdx.y * d + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ void colsum_final_kernel(const float* part, float* out, int d) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= d) return;
+  float s = 0.f;
+  for (int c = 0; c < CS_CHUNKS; ++c) s += part[(int64_t)c * d + n];
+  out[n] = s;
+}
+static int colsum(const float* in, float* out, float* part, int M, int d, hipStream_t st) {
+  ::vog::launch(colsum_partial_kernel, dim3(ceil_div(d, 64), CS_CHUNKS), dim3(256), 0, st, in, part, M, d);
+  ::vog::launch(colsum_final_kernel, dim3(ceil_div(d, 256)), dim3(256), 0, st, (const float*)part, out, d);
+  VOG_LAUNCH_CHECK();
+  return 0;
 }
 
 // y = dy where pre > 0 else 0
@@ -183,7 +234,8 @@ using namespace vog;
 extern "C" int64_t vog_mul_tail_bwd_scratch_bytes(int M, int d, int dh, int dhead) {
   if (M <= 0 || d <= 0 || dh <= 0 || dhead <= 0) return -1;
   // t, x1, u, y, dy, du, dx1, dt, tmp_d (9 x [M,d]); pre1, f?, dpre1 (3 x [M,dh]); h, dh_, hw (3 x [M,dhead]); stats, dlog
-  return ((int64_t)9 * M * d + (int64_t)3 * M * dh + (int64_t)3 * M * dhead + (int64_t)5 * M + 1024) * 4;
+  const int64_t wmax = d > dhead ? d : dhead;
+  return ((int64_t)9 * M * d + (int64_t)3 * M * dh + (int64_t)3 * M * dhead + (int64_t)5 * M + CS_CHUNKS * wmax + 1024) * 4;
 }
 
 extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
@@ -202,7 +254,8 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
   float *pre1 = take((int64_t)M * H1), *dpre1 = take((int64_t)M * H1), *df = take((int64_t)M * H1);
   float *h = take((int64_t)M * HD), *dh = take((int64_t)M * HD), *hw = take((int64_t)M * HD);
   float2* st1 = (float2*)take((int64_t)2 * M); float2* st2 = (float2*)take((int64_t)2 * M);
-  float* dlog = take(M);
+  float* dlog = take((M + 3) / 4 * 4);
+  float* part = take((int64_t)CS_CHUNKS * (d > HD ? d : HD));
   const int64_t nd = (int64_t)M * d, n1 = (int64_t)M * H1;
   auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
   // ---- recompute the forward in fp32
@@ -216,29 +269,29 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
   // ---- score head
   ScoreBwd sb{a->d_mdl_outs, h, a->wl2, dh, hw, dlog, M, a->nfrm, a->nppf, a->nsrl, HD};
   ::vog::launch(score_bwd_kernel, dim3(M), dim3(256), 0, st, sb);
-  ::vog::launch(colsum_kernel, dim3(ceil_div(HD, 64)), dim3(256), 0, st, (const float*)hw, a->g_wl2, M, HD);   // d lin2.2.weight
-  ::vog::launch(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dlog, a->g_bl2, M, 1);                 // d lin2.2.bias
+  VOG_TRY(colsum(hw, a->g_wl2, part, M, HD, st));   // d lin2.2.weight
+  VOG_TRY(colsum(dlog, a->g_bl2, part, M, 1, st));                 // d lin2.2.bias
   VOG_TRY(gemm_f32(dh, 1, HD, y, d, 1, a->g_wl, d, nullptr, 0, HD, d, M, st));                       // d lin2.0.weight = dh^T y
-  ::vog::launch(colsum_kernel, dim3(ceil_div(HD, 64)), dim3(256), 0, st, (const float*)dh, a->g_bl, M, HD);
+  VOG_TRY(colsum(dh, a->g_bl, part, M, HD, st));
   VOG_TRY(gemm_f32(dh, HD, 1, a->wl, d, 1, dy, d, nullptr, 0, M, d, HD, st));                        // dy = dh Wl
   // ---- LayerNorm 2
   ::vog::launch(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)u,
                 (const float2*)st2, a->ln2g, du, tmp, (float*)nullptr, M, d);
-  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)tmp, a->g_ln2g, M, d);
-  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)dy, a->g_ln2b, M, d);
+  VOG_TRY(colsum(tmp, a->g_ln2g, part, M, d, st));
+  VOG_TRY(colsum(dy, a->g_ln2b, part, M, d, st));
   // ---- FFN
   VOG_TRY(gemm_f32(du, 1, d, df, H1, 1, a->g_w2, H1, nullptr, 0, d, H1, M, st));                     // d W2 = du^T f
-  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)du, a->g_b2, M, d);
+  VOG_TRY(colsum(du, a->g_b2, part, M, d, st));
   VOG_TRY(gemm_f32(du, d, 1, a->w2, H1, 1, dpre1, H1, nullptr, 0, M, H1, d, st));                    // df = du W2
   ::vog::launch(relu_bwd_kernel, blocks(n1), dim3(256), 0, st, (const float*)dpre1, (const float*)pre1, dpre1, n1);
   VOG_TRY(gemm_f32(dpre1, 1, H1, x1, d, 1, a->g_w1, d, nullptr, 0, H1, d, M, st));                   // d W1 = dpre1^T x1
-  ::vog::launch(colsum_kernel, dim3(ceil_div(H1, 64)), dim3(256), 0, st, (const float*)dpre1, a->g_b1, M, H1);
+  VOG_TRY(colsum(dpre1, a->g_b1, part, M, H1, st));
   VOG_TRY(gemm_f32(dpre1, H1, 1, a->w1, d, 1, dx1, d, nullptr, 0, M, d, H1, st));                    // dpre1 W1
   // ---- LayerNorm 1 (dx1 = du + dpre1 W1)
   ::vog::launch(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const float*)dx1, (const float*)du, (const float*)t,
                 (const float2*)st1, a->ln1g, dt, tmp, dy, M, d);                                       // dy := dx1 + du (summand of d beta)
-  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)tmp, a->g_ln1g, M, d);
-  ::vog::launch(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, (const float*)dy, a->g_ln1b, M, d);
+  VOG_TRY(colsum(tmp, a->g_ln1g, part, M, d, st));
+  VOG_TRY(colsum(dy, a->g_ln1b, part, M, d, st));
   // ---- Wo and the two inputs
   VOG_TRY(gemm_f32(dt, 1, d, a->attn, d, 1, a->g_wo, d, nullptr, 0, d, d, M, st));                   // d Wo = dt^T a
   if (a->d_attn) VOG_TRY(gemm_f32(dt, d, 1, a->wo, d, 1, a->d_attn, d, nullptr, 0, M, d, d, st));    // da = dt Wo
