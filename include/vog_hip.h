@@ -519,9 +519,38 @@ typedef struct vog_tail_bwd_args {
   float *g_wo, *g_ln1g, *g_ln1b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2g, *g_ln2b, *g_wl, *g_bl, *g_wl2, *g_bl2;
   void* scratch; size_t scratch_bytes;
   int M, d, dh, dhead, n_vid, nfrm, nppf, nsrl;
+  /* round 3, second slice: the same tail for a layer that is NOT followed by the score head (obj_tx, inner mul_tx
+   * layers): no_head = 1, d_y [M, d] = gradient of the layer's output (wl / bl / wl2 / d_mdl_outs / dhead unused).
+   * y_out (optional, any mode) receives the layer's fp32 output; no_head with d_y == NULL recomputes the forward
+   * only (y_out required, no gradient is written). */
+  int no_head; const float* d_y; float* y_out;
 } vog_tail_bwd_args;
 int64_t vog_mul_tail_bwd_scratch_bytes(int M, int d, int dh, int dhead);
 int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream);
+
+/* Attention + Q / K / V projections of one (Rel)EncoderLayer in fp32 (code/transformer_code.py:136-162, 21-31;
+ * box bias code/mdl_vog.py:446-451, 456-490): the other half of the layer's backward (vog_mul_tail_bwd is the
+ * tail). x [S*N, d] = layer input, rows (sequence s, token i); token i = arg*n + p, the bias of (p, q) tiled over
+ * the N/n argument blocks; heads = torch.chunk(d, n_heads) (unequal and odd sizes allowed); scale sqrt(d).
+ *   forward  (d_cat == NULL): cat_out [S*N, d] = concatenated heads softmax((Q K^T + bias) / scale) V.
+ *   backward (d_cat != NULL): g_wq / g_wk / g_wv [d, d], g_pe_w [H, 5], g_pe_b [H] (written), d_x [S*N, d] =
+ *   (accumulate_dx ? d_x : 0) + dQ Wq + dK Wk + dV Wv; cat_out optional.
+ * props [S*n, prop_stride >= 5] = (x1, y1, x2, y2, frame) per proposal, normalised by (vid_w, vid_h, vid_w, vid_h,
+ * nfrm_div) as compute_pe does; props == NULL: no bias (use_rel off). Activations are recomputed (Q, K, V, the
+ * probabilities of one head at a time) in `scratch`. */
+typedef struct vog_attn_f32_args {
+  const float* x; const float* d_cat;
+  const float *wq, *wk, *wv;
+  const float* props; int prop_stride; float vid_w, vid_h, nfrm_div;
+  const float *pe_w, *pe_b;
+  float* cat_out;
+  float *g_wq, *g_wk, *g_wv, *g_pe_w, *g_pe_b;
+  float* d_x; int accumulate_dx;
+  void* scratch; size_t scratch_bytes;
+  int S, N, n, d, n_heads;
+} vog_attn_f32_args;
+int64_t vog_attn_f32_scratch_bytes(int S, int N, int n, int d);
+int vog_attn_f32(const vog_attn_f32_args* a, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)

@@ -71,8 +71,26 @@ def reference_grads(name: str):
             cap[nm] = inp[0]
             inp[0].retain_grad()
         return fn
+    def keep_out(nm):
+        def fn(_m, _inp, out):
+            if nm not in cap:                                                   # first call only
+                cap[nm] = out
+                out.retain_grad()
+        return fn
     hs = [last.selfattn.layer.wo.register_forward_pre_hook(keep("attn")),       # the concatenated heads
-          last.selfattn.layernorm.register_forward_pre_hook(keep("t"))]         # x + attn Wo^T
+          last.selfattn.layernorm.register_forward_pre_hook(keep("t")),         # x + attn Wo^T
+          last.register_forward_pre_hook(keep("mul_in"))]                       # the layer input (both paths)
+    has_obj = hasattr(mdl, "obj_txf") and cfg.mdl.name in ("vog_grnd", "vid_grnd", "vog", "vgrnd") and len(mdl.obj_txf.encoder.layers) > 0
+    if has_obj:
+        ol = mdl.obj_txf.encoder.layers[len(mdl.obj_txf.encoder.layers) - 1]
+        hs += [ol.selfattn.layer.wo.register_forward_pre_hook(keep("obj_attn")),
+               ol.selfattn.layernorm.register_forward_pre_hook(keep("obj_t")),
+               ol.register_forward_pre_hook(keep("obj_in")),
+               ol.register_forward_hook(keep_out("obj_out"))]
+    hs += [mdl.srl_arg_words_out_enc.register_forward_hook(keep_out("lang_enc")),   # relu(linear), before the mask
+           mdl.lstm_out_feat_proj.register_forward_hook(keep_out("lstm_proj")),     # first call: every time step
+           mdl.prop_encoder.register_forward_hook(keep_out("prop_enc")),
+           mdl.seg_encoder.register_forward_hook(keep_out("seg_enc"))]
     import mdl_conc_single as mcs  # noqa: reference modules
     import mdl_conc_sep as mcp
     ct = cfg.ds.conc_type
@@ -95,6 +113,15 @@ def reference_grads(name: str):
     grads = {k: params[n].grad.detach().numpy() for k, n in param_names(layer).items()}
     grads["d_attn"] = cap["attn"].grad.detach().reshape(-1, cap["attn"].shape[-1]).numpy()
     grads["d_x"] = cap["t"].grad.detach().reshape(-1, cap["t"].shape[-1]).numpy()
+    # round 3, second slice onwards: every parameter the loss reaches ("p:<name>") and the gradients at the
+    # seams between the pieces of the backward ("d_<seam>", rows x features)
+    for n, p_ in params.items():
+        if p_.grad is not None:
+            grads["p:" + n] = p_.grad.detach().numpy()
+    for nm, t in cap.items():
+        if nm in ("attn", "t") or t.grad is None:
+            continue
+        grads["d_" + nm] = t.grad.detach().reshape(-1, t.shape[-1]).numpy()
     return grads, float(res["loss"]), layer
 
 
@@ -104,7 +131,7 @@ def make(name: str):
     for k, g in grads.items():
         pack(rec, k, g)
     np.savez_compressed(bwd_path(name), **rec)
-    print(f"{name:36s} loss {loss:.6f}  " + " ".join(f"{k}:{float(rec[k + '__norm']):.3e}" for k in grads),
+    print(f"{name:36s} loss {loss:.6f}  " + " ".join(f"{k}:{float(rec[k + '__norm']):.3e}" for k in grads if not k.startswith("p:")),
           f" {os.path.getsize(bwd_path(name)) / 1024:.0f} KB")
 
 

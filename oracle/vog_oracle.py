@@ -161,7 +161,7 @@ def lang_encode(tokens, lens, sd, num_layers, quant=None):
     return full, hid
 
 
-def retrieve_srl_args(full, capture, inds_msk, sd, quant=None):
+def retrieve_srl_args(full, capture, inds_msk, sd, quant=None, stash=None):
     """reference mdl_vog.py:97-140."""
     B, nv, nsrl, _ = capture.shape
     cap = capture.reshape(B * nv, nsrl, 2)
@@ -170,6 +170,8 @@ def retrieve_srl_args(full, capture, inds_msk, sd, quant=None):
     en = torch.gather(full, 1, cap[..., 1].unsqueeze(-1).expand(-1, -1, D))
     enc = torch.cat([st, en], dim=2).reshape(B, nv, nsrl, 2 * D)
     out = linear(enc, sd, "srl_arg_words_out_enc.0", relu=True, quant=quant)
+    if stash is not None:
+        stash["lang_enc"] = out      # before the argument mask (backward fixtures)
     return out * inds_msk.unsqueeze(-1).to(F32)
 
 
@@ -300,12 +302,13 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
     lens = inp["srl_arg_word_mask_len"].reshape(B * nv)
     full, hid = lang_encode(tok, lens, sd, oc.rnn_layers, quant)
     lang = retrieve_srl_args(full, inp["srl_arg_words_capture"],
-                             inp["srl_arg_inds_msk"], sd, quant)   # [B,nv,5,L]
+                             inp["srl_arg_inds_msk"], sd, quant, stash=st if keep_stages else None)   # [B,nv,5,L]
     st.update(tokens=tok, lstm_full_output=full, final_hidden=hid, lang=lang)
 
     # ---- visual encoders (a13, a12)
     prop = linear(inp["pad_region_feature"].to(F32), sd, "prop_encoder.0", True, quant)
     seg = linear(inp["seg_feature_for_frms"].to(F32), sd, "seg_encoder.0", True, quant)
+    st.update(prop_enc=prop, seg_enc=seg)
     if not sep:
         prop = prop.unsqueeze(1)                                  # [B,1,NP,256]
         seg = seg.unsqueeze(1)                                    # [B,1,F,256]
@@ -329,8 +332,12 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
         else:
             x = ps.reshape(B * nc_v, NP, d)
             bx = normalise_boxes(props5, oc.vid_w, oc.vid_h, 1.0).reshape(B * nc_v, NP, 5)
+        obj_stash = {} if keep_stages else None
         x = transformer(x, bx, 1, sd, "obj_txf", "pe_obj_sub_enc.0",
-                        oc.obj_layers, oc.obj_heads, oc.obj_use_rel, quant)
+                        oc.obj_layers, oc.obj_heads, oc.obj_use_rel, quant, stash=obj_stash)
+        if keep_stages:
+            st.update(obj_tail_attn=obj_stash["tail_attn"], obj_tail_x=obj_stash["tail_x"], obj_tail_t=obj_stash["tail_t"],
+                      obj_boxes=bx, obj_out_seq=x)
         ps = x.reshape(B, nc_v, NP, d)
     st.update(obj_out=ps)
 
@@ -351,7 +358,8 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
         x = transformer(x, bx, nsrl, sd, "mult_txf", "pe_mul_sub_enc.0",
                         oc.mul_layers, oc.mul_heads, oc.mul_use_rel, quant, stash=mul_stash)
         if keep_stages:
-            st.update(mul_out=x, mul_tail_attn=mul_stash["tail_attn"], mul_tail_x=mul_stash["tail_x"], mul_tail_t=mul_stash["tail_t"])
+            st.update(mul_out=x, mul_tail_attn=mul_stash["tail_attn"], mul_tail_x=mul_stash["tail_x"], mul_tail_t=mul_stash["tail_t"],
+                      mul_boxes=bx)
         conc = x.reshape(B * nc_v, nfrm, nsrl, nppf, vld).transpose(1, 2).reshape(
             B, nc_v, nsrl, NP, vld)
 

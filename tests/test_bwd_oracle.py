@@ -42,8 +42,12 @@ def test_oracle_autograd_equals_reference_autograd(name):
     torch.set_num_threads(8)
     out = vo.forward(oc, sdt, inp, keep_stages=True)
     st = out["stages"]
-    st["mul_tail_attn"].retain_grad()
-    st["mul_tail_t"].retain_grad()
+    seams = {"mul_in": "mul_tail_x", "obj_in": "obj_tail_x", "obj_attn": "obj_tail_attn", "obj_t": "obj_tail_t",
+             "obj_out": "obj_out_seq", "lang_enc": "lang_enc", "lstm_proj": "lstm_full_output", "prop_enc": "prop_enc",
+             "seg_enc": "seg_enc"}
+    for k in ["mul_tail_attn", "mul_tail_t"] + list(seams.values()):
+        if k in st:
+            st[k].retain_grad()
     res = vo.loss_forward(oc, out, inp, loss_lambda=float(cfg.loss.loss_lambda))
     assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     res["loss"].backward()
@@ -53,4 +57,17 @@ def test_oracle_autograd_equals_reference_autograd(name):
     d = st["mul_tail_attn"].shape[-1]
     worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=2e-4))
     worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=2e-4))
-    print(name, "worst relative error", worst)
+    # every parameter the loss reaches, and the gradients at the seams between the pieces of the backward
+    n_par = 0
+    for key in g.files:
+        if key.startswith("p:") and key.endswith("__shape"):
+            n = key[2:-len("__shape")]
+            assert sdt[n].grad is not None, n
+            worst = max(worst, check_fixture(g, "p:" + n, sdt[n].grad.numpy(), tol=2e-4))
+            n_par += 1
+    assert n_par >= 50
+    for seam, stage in seams.items():
+        if ("d_" + seam + "__shape") in g.files:
+            t = st[stage]
+            worst = max(worst, check_fixture(g, "d_" + seam, t.grad.reshape(-1, t.shape[-1]).numpy(), tol=2e-4))
+    print(name, "worst relative error", worst, "parameters", n_par)

@@ -408,3 +408,60 @@ def test_device_tail_backward_vs_reference_autograd(name):
 
 def sd_torch(sd):
     return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def _bwd_setup(name):
+    """Oracle fp32 forward (activations at the seams), the device loss gradient on the reference's logits."""
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    dev.update({k: torch.from_numpy(v).cuda() for k, v in tg.items()})
+    g = np.load(mgb.bwd_path(name))
+    _, sd, _, _ = cases.build(name)
+    oc = vo.OracleCfg.from_cfg(cfg, c["vocab"], c["nppf0"])
+    with torch.no_grad():
+        o = vo.forward(oc, vo.to_torch(sd), vo.to_torch(batch), keep_stages=True)
+    ref = np.load(cases.golden_path(name))
+    out = {"mdl_outs": torch.from_numpy(ref["mdl_outs"]).cuda()}
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    with torch.no_grad():
+        ld = loss_fn(out, dev)
+        d_outs = loss_fn.backward(ld)
+    B, nc_v, nsrl, NP = ref["mdl_outs"].shape
+    nfrm = 40 if cfg.ds.conc_type == "temp" else 10
+    return cfg, oc, sd, batch, g, o["stages"], d_outs, (B, nc_v, nsrl, NP, nfrm, NP // nfrm)
+
+
+@pytest.mark.parametrize("name", ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4"])
+def test_device_mul_layer_backward_vs_reference_autograd(name):
+    """The whole last mul_tx layer + score head on the device (`encoder_layer_backward`: attention forward
+    recomputation -> tail backward -> attention / QKV / box-bias backward, fp32): every parameter gradient of the
+    layer, of `lin2` and of `pe_mul_sub_enc`, and the gradient of the layer input, against AUTOGRAD THROUGH THE
+    REFERENCE model + loss. The layer input comes from the CPU oracle's forward."""
+    from tests.test_bwd_oracle import check_fixture
+    cfg, oc, sd, batch, g, st, d_outs, (B, nc_v, nsrl, NP, nfrm, nppf) = _bwd_setup(name)
+    layer = int(g["layer"])
+    d = st["mul_tail_x"].shape[-1]
+    x = st["mul_tail_x"].reshape(-1, d).contiguous().cuda()
+    S, N = B * nc_v * nfrm, nsrl * nppf
+    boxes = None
+    if oc.mul_use_rel:
+        props = torch.from_numpy(batch["pad_proposals"]).float().reshape(-1, batch["pad_proposals"].shape[-1]).cuda()
+        boxes = bwd._Boxes(props, oc.vid_w, oc.vid_h, float(nfrm))
+    # the forward recomputation first: the device's fp32 layer output against the oracle's
+    y, cat = bwd.encoder_layer_forward(sd_torch(sd), "mult_txf", layer, "pe_mul_sub_enc.0", x, S, N, nppf, oc.mul_heads, boxes)
+    torch.cuda.synchronize()
+    ref_cat = st["mul_tail_attn"].reshape(-1, d)
+    assert float((cat.cpu() - ref_cat).abs().max()) <= 1e-4 * float(ref_cat.abs().max())
+    ref_y = st["mul_out"].reshape(-1, d)
+    assert float((y.cpu() - ref_y).abs().max()) <= 1e-4 * float(ref_y.abs().max())
+    res = bwd.encoder_layer_backward(sd_torch(sd), "mult_txf", layer, "pe_mul_sub_enc.0", x, S, N, nppf, oc.mul_heads, boxes,
+                                     head=(d_outs, B * nc_v, nfrm, nppf, nsrl))
+    torch.cuda.synchronize()
+    worst = 0.0
+    names = list(bwd.layer_param_names("mult_txf", layer).values()) + ["lin2.0.weight", "lin2.0.bias", "lin2.2.weight", "lin2.2.bias"]
+    if boxes is not None:
+        names += ["pe_mul_sub_enc.0.weight", "pe_mul_sub_enc.0.bias"]
+    for n in names:
+        worst = max(worst, check_fixture(g, "p:" + n, res[n].cpu().numpy(), tol=1e-3))
+    worst = max(worst, check_fixture(g, "d_mul_in", res["_d_x"].cpu().numpy(), tol=1e-3))
+    print(name, "worst relative gradient error", worst)

@@ -8,9 +8,12 @@ encoder layer's tail on the device (`vog_mul_tail_bwd`, csrc/backward.hip), behi
     mult_txf.encoder.layers.<last>.feedforward.{layer.linear1.*, layer.linear2.*, layernorm.*}
 
 plus the gradients of the tail's two inputs (the concatenated attention heads, the layer input through the
-residual), where the rest of the backward (attention, QKV, encoders, BiLSTM) will attach. fp32; pinned
-against autograd through the reference modules (tests/golden/bwd__*.npz). No optimizer and no gradient
-all-reduce yet.
+residual), where the rest of the backward attaches. fp32; pinned against autograd through the reference
+modules (tests/golden/bwd__*.npz).
+
+Second slice: the attention + Q/K/V half of an encoder layer (`vog_attn_f32`: wq / wk / wv, the box-bias
+Linear(5, H) `pe_*_sub_enc`, the layer input), which with the tail makes `encoder_layer_backward` - one whole
+(Rel)EncoderLayer, with or without the score head behind it.
 """
 from __future__ import annotations
 
@@ -71,4 +74,164 @@ def mul_tail_backward(state_dict, layer: int, attn: torch.Tensor, x: torch.Tenso
     if with_input_grads:
         out["_d_attn"], out["_d_x"] = d_attn, d_x
     out["_keepalive"] = keep
+    return out
+
+
+def layer_param_names(stack: str, layer: int) -> Dict[str, str]:
+    """stack = 'mult_txf' | 'obj_txf' -> the reference's parameter names of one encoder layer."""
+    p = f"{stack}.encoder.layers.{layer}"
+    return {"wq": f"{p}.selfattn.layer.wq.weight", "wk": f"{p}.selfattn.layer.wk.weight",
+            "wv": f"{p}.selfattn.layer.wv.weight", "wo": f"{p}.selfattn.layer.wo.weight",
+            "ln1g": f"{p}.selfattn.layernorm.weight", "ln1b": f"{p}.selfattn.layernorm.bias",
+            "w1": f"{p}.feedforward.layer.linear1.weight", "b1": f"{p}.feedforward.layer.linear1.bias",
+            "w2": f"{p}.feedforward.layer.linear2.weight", "b2": f"{p}.feedforward.layer.linear2.bias",
+            "ln2g": f"{p}.feedforward.layernorm.weight", "ln2b": f"{p}.feedforward.layernorm.bias"}
+
+
+class _Boxes:
+    """Proposal rows of the sequences of a layer: props [S*n, stride >= 5] fp32 on the device, normalisers."""
+
+    def __init__(self, props: torch.Tensor, vid_w: float, vid_h: float, nfrm_div: float):
+        assert props.is_cuda and props.dtype == torch.float32 and props.dim() == 2 and props.shape[1] >= 5
+        self.props, self.vid_w, self.vid_h, self.nfrm_div = props.contiguous(), float(vid_w), float(vid_h), float(nfrm_div)
+
+
+def _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=None, d_x=None, accumulate_dx=False, want_cat=False):
+    lib = L.load()
+    dev = x.device
+    M, d = x.shape
+    assert M == S * N and N % n == 0
+    nb = int(lib.vog_attn_f32_scratch_bytes(S, N, n, d))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    a = L.AttnF32Args()
+    a.x, a.wq, a.wk, a.wv = L.ptr(x), L.ptr(w["wq"]), L.ptr(w["wk"]), L.ptr(w["wv"])
+    keep = [x, scratch]
+    if boxes is not None:
+        a.props, a.prop_stride = L.ptr(boxes.props), boxes.props.shape[1]
+        a.vid_w, a.vid_h, a.nfrm_div = boxes.vid_w, boxes.vid_h, boxes.nfrm_div
+        a.pe_w, a.pe_b = L.ptr(pe[0]), L.ptr(pe[1])
+        assert boxes.props.shape[0] == S * n and pe[0].shape == (n_heads, 5)
+    out = {}
+    if want_cat or d_cat is None:
+        out["cat"] = torch.empty_like(x)
+        a.cat_out = L.ptr(out["cat"])
+    if d_cat is not None:
+        d_cat = d_cat.contiguous()
+        keep.append(d_cat)
+        a.d_cat = L.ptr(d_cat)
+        for k in ("wq", "wk", "wv"):
+            out["g_" + k] = torch.empty_like(w[k])
+            setattr(a, "g_" + k, L.ptr(out["g_" + k]))
+        if boxes is not None:
+            out["g_pe_w"], out["g_pe_b"] = torch.empty_like(pe[0]), torch.empty_like(pe[1])
+            a.g_pe_w, a.g_pe_b = L.ptr(out["g_pe_w"]), L.ptr(out["g_pe_b"])
+        out["d_x"] = d_x if d_x is not None else torch.empty_like(x)
+        a.d_x, a.accumulate_dx = L.ptr(out["d_x"]), 1 if (accumulate_dx and d_x is not None) else 0
+    a.scratch, a.scratch_bytes = L.ptr(scratch), nb
+    a.S, a.N, a.n, a.d, a.n_heads = S, N, n, d, n_heads
+    L.check(lib.vog_attn_f32(C.byref(a), L.stream_ptr()), "vog_attn_f32")
+    out["_keepalive"] = keep
+    return out
+
+
+def _tail_call(w, attn, x, head=None, d_y=None, want_y=False):
+    """head = (w_head dict {wl, bl, wl2}, d_mdl_outs, n_vid, nfrm, nppf, nsrl) or None (then d_y, or forward only)."""
+    lib = L.load()
+    dev = x.device
+    M, d = x.shape
+    dh = w["w1"].shape[0]
+    dhead = head[0]["wl"].shape[0] if head is not None else 0
+    nb = int(lib.vog_mul_tail_bwd_scratch_bytes(M, d, dh, dhead))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    a = L.TailBwdArgs()
+    keep = [attn, x, scratch]
+    a.attn, a.x = L.ptr(attn), L.ptr(x)
+    for k in ("wo", "ln1g", "ln1b", "w1", "b1", "w2", "b2", "ln2g", "ln2b"):
+        setattr(a, k, L.ptr(w[k]))
+    out = {}
+    bwd = head is not None or d_y is not None
+    gkeys = ["wo", "ln1g", "ln1b", "w1", "b1", "w2", "b2", "ln2g", "ln2b"]
+    if head is not None:
+        wh, dmo, n_vid, nfrm, nppf, nsrl = head
+        dmo = dmo.to(torch.float32).contiguous()
+        keep.append(dmo)
+        a.d_mdl_outs = L.ptr(dmo)
+        for k in ("wl", "bl", "wl2"):
+            setattr(a, k, L.ptr(wh[k]))
+        a.n_vid, a.nfrm, a.nppf, a.nsrl, a.dhead = n_vid, nfrm, nppf, nsrl, dhead
+        for k in ("wl", "bl", "wl2", "bl2"):
+            out["g_" + k] = torch.empty_like(wh[k])
+            setattr(a, "g_" + k, L.ptr(out["g_" + k]))
+    else:
+        a.no_head = 1
+        if d_y is not None:
+            d_y = d_y.contiguous()
+            keep.append(d_y)
+            a.d_y = L.ptr(d_y)
+    if bwd:
+        for k in gkeys:
+            out["g_" + k] = torch.empty_like(w[k])
+            setattr(a, "g_" + k, L.ptr(out["g_" + k]))
+        out["d_attn"], out["d_x"] = torch.empty_like(x), torch.empty_like(x)
+        a.d_attn, a.d_x = L.ptr(out["d_attn"]), L.ptr(out["d_x"])
+    if want_y or not bwd:
+        out["y"] = torch.empty_like(x)
+        a.y_out = L.ptr(out["y"])
+    a.scratch, a.scratch_bytes = L.ptr(scratch), nb
+    a.M, a.d, a.dh = M, d, dh
+    L.check(lib.vog_mul_tail_bwd(C.byref(a), L.stream_ptr()), "vog_mul_tail_bwd")
+    out["_keepalive"] = keep
+    return out
+
+
+def _f32(sd, names, dev):
+    return {k: sd[n].detach().to(dev, torch.float32).contiguous() for k, n in names.items()}
+
+
+def encoder_layer_forward(state_dict, stack: str, layer: int, pe_name, x: torch.Tensor, S: int, N: int, n: int,
+                          n_heads: int, boxes=None):
+    """fp32 forward of one (Rel)EncoderLayer (the recomputation the backward starts from) -> (y [S*N, d], cat)."""
+    dev = x.device
+    w = _f32(state_dict, layer_param_names(stack, layer), dev)
+    pe = None
+    if boxes is not None:
+        pe = (state_dict[pe_name + ".weight"].detach().to(dev, torch.float32).contiguous(),
+              state_dict[pe_name + ".bias"].detach().to(dev, torch.float32).contiguous())
+    x = x.contiguous()
+    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes)
+    t = _tail_call(w, f["cat"], x)
+    return t["y"], f["cat"]
+
+
+def encoder_layer_backward(state_dict, stack: str, layer: int, pe_name, x: torch.Tensor, S: int, N: int, n: int,
+                           n_heads: int, boxes=None, d_y: torch.Tensor = None, head=None) -> Dict[str, torch.Tensor]:
+    """Backward of one whole (Rel)EncoderLayer on the device (code/transformer_code.py:128-203).
+
+    x [S*N, d]: the layer's fp32 input. Either `d_y` [S*N, d] (gradient of the layer's output) or `head` =
+    (d_mdl_outs, n_vid, nfrm, nppf, nsrl) when the score head `lin2` follows the layer (last mul_tx layer).
+    boxes = _Boxes(...) when the layer has the relative-position bias. -> {reference parameter name: gradient,
+    '_d_x': gradient of the layer input [S*N, d]}."""
+    dev = x.device
+    names = layer_param_names(stack, layer)
+    w = _f32(state_dict, names, dev)
+    pe = None
+    if boxes is not None:
+        pe = (state_dict[pe_name + ".weight"].detach().to(dev, torch.float32).contiguous(),
+              state_dict[pe_name + ".bias"].detach().to(dev, torch.float32).contiguous())
+    x = x.contiguous()
+    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes)                         # recompute the concatenated heads
+    hd = None
+    if head is not None:
+        hn = {"wl": "lin2.0.weight", "bl": "lin2.0.bias", "wl2": "lin2.2.weight", "bl2": "lin2.2.bias"}
+        wh = _f32(state_dict, hn, dev)
+        hd = (wh,) + tuple(head)
+    t = _tail_call(w, f["cat"], x, head=hd, d_y=d_y)
+    b = _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=t["d_attn"], d_x=t["d_x"], accumulate_dx=True)
+    out = {names[k]: t["g_" + k] for k in ("wo", "ln1g", "ln1b", "w1", "b1", "w2", "b2", "ln2g", "ln2b")}
+    out.update({names[k]: b["g_" + k] for k in ("wq", "wk", "wv")})
+    if head is not None:
+        out.update({hn[k]: t["g_" + k] for k in hn})
+    if boxes is not None:
+        out[pe_name + ".weight"], out[pe_name + ".bias"] = b["g_pe_w"], b["g_pe_b"]
+    out["_d_x"] = b["d_x"]
     return out

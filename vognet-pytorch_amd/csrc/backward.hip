@@ -27,6 +27,9 @@ namespace vog {
 struct GemmF32 {
   const float* a; int64_t am, ak; const float* b; int64_t bk, bn; float* c; int64_t ldc;
   const float* bias; int relu; int M, N, K;
+  int64_t sa, sb, sc;       // batch strides (blockIdx.z)
+  int accum;                // C += ...
+  int scalar;               // any dimensions / alignments: element loads with per-element bounds checks
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
@@ -36,6 +39,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int wm = (wid >> 1) * 64, wn = (wid & 1) * 32;
+  const float* pa = p.a + (int64_t)blockIdx.z * p.sa;
+  const float* pb = p.b + (int64_t)blockIdx.z * p.sb;
+  float* pc = p.c + (int64_t)blockIdx.z * p.sc;
   f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -50,14 +56,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
       int m, k;
       if (a_kfast) { m = idx >> 2; k = (idx & 3) * 4; } else { k = idx >> 5; m = (idx & 31) * 4; }
       const int gm = m0 + m, gk = k0 + k;
-      ra[e] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const float4*>(p.a + (int64_t)gm * p.am + (int64_t)gk * p.ak)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!p.scalar) {
+        ra[e] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const float4*>(pa + (int64_t)gm * p.am + (int64_t)gk * p.ak)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mm = a_kfast ? gm : gm + q, kk = a_kfast ? gk + q : gk;
+          v[q] = (mm < p.M && kk < p.K) ? pa[(int64_t)mm * p.am + (int64_t)kk * p.ak] : 0.f;
+        }
+        ra[e] = make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
     int n, k;
     if (b_nfast) { k = tid >> 4; n = (tid & 15) * 4; } else { n = tid >> 2; k = (tid & 3) * 4; }
     const int gn = n0 + n, gk = k0 + k;
-    rb = (gn < p.N && gk < p.K) ? *reinterpret_cast<const float4*>(p.b + (int64_t)gk * p.bk + (int64_t)gn * p.bn)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!p.scalar) {
+      rb = (gn < p.N && gk < p.K) ? *reinterpret_cast<const float4*>(pb + (int64_t)gk * p.bk + (int64_t)gn * p.bn)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nn = b_nfast ? gn + q : gn, kk = b_nfast ? gk : gk + q;
+        v[q] = (nn < p.N && kk < p.K) ? pb[(int64_t)kk * p.bk + (int64_t)nn * p.bn] : 0.f;
+      }
+      rb = make_float4(v[0], v[1], v[2], v[3]);
+    }
   };
   auto park = [&]() {
 #pragma unroll
@@ -111,19 +137,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
           float v = acc[i][j][r];
           if (p.bias) v += p.bias[n];
           if (p.relu) v = v < 0.f ? 0.f : v;
-          p.c[(int64_t)m * p.ldc + n] = v;
+          float* dst = pc + (int64_t)m * p.ldc + n;
+          *dst = p.accum ? *dst + v : v;
         }
       }
 }
 
-static int gemm_f32(const float* a, int64_t am, int64_t ak, const float* b, int64_t bk, int64_t bn, float* c, int64_t ldc,
-                    const float* bias, int relu, int M, int N, int K, hipStream_t st) {
-  VOG_CHECK_ARG((am == 1 || ak == 1) && (bk == 1 || bn == 1) && (M % 4) == 0 && (N % 4) == 0 && (K % 4) == 0);
-  VOG_CHECK_ARG((am % 4 == 0 || am == 1) && (ak % 4 == 0 || ak == 1) && (bk % 4 == 0 || bk == 1) && (bn % 4 == 0 || bn == 1));
-  GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K};
-  ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128)), dim3(256), 0, st, p);
+static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// batched form; the vector path is chosen when every dimension, stride and pointer allows 16-byte loads
+static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const float* b, int64_t bk, int64_t bn, int64_t sb,
+                      float* c, int64_t ldc, int64_t sc, const float* bias, int relu, int accum, int M, int N, int K, int batch,
+                      hipStream_t st) {
+  VOG_CHECK_ARG((am == 1 || ak == 1) && (bk == 1 || bn == 1) && M > 0 && N > 0 && K > 0 && batch > 0);
+  auto m4 = [](int64_t v) { return (v & 3) == 0; };
+  const bool vec = m4(M) && m4(N) && m4(K) && (m4(am) || am == 1) && (m4(ak) || ak == 1) && (m4(bk) || bk == 1) &&
+                   (m4(bn) || bn == 1) && m4(sa) && m4(sb) && al16(a) && al16(b);
+  GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K, sa, sb, sc, accum, vec ? 0 : 1};
+  ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), batch), dim3(256), 0, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
+}
+static int gemm_f32(const float* a, int64_t am, int64_t ak, const float* b, int64_t bk, int64_t bn, float* c, int64_t ldc,
+                    const float* bias, int relu, int M, int N, int K, hipStream_t st, int accum = 0) {
+  return gemm_f32_b(a, am, ak, 0, b, bk, bn, 0, c, ldc, 0, bias, relu, accum, M, N, K, 1, st);
 }
 
 __device__ __forceinline__ float wsum(float v) {
@@ -222,6 +259,91 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(ScoreBwd a) {
   }
 }
 
+// ---- attention (fp32) ---------------------------------------------------------------------------------
+// normalised boxes (compute_pe code/mdl_vog.py:456-463): bx[r] = (x1/w, y1/h, x2/w, y2/h, frame/nfrm_div), 8 floats per row
+__global__ void norm_boxes_kernel(const float* props, int stride, float vw, float vh, float fdiv, float* bx, int rows) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* q = props + (int64_t)r * stride;
+  float* o = bx + (int64_t)r * 8;
+  o[0] = q[0] / vw; o[1] = q[1] / vh; o[2] = q[2] / vw; o[3] = q[3] / vh; o[4] = q[4] / fdiv; o[5] = o[6] = o[7] = 0.f;
+}
+
+struct AttnRow {
+  float* P;             // [S, N, N] logits in, probabilities out (softmax) | probabilities (ds)
+  float* D;             // [S, N, N] dP in, d logits (before the 1/scale of Q K^T + bias) out (ds)
+  const float* bx;      // [S*n, 8] or null (no relative-position bias)
+  const float* w; const float* b;  // this head's Linear(5, H) row and bias entry (code/mdl_vog.py:446-451), device
+  float* part;          // [S*N, 8] per-row sums of d bias . (box difference, 1) (ds)
+  int S, N, n; float inv_scale;
+};
+
+__device__ __forceinline__ float box_z(const AttnRow& a, const float* bi, const float* bj) {
+  return a.w[0] * (bi[0] - bj[0]) + a.w[1] * (bi[1] - bj[1]) + a.w[2] * (bi[2] - bj[2]) + a.w[3] * (bi[3] - bj[3]) +
+         a.w[4] * (bi[4] - bj[4]) + a.b[0];
+}
+
+// P[row] = softmax((P[row] + relu(w . (box_i - box_j) + b)) / scale): one wave per row (transformer_code.py:136-162)
+__global__ __launch_bounds__(256) void attn_softmax_kernel(AttnRow a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.S * a.N) return;
+  const int s = row / a.N, i = row % a.N;
+  float* pr = a.P + (int64_t)row * a.N;
+  const float* bi = a.bx ? a.bx + ((int64_t)s * a.n + i % a.n) * 8 : nullptr;
+  float mx = -3.0e38f;
+  for (int j = lane; j < a.N; j += 64) {
+    float v = pr[j];
+    if (bi) v += fmaxf(box_z(a, bi, a.bx + ((int64_t)s * a.n + j % a.n) * 8), 0.f);
+    v *= a.inv_scale;
+    pr[j] = v;
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int j = lane; j < a.N; j += 64) { const float e = expf(pr[j] - mx); pr[j] = e; sum += e; }
+  sum = wsum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < a.N; j += 64) pr[j] *= inv;
+}
+
+// D[row] = P (dP - sum_j P dP) / scale  (= d (Q K^T) = d bias); part[row] = sum_j [z > 0] D (box_i - box_j, 1)
+__global__ __launch_bounds__(256) void attn_ds_kernel(AttnRow a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.S * a.N) return;
+  const int s = row / a.N, i = row % a.N;
+  const float* pr = a.P + (int64_t)row * a.N;
+  float* dr = a.D + (int64_t)row * a.N;
+  float rs = 0.f;
+  for (int j = lane; j < a.N; j += 64) rs += pr[j] * dr[j];
+  rs = wsum(rs);
+  const float* bi = a.bx ? a.bx + ((int64_t)s * a.n + i % a.n) * 8 : nullptr;
+  float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j = lane; j < a.N; j += 64) {
+    const float ds = pr[j] * (dr[j] - rs) * a.inv_scale;
+    dr[j] = ds;
+    if (bi) {
+      const float* bj = a.bx + ((int64_t)s * a.n + j % a.n) * 8;
+      if (box_z(a, bi, bj) > 0.f) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) g[c] += ds * (bi[c] - bj[c]);
+        g[5] += ds;
+      }
+    }
+  }
+  if (a.part) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) g[c] = wsum(g[c]);
+    if (lane < 8) a.part[(int64_t)row * 8 + lane] = lane == 0 ? g[0] : lane == 1 ? g[1] : lane == 2 ? g[2] : lane == 3 ? g[3]
+                                                    : lane == 4 ? g[4] : lane == 5 ? g[5] : 0.f;
+  }
+}
+
+__global__ void pe_grad_store_kernel(const float* sum8, float* g_w, float* g_b, int h) {
+  if (threadIdx.x < 5) g_w[h * 5 + threadIdx.x] = sum8[threadIdx.x];
+  if (threadIdx.x == 5) g_b[h] = sum8[5];
+}
+
 __global__ void add_kernel(const float* a, const float* b, float* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
@@ -232,20 +354,28 @@ __global__ void add_kernel(const float* a, const float* b, float* out, int64_t n
 using namespace vog;
 
 extern "C" int64_t vog_mul_tail_bwd_scratch_bytes(int M, int d, int dh, int dhead) {
-  if (M <= 0 || d <= 0 || dh <= 0 || dhead <= 0) return -1;
+  if (M <= 0 || d <= 0 || dh <= 0 || dhead < 0) return -1;
   // t, x1, u, y, dy, du, dx1, dt, tmp_d (9 x [M,d]); pre1, f?, dpre1 (3 x [M,dh]); h, dh_, hw (3 x [M,dhead]); stats, dlog
   const int64_t wmax = d > dhead ? d : dhead;
   return ((int64_t)9 * M * d + (int64_t)3 * M * dh + (int64_t)3 * M * dhead + (int64_t)5 * M + CS_CHUNKS * wmax + 1024) * 4;
 }
 
 extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
-  VOG_CHECK_ARG(a && a->attn && a->x && a->d_mdl_outs && a->scratch && a->M > 0 && a->d > 0 && a->dh > 0 && a->dhead > 0);
-  VOG_CHECK_ARG(a->wo && a->ln1g && a->ln1b && a->w1 && a->b1 && a->w2 && a->b2 && a->ln2g && a->ln2b && a->wl && a->bl && a->wl2);
-  VOG_CHECK_ARG(a->M == a->n_vid * a->nfrm * a->nsrl * a->nppf);
-  if ((int64_t)a->scratch_bytes < vog_mul_tail_bwd_scratch_bytes(a->M, a->d, a->dh, a->dhead))
+  VOG_CHECK_ARG(a && a->attn && a->x && a->scratch && a->M > 0 && a->d > 0 && a->dh > 0);
+  VOG_CHECK_ARG(a->wo && a->ln1g && a->ln1b && a->w1 && a->b1 && a->w2 && a->b2 && a->ln2g && a->ln2b);
+  // no_head: a layer that is not followed by the score head - its output gradient d_y comes from the caller; without
+  // d_y only the forward is recomputed (y_out = the layer's output)
+  const bool head = !a->no_head;
+  const bool fwd_only = a->no_head && !a->d_y;
+  if (fwd_only) VOG_CHECK_ARG(a->y_out);
+  if (head) {
+    VOG_CHECK_ARG(a->d_mdl_outs && a->dhead > 0 && a->wl && a->bl && a->wl2);
+    VOG_CHECK_ARG(a->M == a->n_vid * a->nfrm * a->nsrl * a->nppf);
+  }
+  if ((int64_t)a->scratch_bytes < vog_mul_tail_bwd_scratch_bytes(a->M, a->d, a->dh, head ? a->dhead : 0))
     VOG_FAIL(-2, "vog_mul_tail_bwd: scratch too small");
   hipStream_t st = (hipStream_t)stream;
-  const int M = a->M, d = a->d, H1 = a->dh, HD = a->dhead;
+  const int M = a->M, d = a->d, H1 = a->dh, HD = head ? a->dhead : 0;
   float* s = (float*)a->scratch;
   auto take = [&](int64_t n) { float* r = s; s += n; return r; };
   float *t = take((int64_t)M * d), *x1 = take((int64_t)M * d), *u = take((int64_t)M * d), *y = take((int64_t)M * d);
@@ -265,20 +395,26 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
   ::vog::launch(relu_bwd_kernel, blocks(n1), dim3(256), 0, st, pre1, pre1, df, n1);                  // df = relu(pre1) (reused as f)
   VOG_TRY(gemm_f32(df, H1, 1, a->w2, 1, H1, u, d, a->b2, 0, M, d, H1, st));                          // f W2^T + b2
   ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, u, (const float*)x1, a->ln2g, a->ln2b, y, st2, M, d);   // u += x1
-  VOG_TRY(gemm_f32(y, d, 1, a->wl, 1, d, h, HD, a->bl, 1, M, HD, d, st));                            // h = relu(y Wl^T + bl)
-  // ---- score head
-  ScoreBwd sb{a->d_mdl_outs, h, a->wl2, dh, hw, dlog, M, a->nfrm, a->nppf, a->nsrl, HD};
-  ::vog::launch(score_bwd_kernel, dim3(M), dim3(256), 0, st, sb);
-  VOG_TRY(colsum(hw, a->g_wl2, part, M, HD, st));   // d lin2.2.weight
-  VOG_TRY(colsum(dlog, a->g_bl2, part, M, 1, st));                 // d lin2.2.bias
-  VOG_TRY(gemm_f32(dh, 1, HD, y, d, 1, a->g_wl, d, nullptr, 0, HD, d, M, st));                       // d lin2.0.weight = dh^T y
-  VOG_TRY(colsum(dh, a->g_bl, part, M, HD, st));
-  VOG_TRY(gemm_f32(dh, HD, 1, a->wl, d, 1, dy, d, nullptr, 0, M, d, HD, st));                        // dy = dh Wl
+  if (a->y_out) VOG_HIP(hipMemcpyAsync(a->y_out, y, (size_t)nd * 4, hipMemcpyDeviceToDevice, st));   // the layer's output
+  if (fwd_only) { VOG_LAUNCH_CHECK(); return 0; }
+  const float* dyp = a->d_y;
+  if (head) {
+    VOG_TRY(gemm_f32(y, d, 1, a->wl, 1, d, h, HD, a->bl, 1, M, HD, d, st));                          // h = relu(y Wl^T + bl)
+    // ---- score head
+    ScoreBwd sb{a->d_mdl_outs, h, a->wl2, dh, hw, dlog, M, a->nfrm, a->nppf, a->nsrl, HD};
+    ::vog::launch(score_bwd_kernel, dim3(M), dim3(256), 0, st, sb);
+    VOG_TRY(colsum(hw, a->g_wl2, part, M, HD, st));   // d lin2.2.weight
+    VOG_TRY(colsum(dlog, a->g_bl2, part, M, 1, st));                 // d lin2.2.bias
+    VOG_TRY(gemm_f32(dh, 1, HD, y, d, 1, a->g_wl, d, nullptr, 0, HD, d, M, st));                     // d lin2.0.weight = dh^T y
+    VOG_TRY(colsum(dh, a->g_bl, part, M, HD, st));
+    VOG_TRY(gemm_f32(dh, HD, 1, a->wl, d, 1, dy, d, nullptr, 0, M, d, HD, st));                      // dy = dh Wl
+    dyp = dy;
+  }
   // ---- LayerNorm 2
-  ::vog::launch(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)u,
+  ::vog::launch(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, dyp, (const float*)nullptr, (const float*)u,
                 (const float2*)st2, a->ln2g, du, tmp, (float*)nullptr, M, d);
   VOG_TRY(colsum(tmp, a->g_ln2g, part, M, d, st));
-  VOG_TRY(colsum(dy, a->g_ln2b, part, M, d, st));
+  VOG_TRY(colsum(dyp, a->g_ln2b, part, M, d, st));
   // ---- FFN
   VOG_TRY(gemm_f32(du, 1, d, df, H1, 1, a->g_w2, H1, nullptr, 0, d, H1, M, st));                     // d W2 = du^T f
   VOG_TRY(colsum(du, a->g_b2, part, M, d, st));
@@ -296,6 +432,75 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
   VOG_TRY(gemm_f32(dt, 1, d, a->attn, d, 1, a->g_wo, d, nullptr, 0, d, d, M, st));                   // d Wo = dt^T a
   if (a->d_attn) VOG_TRY(gemm_f32(dt, d, 1, a->wo, d, 1, a->d_attn, d, nullptr, 0, M, d, d, st));    // da = dt Wo
   if (a->d_x) VOG_HIP(hipMemcpyAsync(a->d_x, dt, (size_t)nd * 4, hipMemcpyDeviceToDevice, st));      // dx = dt
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- attention + Q/K/V projections of one (Rel)EncoderLayer in fp32: forward (concatenated heads) and backward ----
+extern "C" int64_t vog_attn_f32_scratch_bytes(int S, int N, int n, int d) {
+  if (S <= 0 || N <= 0 || n <= 0 || d <= 0) return -1;
+  const int64_t M = (int64_t)S * N;
+  return (6 * M * d + 2 * M * N + (int64_t)S * n * 8 + M * 8 + CS_CHUNKS * 8 + 64) * 4 + 256;
+}
+
+extern "C" int vog_attn_f32(const vog_attn_f32_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->x && a->wq && a->wk && a->wv && a->scratch && a->S > 0 && a->N > 0 && a->n > 0 && a->d > 0 && a->n_heads > 0);
+  VOG_CHECK_ARG((a->N % a->n) == 0 && a->n_heads <= a->d);
+  const bool bwd = a->d_cat != nullptr, rel = a->props != nullptr;
+  if (rel) VOG_CHECK_ARG(a->pe_w && a->pe_b && a->prop_stride >= 5 && a->vid_w > 0.f && a->vid_h > 0.f && a->nfrm_div > 0.f);
+  if (bwd) VOG_CHECK_ARG(a->g_wq && a->g_wk && a->g_wv && a->d_x && (!rel || (a->g_pe_w && a->g_pe_b)));
+  if (!bwd) VOG_CHECK_ARG(a->cat_out);
+  if ((int64_t)a->scratch_bytes < vog_attn_f32_scratch_bytes(a->S, a->N, a->n, a->d)) VOG_FAIL(-2, "vog_attn_f32: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int S = a->S, N = a->N, n = a->n, d = a->d, H = a->n_heads, M = S * N;
+  float* s = (float*)(((uintptr_t)a->scratch + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t cnt) { float* r = s; s += (cnt + 3) / 4 * 4; return r; };
+  const int64_t md = (int64_t)M * d, nn = (int64_t)N * N;
+  float *q = take(md), *k = take(md), *v = take(md), *dq = take(md), *dk = take(md), *dv = take(md);
+  float *P = take((int64_t)S * nn), *D = take((int64_t)S * nn);
+  float* bx = take((int64_t)S * n * 8);
+  float* part = take((int64_t)M * 8);
+  float* cpart = take((int64_t)CS_CHUNKS * 8);
+  float* sum8 = take(8);
+  // q, k, v = x W^T  (transformer_code.py:136-150; no bias)
+  VOG_TRY(gemm_f32(a->x, d, 1, a->wq, 1, d, q, d, nullptr, 0, M, d, d, st));
+  VOG_TRY(gemm_f32(a->x, d, 1, a->wk, 1, d, k, d, nullptr, 0, M, d, d, st));
+  VOG_TRY(gemm_f32(a->x, d, 1, a->wv, 1, d, v, d, nullptr, 0, M, d, d, st));
+  if (rel)
+    ::vog::launch(norm_boxes_kernel, dim3(ceil_div(S * n, 256)), dim3(256), 0, st, a->props, a->prop_stride, a->vid_w, a->vid_h,
+                  a->nfrm_div, bx, S * n);
+  const int chunk = (d + H - 1) / H;                       // torch.chunk split sizes (transformer_code.py:66-67)
+  const float inv_scale = 1.0f / sqrtf((float)d);          // scale = sqrt(d_model)
+  const int64_t sx = (int64_t)N * d;
+  for (int h = 0; h < H; ++h) {
+    const int off = h * chunk, dh = (d - off) < chunk ? (d - off) : chunk;
+    if (dh <= 0) VOG_FAIL(-1, "vog_attn_f32: %d heads do not split %d features", H, d);
+    // logits = Q_h K_h^T, then the softmax with the box bias
+    VOG_TRY(gemm_f32_b(q + off, d, 1, sx, k + off, 1, d, sx, P, N, nn, nullptr, 0, 0, N, N, dh, S, st));
+    AttnRow ar{P, D, rel ? bx : nullptr, rel ? a->pe_w + h * 5 : nullptr, rel ? a->pe_b + h : nullptr, bwd && rel ? part : nullptr,
+               S, N, n, inv_scale};
+    ::vog::launch(attn_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, ar);
+    if (a->cat_out)
+      VOG_TRY(gemm_f32_b(P, N, 1, nn, v + off, d, 1, sx, a->cat_out + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));   // O_h = P V_h
+    if (!bwd) continue;
+    VOG_TRY(gemm_f32_b(a->d_cat + off, d, 1, sx, v + off, 1, d, sx, D, N, nn, nullptr, 0, 0, N, N, dh, S, st));       // dP = dO_h V_h^T
+    ::vog::launch(attn_ds_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, ar);
+    VOG_TRY(gemm_f32_b(P, 1, N, nn, a->d_cat + off, d, 1, sx, dv + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));      // dV_h = P^T dO_h
+    VOG_TRY(gemm_f32_b(D, N, 1, nn, k + off, d, 1, sx, dq + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));             // dQ_h = dS K_h
+    VOG_TRY(gemm_f32_b(D, 1, N, nn, q + off, d, 1, sx, dk + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));             // dK_h = dS^T Q_h
+    if (rel) {
+      VOG_TRY(colsum(part, sum8, cpart, M, 8, st));
+      ::vog::launch(pe_grad_store_kernel, dim3(1), dim3(64), 0, st, (const float*)sum8, a->g_pe_w, a->g_pe_b, h);
+    }
+  }
+  if (bwd) {
+    VOG_TRY(gemm_f32(dq, 1, d, a->x, d, 1, a->g_wq, d, nullptr, 0, d, d, M, st));                   // d Wq = dQ^T x
+    VOG_TRY(gemm_f32(dk, 1, d, a->x, d, 1, a->g_wk, d, nullptr, 0, d, d, M, st));
+    VOG_TRY(gemm_f32(dv, 1, d, a->x, d, 1, a->g_wv, d, nullptr, 0, d, d, M, st));
+    VOG_TRY(gemm_f32(dq, d, 1, a->wq, d, 1, a->d_x, d, nullptr, 0, M, d, d, st, a->accumulate_dx ? 1 : 0));   // dx (+)= dQ Wq + dK Wk + dV Wv
+    VOG_TRY(gemm_f32(dk, d, 1, a->wk, d, 1, a->d_x, d, nullptr, 0, M, d, d, st, 1));
+    VOG_TRY(gemm_f32(dv, d, 1, a->wv, d, 1, a->d_x, d, nullptr, 0, M, d, d, st, 1));
+  }
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -190,7 +190,17 @@ class TailBwdArgs(C.Structure):
                                       "g_wo", "g_ln1g", "g_ln1b", "g_w1", "g_b1", "g_w2", "g_b2", "g_ln2g", "g_ln2b",
                                       "g_wl", "g_bl", "g_wl2", "g_bl2", "scratch")]
                 + [("scratch_bytes", C.c_size_t)]
-                + [(n, c_i32) for n in ("M", "d", "dh", "dhead", "n_vid", "nfrm", "nppf", "nsrl")])
+                + [(n, c_i32) for n in ("M", "d", "dh", "dhead", "n_vid", "nfrm", "nppf", "nsrl", "no_head")]
+                + [("d_y", c_vp), ("y_out", c_vp)])
+
+
+class AttnF32Args(C.Structure):
+    _fields_ = [("x", c_vp), ("d_cat", c_vp), ("wq", c_vp), ("wk", c_vp), ("wv", c_vp),
+                ("props", c_vp), ("prop_stride", c_i32), ("vid_w", C.c_float), ("vid_h", C.c_float), ("nfrm_div", C.c_float),
+                ("pe_w", c_vp), ("pe_b", c_vp), ("cat_out", c_vp),
+                ("g_wq", c_vp), ("g_wk", c_vp), ("g_wv", c_vp), ("g_pe_w", c_vp), ("g_pe_b", c_vp),
+                ("d_x", c_vp), ("accumulate_dx", c_i32), ("scratch", c_vp), ("scratch_bytes", C.c_size_t),
+                ("S", c_i32), ("N", c_i32), ("n", c_i32), ("d", c_i32), ("n_heads", c_i32)]
 
 
 class Batch(C.Structure):
@@ -235,6 +245,8 @@ SYMBOLS = {
     "vog_bilstm_layer_supported": (c_i32, [c_i32, c_i32]),
     "vog_mul_tail_bwd_scratch_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "vog_mul_tail_bwd": (c_i32, [C.POINTER(TailBwdArgs), c_vp]),
+    "vog_attn_f32_scratch_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "vog_attn_f32": (c_i32, [C.POINTER(AttnF32Args), c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
