@@ -552,6 +552,32 @@ typedef struct vog_attn_f32_args {
 int64_t vog_attn_f32_scratch_bytes(int S, int N, int n, int d);
 int vog_attn_f32(const vog_attn_f32_args* a, void* stream);
 
+/* Backward of concate_vis_lang_feats + the (frame, argument) regroup in front of mul_tx (code/mdl_vog.py:316-344,
+ * 681-744). d_x [(q, v, f), (arg, p), dobj + dlang] = gradient of mul_tx's input ->
+ *   d_ps   [(q, v), f*nppf + p, dobj]            summed over the arguments,
+ *   d_lang [(q, v | 1), arg, dlang] (optional)   summed over the proposals (and the videos when the argument vectors
+ *   are shared by them: lang_per_vid == 0), zero where inds_msk [(q, v | 1), arg] (int64, optional) is 0
+ *   (retrieve_srl_arg_from_lang_encode's mask, code/mdl_vog.py:138-140). Fixed summation order. */
+int vog_conc_f32_bwd(const float* d_x, float* d_ps, float* d_lang, const int64_t* inds_msk, int n_q, int nc_v, int nfrm,
+                     int nppf, int nsrl, int dobj, int dlang, int lang_per_vid, void* stream);
+
+/* Linear (+ ReLU) in fp32, forward recomputation and backward: y = act(x W^T + b), x [M, K] (row stride ldx, 0 = K),
+ * W [N, K]. dy == NULL: forward only (y required). Otherwise dy [M*rep, ldy] is the gradient of the output rows, each
+ * output row having been replicated `rep` times downstream (segment rows over the proposals of their frame,
+ * concat_prop_seg_feats code/mdl_conc_single.py:51-66; rep = 1 otherwise; ldy = 0 means N; dy may point into a wider
+ * matrix): g_w [N, K], g_b [N] (optional), d_x [M, ldx] (optional; accumulate_dx adds). The prop / segment encoders
+ * (code/mdl_vog.py:291-314), lstm_out_feat_proj and srl_arg_words_out_enc (:250-283, 97-140). */
+typedef struct vog_linear_f32_args {
+  const float* x; int64_t ldx; const float *w, *b; int relu;
+  float* y;
+  const float* dy; int64_t ldy; int rep;
+  float *g_w, *g_b, *d_x; int accumulate_dx;
+  void* scratch; size_t scratch_bytes;
+  int M, N, K;
+} vog_linear_f32_args;
+int64_t vog_linear_f32_scratch_bytes(int M, int N);
+int vog_linear_f32(const vog_linear_f32_args* a, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)
  * ------------------------------------------------------------------------- */

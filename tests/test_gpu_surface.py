@@ -465,3 +465,38 @@ def test_device_mul_layer_backward_vs_reference_autograd(name):
         worst = max(worst, check_fixture(g, "p:" + n, res[n].cpu().numpy(), tol=1e-3))
     worst = max(worst, check_fixture(g, "d_mul_in", res["_d_x"].cpu().numpy(), tol=1e-3))
     print(name, "worst relative gradient error", worst)
+
+
+@pytest.mark.parametrize("name", ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4"])
+def test_device_visual_backward_vs_reference_autograd(name):
+    """lin2 <- mul_tx <- concat / regroup <- obj_tx <- prop / segment encoders, chained on the device from the loss
+    gradient (`visual_backward`): every parameter gradient on that side (49 tensors at cfg 2) and the gradients at the
+    seams against AUTOGRAD THROUGH THE REFERENCE. Only the forward activations at three places come from the CPU
+    oracle (mul_tx input, obj_tx input, the raw features); all gradients are the device's."""
+    from tests.test_bwd_oracle import check_fixture
+    cfg, oc, sd, batch, g, st, d_outs, (B, nc_v, nsrl, NP, nfrm, nppf) = _bwd_setup(name)
+    geo = dict(B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=nsrl, nppf0=oc.nppf0, mul_layers=oc.mul_layers, mul_heads=oc.mul_heads,
+               mul_use_rel=oc.mul_use_rel, obj_layers=oc.obj_layers if (oc.mdl_name == "vgrnd" or oc.obj_to_use) else 0,
+               obj_heads=oc.obj_heads, obj_use_rel=oc.obj_use_rel, obj_one_frm=oc.obj_one_frm, vid_w=oc.vid_w, vid_h=oc.vid_h)
+    assert oc.mul_layers == 1 and geo["obj_layers"] == 1      # inner layer inputs would come from the device's own forward
+    dm = st["mul_tail_x"].shape[-1]
+    dobj = st["obj_tail_x"].shape[-1]
+    acts = {"mul_x": st["mul_tail_x"].reshape(-1, dm).contiguous().cuda(),
+            "obj_x": st["obj_tail_x"].reshape(-1, dobj).contiguous().cuda(),
+            "prop_feat": torch.from_numpy(batch["pad_region_feature"]).float().reshape(-1, batch["pad_region_feature"].shape[-1]).cuda(),
+            "seg_feat": torch.from_numpy(batch["seg_feature_for_frms"]).float().reshape(-1, batch["seg_feature_for_frms"].shape[-1]).cuda(),
+            "props": torch.from_numpy(batch["pad_proposals"]).float().reshape(-1, batch["pad_proposals"].shape[-1]).cuda(),
+            "inds_msk": torch.from_numpy(batch["srl_arg_inds_msk"]).cuda()}
+    res = bwd.visual_backward(sd_torch(sd), geo, acts, d_outs)
+    torch.cuda.synchronize()
+    worst, n_par = 0.0, 0
+    for k, v in res.items():
+        if k.startswith("_"):
+            continue
+        worst = max(worst, check_fixture(g, "p:" + k, v.cpu().numpy(), tol=1e-3))
+        n_par += 1
+    assert n_par == 12 + 4 + 2 + 12 + 2 + 4, n_par
+    worst = max(worst, check_fixture(g, "d_obj_out", res["_d_obj_out"].cpu().numpy(), tol=1e-3))
+    worst = max(worst, check_fixture(g, "d_obj_in", res["_d_prop_seg"].cpu().numpy(), tol=1e-3))
+    worst = max(worst, check_fixture(g, "d_lang_enc", res["_d_lang"].cpu().numpy(), tol=1e-3))
+    print(name, "worst relative gradient error", worst, "parameters", n_par)

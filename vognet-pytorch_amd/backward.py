@@ -235,3 +235,138 @@ def encoder_layer_backward(state_dict, stack: str, layer: int, pe_name, x: torch
         out[pe_name + ".weight"], out[pe_name + ".bias"] = b["g_pe_w"], b["g_pe_b"]
     out["_d_x"] = b["d_x"]
     return out
+
+
+def conc_backward(d_x_mul: torch.Tensor, n_q: int, nc_v: int, nfrm: int, nppf: int, nsrl: int, dobj: int,
+                  inds_msk: torch.Tensor = None, lang_per_vid: bool = False):
+    """Gradient of mul_tx's input -> (d_ps [(q, v)*NP, dobj], d_lang [(q, v|1)*nsrl, dlang]) (`vog_conc_f32_bwd`)."""
+    lib = L.load()
+    vld = d_x_mul.shape[-1]
+    dlang = vld - dobj
+    dev = d_x_mul.device
+    d_x_mul = d_x_mul.contiguous()
+    assert d_x_mul.numel() == n_q * nc_v * nfrm * nsrl * nppf * vld
+    d_ps = torch.empty(n_q * nc_v * nfrm * nppf, dobj, dtype=torch.float32, device=dev)
+    d_lang = torch.empty(n_q * (nc_v if lang_per_vid else 1) * nsrl, dlang, dtype=torch.float32, device=dev) if dlang else None
+    msk = inds_msk.to(dev, torch.int64).contiguous() if inds_msk is not None else None
+    if msk is not None:
+        assert msk.numel() == n_q * (nc_v if lang_per_vid else 1) * nsrl
+    L.check(lib.vog_conc_f32_bwd(L.ptr(d_x_mul), L.ptr(d_ps), L.ptr(d_lang), L.ptr(msk), n_q, nc_v, nfrm, nppf, nsrl, dobj,
+                                 dlang, 1 if lang_per_vid else 0, L.stream_ptr()), "vog_conc_f32_bwd")
+    return d_ps, d_lang
+
+
+def _ptr_view(t: torch.Tensor, col0: int) -> int:
+    """Pointer to column col0 of a contiguous 2-D fp32 tensor (a sub-matrix with the parent's row stride)."""
+    assert t.is_contiguous() and t.dim() == 2 and t.dtype == torch.float32
+    return t.data_ptr() + 4 * col0
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, relu: bool, dy: torch.Tensor = None, dy_col0: int = 0,
+               rep: int = 1, want_dx: bool = False, d_x: torch.Tensor = None, want_y: bool = False):
+    """y = act(x W^T + b) and, with dy, its backward (`vog_linear_f32`). dy may be a wider matrix: the gradient of
+    this layer's outputs is dy[:, dy_col0 : dy_col0 + N]; rep = downstream replication of the output rows.
+    -> dict(y?, g_w, g_b, d_x?)."""
+    lib = L.load()
+    dev = x.device
+    x = x.contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape == (N, K) and w.is_cuda and x.dtype == torch.float32
+    nb = int(lib.vog_linear_f32_scratch_bytes(M, N))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    a = L.LinearF32Args()
+    a.x, a.w, a.b, a.relu = L.ptr(x), L.ptr(w), L.ptr(b) if b is not None else None, 1 if relu else 0
+    out = {}
+    keep = [x, scratch]
+    if want_y or dy is None:
+        out["y"] = torch.empty(M, N, dtype=torch.float32, device=dev)
+        a.y = L.ptr(out["y"])
+    if dy is not None:
+        assert dy.is_contiguous() and dy.dim() == 2 and dy.shape[0] == M * rep and dy_col0 + N <= dy.shape[1]
+        keep.append(dy)
+        a.dy, a.ldy, a.rep = _ptr_view(dy, dy_col0), dy.shape[1], rep
+        out["g_w"] = torch.empty_like(w)
+        a.g_w = L.ptr(out["g_w"])
+        if b is not None:
+            out["g_b"] = torch.empty_like(b)
+            a.g_b = L.ptr(out["g_b"])
+        if want_dx or d_x is not None:
+            out["d_x"] = d_x if d_x is not None else torch.empty_like(x)
+            a.d_x, a.accumulate_dx = L.ptr(out["d_x"]), 1 if d_x is not None else 0
+    a.scratch, a.scratch_bytes = L.ptr(scratch), nb
+    a.M, a.N, a.K = M, N, K
+    L.check(lib.vog_linear_f32(C.byref(a), L.stream_ptr()), "vog_linear_f32")
+    out["_keepalive"] = keep
+    return out
+
+
+def stack_backward(state_dict, stack: str, n_layers: int, pe_name, x0: torch.Tensor, S: int, N: int, n: int, n_heads: int,
+                   boxes=None, d_y: torch.Tensor = None, head=None) -> Dict[str, torch.Tensor]:
+    """(Rel)Transformer stack (code/transformer_code.py:227-279): fp32 forward recomputation layer by layer (each
+    layer's input kept), then `encoder_layer_backward` from the last layer down. -> {parameter name: gradient,
+    '_d_x': gradient of the stack input}. The box-bias Linear is shared by the layers: its gradient is summed."""
+    xs = [x0.contiguous()]
+    for l in range(n_layers - 1):
+        y, _ = encoder_layer_forward(state_dict, stack, l, pe_name, xs[-1], S, N, n, n_heads, boxes)
+        xs.append(y)
+    grads: Dict[str, torch.Tensor] = {}
+    d = d_y
+    for l in range(n_layers - 1, -1, -1):
+        r = encoder_layer_backward(state_dict, stack, l, pe_name, xs[l], S, N, n, n_heads, boxes, d_y=d,
+                                   head=head if l == n_layers - 1 else None)
+        d = r.pop("_d_x")
+        for k, v in r.items():
+            grads[k] = grads[k] + v if k in grads else v          # (torch add on two gradient tensors: pe_* only)
+    grads["_d_x"] = d
+    return grads
+
+
+def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """The visual side of the network behind the loss gradient, on the device in fp32:
+
+        lin2 <- mul_tx <- [obj_tx output | argument vectors] <- obj_tx <- [prop_encoder | seg_encoder]
+
+    geo: B, nc_v, nfrm, nppf, nsrl, nppf0, mul_layers, mul_heads, mul_use_rel, obj_layers, obj_heads, obj_use_rel,
+    obj_one_frm, vid_w, vid_h (the model's geometry); acts: 'mul_x' [S*N, vld] (mul_tx's fp32 input), 'obj_x'
+    [B*nc_v*NP, dobj] (obj_tx's input = the concatenated encoder outputs), 'prop_feat' [B*nc_v*NP, prop_dim],
+    'seg_feat' [B*nc_v*F, seg_dim], 'props' [B*nc_v*NP, >= 5] (pad_proposals), 'inds_msk' [B, nv, nsrl].
+    -> gradients by reference parameter name + '_d_lang' (gradient of the masked argument vectors' pre-mask
+    activations, where the language side's backward attaches)."""
+    g = geo
+    B, nc_v, nfrm, nppf, nsrl = g["B"], g["nc_v"], g["nfrm"], g["nppf"], g["nsrl"]
+    NP = nfrm * nppf
+    out: Dict[str, torch.Tensor] = {}
+    props = acts["props"]
+    mb = _Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
+    r = stack_backward(state_dict, "mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", acts["mul_x"], B * nc_v * nfrm, nsrl * nppf,
+                       nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl))
+    d_mul = r.pop("_d_x")
+    out.update(r)
+    dobj = acts["obj_x"].shape[1]
+    msk = acts["inds_msk"]
+    d_ps, d_lang = conc_backward(d_mul, B, nc_v, nfrm, nppf, nsrl, dobj, inds_msk=msk, lang_per_vid=msk.shape[1] == nc_v and nc_v > 1)
+    out["_d_lang"] = d_lang
+    out["_d_obj_out"] = d_ps
+    if g["obj_layers"] > 0:
+        if g["obj_one_frm"]:
+            S, N, fdiv = B * nc_v * nfrm, nppf, float(nfrm)
+        else:
+            S, N, fdiv = B * nc_v, NP, 1.0
+        ob = _Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
+        r = stack_backward(state_dict, "obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", acts["obj_x"], S, N, N, g["obj_heads"], ob,
+                           d_y=d_ps)
+        d_ps = r.pop("_d_x")
+        out.update(r)
+    out["_d_prop_seg"] = d_ps
+    dev = d_ps.device
+    wp = state_dict["prop_encoder.0.weight"].detach().to(dev, torch.float32).contiguous()
+    bp = state_dict["prop_encoder.0.bias"].detach().to(dev, torch.float32).contiguous()
+    ws = state_dict["seg_encoder.0.weight"].detach().to(dev, torch.float32).contiguous()
+    bs = state_dict["seg_encoder.0.bias"].detach().to(dev, torch.float32).contiguous()
+    penc = wp.shape[0]
+    lp = linear_f32(acts["prop_feat"], wp, bp, True, dy=d_ps, dy_col0=0, rep=1)
+    ls = linear_f32(acts["seg_feat"], ws, bs, True, dy=d_ps, dy_col0=penc, rep=g["nppf0"])
+    out["prop_encoder.0.weight"], out["prop_encoder.0.bias"] = lp["g_w"], lp["g_b"]
+    out["seg_encoder.0.weight"], out["seg_encoder.0.bias"] = ls["g_w"], ls["g_b"]
+    return out

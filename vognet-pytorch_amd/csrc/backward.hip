@@ -344,6 +344,57 @@ __global__ void pe_grad_store_kernel(const float* sum8, float* g_w, float* g_b, 
   if (threadIdx.x == 5) g_b[h] = sum8[5];
 }
 
+// ---- seam between mul_tx's input and (obj_tx output, argument vectors): the backward of concate_vis_lang_feats +
+// the (frame, argument) regroup (code/mdl_vog.py:316-344, 681-744). d_x rows ((bv, f), (arg, p)) x [dobj | dlang].
+//   d_ps[(bv, f*nppf + p), c]  = sum_arg d_x[.., c]                         (every argument saw the same visual row)
+//   d_lang[(b, v | 0, arg), c] = mask * sum_{(v,) f, p} d_x[.., dobj + c]   (every proposal saw the same argument vector)
+struct ConcBwd { const float* dx; float* d_ps; float* d_lang; const int64_t* mask; int n_q, nc_v, nfrm, nppf, nsrl, dobj, dlang, lang_per_vid; };
+__global__ void conc_bwd_ps_kernel(ConcBwd a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.n_q * a.nc_v * a.nfrm * a.nppf * a.dobj;
+  if (i >= total) return;
+  const int c = (int)(i % a.dobj);
+  const int64_t r = i / a.dobj;                              // (bv, f, p)
+  const int pp = (int)(r % a.nppf);
+  const int64_t sf = r / a.nppf;                             // sequence (bv, f)
+  const int vld = a.dobj + a.dlang;
+  float s = 0.f;
+  for (int ar = 0; ar < a.nsrl; ++ar) s += a.dx[((sf * a.nsrl + ar) * a.nppf + pp) * vld + c];
+  a.d_ps[i] = s;
+}
+__global__ void conc_bwd_lang_kernel(ConcBwd a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nvl = a.lang_per_vid ? a.nc_v : 1;
+  const int64_t total = (int64_t)a.n_q * nvl * a.nsrl * a.dlang;
+  if (i >= total) return;
+  const int c = (int)(i % a.dlang);
+  const int64_t r = i / a.dlang;
+  const int ar = (int)(r % a.nsrl);
+  const int64_t bv = r / a.nsrl;                             // (b, v) or b
+  const int vld = a.dobj + a.dlang;
+  float s = 0.f;
+  const int v0 = a.lang_per_vid ? 0 : 0, v1 = a.lang_per_vid ? 1 : a.nc_v;
+  for (int v = v0; v < v1; ++v) {
+    const int64_t q = a.lang_per_vid ? bv : bv * a.nc_v + v;
+    for (int f = 0; f < a.nfrm; ++f)
+      for (int pp = 0; pp < a.nppf; ++pp)
+        s += a.dx[(((q * a.nfrm + f) * a.nsrl + ar) * a.nppf + pp) * vld + a.dobj + c];
+  }
+  a.d_lang[i] = a.mask && a.mask[r] == 0 ? 0.f : s;
+}
+
+// ---- Linear (+ ReLU): y = act(x W^T + b), rows optionally replicated downstream (segment rows: concat_prop_seg_feats)
+// dpre[m, n] = [y > 0] * sum_{j < rep} dy[(m*rep + j) * ldy + n]
+__global__ void lin_dpre_kernel(const float* dy, int64_t ldy, int rep, const float* y, int relu, float* dpre, int M, int N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  const int n = (int)(i % N);
+  const int64_t m = i / N;
+  float s = 0.f;
+  for (int j = 0; j < rep; ++j) s += dy[(m * rep + j) * ldy + n];
+  dpre[i] = (!relu || y[i] > 0.f) ? s : 0.f;
+}
+
 __global__ void add_kernel(const float* a, const float* b, float* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
@@ -501,6 +552,47 @@ extern "C" int vog_attn_f32(const vog_attn_f32_args* a, void* stream) {
     VOG_TRY(gemm_f32(dk, d, 1, a->wk, d, 1, a->d_x, d, nullptr, 0, M, d, d, st, 1));
     VOG_TRY(gemm_f32(dv, d, 1, a->wv, d, 1, a->d_x, d, nullptr, 0, M, d, d, st, 1));
   }
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_conc_f32_bwd(const float* d_x, float* d_ps, float* d_lang, const int64_t* inds_msk, int n_q, int nc_v, int nfrm,
+                                int nppf, int nsrl, int dobj, int dlang, int lang_per_vid, void* stream) {
+  VOG_CHECK_ARG(d_x && d_ps && n_q > 0 && nc_v > 0 && nfrm > 0 && nppf > 0 && nsrl > 0 && dobj > 0 && dlang >= 0);
+  ConcBwd a{d_x, d_ps, d_lang, inds_msk, n_q, nc_v, nfrm, nppf, nsrl, dobj, dlang, lang_per_vid};
+  const int64_t t1 = (int64_t)n_q * nc_v * nfrm * nppf * dobj;
+  ::vog::launch(conc_bwd_ps_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (d_lang && dlang > 0) {
+    const int64_t t2 = (int64_t)n_q * (lang_per_vid ? nc_v : 1) * nsrl * dlang;
+    ::vog::launch(conc_bwd_lang_kernel, dim3((unsigned)((t2 + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  }
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t vog_linear_f32_scratch_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return -1;
+  return ((int64_t)2 * M * N + (int64_t)CS_CHUNKS * N + 64) * 4;
+}
+
+extern "C" int vog_linear_f32(const vog_linear_f32_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->x && a->w && a->M > 0 && a->N > 0 && a->K > 0 && a->scratch);
+  if ((int64_t)a->scratch_bytes < vog_linear_f32_scratch_bytes(a->M, a->N)) VOG_FAIL(-2, "vog_linear_f32: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = a->M, N = a->N, K = a->K;
+  float* y = a->y ? a->y : (float*)a->scratch;
+  float* dpre = (float*)a->scratch + (int64_t)M * N;
+  float* part = dpre + (int64_t)M * N;
+  const int64_t ldx = a->ldx > 0 ? a->ldx : K;
+  VOG_TRY(gemm_f32(a->x, ldx, 1, a->w, 1, K, y, N, a->b, a->relu, M, N, K, st));                     // y = act(x W^T + b)
+  if (!a->dy) { VOG_LAUNCH_CHECK(); return 0; }
+  VOG_CHECK_ARG(a->g_w && a->rep >= 1);
+  const int64_t ldy = a->ldy > 0 ? a->ldy : N;
+  ::vog::launch(lin_dpre_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, a->dy, ldy, a->rep,
+                (const float*)y, a->relu, dpre, M, N);
+  VOG_TRY(gemm_f32(dpre, 1, N, a->x, ldx, 1, a->g_w, K, nullptr, 0, N, K, M, st));                   // d W = dpre^T x
+  if (a->g_b) VOG_TRY(colsum(dpre, a->g_b, part, M, N, st));
+  if (a->d_x) VOG_TRY(gemm_f32(dpre, N, 1, a->w, K, 1, a->d_x, a->ldx > 0 ? a->ldx : K, nullptr, 0, M, K, N, st, a->accumulate_dx ? 1 : 0));
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -194,6 +194,13 @@ class TailBwdArgs(C.Structure):
                 + [("d_y", c_vp), ("y_out", c_vp)])
 
 
+class LinearF32Args(C.Structure):
+    _fields_ = [("x", c_vp), ("ldx", c_i64), ("w", c_vp), ("b", c_vp), ("relu", c_i32), ("y", c_vp),
+                ("dy", c_vp), ("ldy", c_i64), ("rep", c_i32), ("g_w", c_vp), ("g_b", c_vp), ("d_x", c_vp),
+                ("accumulate_dx", c_i32), ("scratch", c_vp), ("scratch_bytes", C.c_size_t),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32)]
+
+
 class AttnF32Args(C.Structure):
     _fields_ = [("x", c_vp), ("d_cat", c_vp), ("wq", c_vp), ("wk", c_vp), ("wv", c_vp),
                 ("props", c_vp), ("prop_stride", c_i32), ("vid_w", C.c_float), ("vid_h", C.c_float), ("nfrm_div", C.c_float),
@@ -247,6 +254,9 @@ SYMBOLS = {
     "vog_mul_tail_bwd": (c_i32, [C.POINTER(TailBwdArgs), c_vp]),
     "vog_attn_f32_scratch_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "vog_attn_f32": (c_i32, [C.POINTER(AttnF32Args), c_vp]),
+    "vog_conc_f32_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 8 + [c_vp]),
+    "vog_linear_f32_scratch_bytes": (c_i64, [c_i32, c_i32]),
+    "vog_linear_f32": (c_i32, [C.POINTER(LinearF32Args), c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
