@@ -578,6 +578,33 @@ typedef struct vog_linear_f32_args {
 int64_t vog_linear_f32_scratch_bytes(int M, int N);
 int vog_linear_f32(const vog_linear_f32_args* a, void* stream);
 
+/* Language side in fp32, forward recomputation and backward: token re-index (get_srl_arg_seq_to_sent_seq
+ * code/mdl_vog.py:67-95) -> embedding -> packed multi-layer BiLSTM (LSTMEncoder utils/mdl_srl_utils.py:114-169) ->
+ * lstm_out_feat_proj on every step (code/mdl_vog.py:250-283) -> argument vectors relu(W [h(start) | h(end)] + b)
+ * (retrieve_srl_arg_from_lang_encode :97-140, before the argument mask).
+ *   words_ind [Bn, words_len], word_mask [Bn, mask_len], lens [Bn], capture [Bn, nsrl, 2]: int64, device, as vog_batch;
+ *   T = longest sentence of the batch; emb [vocab_size + 1, E]; w_ih[l][dir] [4R, E | 2R], w_hh [4R, R], b_* [4R]
+ *   (dir 0 = forward, 1 = reverse; gate order i, f, g, o); w_proj [D, 2R]; w_arg [L, 2D].
+ *   d_lang_enc == NULL: forward only (lang_enc_out [Bn*nsrl, L] and / or full_out [Bn*T, D]).
+ *   Otherwise d_lang_enc [Bn*nsrl, L] = gradient of the argument vectors (already masked) and every g_* is written:
+ *   back-propagation through time with packed-sequence semantics (a sentence's state is frozen past its length, its
+ *   outputs there are zero). The projection of final_hidden feeds only the sep head and gets no gradient here. */
+typedef struct vog_lang_f32_args {
+  const int64_t *words_ind, *word_mask, *lens, *capture;
+  int Bn, nsrl, words_len, mask_len, T, vocab_size, E, R, layers, D, L;
+  const float* emb;
+  const float* w_ih[4][2]; const float* w_hh[4][2]; const float* b_ih[4][2]; const float* b_hh[4][2];
+  const float *w_proj, *b_proj, *w_arg, *b_arg;
+  const float* d_lang_enc;
+  float *lang_enc_out, *full_out;
+  float* g_emb;
+  float* g_w_ih[4][2]; float* g_w_hh[4][2]; float* g_b_ih[4][2]; float* g_b_hh[4][2];
+  float *g_w_proj, *g_b_proj, *g_w_arg, *g_b_arg;
+  void* scratch; size_t scratch_bytes;
+} vog_lang_f32_args;
+int64_t vog_lang_f32_scratch_bytes(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L);
+int vog_lang_f32(const vog_lang_f32_args* a, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)
  * ------------------------------------------------------------------------- */

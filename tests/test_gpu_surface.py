@@ -500,3 +500,45 @@ def test_device_visual_backward_vs_reference_autograd(name):
     worst = max(worst, check_fixture(g, "d_obj_in", res["_d_prop_seg"].cpu().numpy(), tol=1e-3))
     worst = max(worst, check_fixture(g, "d_lang_enc", res["_d_lang"].cpu().numpy(), tol=1e-3))
     print(name, "worst relative gradient error", worst, "parameters", n_par)
+
+
+@pytest.mark.parametrize("name", ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4"])
+def test_device_full_backward_vs_reference_autograd(name):
+    """The whole network behind the loss on the device in fp32: `visual_backward` (lin2, mul_tx, obj_tx, encoders) and,
+    from its gradient of the argument vectors, `language_backward` (srl_arg_words_out_enc, lstm_out_feat_proj, the
+    packed 2-layer BiLSTM through time, the embedding): EVERY parameter the reference's loss.backward() reaches
+    (59 tensors at cfg 2) against autograd through the reference model + loss. The language side recomputes its own
+    forward on the device (checked against the oracle's argument vectors)."""
+    from tests.test_bwd_oracle import check_fixture
+    cfg, oc, sd, batch, g, st, d_outs, (B, nc_v, nsrl, NP, nfrm, nppf) = _bwd_setup(name)
+    geo = dict(B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=nsrl, nppf0=oc.nppf0, mul_layers=oc.mul_layers, mul_heads=oc.mul_heads,
+               mul_use_rel=oc.mul_use_rel, obj_layers=oc.obj_layers if (oc.mdl_name == "vgrnd" or oc.obj_to_use) else 0,
+               obj_heads=oc.obj_heads, obj_use_rel=oc.obj_use_rel, obj_one_frm=oc.obj_one_frm, vid_w=oc.vid_w, vid_h=oc.vid_h)
+    dm, dobj = st["mul_tail_x"].shape[-1], st["obj_tail_x"].shape[-1]
+    acts = {"mul_x": st["mul_tail_x"].reshape(-1, dm).contiguous().cuda(),
+            "obj_x": st["obj_tail_x"].reshape(-1, dobj).contiguous().cuda(),
+            "prop_feat": torch.from_numpy(batch["pad_region_feature"]).float().reshape(-1, batch["pad_region_feature"].shape[-1]).cuda(),
+            "seg_feat": torch.from_numpy(batch["seg_feature_for_frms"]).float().reshape(-1, batch["seg_feature_for_frms"].shape[-1]).cuda(),
+            "props": torch.from_numpy(batch["pad_proposals"]).float().reshape(-1, batch["pad_proposals"].shape[-1]).cuda(),
+            "inds_msk": torch.from_numpy(batch["srl_arg_inds_msk"]).cuda()}
+    sdt = sd_torch(sd)
+    res = bwd.visual_backward(sdt, geo, acts, d_outs)
+    dev_batch = {k: torch.from_numpy(batch[k]).cuda() for k in ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len",
+                                                                 "srl_arg_words_capture")}
+    T = int(batch["srl_arg_word_mask_len"].max())
+    lg = bwd.language_backward(sdt, dev_batch, T, oc.rnn_layers, d_lang_enc=res["_d_lang"])
+    torch.cuda.synchronize()
+    # the language side's own forward: argument vectors before the mask
+    ref_le = st["lang_enc"].reshape(-1, st["lang_enc"].shape[-1])
+    assert float((lg["_lang_enc"].cpu() - ref_le).abs().max()) <= 1e-4 * float(ref_le.abs().max())
+    res.update(lg)
+    worst, n_par = 0.0, 0
+    have = {k[2:-len("__shape")] for k in g.files if k.startswith("p:") and k.endswith("__shape")}
+    for k, v in res.items():
+        if k.startswith("_"):
+            continue
+        worst = max(worst, check_fixture(g, "p:" + k, v.cpu().numpy(), tol=1e-3))
+        n_par += 1
+    missing = have - {k for k in res if not k.startswith("_")}
+    assert not missing, missing
+    print(name, "worst relative gradient error", worst, "parameters", n_par)

@@ -370,3 +370,65 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
     out["prop_encoder.0.weight"], out["prop_encoder.0.bias"] = lp["g_w"], lp["g_b"]
     out["seg_encoder.0.weight"], out["seg_encoder.0.bias"] = ls["g_w"], ls["g_b"]
     return out
+
+
+def lang_param_names(layers: int) -> Dict[str, str]:
+    n = {"emb": "lstm_encoder.embed_tokens.weight", "w_proj": "lstm_out_feat_proj.0.weight", "b_proj": "lstm_out_feat_proj.0.bias",
+         "w_arg": "srl_arg_words_out_enc.0.weight", "b_arg": "srl_arg_words_out_enc.0.bias"}
+    for l in range(layers):
+        for dr, sfx in enumerate(("", "_reverse")):
+            for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                n[f"{k}:{l}:{dr}"] = f"lstm_encoder.lstm.{k}_l{l}{sfx}"
+    return n
+
+
+def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+    """The language side on the device in fp32 (`vog_lang_f32`): embedding, packed BiLSTM (back-propagation through
+    time), lstm_out_feat_proj, srl_arg_words_out_enc. batch: the model's input dict (device int64 tensors
+    srl_arg_words_ind [B, nv, nsrl, sl], srl_arg_word_mask [B, nv, ml], srl_arg_word_mask_len [B, nv],
+    srl_arg_words_capture [B, nv, nsrl, 2]). d_lang_enc [B*nv*nsrl, L] (`visual_backward`'s '_d_lang') or None for
+    the forward only. -> {parameter name: gradient} (+ '_lang_enc', '_full' forward activations)."""
+    lib = L.load()
+    words = batch["srl_arg_words_ind"]
+    dev = words.device
+    B, nv, nsrl, sl = words.shape
+    Bn = B * nv
+    names = lang_param_names(layers)
+    w = {k: state_dict[n].detach().to(dev, torch.float32).contiguous() for k, n in names.items()}
+    E, R = w["emb"].shape[1], w["weight_hh:0:0"].shape[1]
+    D, Lo = w["w_proj"].shape[0], w["w_arg"].shape[0]
+    a = L.LangF32Args()
+    ints = [words.reshape(Bn, nsrl * sl).to(torch.int64).contiguous(),
+            batch["srl_arg_word_mask"].reshape(Bn, -1).to(torch.int64).contiguous(),
+            batch["srl_arg_word_mask_len"].reshape(Bn).to(torch.int64).contiguous(),
+            batch["srl_arg_words_capture"].reshape(Bn, nsrl, 2).to(torch.int64).contiguous()]
+    a.words_ind, a.word_mask, a.lens, a.capture = (L.ptr(t) for t in ints)
+    a.Bn, a.nsrl, a.words_len, a.mask_len, a.T = Bn, nsrl, nsrl * sl, ints[1].shape[1], T
+    a.vocab_size, a.E, a.R, a.layers, a.D, a.L = w["emb"].shape[0] - 1, E, R, layers, D, Lo
+    a.emb = L.ptr(w["emb"])
+    for l in range(layers):
+        for dr in range(2):
+            a.w_ih[l][dr], a.w_hh[l][dr] = L.ptr(w[f"weight_ih:{l}:{dr}"]), L.ptr(w[f"weight_hh:{l}:{dr}"])
+            a.b_ih[l][dr], a.b_hh[l][dr] = L.ptr(w[f"bias_ih:{l}:{dr}"]), L.ptr(w[f"bias_hh:{l}:{dr}"])
+    a.w_proj, a.b_proj, a.w_arg, a.b_arg = L.ptr(w["w_proj"]), L.ptr(w["b_proj"]), L.ptr(w["w_arg"]), L.ptr(w["b_arg"])
+    out = {"_lang_enc": torch.empty(Bn * nsrl, Lo, dtype=torch.float32, device=dev),
+           "_full": torch.empty(Bn * T, D, dtype=torch.float32, device=dev)}
+    a.lang_enc_out, a.full_out = L.ptr(out["_lang_enc"]), L.ptr(out["_full"])
+    g = {}
+    if d_lang_enc is not None:
+        d_lang_enc = d_lang_enc.to(torch.float32).contiguous()
+        assert d_lang_enc.shape == (Bn * nsrl, Lo)
+        a.d_lang_enc = L.ptr(d_lang_enc)
+        g = {k: torch.empty_like(v) for k, v in w.items()}
+        a.g_emb, a.g_w_proj, a.g_b_proj, a.g_w_arg, a.g_b_arg = (L.ptr(g[k]) for k in ("emb", "w_proj", "b_proj", "w_arg", "b_arg"))
+        for l in range(layers):
+            for dr in range(2):
+                a.g_w_ih[l][dr], a.g_w_hh[l][dr] = L.ptr(g[f"weight_ih:{l}:{dr}"]), L.ptr(g[f"weight_hh:{l}:{dr}"])
+                a.g_b_ih[l][dr], a.g_b_hh[l][dr] = L.ptr(g[f"bias_ih:{l}:{dr}"]), L.ptr(g[f"bias_hh:{l}:{dr}"])
+    nb = int(lib.vog_lang_f32_scratch_bytes(Bn, T, nsrl, E, R, layers, D, Lo))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    a.scratch, a.scratch_bytes = L.ptr(scratch), nb
+    L.check(lib.vog_lang_f32(C.byref(a), L.stream_ptr()), "vog_lang_f32")
+    out.update({names[k]: v for k, v in g.items()})
+    out["_keepalive"] = [ints, w, scratch, d_lang_enc]
+    return out

@@ -596,3 +596,270 @@ extern "C" int vog_linear_f32(const vog_linear_f32_args* a, void* stream) {
   VOG_LAUNCH_CHECK();
   return 0;
 }
+
+// =====================================================================================================================
+// Language side in fp32: token re-index -> embedding -> packed multi-layer BiLSTM -> lstm_out_feat_proj -> argument
+// vectors (code/mdl_vog.py:67-140, 250-283; utils/mdl_srl_utils.py:114-169), forward recomputation and backward
+// (back-propagation through time with packed-sequence semantics: a sentence's state is frozen past its length).
+// =====================================================================================================================
+namespace vog {
+
+__global__ void lang_tokens_kernel(const int64_t* words, const int64_t* mask, int64_t* tok, int Bn, int T, int wlen, int mlen, int V) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bn * T) return;
+  const int bn = i / T, t = i % T;
+  const int64_t m = mask[(int64_t)bn * mlen + t];
+  tok[i] = m >= 0 ? words[(int64_t)bn * wlen + m] : V;
+}
+__global__ void embed_gather_kernel(const float* emb, const int64_t* tok, float* x, int rows, int E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * E) return;
+  x[i] = emb[tok[i / E] * E + i % E];
+}
+// g_emb[v, c] = sum over the token positions holding v (fixed order)
+__global__ void embed_scatter_kernel(const float* dx, const int64_t* tok, float* g, int rows, int E, int nv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nv * E) return;
+  const int64_t v = i / E; const int c = (int)(i % E);
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) if (tok[r] == v) s += dx[(int64_t)r * E + c];
+  g[i] = s;
+}
+__global__ void vec_add_kernel(const float* a, const float* b, float* o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+__global__ void argvec_gather_kernel(const float* full, const int64_t* cap, float* enc, int Bn, int nsrl, int T, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Bn * nsrl * 2 * D) return;
+  const int c = (int)(i % (2 * D));
+  const int64_t r = i / (2 * D);
+  const int64_t bn = r / nsrl;
+  const int64_t t = cap[r * 2 + (c >= D ? 1 : 0)];
+  enc[i] = full[(bn * T + t) * D + (c >= D ? c - D : c)];
+}
+__global__ void argvec_scatter_kernel(const float* denc, const int64_t* cap, float* dfull, int Bn, int nsrl, int T, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Bn * T * D) return;
+  const int c = (int)(i % D);
+  const int64_t r = i / D;
+  const int64_t bn = r / T; const int t = (int)(r % T);
+  float s = 0.f;
+  for (int a = 0; a < nsrl; ++a) {
+    const int64_t q = bn * nsrl + a;
+    if (cap[q * 2] == t) s += denc[q * 2 * D + c];
+    if (cap[q * 2 + 1] == t) s += denc[q * 2 * D + D + c];
+  }
+  dfull[i] = s;
+}
+
+struct LstmStep {
+  const float* gpre;      // [Bn, 4R] h_{s-1} W_hh^T
+  const float* xg;        // [Bn*T, 4R] x W_ih^T + b_ih + b_hh
+  const int64_t* lens;
+  float* gates;           // [T, Bn, 4R] activated (i, f, g, o)
+  float* c;               // [T+1, Bn, R] slot s+1 = state after step s, slot 0 = 0
+  float* h;               // [T+1, Bn, R]
+  float* out;             // [Bn, T, 2R]
+  int Bn, T, R, s, reverse;
+  // backward
+  const float* d_out;     // [Bn, T, 2R]
+  const float* dh_cur; float* dh_nxt; float* dc;   // [Bn, R]
+  float* dGs;             // [T, Bn, 4R] by step
+  float* dGp;             // [Bn, T, 4R] by position (zero where a sentence has ended)
+};
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void lstm_cell_fwd_kernel(LstmStep a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.Bn * a.R) return;
+  const int bn = i / a.R, r = i % a.R, R = a.R;
+  const int len = (int)a.lens[bn];
+  const bool active = a.s < len;
+  const int pos = a.reverse ? (len - 1 - a.s > 0 ? len - 1 - a.s : 0) : a.s;
+  const int64_t st = ((int64_t)a.s * a.Bn + bn), st1 = ((int64_t)(a.s + 1) * a.Bn + bn);
+  float* gt = a.gates + st * 4 * R;
+  if (!active) {
+    a.c[st1 * R + r] = a.c[st * R + r];
+    a.h[st1 * R + r] = a.h[st * R + r];
+    gt[r] = gt[R + r] = gt[2 * R + r] = gt[3 * R + r] = 0.f;
+    return;
+  }
+  const float* gp = a.gpre + (int64_t)bn * 4 * R;
+  const float* xg = a.xg + ((int64_t)bn * a.T + pos) * 4 * R;
+  const float gi = sigm(gp[r] + xg[r]), gf = sigm(gp[R + r] + xg[R + r]);
+  const float gg = tanhf(gp[2 * R + r] + xg[2 * R + r]), go = sigm(gp[3 * R + r] + xg[3 * R + r]);
+  const float cn = gf * a.c[st * R + r] + gi * gg;
+  const float hn = go * tanhf(cn);
+  gt[r] = gi; gt[R + r] = gf; gt[2 * R + r] = gg; gt[3 * R + r] = go;
+  a.c[st1 * R + r] = cn;
+  a.h[st1 * R + r] = hn;
+  a.out[((int64_t)bn * a.T + pos) * 2 * R + (a.reverse ? R : 0) + r] = hn;
+}
+
+__global__ void lstm_cell_bwd_kernel(LstmStep a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.Bn * a.R) return;
+  const int bn = i / a.R, r = i % a.R, R = a.R;
+  const int len = (int)a.lens[bn];
+  const bool active = a.s < len;
+  const int pos = a.reverse ? (len - 1 - a.s > 0 ? len - 1 - a.s : 0) : a.s;
+  const int64_t st = ((int64_t)a.s * a.Bn + bn), st1 = ((int64_t)(a.s + 1) * a.Bn + bn);
+  float* gs = a.dGs + st * 4 * R;
+  if (!active) {
+    a.dh_nxt[i] = a.dh_cur[i];                       // frozen state: the gradient passes through
+    gs[r] = gs[R + r] = gs[2 * R + r] = gs[3 * R + r] = 0.f;
+    return;
+  }
+  const float* gt = a.gates + st * 4 * R;
+  const float gi = gt[r], gf = gt[R + r], gg = gt[2 * R + r], go = gt[3 * R + r];
+  const float tc = tanhf(a.c[st1 * R + r]);
+  const float dh = a.d_out[((int64_t)bn * a.T + pos) * 2 * R + (a.reverse ? R : 0) + r] + a.dh_cur[i];
+  const float dc = a.dc[i] + dh * go * (1.f - tc * tc);
+  const float d_i = dc * gg * gi * (1.f - gi), d_f = dc * a.c[st * R + r] * gf * (1.f - gf);
+  const float d_g = dc * gi * (1.f - gg * gg), d_o = dh * tc * go * (1.f - go);
+  a.dc[i] = dc * gf;
+  a.dh_nxt[i] = 0.f;                                 // + dGs W_hh (accumulating GEMM behind this kernel)
+  gs[r] = d_i; gs[R + r] = d_f; gs[2 * R + r] = d_g; gs[3 * R + r] = d_o;
+  float* gp = a.dGp + ((int64_t)bn * a.T + pos) * 4 * R;
+  gp[r] = d_i; gp[R + r] = d_f; gp[2 * R + r] = d_g; gp[3 * R + r] = d_o;
+}
+
+}  // namespace vog
+
+static int64_t lang_scratch_floats(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L) {
+  const int64_t BT = (int64_t)Bn * T;
+  const int64_t kin_max = E > 2 * R ? E : 2 * R;
+  int64_t n = 0;
+  n += BT * 2 + 16;                                    // tokens (int64)
+  n += BT * E;                                         // x0
+  n += (int64_t)layers * BT * 2 * R;                   // layer outputs
+  n += (int64_t)layers * 2 * (BT * 4 * R               // xg
+                              + BT * 4 * R             // gates
+                              + 2 * (int64_t)(T + 1) * Bn * R);   // c, h
+  n += (int64_t)Bn * 4 * R;                            // gpre
+  n += 2 * BT * 4 * R;                                 // dGs, dGp
+  n += 3 * (int64_t)Bn * R;                            // dh x2, dc
+  n += 4 * (int64_t)R;                                 // bias sum
+  n += 2 * BT * kin_max;                               // d_x of a layer (two buffers: current layer's d_out / next)
+  n += BT * D * 2;                                     // full, d_full
+  n += (int64_t)Bn * nsrl * (2 * D) * 2;               // enc, d_enc
+  n += (int64_t)Bn * nsrl * L * 2 + (int64_t)CS_CHUNKS * (4 * R > L ? 4 * R : L);
+  n += BT * D * 2 + BT * 2 * R;                        // linear scratch (y, dpre) for the projection
+  return n + 4096;
+}
+
+extern "C" int64_t vog_lang_f32_scratch_bytes(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L) {
+  if (Bn <= 0 || T <= 0 || nsrl <= 0 || E <= 0 || R <= 0 || layers <= 0 || layers > 4 || D <= 0 || L <= 0) return -1;
+  return lang_scratch_floats(Bn, T, nsrl, E, R, layers, D, L) * 4;
+}
+
+extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
+  VOG_CHECK_ARG(a && a->words_ind && a->word_mask && a->lens && a->capture && a->emb && a->w_proj && a->b_proj && a->w_arg && a->b_arg);
+  VOG_CHECK_ARG(a->Bn > 0 && a->T > 0 && a->nsrl > 0 && a->E > 0 && a->R > 0 && a->layers > 0 && a->layers <= 4 && a->D > 0 && a->L > 0);
+  VOG_CHECK_ARG(a->T <= a->mask_len && a->scratch);
+  if ((int64_t)a->scratch_bytes < vog_lang_f32_scratch_bytes(a->Bn, a->T, a->nsrl, a->E, a->R, a->layers, a->D, a->L))
+    VOG_FAIL(-2, "vog_lang_f32: scratch too small");
+  for (int l = 0; l < a->layers; ++l)
+    for (int dr = 0; dr < 2; ++dr) VOG_CHECK_ARG(a->w_ih[l][dr] && a->w_hh[l][dr] && a->b_ih[l][dr] && a->b_hh[l][dr]);
+  const bool bwd = a->d_lang_enc != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int Bn = a->Bn, T = a->T, nsrl = a->nsrl, E = a->E, R = a->R, NL = a->layers, D = a->D, L = a->L;
+  const int BT = Bn * T, G = 4 * R;
+  float* s = (float*)(((uintptr_t)a->scratch + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t cnt) { float* r = s; s += (cnt + 63) / 64 * 64; return r; };
+  auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  int64_t* tok = (int64_t*)take((int64_t)BT * 2 + 16);
+  float* x0 = take((int64_t)BT * E);
+  float* lout[4]; float *xg[4][2], *gates[4][2], *cst[4][2], *hst[4][2];
+  for (int l = 0; l < NL; ++l) {
+    lout[l] = take((int64_t)BT * 2 * R);
+    for (int dr = 0; dr < 2; ++dr) {
+      xg[l][dr] = take((int64_t)BT * G); gates[l][dr] = take((int64_t)BT * G);
+      cst[l][dr] = take((int64_t)(T + 1) * Bn * R); hst[l][dr] = take((int64_t)(T + 1) * Bn * R);
+    }
+  }
+  float* gpre = take((int64_t)Bn * G);
+  float *dGs = take((int64_t)BT * G), *dGp = take((int64_t)BT * G);
+  float *dh0 = take((int64_t)Bn * R), *dh1 = take((int64_t)Bn * R), *dc = take((int64_t)Bn * R);
+  float* bsum = take(G);
+  const int kin_max = E > 2 * R ? E : 2 * R;
+  float *dxa = take((int64_t)BT * kin_max), *dxb = take((int64_t)BT * kin_max);
+  float *full = take((int64_t)BT * D), *dfull = take((int64_t)BT * D);
+  float *enc = take((int64_t)Bn * nsrl * 2 * D), *denc = take((int64_t)Bn * nsrl * 2 * D);
+  float *lenc = take((int64_t)Bn * nsrl * L), *dpre = take((int64_t)Bn * nsrl * L);
+  float* part = take((int64_t)CS_CHUNKS * (G > L ? G : L));
+  float* dpre2 = take((int64_t)BT * D);
+  // ---- forward recomputation
+  ::vog::launch(lang_tokens_kernel, blocks(BT), dim3(256), 0, st, a->words_ind, a->word_mask, tok, Bn, T, a->words_len, a->mask_len,
+                a->vocab_size);
+  ::vog::launch(embed_gather_kernel, blocks((int64_t)BT * E), dim3(256), 0, st, a->emb, (const int64_t*)tok, x0, BT, E);
+  for (int l = 0; l < NL; ++l) {
+    const float* xin = l == 0 ? x0 : lout[l - 1];
+    const int K = l == 0 ? E : 2 * R;
+    VOG_HIP(hipMemsetAsync(lout[l], 0, (size_t)BT * 2 * R * 4, st));             // zero past each sentence's length
+    for (int dr = 0; dr < 2; ++dr) {
+      ::vog::launch(vec_add_kernel, blocks(G), dim3(256), 0, st, a->b_ih[l][dr], a->b_hh[l][dr], bsum, G);
+      VOG_TRY(gemm_f32(xin, K, 1, a->w_ih[l][dr], 1, K, xg[l][dr], G, bsum, 0, BT, G, K, st));
+      VOG_HIP(hipMemsetAsync(cst[l][dr], 0, (size_t)Bn * R * 4, st));
+      VOG_HIP(hipMemsetAsync(hst[l][dr], 0, (size_t)Bn * R * 4, st));
+      for (int t = 0; t < T; ++t) {
+        VOG_TRY(gemm_f32(hst[l][dr] + (int64_t)t * Bn * R, R, 1, a->w_hh[l][dr], 1, R, gpre, G, nullptr, 0, Bn, G, R, st));
+        LstmStep ls{}; ls.gpre = gpre; ls.xg = xg[l][dr]; ls.lens = a->lens; ls.gates = gates[l][dr]; ls.c = cst[l][dr];
+        ls.h = hst[l][dr]; ls.out = lout[l]; ls.Bn = Bn; ls.T = T; ls.R = R; ls.s = t; ls.reverse = dr;
+        ::vog::launch(lstm_cell_fwd_kernel, blocks((int64_t)Bn * R), dim3(256), 0, st, ls);
+      }
+    }
+  }
+  VOG_TRY(gemm_f32(lout[NL - 1], 2 * R, 1, a->w_proj, 1, 2 * R, full, D, a->b_proj, 1, BT, D, 2 * R, st));   // relu(x W^T + b), every step
+  ::vog::launch(argvec_gather_kernel, blocks((int64_t)Bn * nsrl * 2 * D), dim3(256), 0, st, (const float*)full, a->capture, enc, Bn,
+                nsrl, T, D);
+  VOG_TRY(gemm_f32(enc, 2 * D, 1, a->w_arg, 1, 2 * D, lenc, L, a->b_arg, 1, Bn * nsrl, L, 2 * D, st));
+  if (a->lang_enc_out) VOG_HIP(hipMemcpyAsync(a->lang_enc_out, lenc, (size_t)Bn * nsrl * L * 4, hipMemcpyDeviceToDevice, st));
+  if (a->full_out) VOG_HIP(hipMemcpyAsync(a->full_out, full, (size_t)BT * D * 4, hipMemcpyDeviceToDevice, st));
+  if (!bwd) { VOG_LAUNCH_CHECK(); return 0; }
+  VOG_CHECK_ARG(a->g_emb && a->g_w_proj && a->g_b_proj && a->g_w_arg && a->g_b_arg);
+  // ---- srl_arg_words_out_enc
+  const int MA = Bn * nsrl;
+  ::vog::launch(lin_dpre_kernel, blocks((int64_t)MA * L), dim3(256), 0, st, a->d_lang_enc, (int64_t)L, 1, (const float*)lenc, 1, dpre, MA, L);
+  VOG_TRY(gemm_f32(dpre, 1, L, enc, 2 * D, 1, a->g_w_arg, 2 * D, nullptr, 0, L, 2 * D, MA, st));
+  VOG_TRY(colsum(dpre, a->g_b_arg, part, MA, L, st));
+  VOG_TRY(gemm_f32(dpre, L, 1, a->w_arg, 2 * D, 1, denc, 2 * D, nullptr, 0, MA, 2 * D, L, st));
+  ::vog::launch(argvec_scatter_kernel, blocks((int64_t)BT * D), dim3(256), 0, st, (const float*)denc, a->capture, dfull, Bn, nsrl, T, D);
+  // ---- lstm_out_feat_proj (the per-step call; the call on final_hidden feeds only the sep head)
+  ::vog::launch(lin_dpre_kernel, blocks((int64_t)BT * D), dim3(256), 0, st, (const float*)dfull, (int64_t)D, 1, (const float*)full, 1, dpre2, BT, D);
+  VOG_TRY(gemm_f32(dpre2, 1, D, lout[NL - 1], 2 * R, 1, a->g_w_proj, 2 * R, nullptr, 0, D, 2 * R, BT, st));
+  VOG_TRY(colsum(dpre2, a->g_b_proj, part, BT, D, st));
+  float* d_out = dxa; float* d_in = dxb;
+  VOG_TRY(gemm_f32(dpre2, D, 1, a->w_proj, 2 * R, 1, d_out, 2 * R, nullptr, 0, BT, 2 * R, D, st));
+  // ---- BiLSTM, top layer first
+  for (int l = NL - 1; l >= 0; --l) {
+    const float* xin = l == 0 ? x0 : lout[l - 1];
+    const int K = l == 0 ? E : 2 * R;
+    for (int dr = 0; dr < 2; ++dr) {
+      VOG_CHECK_ARG(a->g_w_ih[l][dr] && a->g_w_hh[l][dr] && a->g_b_ih[l][dr] && a->g_b_hh[l][dr]);
+      VOG_HIP(hipMemsetAsync(dGp, 0, (size_t)BT * G * 4, st));
+      VOG_HIP(hipMemsetAsync(dh0, 0, (size_t)Bn * R * 4, st));
+      VOG_HIP(hipMemsetAsync(dc, 0, (size_t)Bn * R * 4, st));
+      float *cur = dh0, *nxt = dh1;
+      for (int t = T - 1; t >= 0; --t) {
+        LstmStep ls{}; ls.lens = a->lens; ls.gates = gates[l][dr]; ls.c = cst[l][dr]; ls.h = hst[l][dr]; ls.Bn = Bn; ls.T = T; ls.R = R;
+        ls.s = t; ls.reverse = dr; ls.d_out = d_out; ls.dh_cur = cur; ls.dh_nxt = nxt; ls.dc = dc; ls.dGs = dGs; ls.dGp = dGp;
+        ::vog::launch(lstm_cell_bwd_kernel, blocks((int64_t)Bn * R), dim3(256), 0, st, ls);
+        // dh_{s-1} += dG_s W_hh
+        VOG_TRY(gemm_f32(dGs + (int64_t)t * Bn * G, G, 1, a->w_hh[l][dr], R, 1, nxt, R, nullptr, 0, Bn, R, G, st, 1));
+        float* sw = cur; cur = nxt; nxt = sw;
+      }
+      VOG_TRY(gemm_f32(dGs, 1, G, hst[l][dr], R, 1, a->g_w_hh[l][dr], R, nullptr, 0, G, R, BT, st));          // sum_s dG_s^T h_{s-1}
+      VOG_TRY(gemm_f32(dGp, 1, G, xin, K, 1, a->g_w_ih[l][dr], K, nullptr, 0, G, K, BT, st));                   // dG^T x
+      VOG_TRY(colsum(dGp, a->g_b_ih[l][dr], part, BT, G, st));
+      VOG_HIP(hipMemcpyAsync(a->g_b_hh[l][dr], a->g_b_ih[l][dr], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+      VOG_TRY(gemm_f32(dGp, G, 1, a->w_ih[l][dr], K, 1, d_in, K, nullptr, 0, BT, K, G, st, dr));               // d x (both directions)
+    }
+    float* sw = d_out; d_out = d_in; d_in = sw;
+  }
+  const int nv = a->vocab_size + 1;
+  ::vog::launch(embed_scatter_kernel, blocks((int64_t)nv * E), dim3(256), 0, st, (const float*)d_out, (const int64_t*)tok, a->g_emb, BT, E, nv);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}

@@ -201,6 +201,19 @@ class LinearF32Args(C.Structure):
                 ("M", c_i32), ("N", c_i32), ("K", c_i32)]
 
 
+_P42 = (c_vp * 2) * 4
+
+
+class LangF32Args(C.Structure):
+    _fields_ = ([(n, c_vp) for n in ("words_ind", "word_mask", "lens", "capture")]
+                + [(n, c_i32) for n in ("Bn", "nsrl", "words_len", "mask_len", "T", "vocab_size", "E", "R", "layers", "D", "L")]
+                + [("emb", c_vp), ("w_ih", _P42), ("w_hh", _P42), ("b_ih", _P42), ("b_hh", _P42)]
+                + [(n, c_vp) for n in ("w_proj", "b_proj", "w_arg", "b_arg", "d_lang_enc", "lang_enc_out", "full_out", "g_emb")]
+                + [("g_w_ih", _P42), ("g_w_hh", _P42), ("g_b_ih", _P42), ("g_b_hh", _P42)]
+                + [(n, c_vp) for n in ("g_w_proj", "g_b_proj", "g_w_arg", "g_b_arg", "scratch")]
+                + [("scratch_bytes", C.c_size_t)])
+
+
 class AttnF32Args(C.Structure):
     _fields_ = [("x", c_vp), ("d_cat", c_vp), ("wq", c_vp), ("wk", c_vp), ("wv", c_vp),
                 ("props", c_vp), ("prop_stride", c_i32), ("vid_w", C.c_float), ("vid_h", C.c_float), ("nfrm_div", C.c_float),
@@ -257,6 +270,8 @@ SYMBOLS = {
     "vog_conc_f32_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 8 + [c_vp]),
     "vog_linear_f32_scratch_bytes": (c_i64, [c_i32, c_i32]),
     "vog_linear_f32": (c_i32, [C.POINTER(LinearF32Args), c_vp]),
+    "vog_lang_f32_scratch_bytes": (c_i64, [c_i32] * 8),
+    "vog_lang_f32": (c_i32, [C.POINTER(LangF32Args), c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
