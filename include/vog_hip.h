@@ -605,6 +605,24 @@ typedef struct vog_lang_f32_args {
 int64_t vog_lang_f32_scratch_bytes(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L);
 int vog_lang_f32(const vog_lang_f32_args* a, void* stream);
 
+/* The remaining forward pieces of the fp32 training path (the forward vog_*_bwd differentiate, kept in fp32 with
+ * its activations; the 16-bit inference forward above keeps none):
+ *   vog_concat_rows_f32: out[m, :Na] = a[m / rep_a], out[m, Na:] = b[m / rep_b] (concat_prop_seg_feats: rep_b = nppf0);
+ *   vog_conc_f32_fwd:    mul_tx's input from obj_tx's output and the (masked) argument vectors - the forward of
+ *                        vog_conc_f32_bwd, same argument meaning;
+ *   vog_score_head_f32:  mdl_outs [n_vid, nsrl, nfrm*nppf] = lin2(y) regrouped (code/mdl_vog.py:224-230, 724-737),
+ *                        scratch >= M * dhead * 4 bytes.
+ * vog_adam_f32: one torch.optim.Adam step (no weight decay / amsgrad; the reference uses betas (0.9, 0.99),
+ * code/main_dist.py:55) on one parameter tensor; step counts from 1. */
+int vog_concat_rows_f32(const float* a, int Na, int rep_a, const float* b, int Nb, int rep_b, float* out, int M, void* stream);
+int vog_conc_f32_fwd(const float* ps, const float* lang, const int64_t* inds_msk, float* out, int n_q, int nc_v, int nfrm, int nppf,
+                     int nsrl, int dobj, int dlang, int lang_per_vid, void* stream);
+int vog_score_head_f32(const float* y, const float* wl, const float* bl, const float* wl2, const float* bl2, float* mdl_outs,
+                       void* scratch, size_t scratch_bytes, int M, int d, int dhead, int n_vid, int nfrm, int nppf, int nsrl,
+                       void* stream);
+int vog_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                 void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)
  * ------------------------------------------------------------------------- */

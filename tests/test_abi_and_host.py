@@ -156,7 +156,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
              "vog_attn_struct_args": L.AttnStructArgs, "vog_visprep_args": L.VisprepArgs,
              "vog_lstm_step_args": L.LstmStepArgs, "vog_lstm_layer_args": L.LstmLayerArgs,
              "vog_vislang_args": L.VislangArgs, "vog_score_args": L.ScoreArgs,
-             "vog_predcmp_args": L.PredcmpArgs, "vog_pred_args": L.PredArgs, "vog_tx_tail_args": L.TxTailArgs, "vog_encoder_layer_args": L.EncoderLayerArgs, "vog_visenc_args": L.VisencArgs, "vog_loss_args": L.LossArgs, "vog_tail_bwd_args": L.TailBwdArgs, "vog_assemble_args": L.AssembleArgs,
+             "vog_predcmp_args": L.PredcmpArgs, "vog_pred_args": L.PredArgs, "vog_tx_tail_args": L.TxTailArgs, "vog_encoder_layer_args": L.EncoderLayerArgs, "vog_visenc_args": L.VisencArgs, "vog_loss_args": L.LossArgs, "vog_tail_bwd_args": L.TailBwdArgs, "vog_attn_f32_args": L.AttnF32Args, "vog_linear_f32_args": L.LinearF32Args, "vog_lang_f32_args": L.LangF32Args, "vog_assemble_args": L.AssembleArgs,
              "vog_model_desc": L.ModelDesc, "vog_batch": L.Batch}
     gcc = shutil.which("gcc")
     assert gcc, "gcc is part of the image"

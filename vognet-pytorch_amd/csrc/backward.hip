@@ -863,3 +863,106 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   VOG_LAUNCH_CHECK();
   return 0;
 }
+
+// =====================================================================================================================
+// The remaining forward pieces of the fp32 training path (concatenations, score head) and the optimizer step
+// =====================================================================================================================
+namespace vog {
+
+// out[m, :Na] = a[m / rep_a], out[m, Na:] = b[m / rep_b]        (concat_prop_seg_feats code/mdl_conc_single.py:51-66)
+__global__ void concat_rows_kernel(const float* a, int Na, int rep_a, const float* b, int Nb, int rep_b, float* out, int M) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = Na + Nb;
+  if (i >= (int64_t)M * W) return;
+  const int c = (int)(i % W);
+  const int64_t m = i / W;
+  out[i] = c < Na ? a[(m / rep_a) * Na + c] : b[(m / rep_b) * Nb + (c - Na)];
+}
+
+// x_mul[((q, v), f), (arg, p), :] = [ps[(q, v), f*nppf + p, :] | mask * lang[(q, v | 0), arg, :]]   (code/mdl_vog.py:316-344, 681-700)
+__global__ void conc_fwd_kernel(const float* ps, const float* lang, const int64_t* mask, float* out, int n_q, int nc_v, int nfrm,
+                                int nppf, int nsrl, int dobj, int dlang, int lang_per_vid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int vld = dobj + dlang;
+  const int64_t total = (int64_t)n_q * nc_v * nfrm * nsrl * nppf * vld;
+  if (i >= total) return;
+  const int c = (int)(i % vld);
+  int64_t r = i / vld;
+  const int pp = (int)(r % nppf); r /= nppf;
+  const int ar = (int)(r % nsrl); r /= nsrl;
+  const int f = (int)(r % nfrm);
+  const int64_t qv = r / nfrm;
+  if (c < dobj) { out[i] = ps[((qv * nfrm + f) * nppf + pp) * dobj + c]; return; }
+  const int64_t lr = (lang_per_vid ? qv : qv / nc_v) * nsrl + ar;
+  out[i] = (mask && mask[lr] == 0) ? 0.f : lang[lr * dlang + (c - dobj)];
+}
+
+// mdl_outs[v, arg, f*nppf + p] = h[row] . w2 + b2, row = ((v, f), (arg, p))      (code/mdl_vog.py:224-230, 724-737)
+__global__ __launch_bounds__(256) void score_fwd_kernel(const float* h, const float* w2, const float* b2, float* outs, int M, int HD,
+                                                        int nfrm, int nppf, int nsrl) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float s = 0.f;
+  for (int i = lane; i < HD; i += 64) s += h[(int64_t)row * HD + i] * w2[i];
+  s = wsum(s);
+  if (lane == 0) {
+    const int N = nsrl * nppf, sq = row / N, j = row % N, v = sq / nfrm, f = sq % nfrm, ar = j / nppf, pp = j % nppf;
+    outs[((int64_t)v * nsrl + ar) * ((int64_t)nfrm * nppf) + (int64_t)f * nppf + pp] = s + b2[0];
+  }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad): the reference's optimizer, betas (0.9, 0.99) (code/main_dist.py:55)
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace vog
+
+extern "C" int vog_concat_rows_f32(const float* a, int Na, int rep_a, const float* b, int Nb, int rep_b, float* out, int M, void* stream) {
+  VOG_CHECK_ARG(a && b && out && Na > 0 && Nb > 0 && rep_a >= 1 && rep_b >= 1 && M > 0);
+  ::vog::launch(concat_rows_kernel, dim3((unsigned)(((int64_t)M * (Na + Nb) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, Na,
+                rep_a, b, Nb, rep_b, out, M);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_conc_f32_fwd(const float* ps, const float* lang, const int64_t* inds_msk, float* out, int n_q, int nc_v, int nfrm,
+                                int nppf, int nsrl, int dobj, int dlang, int lang_per_vid, void* stream) {
+  VOG_CHECK_ARG(ps && lang && out && n_q > 0 && nc_v > 0 && nfrm > 0 && nppf > 0 && nsrl > 0 && dobj > 0 && dlang > 0);
+  const int64_t total = (int64_t)n_q * nc_v * nfrm * nsrl * nppf * (dobj + dlang);
+  ::vog::launch(conc_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ps, lang, inds_msk, out, n_q,
+                nc_v, nfrm, nppf, nsrl, dobj, dlang, lang_per_vid);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_score_head_f32(const float* y, const float* wl, const float* bl, const float* wl2, const float* bl2, float* mdl_outs,
+                                  void* scratch, size_t scratch_bytes, int M, int d, int dhead, int n_vid, int nfrm, int nppf, int nsrl,
+                                  void* stream) {
+  VOG_CHECK_ARG(y && wl && bl && wl2 && bl2 && mdl_outs && scratch && M > 0 && d > 0 && dhead > 0 && M == n_vid * nfrm * nppf * nsrl);
+  if (scratch_bytes < (size_t)M * dhead * 4) VOG_FAIL(-2, "vog_score_head_f32: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* h = (float*)scratch;
+  VOG_TRY(gemm_f32(y, d, 1, wl, 1, d, h, dhead, bl, 1, M, dhead, d, st));
+  ::vog::launch(score_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const float*)h, wl2, bl2, mdl_outs, M, dhead, nfrm, nppf, nsrl);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            int step, void* stream) {
+  VOG_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  ::vog::launch(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                bc1, sqrtf(bc2));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}

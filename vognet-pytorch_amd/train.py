@@ -1,0 +1,141 @@
+"""the training step of the reference's `Learner.train_epoch` (utils/trn_utils.py:485-532) for the
+VOGNet model on the device:
+
+    out = mdl(batch); loss = loss_fn(out, batch); loss.backward(); optimizer.step()
+
+as forward (fp32, activations kept at the seams) -> `LossB_*` (vog_loss_fwd) -> `LossB_*.backward` (vog_loss_bwd) ->
+`visual_backward` + `language_backward` (csrc/backward.hip) -> gradient all-reduce over the ranks
+(`dist.all_reduce_grads`, the DistributedDataParallel step of code/main_dist.py:72-85) -> Adam (vog_adam_f32; the
+reference's `torch.optim.Adam(betas=(0.9, 0.99))`, code/main_dist.py:55). Everything is a C-ABI call into
+libvog_hip.so; torch tensors are device containers.
+
+This is the fp32 path that pins the MATH against autograd through the reference (every parameter gradient, three
+Adam steps); it shares no kernel with the 16-bit inference forward and is not tuned (one GEMM per BiLSTM time step).
+Not built: dropout (the reference trains with p = 0.1 masks drawn from torch's generator - a step here equals the
+reference's with the model in eval mode), the sep / svsq verb head, the igrnd / vgrnd variants.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import backward as BW
+from . import lib as L
+from .engine import model_desc_from_cfg
+
+
+class FP32Trainer:
+    def __init__(self, cfg, comm, state_dict: Dict[str, torch.Tensor], loss_fn, lr: Optional[float] = None,
+                 betas=(0.9, 0.99), eps: float = 1e-8, device: str = "cuda", process_group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FP32Trainer needs a GPU (libvog_hip.so kernels; there is no CPU fallback)")
+        self.lib = L.load()
+        self.cfg, self.loss_fn = cfg, loss_fn
+        d = model_desc_from_cfg(cfg, comm)
+        if cfg.mdl.name != "vog" or cfg.ds.conc_type not in ("temp", "spat"):
+            raise NotImplementedError("the device training step covers mdl.name = vog with conc_type temp / spat")
+        self.desc = d
+        self.dev = torch.device(device)
+        self.params = {k: v.detach().to(self.dev, torch.float32).contiguous().clone() for k, v in state_dict.items()
+                       if torch.is_tensor(v) and v.is_floating_point()}
+        self.m: Dict[str, torch.Tensor] = {}
+        self.v: Dict[str, torch.Tensor] = {}
+        self.lr = float(cfg.train.lr if lr is None else lr)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self.num_it = 0
+        self.pg = process_group
+
+    # ---- geometry of one batch (Conc{TEMP,SPAT}: code/mdl_conc_single.py:24-37, 131-143)
+    def _geo(self, batch):
+        d = self.desc
+        B = batch["srl_arg_words_ind"].shape[0]
+        ncmp = batch["num_cmp_msk"].shape[1]
+        if self.cfg.ds.conc_type == "temp":
+            nfrm, nppf = ncmp * d.nfrm0, d.nppf0
+        else:
+            nfrm, nppf = d.nfrm0, ncmp * d.nppf0
+        return dict(B=B, nc_v=1, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers, mul_heads=d.mul_heads,
+                    mul_use_rel=bool(d.mul_use_rel), obj_layers=d.obj_layers if d.obj_to_use else 0, obj_heads=d.obj_heads,
+                    obj_use_rel=bool(d.obj_use_rel), obj_one_frm=bool(d.obj_one_frm), vid_w=d.vid_w, vid_h=d.vid_h)
+
+    def _stack_forward(self, stack, n_layers, pe_name, x, S, N, n, heads, boxes):
+        for l in range(n_layers):
+            x, _ = BW.encoder_layer_forward(self.params, stack, l, pe_name, x, S, N, n, heads, boxes)
+        return x
+
+    def forward(self, batch):
+        """fp32 forward on the device -> (mdl_outs [B, 1, nsrl, NP], activations at the seams of the backward)."""
+        g = self._geo(batch)
+        p, lib, st = self.params, self.lib, L.stream_ptr()
+        B, nfrm, nppf, nsrl = g["B"], g["nfrm"], g["nppf"], g["nsrl"]
+        NP = nfrm * nppf
+        T = int(batch["srl_arg_word_mask_len"].max())
+        lang = BW.language_backward(p, batch, T, self.desc.rnn_layers)["_lang_enc"]
+        f32 = lambda k: batch[k].to(self.dev, torch.float32)
+        prop_feat = f32("pad_region_feature").reshape(B * NP, -1).contiguous()
+        seg_feat = f32("seg_feature_for_frms").reshape(-1, batch["seg_feature_for_frms"].shape[-1]).contiguous()
+        props = f32("pad_proposals").reshape(B * NP, -1).contiguous()
+        pe = BW.linear_f32(prop_feat, p["prop_encoder.0.weight"], p["prop_encoder.0.bias"], True)["y"]
+        se = BW.linear_f32(seg_feat, p["seg_encoder.0.weight"], p["seg_encoder.0.bias"], True)["y"]
+        assert seg_feat.shape[0] * g["nppf0"] == B * NP
+        obj_x = torch.empty(B * NP, pe.shape[1] + se.shape[1], dtype=torch.float32, device=self.dev)
+        L.check(lib.vog_concat_rows_f32(L.ptr(pe), pe.shape[1], 1, L.ptr(se), se.shape[1], g["nppf0"], L.ptr(obj_x), B * NP, st),
+                "vog_concat_rows_f32")
+        obj_out = obj_x
+        if g["obj_layers"] > 0:
+            if g["obj_one_frm"]:
+                S, N, fdiv = B * nfrm, nppf, float(nfrm)
+            else:
+                S, N, fdiv = B, NP, 1.0
+            ob = BW._Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
+            obj_out = self._stack_forward("obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", obj_x, S, N, N, g["obj_heads"], ob)
+        msk = batch["srl_arg_inds_msk"].to(self.dev, torch.int64).contiguous()
+        dobj, dlang = obj_out.shape[1], lang.shape[1]
+        mul_x = torch.empty(B * nfrm * nsrl * nppf, dobj + dlang, dtype=torch.float32, device=self.dev)
+        L.check(lib.vog_conc_f32_fwd(L.ptr(obj_out), L.ptr(lang), L.ptr(msk), L.ptr(mul_x), B, 1, nfrm, nppf, nsrl, dobj, dlang, 0, st),
+                "vog_conc_f32_fwd")
+        mb = BW._Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
+        y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, B * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb)
+        M, dm = y.shape
+        dhead = p["lin2.0.weight"].shape[0]
+        scratch = torch.empty(M * dhead, dtype=torch.float32, device=self.dev)
+        outs = torch.empty(B, 1, nsrl, NP, dtype=torch.float32, device=self.dev)
+        L.check(lib.vog_score_head_f32(L.ptr(y), L.ptr(p["lin2.0.weight"]), L.ptr(p["lin2.0.bias"]), L.ptr(p["lin2.2.weight"]),
+                                       L.ptr(p["lin2.2.bias"]), L.ptr(outs), L.ptr(scratch), scratch.numel() * 4, M, dm, dhead, B,
+                                       nfrm, nppf, nsrl, st), "vog_score_head_f32")
+        acts = {"mul_x": mul_x, "obj_x": obj_x, "prop_feat": prop_feat, "seg_feat": seg_feat, "props": props, "inds_msk": msk, "T": T}
+        return outs, acts, g
+
+    def gradients(self, batch):
+        """-> (loss dict, {parameter name: gradient}) of one batch (no update)."""
+        outs, acts, g = self.forward(batch)
+        ld = self.loss_fn({"mdl_outs": outs}, batch)
+        d_outs = self.loss_fn.backward(ld)
+        grads = BW.visual_backward(self.params, g, acts, d_outs)
+        lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"])
+        grads.update(lg)
+        return ld, {k: v for k, v in grads.items() if not k.startswith("_")}
+
+    def step(self, batch):
+        """One `train_epoch` iteration: forward, loss, backward, (all-reduce,) Adam. -> the loss dict."""
+        ld, grads = self.gradients(batch)
+        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                   and torch.distributed.get_world_size() > 1):
+            from .dist import all_reduce_grads
+            all_reduce_grads(grads, average=True)
+        self.num_it += 1
+        st = L.stream_ptr()
+        for k in sorted(grads):
+            p = self.params[k]
+            if k not in self.m:
+                self.m[k], self.v[k] = torch.zeros_like(p), torch.zeros_like(p)
+            gk = grads[k].contiguous()
+            L.check(self.lib.vog_adam_f32(L.ptr(p), L.ptr(gk), L.ptr(self.m[k]), L.ptr(self.v[k]), p.numel(), self.lr, self.betas[0],
+                                          self.betas[1], self.eps, self.num_it, st), "vog_adam_f32")
+        return ld
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The parameters under the reference's key names (load into the inference model with `load_state_dict`)."""
+        return {k: v.clone() for k, v in self.params.items()}
