@@ -10,9 +10,14 @@ called as `eval_fn(mdl, loss_fn, dl, dl_name, rank=..., pred_path=<tmp_path>/pre
 forward -> device loss -> prediction records -> ONE cross-rank exchange per 16 batches (dist.RecordRing) ->
 rank 0 writes `<pred_path>/<dl_name>_0.pkl` and scores it when the annotation files of cfg.ds exist; the
 loss and metric dicts are printed like the reference prints them, followed by one JSON line.
-The trainer (`Learner.fit`) and the dataset readers are out of scope: without the
-530 GB dataset the loader is a list of synthetic batches (`--synthetic_batches=N`, the last one a query
-short like the tail batch of a `drop_last=False` validation loader).
+Without `only_val` / `only_test` it runs `Learner.fit` (code/main_dist.py:125 -> utils/trn_utils.py:701-775) through
+`train.fit`: per epoch the device training step (`train.FP32Trainer`: fp32 forward -> loss -> backward -> gradient
+all-reduce -> Adam) over the training batches, then the validation flow above on the inference model carrying the
+new weights, and `<tmp_path>/models/<uid>.pth` in the reference's checkpoint layout; `--train.resume=True` loads
+it back (model + optimizer), as `Learner.load_model_dict`.
+The dataset readers are out of scope: without the 530 GB dataset the loaders are lists of
+synthetic batches (`--synthetic_batches=N`, the last validation batch a query short like the tail batch of a
+`drop_last=False` loader).
 """
 from __future__ import annotations
 
@@ -67,16 +72,16 @@ def learner_init(uid: str, cfg):
     return mdl, loss_fn, evl, comm
 
 
-def synthetic_loader(cfg, comm, n_batches: int, rank: int, world: int):
+def synthetic_loader(cfg, comm, n_batches: int, rank: int, world: int, train: bool = False):
     """Validation batches with every key the forward, the loss and the evaluator read,
     this rank's contiguous share (dist.shard_indices = NewDistributedSampler, utils/trn_utils.py:127-156);
     the last batch is one query short (validation loaders keep the tail, trn_utils.py:200-203)."""
     import numpy as np
-    bs = int(cfg.train.bsv)
+    bs = int(cfg.train.bs if train else cfg.train.bsv)
     ct = cfg.ds.conc_type
     out = []
     for i in D.shard_indices(n_batches, rank, world):
-        b = synth.make_batch(ct, bs, comm["num_prop_per_frm"], vocab_size=comm["vocab_size"], seed=1000 * i)
+        b = synth.make_batch(ct, bs, comm["num_prop_per_frm"], vocab_size=comm["vocab_size"], seed=1000 * i + (500000 if train else 0))
         b.update(synth.make_targets(b, ct, comm["num_prop_per_frm"], seed=i))
         ncmp = b["num_cmp_msk"].shape[1]
         rng = np.random.default_rng(77 + i)
@@ -84,7 +89,7 @@ def synthetic_loader(cfg, comm, n_batches: int, rank: int, world: int):
         b.update({"ann_idx": np.arange(i * bs, (i + 1) * bs, dtype=np.int64),
                   "sent_idx": np.arange(i * bs, (i + 1) * bs, dtype=np.int64),
                   "permute": perm, "permute_inv": np.argsort(perm, axis=1).astype(np.int64)})
-        if i == n_batches - 1 and bs > 1:
+        if i == n_batches - 1 and bs > 1 and not train:
             b = {k: v[: bs - 1] for k, v in b.items()}
         out.append({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()})
     return out
@@ -105,12 +110,27 @@ def main_dist(uid: str, **kwargs):
     cfg = post_proc_config(cfg)
     cfg.freeze()
     mdl, loss_fn, evl, comm = learner_init(uid, cfg)
-    if not (cfg.only_val or cfg.only_test):
-        raise NotImplementedError(
-            "training (Learner.fit) is outside the forward hot path; run with --only_val=True")
     rank, world = D.get_rank(), D.get_world_size()
     # Learner.init_log_dirs (utils/trn_utils.py:341-368): <data.path = cfg.misc.tmp_path>/predictions/<uid>
     pred_path = Path(cfg.misc.tmp_path) / "predictions" / uid
+    if not (cfg.only_val or cfg.only_test):
+        from . import train as TR
+        model_file = Path(cfg.misc.tmp_path) / "models" / f"{uid}.pth"
+        tr = TR.FP32Trainer(cfg, comm, mdl.state_dict(), loss_fn, lr=float(cfg.train.lr))
+        if cfg.train.resume and model_file.exists():
+            ck = torch.load(model_file.open("rb"), weights_only=False)
+            tr.params.update({k: v.to(tr.dev, torch.float32).contiguous() for k, v in ck["model_state_dict"].items()})
+            if cfg.train.load_opt:
+                tr.load_optimizer_state_dict(ck["optimizer_state_dict"])
+        train_dl = synthetic_loader(cfg, comm, n_batches, rank, world, train=True)
+        valid_dl = synthetic_loader(cfg, comm, max(2, n_batches // 2), rank, world)
+        t0 = time.time()
+        hist = TR.fit(tr, mdl, evl, train_dl, valid_dl, int(cfg.train.epochs), model_file, pred_path, rank=rank)
+        torch.cuda.synchronize()
+        if D.is_main_process():
+            print(json.dumps({"uid": uid, "world": world, "epochs": len(hist), "train_steps": tr.num_it, "seconds": time.time() - t0,
+                              "model_file": str(model_file), "history": hist}))
+        return hist
     dl_name = "valid" if cfg.only_val else "test"
     dl = synthetic_loader(cfg, comm, n_batches, rank, world)
     nq_local = sum(int(b["num_cmp_msk"].shape[0]) for b in dl)

@@ -139,3 +139,73 @@ class FP32Trainer:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """The parameters under the reference's key names (load into the inference model with `load_state_dict`)."""
         return {k: v.clone() for k, v in self.params.items()}
+
+    # ---- checkpoint in the reference's layout (Learner.save_model_dict / load_model_dict, utils/trn_utils.py:533-630)
+    def optimizer_state_dict(self):
+        """torch.optim.Adam.state_dict() layout (parameters numbered in state-dict key order)."""
+        keys = list(self.params)
+        state = {i: {"step": torch.tensor(float(self.num_it)), "exp_avg": self.m[k].clone(), "exp_avg_sq": self.v[k].clone()}
+                 for i, k in enumerate(keys) if k in self.m}
+        return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0,
+                                                  "amsgrad": False, "params": list(range(len(keys)))}]}
+
+    def load_optimizer_state_dict(self, osd):
+        keys = list(self.params)
+        for i, stt in osd["state"].items():
+            k = keys[int(i)]
+            self.m[k] = stt["exp_avg"].to(self.dev, torch.float32).contiguous().clone()
+            self.v[k] = stt["exp_avg_sq"].to(self.dev, torch.float32).contiguous().clone()
+            self.num_it = int(stt["step"])
+        g = osd["param_groups"][0]
+        self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+
+
+class SmoothenDict:
+    """Exponentially smoothed loss values with bias correction (utils/trn_utils.py:228-262: SmoothenValue / SmoothenDict)."""
+
+    def __init__(self, keys, beta: float):
+        self.keys, self.beta, self.n = list(keys), beta, 0
+        self.mov = {k: 0.0 for k in self.keys}
+        self.smooth = {k: 0.0 for k in self.keys}
+
+    def add_value(self, d):
+        self.n += 1
+        for k in self.keys:
+            self.mov[k] = self.beta * self.mov[k] + (1 - self.beta) * float(d[k])
+            self.smooth[k] = self.mov[k] / (1 - self.beta ** self.n)
+
+
+def fit(trainer: FP32Trainer, mdl, evl, train_dl, valid_dl, epochs: int, model_file, pred_path, rank: int = 0,
+        log=print):
+    """`Learner.fit` (utils/trn_utils.py:701-775): per epoch one pass over the training loader (`train_epoch`), the
+    reference's validation flow on the inference model carrying the new weights (`Learner.validate` -> the evaluator:
+    16-bit HIP forward, device loss, records, metrics), and a checkpoint in the reference's layout whenever the first
+    metric improves. -> list of per-epoch dicts."""
+    import json
+    from . import dist as D
+    best_met, hist = -1.0, []
+    loss_keys, met_keys = trainer.loss_fn.loss_keys, evl.met_keys
+    for epoch in range(1, epochs + 1):
+        sm = SmoothenDict(loss_keys, 0.9)
+        for batch in train_dl:
+            batch = {k: v.to(trainer.dev) for k, v in batch.items()}
+            sm.add_value(trainer.step(batch))
+        D.synchronize()
+        mdl.load_state_dict(trainer.state_dict(), strict=False)
+        mdl.refresh_weights()
+        with torch.no_grad():
+            val_loss, val_acc = evl(mdl, trainer.loss_fn, valid_dl, "valid", rank=rank, pred_path=pred_path)
+        met = float(val_acc[met_keys[0]])
+        rec = {"epochs": epoch, **{"trn_" + k: sm.smooth[k] for k in loss_keys},
+               **{"val_" + k: float(val_loss[k]) for k in loss_keys}, **{"val_" + k: float(val_acc[k]) for k in met_keys}}
+        hist.append(rec)
+        if D.is_main_process():
+            log("  ".join(f"{k} {v:.4f}" if isinstance(v, float) else f"{k} {v}" for k, v in rec.items()))
+            if best_met < met or epoch == epochs and not model_file.exists():
+                best_met = max(best_met, met)
+                model_file.parent.mkdir(parents=True, exist_ok=True)
+                torch.save({"model_state_dict": {k: v.cpu() for k, v in trainer.state_dict().items()},
+                            "optimizer_state_dict": trainer.optimizer_state_dict(), "num_it": trainer.num_it, "num_epoch": epoch,
+                            "cfgtxt": json.dumps(trainer.cfg, default=str), "best_met": best_met}, model_file.open("wb"))
+        D.synchronize()
+    return hist
