@@ -145,6 +145,71 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// ---- C[M <= 16, N] = A[M, K] . W[N, K]^T (+ bias, relu, accumulate): the recurrent products of the BiLSTM (M = number of
+// sentences). A weight-stream kernel: the 128 x 64 tile GEMM above launches N / 64 workgroups that each walk all of K
+// (262 us for dh = dG W_hh at cfg 2); here one WAVE owns CPW output columns, reads their weight rows with 16-byte
+// loads (1 KiB per wave and instruction, CPW * K / 256 of them in flight) and the M activation rows from LDS.
+template <int MT, int CPW>
+__global__ __launch_bounds__(256) void skinny_f32_kernel(GemmF32 p) {
+  constexpr int KC = 1024;
+  __shared__ __attribute__((aligned(16))) float As[MT][KC];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n0 = (blockIdx.x * 4 + wid) * CPW;
+  float acc[CPW][MT];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += KC) {
+    const int kc = p.K - k0 < KC ? p.K - k0 : KC;
+    __syncthreads();
+    for (int i = tid * 4; i < MT * KC; i += 256 * 4) {
+      const int m = i / KC, k = i % KC;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M && k < kc) v = *reinterpret_cast<const float4*>(p.a + (int64_t)m * p.am + k0 + k);
+      *reinterpret_cast<float4*>(&As[m][k]) = v;
+    }
+    __syncthreads();
+    for (int kk = lane * 4; kk < kc; kk += 256) {
+      float4 w[CPW];
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+        w[c] = (n0 + c < p.N) ? *reinterpret_cast<const float4*>(p.b + (int64_t)(n0 + c) * p.bn + k0 + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[m][kk]);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[c][m] += a.x * w[c].x + a.y * w[c].y + a.z * w[c].z + a.w * w[c].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPW; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v = acc[c][m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && m < p.M && n0 + c < p.N) {
+        if (p.bias) v += p.bias[n0 + c];
+        if (p.relu) v = v < 0.f ? 0.f : v;
+        float* dst = p.c + (int64_t)m * p.ldc + n0 + c;
+        *dst = p.accum ? *dst + v : v;
+      }
+    }
+}
+
+// out[n, k] = in[k, n]  (W_hh^T for the backward recurrence, once per layer, direction and step() call)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* in, float* out, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < rows && bx + tx < cols) t[j][tx] = in[(int64_t)(by + j) * cols + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < cols && by + tx < rows) out[(int64_t)(bx + j) * rows + by + tx] = t[tx][j];
+}
+
 // batched form; the vector path is chosen when every dimension, stride and pointer allows 16-byte loads
 static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const float* b, int64_t bk, int64_t bn, int64_t sb,
                       float* c, int64_t ldc, int64_t sc, const float* bias, int relu, int accum, int M, int N, int K, int batch,
@@ -154,6 +219,17 @@ static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const 
   const bool vec = m4(M) && m4(N) && m4(K) && (m4(am) || am == 1) && (m4(ak) || ak == 1) && (m4(bk) || bk == 1) &&
                    (m4(bn) || bn == 1) && m4(sa) && m4(sb) && al16(a) && al16(b);
   GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K, sa, sb, sc, accum, vec ? 0 : 1};
+  if (batch == 1 && M <= 16 && ak == 1 && bk == 1 && m4(K) && m4(am) && m4(bn) && al16(a) && al16(b) && N >= 256) {
+    // few rows against a K-contiguous weight matrix: weight-stream kernel (one wave per 1 / 4 output columns)
+    const bool wide = N >= 2048;
+    const int cols_per_wg = 4 * (wide ? 4 : 1);
+    const dim3 grid(ceil_div(N, cols_per_wg));
+    if (M <= 4) { if (wide) ::vog::launch((skinny_f32_kernel<4, 4>), grid, dim3(256), 0, st, p); else ::vog::launch((skinny_f32_kernel<4, 1>), grid, dim3(256), 0, st, p); }
+    else if (M <= 8) { if (wide) ::vog::launch((skinny_f32_kernel<8, 4>), grid, dim3(256), 0, st, p); else ::vog::launch((skinny_f32_kernel<8, 1>), grid, dim3(256), 0, st, p); }
+    else { if (wide) ::vog::launch((skinny_f32_kernel<16, 2>), dim3(ceil_div(N, 8)), dim3(256), 0, st, p); else ::vog::launch((skinny_f32_kernel<16, 1>), grid, dim3(256), 0, st, p); }
+    VOG_LAUNCH_CHECK();
+    return 0;
+  }
   ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), batch), dim3(256), 0, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -746,6 +822,7 @@ static int64_t lang_scratch_floats(int Bn, int T, int nsrl, int E, int R, int la
   n += (int64_t)Bn * nsrl * (2 * D) * 2;               // enc, d_enc
   n += (int64_t)Bn * nsrl * L * 2 + (int64_t)CS_CHUNKS * (4 * R > L ? 4 * R : L);
   n += BT * D * 2 + BT * 2 * R;                        // linear scratch (y, dpre) for the projection
+  n += (int64_t)4 * R * R;                             // W_hh^T of the direction in flight
   return n + 4096;
 }
 
@@ -790,6 +867,7 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   float *lenc = take((int64_t)Bn * nsrl * L), *dpre = take((int64_t)Bn * nsrl * L);
   float* part = take((int64_t)CS_CHUNKS * (G > L ? G : L));
   float* dpre2 = take((int64_t)BT * D);
+  float* whh_t = take((int64_t)G * R);
   // ---- forward recomputation
   ::vog::launch(lang_tokens_kernel, blocks(BT), dim3(256), 0, st, a->words_ind, a->word_mask, tok, Bn, T, a->words_len, a->mask_len,
                 a->vocab_size);
@@ -842,12 +920,13 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
       VOG_HIP(hipMemsetAsync(dh0, 0, (size_t)Bn * R * 4, st));
       VOG_HIP(hipMemsetAsync(dc, 0, (size_t)Bn * R * 4, st));
       float *cur = dh0, *nxt = dh1;
+      ::vog::launch(transpose_f32_kernel, dim3(ceil_div(R, 32), ceil_div(G, 32)), dim3(256), 0, st, a->w_hh[l][dr], whh_t, G, R);   // [R, 4R]
       for (int t = T - 1; t >= 0; --t) {
         LstmStep ls{}; ls.lens = a->lens; ls.gates = gates[l][dr]; ls.c = cst[l][dr]; ls.h = hst[l][dr]; ls.Bn = Bn; ls.T = T; ls.R = R;
         ls.s = t; ls.reverse = dr; ls.d_out = d_out; ls.dh_cur = cur; ls.dh_nxt = nxt; ls.dc = dc; ls.dGs = dGs; ls.dGp = dGp;
         ::vog::launch(lstm_cell_bwd_kernel, blocks((int64_t)Bn * R), dim3(256), 0, st, ls);
         // dh_{s-1} += dG_s W_hh
-        VOG_TRY(gemm_f32(dGs + (int64_t)t * Bn * G, G, 1, a->w_hh[l][dr], R, 1, nxt, R, nullptr, 0, Bn, R, G, st, 1));
+        VOG_TRY(gemm_f32(dGs + (int64_t)t * Bn * G, G, 1, whh_t, 1, G, nxt, R, nullptr, 0, Bn, R, G, st, 1));
         float* sw = cur; cur = nxt; nxt = sw;
       }
       VOG_TRY(gemm_f32(dGs, 1, G, hst[l][dr], R, 1, a->g_w_hh[l][dr], R, nullptr, 0, G, R, BT, st));          // sum_s dG_s^T h_{s-1}
