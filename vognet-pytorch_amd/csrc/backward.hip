@@ -14,6 +14,7 @@
 //   f = relu(x1 W1^T + b1)    u = f W2^T + b2 + x1      y = LN2(u)
 //   h = relu(y Wl^T + bl)     logit = h . w2 + b2'      mdl_outs[v, arg, frame*nppf + p] = logit(row)
 #include <map>
+#include <mutex>
 #include <string>
 #include "common.h"
 
@@ -30,6 +31,7 @@ struct GemmF32 {
   int64_t sa, sb, sc;       // batch strides (blockIdx.z)
   int accum;                // C += ...
   int scalar;               // any dimensions / alignments: element loads with per-element bounds checks
+  int kchunk;               // split K: block z handles k in [z * kchunk, ...) (sa / sb advance a / b by a chunk, sc = one partial C)
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
   const float* pa = p.a + (int64_t)blockIdx.z * p.sa;
   const float* pb = p.b + (int64_t)blockIdx.z * p.sb;
   float* pc = p.c + (int64_t)blockIdx.z * p.sc;
+  const int KL = p.kchunk ? (p.K - (int)blockIdx.z * p.kchunk < p.kchunk ? p.K - (int)blockIdx.z * p.kchunk : p.kchunk) : p.K;
   f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -57,14 +60,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
       if (a_kfast) { m = idx >> 2; k = (idx & 3) * 4; } else { k = idx >> 5; m = (idx & 31) * 4; }
       const int gm = m0 + m, gk = k0 + k;
       if (!p.scalar) {
-        ra[e] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const float4*>(pa + (int64_t)gm * p.am + (int64_t)gk * p.ak)
+        ra[e] = (gm < p.M && gk < KL) ? *reinterpret_cast<const float4*>(pa + (int64_t)gm * p.am + (int64_t)gk * p.ak)
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int mm = a_kfast ? gm : gm + q, kk = a_kfast ? gk + q : gk;
-          v[q] = (mm < p.M && kk < p.K) ? pa[(int64_t)mm * p.am + (int64_t)kk * p.ak] : 0.f;
+          v[q] = (mm < p.M && kk < KL) ? pa[(int64_t)mm * p.am + (int64_t)kk * p.ak] : 0.f;
         }
         ra[e] = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -73,14 +76,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
     if (b_nfast) { k = tid >> 4; n = (tid & 15) * 4; } else { n = tid >> 2; k = (tid & 3) * 4; }
     const int gn = n0 + n, gk = k0 + k;
     if (!p.scalar) {
-      rb = (gn < p.N && gk < p.K) ? *reinterpret_cast<const float4*>(pb + (int64_t)gk * p.bk + (int64_t)gn * p.bn)
+      rb = (gn < p.N && gk < KL) ? *reinterpret_cast<const float4*>(pb + (int64_t)gk * p.bk + (int64_t)gn * p.bn)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nn = b_nfast ? gn + q : gn, kk = b_nfast ? gk : gk + q;
-        v[q] = (nn < p.N && kk < p.K) ? pb[(int64_t)kk * p.bk + (int64_t)nn * p.bn] : 0.f;
+        v[q] = (nn < p.N && kk < KL) ? pb[(int64_t)kk * p.bk + (int64_t)nn * p.bn] : 0.f;
       }
       rb = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -106,10 +109,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
     }
   };
   fetch(0);
-  for (int k0 = 0; k0 < p.K; k0 += TK) {
+  for (int k0 = 0; k0 < KL; k0 += TK) {
     park();
     __syncthreads();
-    if (k0 + TK < p.K) fetch(k0 + TK);
+    if (k0 + TK < KL) fetch(k0 + TK);
 #pragma unroll
     for (int ks = 0; ks < TK; ks += 4) {
       const int kq = ks + (lane >> 4);
@@ -210,6 +213,36 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* in, flo
     if (bx + j < cols && by + tx < rows) out[(int64_t)(bx + j) * rows + by + tx] = t[tx][j];
 }
 
+// out = (accum ? out : 0) + sum_z part[z] (+ bias, relu), z in order: the second half of a split-K product
+__global__ void splitk_reduce_kernel(const float* part, int S, float* c, int64_t ldc, const float* bias, int relu, int accum, int M, int N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  const int n = (int)(i % N);
+  const int64_t m = i / N;
+  float v = 0.f;
+  for (int z = 0; z < S; ++z) v += part[(int64_t)z * M * N + i];
+  if (bias) v += bias[n];
+  if (relu) v = v < 0.f ? 0.f : v;
+  float* dst = c + m * ldc + n;
+  *dst = accum ? *dst + v : v;
+}
+
+// partial products of split-K launches: one buffer per stream, grown on demand (training path only; never under graph capture)
+static float* splitk_scratch(hipStream_t st, size_t bytes) {
+  static std::mutex mu;
+  static std::map<hipStream_t, std::pair<float*, size_t>> bufs;
+  std::lock_guard<std::mutex> g(mu);
+  auto& b = bufs[st];
+  if (b.second < bytes) {
+    if (b.first) { (void)hipStreamSynchronize(st); (void)hipFree(b.first); }
+    b.first = nullptr; b.second = 0;
+    const size_t want = bytes < ((size_t)16 << 20) ? ((size_t)16 << 20) : bytes;
+    if (hipMalloc(&b.first, want) != hipSuccess) return nullptr;
+    b.second = want;
+  }
+  return b.first;
+}
+
 // batched form; the vector path is chosen when every dimension, stride and pointer allows 16-byte loads
 static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const float* b, int64_t bk, int64_t bn, int64_t sb,
                       float* c, int64_t ldc, int64_t sc, const float* bias, int relu, int accum, int M, int N, int K, int batch,
@@ -218,7 +251,7 @@ static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const 
   auto m4 = [](int64_t v) { return (v & 3) == 0; };
   const bool vec = m4(M) && m4(N) && m4(K) && (m4(am) || am == 1) && (m4(ak) || ak == 1) && (m4(bk) || bk == 1) &&
                    (m4(bn) || bn == 1) && m4(sa) && m4(sb) && al16(a) && al16(b);
-  GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K, sa, sb, sc, accum, vec ? 0 : 1};
+  GemmF32 p{a, am, ak, b, bk, bn, c, ldc, bias, relu, M, N, K, sa, sb, sc, accum, vec ? 0 : 1, 0};
   if (batch == 1 && M <= 16 && ak == 1 && bk == 1 && m4(K) && m4(am) && m4(bn) && al16(a) && al16(b) && N >= 256) {
     // few rows against a K-contiguous weight matrix: weight-stream kernel (one wave per 1 / 4 output columns)
     const bool wide = N >= 2048;
@@ -229,6 +262,26 @@ static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const 
     else { if (wide) ::vog::launch((skinny_f32_kernel<16, 2>), dim3(ceil_div(N, 8)), dim3(256), 0, st, p); else ::vog::launch((skinny_f32_kernel<16, 1>), grid, dim3(256), 0, st, p); }
     VOG_LAUNCH_CHECK();
     return 0;
+  }
+  const int tiles = ceil_div(N, 64) * ceil_div(M, 128);
+  if (batch == 1 && tiles <= 96 && K >= 1024) {
+    // few output tiles, long K (the weight gradients: K = rows of the batch): split K over the chip, fixed-order reduction
+    int S = 256 / tiles; if (S > K / 256) S = K / 256; if (S > 32) S = 32;
+    if (S >= 2) {
+      const int kchunk = ceil_div(ceil_div(K, S), 16) * 16;
+      S = ceil_div(K, kchunk);
+      float* part = splitk_scratch(st, (size_t)S * M * N * 4);
+      if (!part) VOG_FAIL(-3, "gemm_f32: no memory for %d split-K partials", S);
+      GemmF32 q = p;
+      q.c = part; q.ldc = N; q.bias = nullptr; q.relu = 0; q.accum = 0; q.kchunk = kchunk;
+      q.sa = (int64_t)kchunk * ak; q.sb = (int64_t)kchunk * bk; q.sc = (int64_t)M * N;
+      if (!(m4(q.sa) && m4(q.sb))) q.scalar = 1;
+      ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), S), dim3(256), 0, st, q);
+      ::vog::launch(splitk_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, (const float*)part, S, c, ldc,
+                    bias, relu, accum, M, N);
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
   }
   ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), batch), dim3(256), 0, st, p);
   VOG_LAUNCH_CHECK();
