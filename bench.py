@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="aql: one kernel per row (no lang/vis row sharing)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--set", action="append", metavar="OPTION=INT", help="vog_ctx_set_int switch (A/B measurements)")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the side measurement of the fp32 training step")
     ap.add_argument("--kernel-iters", type=int, default=100)
     ap.add_argument("--throughput-only", action="store_true",
@@ -335,6 +336,9 @@ def main():
     persistent = not args.lstm_steps and (args.mode != "aql" or
                                           max(1, args.queues) * max(1, args.interleave) <= 4)
     eng.set_option("lstm_persistent", int(persistent))
+    for kv in args.set or []:            # engine switches for A/B runs, e.g. --set fused_pred=0 (defaults are what `value` is for)
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     cfg_id = int(args.workload[3:])
     aql = args.mode == "aql"
 

@@ -228,6 +228,7 @@ int vog_residual_layernorm(const float* x, const float* gamma, const float* beta
  *   x1_scratch: vog_tx_tail_scratch_bytes(M, d) bytes (0 for d = 512), workgroup-private spill slab
  * Shapes: d in {512, 768}, dh = d/2 (vog_tx_tail_supported); other shapes use the unfused entries. */
 struct vog_score_args;
+struct vog_pred_args;
 typedef struct vog_tx_tail_args {
   const void* attn16; int kwo;
   const void* wo_p; const void* w1_p; const void* w2_p;
@@ -240,6 +241,11 @@ typedef struct vog_tx_tail_args {
   int head_dtype;                                /* vog_dtype of wl_p (VOG_F16) */
   float* x1_scratch;
   int M, d, dh; vog_dtype dtype;
+  /* round 3: with `score`, the prediction head (vog_pred_head) in the same launch: every workgroup writes its scores
+   * through and counts itself in at *pred_counter (one zeroed uint per launch); the workgroup that arrives last runs
+   * the head for the whole batch, reading mdl_outs_eval past L1 / L2 - nobody waits. pred->outs_eval must be
+   * score->outs_eval; not for sep / svsq (the head reads pred_cmp's fin_scores). Bit-identical to vog_pred_head. */
+  const struct vog_pred_args* pred; unsigned int* pred_counter;
 } vog_tx_tail_args;
 int vog_tx_tail_supported(int d, int dh, int kwo);
 int64_t vog_tx_tail_scratch_bytes(int M, int d);

@@ -191,6 +191,33 @@ def test_argvec_tail_equals_separate_launch(name, pair):
             assert torch.equal(a[k], b[k]), (name, k)
 
 
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8", "small/vog_spat",
+                                  "small/vog_temp"])
+def test_pred_head_in_score_tail_equals_separate_launch(name):
+    """fused_pred (off by default: measured no faster): the prediction head runs in the last mul_tx tail's launch - every workgroup writes its
+    scores through and counts itself in, the last one to arrive runs `pred_item` for the whole batch - vs the
+    stand-alone vog_pred_head launch: same device function -> bit-identical records, over replays (the counter is
+    re-zeroed by the prologue) and under a captured graph on 4 streams."""
+    if not os.path.exists(cases.golden_path(name)):
+        pytest.skip("no golden for " + name)
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("fused_pred", 0)
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("fused_pred", 1)
+    for _ in range(5):
+        b = eng.forward(dev)
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (name, k)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    slots = [eng.make_slot({k: v.cpu() for k, v in dev.items()}, graph=True) for _ in range(4)]
+    for it in range(200):
+        slots[it % 4].launch(streams[it % 4])
+    torch.cuda.synchronize()
+    for sl in slots:
+        assert torch.equal(sl.out["pred_rec"], a["pred_rec"]) and torch.equal(sl.out["mdl_outs_eval"], a["mdl_outs_eval"])
+
+
 @pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
                                   "full/cfg1_igrnd_spat_gt5_bs2"])
 def test_fused_lstm_input_projection_matches_separate_gemm(name):

@@ -4,6 +4,7 @@
 // restatements; only the MFMA contractions run in 16 bit).
 #include "common.h"
 #include "argvec_dev.h"
+#include "pred_dev.h"
 
 namespace vog {
 
@@ -432,66 +433,7 @@ __global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t
 }
 
 __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
-  // one thread per (query, arg, frame, video): arg-max over the proposals of that video's frame
-  // and the box gather; the thread of video 0 also does the pred_cmp arg-max over the videos
-  // (it re-reads the ncmp x nppf0 scores: all addresses are known up front, so the kernel is two
-  // dependent memory levels deep instead of 2 x ncmp)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int per_q = a.nsrl * a.nfrm0 * a.ncmp;
-  if (i >= a.B * per_q) return;
-  const int b = i / per_q, r = i % per_q;
-  const int arg = r / (a.nfrm0 * a.ncmp), f = (r / a.ncmp) % a.nfrm0, c = r % a.ncmp;
-  const int npv = a.nfrm0 * a.nppf0;
-  unsigned char* rec = reinterpret_cast<unsigned char*>(a.rec) + (int64_t)b * rec_bytes;
-  float* boxes = reinterpret_cast<float*>(rec);
-  float* scores = boxes + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 7;
-  int64_t* idx = reinterpret_cast<int64_t*>(rec + (int64_t)a.nsrl * a.ncmp * a.nfrm0 * 8 * 4);
-  auto first_prop = [&](int cc, int64_t* e0, int64_t* p0) {   // in outs_eval / in props
-    if (a.conc_type == VOG_CONC_SPAT) {
-      const int r0 = (f * a.ncmp + cc) * a.nppf0;
-      *e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
-      *p0 = (int64_t)b * a.ncmp * npv + r0;
-    } else if (a.conc_type == VOG_CONC_TEMP) {
-      const int r0 = (cc * a.nfrm0 + f) * a.nppf0;
-      *e0 = ((int64_t)b * a.nsrl + arg) * ((int64_t)a.ncmp * npv) + r0;
-      *p0 = (int64_t)b * a.ncmp * npv + r0;
-    } else {
-      *e0 = (((int64_t)b * a.ncmp + cc) * a.nsrl + arg) * npv + (int64_t)f * a.nppf0;
-      *p0 = ((int64_t)b * a.ncmp + cc) * npv + (int64_t)f * a.nppf0;
-    }
-  };
-  int64_t e0, p0;
-  first_prop(c, &e0, &p0);
-  float best = a.outs_eval[e0];
-  int bi = 0;
-  for (int k = 1; k < a.nppf0; ++k) {
-    const float v = a.outs_eval[e0 + k];
-    if (v > best) { best = v; bi = k; }          // first maximum wins (torch.max on CPU)
-  }
-  const int64_t o = ((int64_t)arg * a.ncmp + c) * a.nfrm0 + f;
-  const float* pr = a.props + (p0 + bi) * 7;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) boxes[o * 7 + k] = pr[k];
-  scores[o] = best;
-  if (c != 0) return;
-  int64_t out = 0;
-  if (a.conc_type == VOG_CONC_SPAT) {
-    float best_c = best;                         // video 0; first maximum over the videos
-    for (int cc = 1; cc < a.ncmp; ++cc) {
-      int64_t e1, p1;
-      first_prop(cc, &e1, &p1);
-      float bc = a.outs_eval[e1];
-      for (int k = 1; k < a.nppf0; ++k) bc = fmaxf(bc, a.outs_eval[e1 + k]);
-      if (bc > best_c) { best_c = bc; out = cc; }
-    }
-  } else if (a.conc_type == VOG_CONC_SEP) {
-    float bf = a.fin_scores[(int64_t)b * a.ncmp];
-    for (int cc = 1; cc < a.ncmp; ++cc) {
-      const float v = a.fin_scores[(int64_t)b * a.ncmp + cc];
-      if (v > bf) { bf = v; out = cc; }
-    }
-  }
-  idx[(int64_t)arg * a.nfrm0 + f] = out;
+  pred_item<false>(a, rec_bytes, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -95,6 +95,8 @@ struct vog_ctx {
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
+  int fused_pred = 0;                   // 1: the prediction head runs in the score tail's launch (its last workgroup; txtail_dev.h).
+                                        // Bit-identical and one launch less, but no faster (55.4 vs 55.8 k queries/s): off
   int fused_argvec = 0;                 // 1: argument vectors inside the language out-projection's launch (vog_argvec_tail): one
                                         // launch less, but the in-launch arrival wait costs more than the boundary it removes
                                         // (210.6 vs 205.2 us per forward, 72.6 vs 70.6 us per batch with 4 in flight): off
@@ -334,6 +336,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_sync_" + std::to_string(l), 1024);   // [2] timeout, [16 + 16 dir + xcc] workgroups arrived per XCC id
   }
   p.add("argvec_sync", 256);                          // arrival counter of the out-projection's argument-vector tail
+  p.add("pred_sync", 256);                            // arrival counter of the score tail's prediction head
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -405,7 +408,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
                      int npad, int spv, int n_box, float fdiv, int last_dt, std::vector<Step>& steps,
                      const float** out32, const void** out16,
                      const vog_vislang_args* structured = nullptr, const void* vis16 = nullptr,
-                     bool last_needs_f32 = true, const vog_score_args* score = nullptr) {
+                     bool last_needs_f32 = true, const vog_score_args* score = nullptr,
+                     const vog_pred_args* pred = nullptr, unsigned int* pred_counter = nullptr, bool* pred_done = nullptr) {
   const std::string n(nm);
   const vog_model_desc& d = c->d;
   const vog_dtype dt = (vog_dtype)d.tx_dtype;
@@ -479,10 +483,15 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       if (with_score) { sc = *score; ta.wl_p = c->w_lin2_p; ta.bl = c->b_lin2; ta.y32 = nullptr; ta.y16 = nullptr; }
       vog_vislang_args sv{};
       if (fact) sv = *structured;
+      // the prediction head rides in the score tail's launch (its last workgroup runs it): one launch less
+      const bool with_pred = with_score && pred && pred_counter;
+      vog_pred_args pr{};
+      if (with_pred) { pr = *pred; ta.pred_counter = pred_counter; if (pred_done) *pred_done = true; }
       steps.push_back({n + "_tail", [=](hipStream_t st) {
         vog_tx_tail_args t2 = ta;
         if (fact) t2.res_vislang = &sv;
         if (with_score) t2.score = &sc;
+        if (with_pred) t2.pred = &pr;
         return vog_tx_tail_fwd(&t2, st); }});
       if (with_score) *out16 = nullptr;            // tells the caller that lin2 + score already ran
       cur32 = o32;
@@ -813,10 +822,18 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   sa.n_vid = g.n_vid; sa.nfrm = g.nfrm; sa.nppf = g.nppf; sa.nsrl = d.nsrl; sa.dh = 256;
   sa.conc_type = d.conc_type; sa.ncmp = g.ncmp; sa.nc_v = g.nc_v; sa.nvl = g.nvl;
   sa.nfrm0 = d.nfrm0; sa.nppf0 = d.nppf0;
+  vog_pred_args pr{};
+  pr.outs_eval = b->mdl_outs_eval; pr.props = b->pad_proposals; pr.fin_scores = b->fin_scores;
+  pr.rec = b->pred_rec; pr.B = g.B; pr.ncmp = g.ncmp; pr.nsrl = d.nsrl; pr.nfrm0 = d.nfrm0;
+  pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
+  bool pred_done = false;
+  // (sep / svsq: the head reads fin_scores of pred_cmp, which runs after the tail; p100: the wave-per-item head)
+  const bool pred_in_tail = c->fused_pred && b->pred_rec && !g.sep && d.nppf0 < 32;
   if (has_mul(d))
     tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
              (float)g.nfrm, d.enc_dtype, steps, &x32, &x16, structured ? &va : nullptr, vis16,
-             /*last_needs_f32=*/false, d.enc_dtype == VOG_F16 ? &sa : nullptr);
+             /*last_needs_f32=*/false, d.enc_dtype == VOG_F16 ? &sa : nullptr,
+             pred_in_tail ? &pr : nullptr, pred_in_tail ? ws.at<unsigned int>("pred_sync") : nullptr, &pred_done);
   // ---- score head (a9 tail / a20 / a17); x16 == NULL: the fused mul_tx tail already ran it
   if (x16 != nullptr) {
     vog_gemm_args l2{}; l2.c16_dtype = -1;
@@ -839,13 +856,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     pa.NP = g.NP; pa.nfrm0 = d.nfrm0; pa.nppf0 = d.nppf0; pa.L = g.L; pa.dp0 = d.prop_enc; pa.dps = g.d_obj;
     steps.push_back({"pred_cmp", [=](hipStream_t st) { return vog_pred_cmp_head(&pa, st); }});
   }
-  if (b->pred_rec) {
-    vog_pred_args pr{};
-    pr.outs_eval = b->mdl_outs_eval; pr.props = b->pad_proposals; pr.fin_scores = b->fin_scores;
-    pr.rec = b->pred_rec; pr.B = g.B; pr.ncmp = g.ncmp; pr.nsrl = d.nsrl; pr.nfrm0 = d.nfrm0;
-    pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
+  if (b->pred_rec && !pred_done)
     steps.push_back({"pred_head", [=](hipStream_t st) { return vog_pred_head(&pr, st); }});
-  }
   // ---- horizontal fusion (pair.hip): the language chain and the visual chain are independent until
   // mul_tx's attention, and neither fills the chip (the persistent BiLSTM layer holds 64 CUs for
   // ~46 us): step i of one shares a launch with step i of the other. The visual step moves up to the
@@ -1342,6 +1354,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_argvec") == 0) { c->fused_argvec = value ? 1 : 0; return 0; }
+  if (strcmp(name, "fused_pred") == 0) { c->fused_pred = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }

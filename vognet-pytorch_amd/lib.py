@@ -119,7 +119,7 @@ class TxTailArgs(C.Structure):
                 ("ln1g", c_vp), ("ln1b", c_vp), ("b1", c_vp), ("b2", c_vp), ("ln2g", c_vp), ("ln2b", c_vp),
                 ("y32", c_vp), ("y16", c_vp), ("y16_dtype", c_i32), ("wl_p", c_vp), ("bl", c_vp),
                 ("score", c_vp), ("head_dtype", c_i32), ("x1_scratch", c_vp),
-                ("M", c_i32), ("d", c_i32), ("dh", c_i32), ("dtype", c_i32)]
+                ("M", c_i32), ("d", c_i32), ("dh", c_i32), ("dtype", c_i32), ("pred", c_vp), ("pred_counter", c_vp)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
