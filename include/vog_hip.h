@@ -607,6 +607,7 @@ typedef struct vog_lang_f32_args {
   float* g_w_ih[4][2]; float* g_w_hh[4][2]; float* g_b_ih[4][2]; float* g_b_hh[4][2];
   float *g_w_proj, *g_b_proj, *g_w_arg, *g_b_arg;
   void* scratch; size_t scratch_bytes;
+  float* hid_out;   /* optional [Bn, D]: lstm_out_feat_proj(final_hidden[-1]) - the verb feature of the sep head */
 } vog_lang_f32_args;
 int64_t vog_lang_f32_scratch_bytes(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L);
 int vog_lang_f32(const vog_lang_f32_args* a, void* stream);
@@ -628,6 +629,8 @@ int vog_score_head_f32(const float* y, const float* wl, const float* bl, const f
                        void* stream);
 int vog_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                  void* stream);
+/* out[g, n] = mean over f of x[g, f, n] (the segment mean of the sep verb head, code/mdl_conc_sep.py:64-129) */
+int vog_row_mean_f32(const float* x, float* out, int G, int F, int N, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole forward (replaces Conc{TEMP,SPAT,SEP}.forward + the evaluator head)

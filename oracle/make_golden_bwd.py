@@ -22,7 +22,7 @@ import torch
 from oracle import cases, ref_import
 from oracle.make_golden_loss import targets_for
 
-BWD_CASES = ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4"]
+BWD_CASES = ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16"]
 N_SAMPLE = 4096
 
 

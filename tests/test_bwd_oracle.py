@@ -13,7 +13,7 @@ from oracle import make_golden_bwd as mgb
 from oracle import vog_oracle as vo
 from oracle.make_golden_loss import targets_for
 
-CASES = [n for n in mgb.BWD_CASES if n.startswith("small/")] + ["full/cfg2_vog_spat_gt5_bs4"]
+CASES = [n for n in mgb.BWD_CASES if n.startswith("small/")] + ["full/cfg2_vog_spat_gt5_bs4", "full/cfg5_vog_svsq_gt5_bs16"]
 
 
 def check_fixture(g, key, got, tol=1e-3):
@@ -51,23 +51,28 @@ def test_oracle_autograd_equals_reference_autograd(name):
     res = vo.loss_forward(oc, out, inp, loss_lambda=float(cfg.loss.loss_lambda))
     assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     res["loss"].backward()
+    # bound, relative to each tensor's largest entry: 2e-4 for the small cases (measured 2e-7); 2e-3 at full size, where two
+    # fp32 computations with different summation orders (the reference's fused nn.LSTM / nn.Linear vs the oracle's loops)
+    # can put a ReLU pre-activation of ~1e-7 on either side of zero - one row's contribution to a weight gradient then
+    # differs (measured 6e-4 on linear1.weight at cfg 5, 2e-7 at cfg 2)
+    TOL = 2e-3 if name.startswith("full/") else 2e-4
     worst = 0.0
     for k, n in mgb.param_names(layer).items():
-        worst = max(worst, check_fixture(g, k, sdt[n].grad.numpy(), tol=2e-4))
+        worst = max(worst, check_fixture(g, k, sdt[n].grad.numpy(), tol=TOL))
     d = st["mul_tail_attn"].shape[-1]
-    worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=2e-4))
-    worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=2e-4))
+    worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=TOL))
+    worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=TOL))
     # every parameter the loss reaches, and the gradients at the seams between the pieces of the backward
     n_par = 0
     for key in g.files:
         if key.startswith("p:") and key.endswith("__shape"):
             n = key[2:-len("__shape")]
             assert sdt[n].grad is not None, n
-            worst = max(worst, check_fixture(g, "p:" + n, sdt[n].grad.numpy(), tol=2e-4))
+            worst = max(worst, check_fixture(g, "p:" + n, sdt[n].grad.numpy(), tol=TOL))
             n_par += 1
     assert n_par >= 50
     for seam, stage in seams.items():
         if ("d_" + seam + "__shape") in g.files:
             t = st[stage]
-            worst = max(worst, check_fixture(g, "d_" + seam, t.grad.reshape(-1, t.shape[-1]).numpy(), tol=2e-4))
+            worst = max(worst, check_fixture(g, "d_" + seam, t.grad.reshape(-1, t.shape[-1]).numpy(), tol=TOL))
     print(name, "worst relative error", worst, "parameters", n_par)

@@ -544,7 +544,7 @@ def test_device_full_backward_vs_reference_autograd(name):
     print(name, "worst relative gradient error", worst, "parameters", n_par)
 
 
-@pytest.mark.parametrize("name", ["small/vog_spat", "full/cfg2_vog_spat_gt5_bs4"])
+@pytest.mark.parametrize("name", ["small/vog_spat", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16"])
 def test_device_training_steps_vs_oracle_adam(name):
     """`FP32Trainer.step` x 3 on the device (fp32 forward with its own activations -> device loss -> loss gradient ->
     visual / language backward -> Adam, all C-ABI calls) against the same three steps on the CPU: autograd through
@@ -568,10 +568,16 @@ def test_device_training_steps_vs_oracle_adam(name):
     # pre-activation is ~1e-7 can land on the other side of zero, which moves one row's contribution to dW -
     # measured 9e-7 with the current summation order, 1.6e-3 with an earlier one)
     ref_outs = torch.from_numpy(np.load(cases.golden_path(name))["mdl_outs"])
-    outs = tr.forward(dev)[0].cpu()
+    fo = tr.forward(dev)[0]
+    outs = fo["mdl_outs"].cpu()
     assert float((outs - ref_outs).abs().max()) <= 1e-4 * float(ref_outs.abs().max())
+    if "vidf_outs" in fo:                                   # sep / svsq: the verb head's logits (reported as verb_loss)
+        ref_v = torch.from_numpy(np.load(cases.golden_path(name))["vidf_outs"])
+        assert float((fo["vidf_outs"].cpu() - ref_v).abs().max()) <= 1e-4 * max(1.0, float(ref_v.abs().max()))
     worst = max(check_fixture(g, "p:" + k, v.cpu().numpy(), tol=5e-3) for k, v in grads.items())
     assert len(grads) == 57
+    if "verb_loss" in ld:
+        assert float(ld["verb_loss"]) > 0
     dev_losses = [float(tr.step(dev)["loss"]) for _ in range(steps)]
     torch.cuda.synchronize()
     # CPU: oracle autograd + torch Adam

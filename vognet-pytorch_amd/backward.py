@@ -346,13 +346,14 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
     dobj = acts["obj_x"].shape[1]
     msk = acts["inds_msk"]
     d_ps, d_lang = conc_backward(d_mul, B, nc_v, nfrm, nppf, nsrl, dobj, inds_msk=msk, lang_per_vid=msk.shape[1] == nc_v and nc_v > 1)
+    S0 = B * nc_v
     out["_d_lang"] = d_lang
     out["_d_obj_out"] = d_ps
     if g["obj_layers"] > 0:
         if g["obj_one_frm"]:
-            S, N, fdiv = B * nc_v * nfrm, nppf, float(nfrm)
+            S, N, fdiv = S0 * nfrm, nppf, float(nfrm)
         else:
-            S, N, fdiv = B * nc_v, NP, 1.0
+            S, N, fdiv = S0, NP, 1.0
         ob = _Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
         r = stack_backward(state_dict, "obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", acts["obj_x"], S, N, N, g["obj_heads"], ob,
                            d_y=d_ps)
@@ -412,8 +413,9 @@ def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: 
             a.b_ih[l][dr], a.b_hh[l][dr] = L.ptr(w[f"bias_ih:{l}:{dr}"]), L.ptr(w[f"bias_hh:{l}:{dr}"])
     a.w_proj, a.b_proj, a.w_arg, a.b_arg = L.ptr(w["w_proj"]), L.ptr(w["b_proj"]), L.ptr(w["w_arg"]), L.ptr(w["b_arg"])
     out = {"_lang_enc": torch.empty(Bn * nsrl, Lo, dtype=torch.float32, device=dev),
-           "_full": torch.empty(Bn * T, D, dtype=torch.float32, device=dev)}
-    a.lang_enc_out, a.full_out = L.ptr(out["_lang_enc"]), L.ptr(out["_full"])
+           "_full": torch.empty(Bn * T, D, dtype=torch.float32, device=dev),
+           "_hid": torch.empty(Bn, D, dtype=torch.float32, device=dev)}
+    a.lang_enc_out, a.full_out, a.hid_out = L.ptr(out["_lang_enc"]), L.ptr(out["_full"]), L.ptr(out["_hid"])
     g = {}
     if d_lang_enc is not None:
         d_lang_enc = d_lang_enc.to(torch.float32).contiguous()

@@ -856,6 +856,8 @@ __global__ void lstm_cell_bwd_kernel(LstmStep a) {
 
 }  // namespace vog
 
+namespace vog { __global__ void concat_rows_kernel(const float* a, int Na, int rep_a, const float* b, int Nb, int rep_b, float* out, int M); }
+
 static int64_t lang_scratch_floats(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L) {
   const int64_t BT = (int64_t)Bn * T;
   const int64_t kin_max = E > 2 * R ? E : 2 * R;
@@ -946,6 +948,15 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   ::vog::launch(argvec_gather_kernel, blocks((int64_t)Bn * nsrl * 2 * D), dim3(256), 0, st, (const float*)full, a->capture, enc, Bn,
                 nsrl, T, D);
   VOG_TRY(gemm_f32(enc, 2 * D, 1, a->w_arg, 1, 2 * D, lenc, L, a->b_arg, 1, Bn * nsrl, L, 2 * D, st));
+  if (a->hid_out) {
+    // final_hidden = [h_fwd after the last valid step | h_bwd after its last step (position 0)] of the top layer: the state
+    // slot T (frozen past each sentence's length), then the same projection (code/mdl_vog.py:270-283)
+    float* fin = dpre2;                                                      // [Bn, 2R] (free until the backward)
+    VOG_CHECK_ARG((int64_t)Bn * 2 * R <= (int64_t)BT * D + (int64_t)G * R);   // dpre2 and whh_t are adjacent
+    ::vog::launch(concat_rows_kernel, blocks((int64_t)Bn * 2 * R), dim3(256), 0, st, (const float*)(hst[NL - 1][0] + (int64_t)T * Bn * R), R, 1,
+                  (const float*)(hst[NL - 1][1] + (int64_t)T * Bn * R), R, 1, fin, Bn);
+    VOG_TRY(gemm_f32(fin, 2 * R, 1, a->w_proj, 1, 2 * R, a->hid_out, D, a->b_proj, 1, Bn, D, 2 * R, st));
+  }
   if (a->lang_enc_out) VOG_HIP(hipMemcpyAsync(a->lang_enc_out, lenc, (size_t)Bn * nsrl * L * 4, hipMemcpyDeviceToDevice, st));
   if (a->full_out) VOG_HIP(hipMemcpyAsync(a->full_out, full, (size_t)BT * D * 4, hipMemcpyDeviceToDevice, st));
   if (!bwd) { VOG_LAUNCH_CHECK(); return 0; }
@@ -1043,6 +1054,17 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* h, const fl
   }
 }
 
+// out[g, n] = mean_f x[g, f, n]   (seg_feats.mean(dim=-2) of the sep verb head, code/mdl_conc_sep.py:64-129)
+__global__ void row_mean_kernel(const float* x, float* out, int G, int F, int N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)G * N) return;
+  const int n = (int)(i % N);
+  const int64_t g = i / N;
+  float s = 0.f;
+  for (int f = 0; f < F; ++f) s += x[(g * F + f) * N + n];
+  out[i] = s / (float)F;
+}
+
 // torch.optim.Adam (no weight decay, no amsgrad): the reference's optimizer, betas (0.9, 0.99) (code/main_dist.py:55)
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                             float bc1, float bc2_sqrt) {
@@ -1095,6 +1117,13 @@ extern "C" int vog_adam_f32(float* p, const float* g, float* m, float* v, int64_
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   ::vog::launch(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                 bc1, sqrtf(bc2));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vog_row_mean_f32(const float* x, float* out, int G, int F, int N, void* stream) {
+  VOG_CHECK_ARG(x && out && G > 0 && F > 0 && N > 0);
+  ::vog::launch(row_mean_kernel, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, G, F, N);
   VOG_LAUNCH_CHECK();
   return 0;
 }

@@ -211,7 +211,7 @@ class LangF32Args(C.Structure):
                 + [(n, c_vp) for n in ("w_proj", "b_proj", "w_arg", "b_arg", "d_lang_enc", "lang_enc_out", "full_out", "g_emb")]
                 + [("g_w_ih", _P42), ("g_w_hh", _P42), ("g_b_ih", _P42), ("g_b_hh", _P42)]
                 + [(n, c_vp) for n in ("g_w_proj", "g_b_proj", "g_w_arg", "g_b_arg", "scratch")]
-                + [("scratch_bytes", C.c_size_t)])
+                + [("scratch_bytes", C.c_size_t), ("hid_out", c_vp)])
 
 
 class AttnF32Args(C.Structure):
@@ -276,6 +276,7 @@ SYMBOLS = {
     "vog_conc_f32_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 8 + [c_vp]),
     "vog_score_head_f32": (c_i32, [c_vp] * 7 + [C.c_size_t] + [c_i32] * 7 + [c_vp]),
     "vog_adam_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, c_vp]),
+    "vog_row_mean_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_bilstm_layer": (c_i32, [C.POINTER(LstmLayerArgs), c_vp]),
     "vog_lstm_schedule": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),

@@ -34,8 +34,8 @@ class FP32Trainer:
         self.lib = L.load()
         self.cfg, self.loss_fn = cfg, loss_fn
         d = model_desc_from_cfg(cfg, comm)
-        if cfg.mdl.name != "vog" or cfg.ds.conc_type not in ("temp", "spat"):
-            raise NotImplementedError("the device training step covers mdl.name = vog with conc_type temp / spat")
+        if cfg.mdl.name != "vog":
+            raise NotImplementedError("the device training step covers mdl.name = vog (every conc_type); igrnd / vgrnd have no mul_tx")
         self.desc = d
         self.dev = torch.device(device)
         self.params = {k: v.detach().to(self.dev, torch.float32).contiguous().clone() for k, v in state_dict.items()
@@ -52,11 +52,14 @@ class FP32Trainer:
         d = self.desc
         B = batch["srl_arg_words_ind"].shape[0]
         ncmp = batch["num_cmp_msk"].shape[1]
+        nc_v = 1
         if self.cfg.ds.conc_type == "temp":
             nfrm, nppf = ncmp * d.nfrm0, d.nppf0
-        else:
+        elif self.cfg.ds.conc_type == "spat":
             nfrm, nppf = d.nfrm0, ncmp * d.nppf0
-        return dict(B=B, nc_v=1, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers, mul_heads=d.mul_heads,
+        else:                                           # sep / svsq: every video is its own sequence set (mdl_conc_sep.py:14-26)
+            nc_v, nfrm, nppf = ncmp, d.nfrm0, d.nppf0
+        return dict(B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers, mul_heads=d.mul_heads,
                     mul_use_rel=bool(d.mul_use_rel), obj_layers=d.obj_layers if d.obj_to_use else 0, obj_heads=d.obj_heads,
                     obj_use_rel=bool(d.obj_use_rel), obj_one_frm=bool(d.obj_one_frm), vid_w=d.vid_w, vid_h=d.vid_h)
 
@@ -66,52 +69,71 @@ class FP32Trainer:
         return x
 
     def forward(self, batch):
-        """fp32 forward on the device -> (mdl_outs [B, 1, nsrl, NP], activations at the seams of the backward)."""
+        """fp32 forward on the device -> ({'mdl_outs' [B, nc_v, nsrl, NP] (, 'vidf_outs' [B, ncmp])}, activations at the seams of
+        the backward, geometry)."""
         g = self._geo(batch)
         p, lib, st = self.params, self.lib, L.stream_ptr()
-        B, nfrm, nppf, nsrl = g["B"], g["nfrm"], g["nppf"], g["nsrl"]
+        B, nc_v, nfrm, nppf, nsrl = g["B"], g["nc_v"], g["nfrm"], g["nppf"], g["nsrl"]
         NP = nfrm * nppf
+        BV = B * nc_v                                                   # model "videos" (sequence sets)
         T = int(batch["srl_arg_word_mask_len"].max())
-        lang = BW.language_backward(p, batch, T, self.desc.rnn_layers)["_lang_enc"]
+        lf = BW.language_backward(p, batch, T, self.desc.rnn_layers)
+        lang = lf["_lang_enc"]
         f32 = lambda k: batch[k].to(self.dev, torch.float32)
-        prop_feat = f32("pad_region_feature").reshape(B * NP, -1).contiguous()
+        prop_feat = f32("pad_region_feature").reshape(BV * NP, -1).contiguous()
         seg_feat = f32("seg_feature_for_frms").reshape(-1, batch["seg_feature_for_frms"].shape[-1]).contiguous()
-        props = f32("pad_proposals").reshape(B * NP, -1).contiguous()
+        props = f32("pad_proposals").reshape(BV * NP, -1).contiguous()
         pe = BW.linear_f32(prop_feat, p["prop_encoder.0.weight"], p["prop_encoder.0.bias"], True)["y"]
         se = BW.linear_f32(seg_feat, p["seg_encoder.0.weight"], p["seg_encoder.0.bias"], True)["y"]
-        assert seg_feat.shape[0] * g["nppf0"] == B * NP
-        obj_x = torch.empty(B * NP, pe.shape[1] + se.shape[1], dtype=torch.float32, device=self.dev)
-        L.check(lib.vog_concat_rows_f32(L.ptr(pe), pe.shape[1], 1, L.ptr(se), se.shape[1], g["nppf0"], L.ptr(obj_x), B * NP, st),
+        assert seg_feat.shape[0] * g["nppf0"] == BV * NP
+        obj_x = torch.empty(BV * NP, pe.shape[1] + se.shape[1], dtype=torch.float32, device=self.dev)
+        L.check(lib.vog_concat_rows_f32(L.ptr(pe), pe.shape[1], 1, L.ptr(se), se.shape[1], g["nppf0"], L.ptr(obj_x), BV * NP, st),
                 "vog_concat_rows_f32")
         obj_out = obj_x
         if g["obj_layers"] > 0:
             if g["obj_one_frm"]:
-                S, N, fdiv = B * nfrm, nppf, float(nfrm)
+                S, N, fdiv = BV * nfrm, nppf, float(nfrm)
             else:
-                S, N, fdiv = B, NP, 1.0
+                S, N, fdiv = BV, NP, 1.0
             ob = BW._Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
             obj_out = self._stack_forward("obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", obj_x, S, N, N, g["obj_heads"], ob)
         msk = batch["srl_arg_inds_msk"].to(self.dev, torch.int64).contiguous()
+        nv = msk.shape[1]
+        assert nv in (1, nc_v), "language axis does not match conc_type"
+        lang_per_vid = 1 if (nv == nc_v and nc_v > 1) else 0
         dobj, dlang = obj_out.shape[1], lang.shape[1]
-        mul_x = torch.empty(B * nfrm * nsrl * nppf, dobj + dlang, dtype=torch.float32, device=self.dev)
-        L.check(lib.vog_conc_f32_fwd(L.ptr(obj_out), L.ptr(lang), L.ptr(msk), L.ptr(mul_x), B, 1, nfrm, nppf, nsrl, dobj, dlang, 0, st),
-                "vog_conc_f32_fwd")
+        mul_x = torch.empty(BV * nfrm * nsrl * nppf, dobj + dlang, dtype=torch.float32, device=self.dev)
+        L.check(lib.vog_conc_f32_fwd(L.ptr(obj_out), L.ptr(lang), L.ptr(msk), L.ptr(mul_x), B, nc_v, nfrm, nppf, nsrl, dobj, dlang,
+                                     lang_per_vid, st), "vog_conc_f32_fwd")
         mb = BW._Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
-        y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, B * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb)
+        y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb)
         M, dm = y.shape
         dhead = p["lin2.0.weight"].shape[0]
         scratch = torch.empty(M * dhead, dtype=torch.float32, device=self.dev)
-        outs = torch.empty(B, 1, nsrl, NP, dtype=torch.float32, device=self.dev)
+        outs = torch.empty(B, nc_v, nsrl, NP, dtype=torch.float32, device=self.dev)
         L.check(lib.vog_score_head_f32(L.ptr(y), L.ptr(p["lin2.0.weight"]), L.ptr(p["lin2.0.bias"]), L.ptr(p["lin2.2.weight"]),
-                                       L.ptr(p["lin2.2.bias"]), L.ptr(outs), L.ptr(scratch), scratch.numel() * 4, M, dm, dhead, B,
+                                       L.ptr(p["lin2.2.bias"]), L.ptr(outs), L.ptr(scratch), scratch.numel() * 4, M, dm, dhead, BV,
                                        nfrm, nppf, nsrl, st), "vog_score_head_f32")
+        out = {"mdl_outs": outs}
+        if self.cfg.ds.conc_type in ("sep", "svsq"):
+            # verb head (mdl_conc_sep.py:64-129): reported by LossB_SEP as verb_loss; the reference's `loss` does not include
+            # it (`out_loss = mdl_out_loss`, mdl_conc_sep.py:434-436), so nothing flows back through it
+            hid = lf["_hid"]                                            # [B*nv, D]
+            Fv = seg_feat.shape[0] // BV
+            seg_mean = torch.empty(BV, se.shape[1], dtype=torch.float32, device=self.dev)
+            L.check(lib.vog_row_mean_f32(L.ptr(se), L.ptr(seg_mean), BV, Fv, se.shape[1], st), "vog_row_mean_f32")
+            sv = torch.empty(BV, hid.shape[1] + se.shape[1], dtype=torch.float32, device=self.dev)
+            L.check(lib.vog_concat_rows_f32(L.ptr(hid), hid.shape[1], 1 if nv == nc_v else nc_v, L.ptr(seg_mean), se.shape[1], 1,
+                                            L.ptr(sv), BV, st), "vog_concat_rows_f32")
+            h1 = BW.linear_f32(sv, p["seg_verb_classf.0.weight"], p["seg_verb_classf.0.bias"], True)["y"]
+            out["vidf_outs"] = BW.linear_f32(h1, p["seg_verb_classf.2.weight"], p["seg_verb_classf.2.bias"], False)["y"].reshape(B, nc_v)
         acts = {"mul_x": mul_x, "obj_x": obj_x, "prop_feat": prop_feat, "seg_feat": seg_feat, "props": props, "inds_msk": msk, "T": T}
-        return outs, acts, g
+        return out, acts, g
 
     def gradients(self, batch):
         """-> (loss dict, {parameter name: gradient}) of one batch (no update)."""
-        outs, acts, g = self.forward(batch)
-        ld = self.loss_fn({"mdl_outs": outs}, batch)
+        out, acts, g = self.forward(batch)
+        ld = self.loss_fn(out, batch)
         d_outs = self.loss_fn.backward(ld)
         grads = BW.visual_backward(self.params, g, acts, d_outs)
         lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"])
