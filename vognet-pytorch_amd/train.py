@@ -12,7 +12,8 @@ libvog_hip.so; torch tensors are device containers.
 This is the fp32 path that pins the MATH against autograd through the reference (every parameter gradient, three
 Adam steps); it shares no kernel with the 16-bit inference forward and is not tuned (one GEMM per BiLSTM time step).
 Not built: dropout (the reference trains with p = 0.1 masks drawn from torch's generator - a step here equals the
-reference's with the model in eval mode), the sep / svsq verb head, the igrnd / vgrnd variants.
+reference's with the model in eval mode), the igrnd / vgrnd variants. For sep / svsq the verb head runs forward only:
+the reference's `loss` excludes verb_loss (code/mdl_conc_sep.py:434-436).
 """
 from __future__ import annotations
 
