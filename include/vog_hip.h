@@ -629,6 +629,12 @@ int vog_score_head_f32(const float* y, const float* wl, const float* bl, const f
                        void* stream);
 int vog_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                  void* stream);
+/* Backward of vog_score_head_f32 alone (ImgGrnd / VidGrnd: lin2 reads the [vis | lang] token matrix directly,
+ * code/mdl_vog.py:224-230, 286-344): g_wl [dhead, d], g_bl [dhead], g_wl2 [dhead], g_bl2 [1], d_x [M, d] (optional). */
+int64_t vog_score_head_f32_bwd_scratch_bytes(int M, int d, int dhead);
+int vog_score_head_f32_bwd(const float* x, const float* d_mdl_outs, const float* wl, const float* bl, const float* wl2,
+                           float* g_wl, float* g_bl, float* g_wl2, float* g_bl2, float* d_x, void* scratch, size_t scratch_bytes,
+                           int M, int d, int dhead, int n_vid, int nfrm, int nppf, int nsrl, void* stream);
 /* out[g, n] = mean over f of x[g, f, n] (the segment mean of the sep verb head, code/mdl_conc_sep.py:64-129) */
 int vog_row_mean_f32(const float* x, float* out, int G, int F, int N, void* stream);
 

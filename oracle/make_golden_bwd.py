@@ -22,7 +22,8 @@ import torch
 from oracle import cases, ref_import
 from oracle.make_golden_loss import targets_for
 
-BWD_CASES = ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16"]
+BWD_CASES = ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16",
+             "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2"]
 N_SAMPLE = 4096
 
 
@@ -62,8 +63,9 @@ def reference_grads(name: str):
     mdl = ref_import.build_model(cfg, c["vocab"], c["nppf0"], sd)
     for p in mdl.parameters():
         p.requires_grad_(True)
-    layer = len(mdl.mult_txf.encoder.layers) - 1
-    last = mdl.mult_txf.encoder.layers[layer]
+    has_mul = hasattr(mdl, "mult_txf")
+    layer = len(mdl.mult_txf.encoder.layers) - 1 if has_mul else 0
+    last = mdl.mult_txf.encoder.layers[layer] if has_mul else None
     cap = {}
 
     def keep(nm):
@@ -77,10 +79,12 @@ def reference_grads(name: str):
                 cap[nm] = out
                 out.retain_grad()
         return fn
-    hs = [last.selfattn.layer.wo.register_forward_pre_hook(keep("attn")),       # the concatenated heads
-          last.selfattn.layernorm.register_forward_pre_hook(keep("t")),         # x + attn Wo^T
-          last.register_forward_pre_hook(keep("mul_in"))]                       # the layer input (both paths)
-    has_obj = hasattr(mdl, "obj_txf") and cfg.mdl.name in ("vog_grnd", "vid_grnd", "vog", "vgrnd") and len(mdl.obj_txf.encoder.layers) > 0
+    hs = []
+    if has_mul:
+        hs = [last.selfattn.layer.wo.register_forward_pre_hook(keep("attn")),       # the concatenated heads
+              last.selfattn.layernorm.register_forward_pre_hook(keep("t")),         # x + attn Wo^T
+              last.register_forward_pre_hook(keep("mul_in"))]                       # the layer input (both paths)
+    has_obj = hasattr(mdl, "obj_txf") and cfg.mdl.name in ("vog", "vgrnd") and len(mdl.obj_txf.encoder.layers) > 0
     if has_obj:
         ol = mdl.obj_txf.encoder.layers[len(mdl.obj_txf.encoder.layers) - 1]
         hs += [ol.selfattn.layer.wo.register_forward_pre_hook(keep("obj_attn")),
@@ -110,9 +114,10 @@ def reference_grads(name: str):
         for h in hs:
             h.remove()
     params = dict(mdl.named_parameters())
-    grads = {k: params[n].grad.detach().numpy() for k, n in param_names(layer).items()}
-    grads["d_attn"] = cap["attn"].grad.detach().reshape(-1, cap["attn"].shape[-1]).numpy()
-    grads["d_x"] = cap["t"].grad.detach().reshape(-1, cap["t"].shape[-1]).numpy()
+    grads = {k: params[n].grad.detach().numpy() for k, n in param_names(layer).items() if n in params and params[n].grad is not None}
+    if "attn" in cap and cap["attn"].grad is not None:       # (ImgGrnd / VidGrnd have no mul_tx: these hooks never fire)
+        grads["d_attn"] = cap["attn"].grad.detach().reshape(-1, cap["attn"].shape[-1]).numpy()
+        grads["d_x"] = cap["t"].grad.detach().reshape(-1, cap["t"].shape[-1]).numpy()
     # round 3, second slice onwards: every parameter the loss reaches ("p:<name>") and the gradients at the
     # seams between the pieces of the backward ("d_<seam>", rows x features)
     for n, p_ in params.items():

@@ -13,7 +13,7 @@ from oracle import make_golden_bwd as mgb
 from oracle import vog_oracle as vo
 from oracle.make_golden_loss import targets_for
 
-CASES = [n for n in mgb.BWD_CASES if n.startswith("small/")] + ["full/cfg2_vog_spat_gt5_bs4", "full/cfg5_vog_svsq_gt5_bs16"]
+CASES = list(mgb.BWD_CASES)
 
 
 def check_fixture(g, key, got, tol=1e-3):
@@ -58,10 +58,12 @@ def test_oracle_autograd_equals_reference_autograd(name):
     TOL = 2e-3 if name.startswith("full/") else 2e-4
     worst = 0.0
     for k, n in mgb.param_names(layer).items():
-        worst = max(worst, check_fixture(g, k, sdt[n].grad.numpy(), tol=TOL))
-    d = st["mul_tail_attn"].shape[-1]
-    worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=TOL))
-    worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=TOL))
+        if (k + "__shape") in g.files:                       # (ImgGrnd / VidGrnd: no mul_tx layer, lin2 only)
+            worst = max(worst, check_fixture(g, k, sdt[n].grad.numpy(), tol=TOL))
+    if "mul_tail_attn" in st:
+        d = st["mul_tail_attn"].shape[-1]
+        worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=TOL))
+        worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=TOL))
     # every parameter the loss reaches, and the gradients at the seams between the pieces of the backward
     n_par = 0
     for key in g.files:
@@ -70,7 +72,7 @@ def test_oracle_autograd_equals_reference_autograd(name):
             assert sdt[n].grad is not None, n
             worst = max(worst, check_fixture(g, "p:" + n, sdt[n].grad.numpy(), tol=TOL))
             n_par += 1
-    assert n_par >= 50
+    assert n_par == {"vog": 57, "vgrnd": 43, "igrnd": 29}[cfg.mdl.name], n_par
     for seam, stage in seams.items():
         if ("d_" + seam + "__shape") in g.files:
             t = st[stage]

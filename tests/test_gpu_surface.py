@@ -544,7 +544,8 @@ def test_device_full_backward_vs_reference_autograd(name):
     print(name, "worst relative gradient error", worst, "parameters", n_par)
 
 
-@pytest.mark.parametrize("name", ["small/vog_spat", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16"])
+@pytest.mark.parametrize("name", ["small/vog_spat", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16",
+                                  "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2"])
 def test_device_training_steps_vs_oracle_adam(name):
     """`FP32Trainer.step` x 3 on the device (fp32 forward with its own activations -> device loss -> loss gradient ->
     visual / language backward -> Adam, all C-ABI calls) against the same three steps on the CPU: autograd through
@@ -575,7 +576,7 @@ def test_device_training_steps_vs_oracle_adam(name):
         ref_v = torch.from_numpy(np.load(cases.golden_path(name))["vidf_outs"])
         assert float((fo["vidf_outs"].cpu() - ref_v).abs().max()) <= 1e-4 * max(1.0, float(ref_v.abs().max()))
     worst = max(check_fixture(g, "p:" + k, v.cpu().numpy(), tol=5e-3) for k, v in grads.items())
-    assert len(grads) == 57
+    assert len(grads) == {"vog": 57, "vgrnd": 43, "igrnd": 29}[cfg.mdl.name]
     if "verb_loss" in ld:
         assert float(ld["verb_loss"]) > 0
     dev_losses = [float(tr.step(dev)["loss"]) for _ in range(steps)]

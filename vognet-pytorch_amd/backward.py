@@ -322,6 +322,25 @@ def stack_backward(state_dict, stack: str, n_layers: int, pe_name, x0: torch.Ten
     return grads
 
 
+def score_head_backward(state_dict, x: torch.Tensor, d_mdl_outs: torch.Tensor, n_vid: int, nfrm: int, nppf: int, nsrl: int):
+    """lin2 alone (`vog_score_head_f32_bwd`) -> (d_x [M, d], {lin2.* gradients})."""
+    lib = L.load()
+    dev = x.device
+    M, d = x.shape
+    hn = {"wl": "lin2.0.weight", "bl": "lin2.0.bias", "wl2": "lin2.2.weight", "bl2": "lin2.2.bias"}
+    w = _f32(state_dict, hn, dev)
+    dhead = w["wl"].shape[0]
+    g = {k: torch.empty_like(v) for k, v in w.items()}
+    d_x = torch.empty_like(x)
+    nb = int(lib.vog_score_head_f32_bwd_scratch_bytes(M, d, dhead))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dmo = d_mdl_outs.to(torch.float32).contiguous()
+    L.check(lib.vog_score_head_f32_bwd(L.ptr(x.contiguous()), L.ptr(dmo), L.ptr(w["wl"]), L.ptr(w["bl"]), L.ptr(w["wl2"]),
+                                       L.ptr(g["wl"]), L.ptr(g["bl"]), L.ptr(g["wl2"]), L.ptr(g["bl2"]), L.ptr(d_x), L.ptr(scratch), nb,
+                                       M, d, dhead, n_vid, nfrm, nppf, nsrl, L.stream_ptr()), "vog_score_head_f32_bwd")
+    return d_x, {hn[k]: v for k, v in g.items()}
+
+
 def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor) -> Dict[str, torch.Tensor]:
     """The visual side of the network behind the loss gradient, on the device in fp32:
 
@@ -338,14 +357,21 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
     NP = nfrm * nppf
     out: Dict[str, torch.Tensor] = {}
     props = acts["props"]
-    mb = _Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
-    r = stack_backward(state_dict, "mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", acts["mul_x"], B * nc_v * nfrm, nsrl * nppf,
-                       nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl))
-    d_mul = r.pop("_d_x")
-    out.update(r)
+    if g["mul_layers"] > 0:
+        mb = _Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
+        r = stack_backward(state_dict, "mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", acts["mul_x"], B * nc_v * nfrm, nsrl * nppf,
+                           nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl))
+        d_mul = r.pop("_d_x")
+        out.update(r)
+    else:
+        # ImgGrnd / VidGrnd: lin2 reads the [vis | lang] tokens directly (rows (video, arg, proposal): nfrm = 1, nppf = NP)
+        d_mul, hg = score_head_backward(state_dict, acts["mul_x"], d_mdl_outs, B * nc_v, 1, NP, nsrl)
+        out.update(hg)
+        nfrm, nppf = 1, NP
     dobj = acts["obj_x"].shape[1]
     msk = acts["inds_msk"]
     d_ps, d_lang = conc_backward(d_mul, B, nc_v, nfrm, nppf, nsrl, dobj, inds_msk=msk, lang_per_vid=msk.shape[1] == nc_v and nc_v > 1)
+    nfrm, nppf = g["nfrm"], g["nppf"]
     S0 = B * nc_v
     out["_d_lang"] = d_lang
     out["_d_obj_out"] = d_ps

@@ -1127,3 +1127,31 @@ extern "C" int vog_row_mean_f32(const float* x, float* out, int G, int F, int N,
   VOG_LAUNCH_CHECK();
   return 0;
 }
+
+// lin2 alone (ImgGrnd / VidGrnd: the score head reads the [vis | lang] token matrix directly, code/mdl_vog.py:224-230,
+// 286-344): gradients of lin2.{0,2} and of its input. x [M, d], rows ((video, frame), (arg, p)) as vog_score_head_f32
+// (frame-free models: nfrm = 1, nppf = NP). scratch >= 4 * M * dhead * 4 + 64 * max(d, dhead) * 4 + 4 * M bytes.
+extern "C" int64_t vog_score_head_f32_bwd_scratch_bytes(int M, int d, int dhead) {
+  if (M <= 0 || d <= 0 || dhead <= 0) return -1;
+  return ((int64_t)3 * M * dhead + (int64_t)CS_CHUNKS * (d > dhead ? d : dhead) + M + 1024) * 4;
+}
+extern "C" int vog_score_head_f32_bwd(const float* x, const float* d_mdl_outs, const float* wl, const float* bl, const float* wl2,
+                                      float* g_wl, float* g_bl, float* g_wl2, float* g_bl2, float* d_x, void* scratch,
+                                      size_t scratch_bytes, int M, int d, int dhead, int n_vid, int nfrm, int nppf, int nsrl, void* stream) {
+  VOG_CHECK_ARG(x && d_mdl_outs && wl && bl && wl2 && g_wl && g_bl && g_wl2 && g_bl2 && scratch && M == n_vid * nfrm * nppf * nsrl);
+  if ((int64_t)scratch_bytes < vog_score_head_f32_bwd_scratch_bytes(M, d, dhead)) VOG_FAIL(-2, "vog_score_head_f32_bwd: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* s = (float*)scratch;
+  float *h = s, *dh = h + (int64_t)M * dhead, *hw = dh + (int64_t)M * dhead, *dlog = hw + (int64_t)M * dhead;
+  float* part = dlog + (M + 3) / 4 * 4;
+  VOG_TRY(gemm_f32(x, d, 1, wl, 1, d, h, dhead, bl, 1, M, dhead, d, st));
+  ScoreBwd sb{d_mdl_outs, h, wl2, dh, hw, dlog, M, nfrm, nppf, nsrl, dhead};
+  ::vog::launch(score_bwd_kernel, dim3(M), dim3(256), 0, st, sb);
+  VOG_TRY(colsum(hw, g_wl2, part, M, dhead, st));
+  VOG_TRY(colsum(dlog, g_bl2, part, M, 1, st));
+  VOG_TRY(gemm_f32(dh, 1, dhead, x, d, 1, g_wl, d, nullptr, 0, dhead, d, M, st));
+  VOG_TRY(colsum(dh, g_bl, part, M, dhead, st));
+  if (d_x) VOG_TRY(gemm_f32(dh, dhead, 1, wl, d, 1, d_x, d, nullptr, 0, M, d, dhead, st));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}

@@ -11,8 +11,8 @@ libvog_hip.so; torch tensors are device containers.
 
 This is the fp32 path that pins the MATH against autograd through the reference (every parameter gradient, three
 Adam steps); it shares no kernel with the 16-bit inference forward and is not tuned (one GEMM per BiLSTM time step).
-Not built: dropout (the reference trains with p = 0.1 masks drawn from torch's generator - a step here equals the
-reference's with the model in eval mode), the igrnd / vgrnd variants. For sep / svsq the verb head runs forward only:
+Covers ImgGrnd / VidGrnd / VOGNet with every conc_type. Not built: dropout (the reference trains with p = 0.1 masks drawn
+from torch's generator - a step here equals the reference's with the model in eval mode). For sep / svsq the verb head runs forward only:
 the reference's `loss` excludes verb_loss (code/mdl_conc_sep.py:434-436).
 """
 from __future__ import annotations
@@ -35,8 +35,8 @@ class FP32Trainer:
         self.lib = L.load()
         self.cfg, self.loss_fn = cfg, loss_fn
         d = model_desc_from_cfg(cfg, comm)
-        if cfg.mdl.name != "vog":
-            raise NotImplementedError("the device training step covers mdl.name = vog (every conc_type); igrnd / vgrnd have no mul_tx")
+        if cfg.mdl.name not in ("vog", "vgrnd", "igrnd"):
+            raise NotImplementedError(f"no device training step for mdl.name = {cfg.mdl.name}")
         self.desc = d
         self.dev = torch.device(device)
         self.params = {k: v.detach().to(self.dev, torch.float32).contiguous().clone() for k, v in state_dict.items()
@@ -60,8 +60,10 @@ class FP32Trainer:
             nfrm, nppf = d.nfrm0, ncmp * d.nppf0
         else:                                           # sep / svsq: every video is its own sequence set (mdl_conc_sep.py:14-26)
             nc_v, nfrm, nppf = ncmp, d.nfrm0, d.nppf0
-        return dict(B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers, mul_heads=d.mul_heads,
-                    mul_use_rel=bool(d.mul_use_rel), obj_layers=d.obj_layers if d.obj_to_use else 0, obj_heads=d.obj_heads,
+        name = self.cfg.mdl.name                       # ImgGrnd: encoders + lin2; VidGrnd: + obj_tx; VOGNet: + mul_tx (mdl_vog.py:286-744)
+        has_obj = name == "vgrnd" or (name == "vog" and d.obj_to_use)
+        return dict(B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers if name == "vog" else 0,
+                    mul_heads=d.mul_heads, mul_use_rel=bool(d.mul_use_rel), obj_layers=d.obj_layers if has_obj else 0, obj_heads=d.obj_heads,
                     obj_use_rel=bool(d.obj_use_rel), obj_one_frm=bool(d.obj_one_frm), vid_w=d.vid_w, vid_h=d.vid_h)
 
     def _stack_forward(self, stack, n_layers, pe_name, x, S, N, n, heads, boxes):
@@ -103,18 +105,22 @@ class FP32Trainer:
         assert nv in (1, nc_v), "language axis does not match conc_type"
         lang_per_vid = 1 if (nv == nc_v and nc_v > 1) else 0
         dobj, dlang = obj_out.shape[1], lang.shape[1]
+        # the [vis | lang] tokens: regrouped per frame for mul_tx, in (video, arg, proposal) order when lin2 reads them directly
+        hf, hp = (nfrm, nppf) if g["mul_layers"] > 0 else (1, NP)
         mul_x = torch.empty(BV * nfrm * nsrl * nppf, dobj + dlang, dtype=torch.float32, device=self.dev)
-        L.check(lib.vog_conc_f32_fwd(L.ptr(obj_out), L.ptr(lang), L.ptr(msk), L.ptr(mul_x), B, nc_v, nfrm, nppf, nsrl, dobj, dlang,
+        L.check(lib.vog_conc_f32_fwd(L.ptr(obj_out), L.ptr(lang), L.ptr(msk), L.ptr(mul_x), B, nc_v, hf, hp, nsrl, dobj, dlang,
                                      lang_per_vid, st), "vog_conc_f32_fwd")
-        mb = BW._Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
-        y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb)
+        y = mul_x
+        if g["mul_layers"] > 0:
+            mb = BW._Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
+            y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb)
         M, dm = y.shape
         dhead = p["lin2.0.weight"].shape[0]
         scratch = torch.empty(M * dhead, dtype=torch.float32, device=self.dev)
         outs = torch.empty(B, nc_v, nsrl, NP, dtype=torch.float32, device=self.dev)
         L.check(lib.vog_score_head_f32(L.ptr(y), L.ptr(p["lin2.0.weight"]), L.ptr(p["lin2.0.bias"]), L.ptr(p["lin2.2.weight"]),
                                        L.ptr(p["lin2.2.bias"]), L.ptr(outs), L.ptr(scratch), scratch.numel() * 4, M, dm, dhead, BV,
-                                       nfrm, nppf, nsrl, st), "vog_score_head_f32")
+                                       hf, hp, nsrl, st), "vog_score_head_f32")
         out = {"mdl_outs": outs}
         if self.cfg.ds.conc_type in ("sep", "svsq"):
             # verb head (mdl_conc_sep.py:64-129): reported by LossB_SEP as verb_loss; the reference's `loss` does not include
