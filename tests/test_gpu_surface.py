@@ -545,7 +545,8 @@ def test_device_full_backward_vs_reference_autograd(name):
 
 
 @pytest.mark.parametrize("name", ["small/vog_spat", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16",
-                                  "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2"])
+                                  "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2",
+                                  "full/cfg2_ragged", "small/vog_sep_cmpmsk"])
 def test_device_training_steps_vs_oracle_adam(name):
     """`FP32Trainer.step` x 3 on the device (fp32 forward with its own activations -> device loss -> loss gradient ->
     visual / language backward -> Adam, all C-ABI calls) against the same three steps on the CPU: autograd through
