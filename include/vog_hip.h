@@ -530,6 +530,10 @@ typedef struct vog_tail_bwd_args {
    * y_out (optional, any mode) receives the layer's fp32 output; no_head with d_y == NULL recomputes the forward
    * only (y_out required, no gradient is written). */
   int no_head; const float* d_y; float* y_out;
+  /* train-mode dropout of the two sub-layer outputs (ResidualBlock: x + dropout(layer(x)), transformer_code.py:31):
+   * probability drop_p (0 = off), masks from the counter-based generator of csrc/backward.hip (seed, sites drop_site + 1
+   * and drop_site + 2, element = row * d + column); forward recomputation and backward use the same masks. */
+  float drop_p; unsigned long long drop_seed; int drop_site;
 } vog_tail_bwd_args;
 int64_t vog_mul_tail_bwd_scratch_bytes(int M, int d, int dh, int dhead);
 int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream);
@@ -554,6 +558,9 @@ typedef struct vog_attn_f32_args {
   float* d_x; int accumulate_dx;
   void* scratch; size_t scratch_bytes;
   int S, N, n, d, n_heads;
+  /* train-mode dropout on the attention probabilities (transformer_code.py:50, 153): element ((s*H + h)*N + i)*N + j of
+   * site drop_site; 0 = off */
+  float drop_p; unsigned long long drop_seed; int drop_site;
 } vog_attn_f32_args;
 int64_t vog_attn_f32_scratch_bytes(int S, int N, int n, int d);
 int vog_attn_f32(const vog_attn_f32_args* a, void* stream);
@@ -608,6 +615,9 @@ typedef struct vog_lang_f32_args {
   float *g_w_proj, *g_b_proj, *g_w_arg, *g_b_arg;
   void* scratch; size_t scratch_bytes;
   float* hid_out;   /* optional [Bn, D]: lstm_out_feat_proj(final_hidden[-1]) - the verb feature of the sep head */
+  /* train-mode dropout of LSTMEncoder (utils/mdl_srl_utils.py:104, 128, 150): drop_in on the embedded tokens (site 1),
+   * drop_out behind every BiLSTM layer (site 2 + l between layers, 10 on the output); 0 = off */
+  float drop_in, drop_out; unsigned long long drop_seed;
 } vog_lang_f32_args;
 int64_t vog_lang_f32_scratch_bytes(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L);
 int vog_lang_f32(const vog_lang_f32_args* a, void* stream);

@@ -77,6 +77,36 @@ def _q(quant, scope, *xs):
 # --------------------------------------------------------------------------- #
 # language side
 # --------------------------------------------------------------------------- #
+def drop_mask(seed: int, site: int, shape, p: float) -> torch.Tensor:
+    """Dropout multipliers (0 or 1 / (1 - p)) of the counter-based generator the DEVICE training path uses
+    (csrc/backward.hip::drop_scale): element idx (row-major) of site `site` is kept iff the top 32 bits of
+    splitmix64(seed * 0x9E3779B97F4A7C15 + site * 0xBF58476D1CE4E5B9 + idx) are >= p * 2^32. The reference draws its masks
+    from torch's generator (nn.Dropout / F.dropout, transformer_code.py:26-50, utils/mdl_srl_utils.py:128-150), which no
+    other implementation can reproduce; with THESE masks the oracle's autograd is what the device must equal."""
+    import numpy as np
+    n = int(np.prod(shape))
+    p32 = float(np.float32(p))
+    thr = np.uint64(int(p32 * 4294967296.0))
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(site) * np.uint64(0xBF58476D1CE4E5B9)
+             + np.arange(n, dtype=np.uint64))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    keep = (z >> np.uint64(32)) >= thr
+    inv = np.float32(1.0 / (1.0 - p32))
+    return torch.from_numpy(np.where(keep, inv, np.float32(0)).astype(np.float32).reshape(shape))
+
+
+# dropout sites (the same numbers in vognet-pytorch_amd/train.py): language 1 = embeddings, 2 + l = behind BiLSTM layer l
+# (inter-layer dropout of nn.LSTM), 10 = LSTM output; transformer stack k (1 = obj_tx, 2 = mul_tx), layer l: 100 k + 10 l + {0: attention
+# probabilities [S, H, N, N], 1: the attention sub-layer's output, 2: the feed-forward sub-layer's output}
+def _drop(drop, site, x, p):
+    if drop is None or p <= 0.0:
+        return x
+    return x * drop_mask(drop, site, x.shape, p)
+
+
 def srl_arg_seq_to_sent_seq(words_ind, word_mask, vocab_size):
     """Token re-index (reference mdl_vog.py:67-95).
     tok[b,t] = words[b, m[b,t]] if m[b,t] >= 0 else V. Does NOT mutate inputs."""
@@ -115,13 +145,13 @@ def _lstm_dir(xg, w_hh, lens, reverse, quant):
     return out, h
 
 
-def lstm_encoder(tokens, lens, sd, num_layers, quant=None):
+def lstm_encoder(tokens, lens, sd, num_layers, quant=None, drop=None, p_in=0.1, p_out=0.1):
     """Embedding + packed multi-layer BiLSTM (reference
     utils/mdl_srl_utils.py:114-169).
     Returns (x [Bn,T,2R] zero past each length, final_hidden_last [Bn,2R] =
     [h_fwd(last valid) || h_bwd(step 0)] of the top layer)."""
     emb = sd["lstm_encoder.embed_tokens.weight"]
-    x = emb[tokens]                                          # [Bn,T,E]
+    x = _drop(drop, 1, emb[tokens], p_in)                    # [Bn,T,E]   (F.dropout(x, dropout_in), mdl_srl_utils.py:128)
     hf = hb = None
     for l in range(num_layers):
         outs = []
@@ -139,6 +169,8 @@ def lstm_encoder(tokens, lens, sd, num_layers, quant=None):
             else:
                 hf = h
         x = torch.cat(outs, dim=2)
+        # nn.LSTM(dropout=dropout_out) between the layers, F.dropout(x, dropout_out) on the output (mdl_srl_utils.py:104,150)
+        x = _drop(drop, 2 + l if l < num_layers - 1 else 10, x, p_out)
     return x, torch.cat([hf, hb], dim=1)
 
 
@@ -151,11 +183,11 @@ def linear(x, sd, name, relu=False, quant=None, scope="enc"):
     return torch.relu(y) if relu else y
 
 
-def lang_encode(tokens, lens, sd, num_layers, quant=None):
+def lang_encode(tokens, lens, sd, num_layers, quant=None, drop=None):
     """reference mdl_vog.py:250-283: truncate to T = max len, LSTM, then
     lstm_out_feat_proj on every step and on final_hidden[-1]."""
     T = int(lens.max().item())
-    x, fin = lstm_encoder(tokens[:, :T].contiguous(), lens, sd, num_layers, quant)
+    x, fin = lstm_encoder(tokens[:, :T].contiguous(), lens, sd, num_layers, quant, drop=drop)
     full = linear(x, sd, "lstm_out_feat_proj.0", relu=True, quant=quant)
     hid = linear(fin, sd, "lstm_out_feat_proj.0", relu=True, quant=quant)
     return full, hid
@@ -217,7 +249,7 @@ def layer_norm(x, g, b, eps=1e-5):
 
 
 def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
-                  quant=None, scope="tx", stash=None):
+                  quant=None, scope="tx", stash=None, drop=None, site0=0, p_drop=0.0):
     """One (Rel)EncoderLayer (transformer_code.py:84-95,189-203,136-186,
     21-31,73-81). x [S,N,d]; boxes [S,n,5] normalised, N = nsrl*n, token index
     = arg*n + p; the bias on (n x n) is tiled over the nsrl x nsrl arg blocks
@@ -231,6 +263,7 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
     scale = math.sqrt(d)
     heads = []
     off = 0
+    pm = drop_mask(drop, site0, (S, n_heads, N, N), p_drop) if (drop is not None and p_drop > 0) else None
     for h, dh in enumerate(chunk_sizes(d, n_heads)):
         qh, kh, vh = (t[..., off:off + dh] for t in (q, k, v))
         off += dh
@@ -243,6 +276,8 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
                 bh = bh.repeat(1, nsrl, nsrl)
             logits = logits + bh
         attn = torch.softmax(logits / scale, dim=-1)
+        if pm is not None:
+            attn = attn * pm[:, h]                          # self.dropout(F.softmax(...)) (transformer_code.py:50,153)
         attn, vh = _q(quant, scope, attn, vh)
         heads.append(attn @ vh)
     cat = torch.cat(heads, dim=-1)
@@ -250,7 +285,7 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
         stash["tail_attn"] = cat
         stash["tail_x"] = x
     a = _q(quant, scope, cat) @ _q(quant, scope, sd[p + "wo.weight"]).t()
-    t = x + a
+    t = x + _drop(drop, site0 + 1, a, p_drop)               # ResidualBlock: x + dropout(layer(x)) (transformer_code.py:31)
     if stash is not None:
         stash["tail_t"] = t          # its gradient = the gradient of the layer input THROUGH THE TAIL (residual path)
     x1 = layer_norm(t, sd[f"{prefix}.selfattn.layernorm.weight"],
@@ -259,17 +294,19 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
     hdn = torch.relu(_q(quant, scope, x1) @ _q(quant, scope, sd[f + "linear1.weight"]).t()
                      + sd[f + "linear1.bias"])
     y = _q(quant, scope, hdn) @ _q(quant, scope, sd[f + "linear2.weight"]).t() + sd[f + "linear2.bias"]
+    y = _drop(drop, site0 + 2, y, p_drop)
     return layer_norm(x1 + y, sd[f"{prefix}.feedforward.layernorm.weight"],
                       sd[f"{prefix}.feedforward.layernorm.bias"])
 
 
 def transformer(x, boxes, nsrl, sd, name, pe_name, n_layers, n_heads, use_rel,
-                quant=None, stash=None):
+                quant=None, stash=None, drop=None, stack_id=0, p_drop=0.0):
     """(Rel)Transformer: stack, return last layer output
     (transformer_code.py:227-241,244-279)."""
     for l in range(n_layers):
         x = encoder_layer(x, boxes, nsrl, sd, f"{name}.encoder.layers.{l}",
-                          pe_name, n_heads, use_rel, quant, stash=stash if l == n_layers - 1 else None)
+                          pe_name, n_heads, use_rel, quant, stash=stash if l == n_layers - 1 else None,
+                          drop=drop, site0=100 * stack_id + 10 * l, p_drop=p_drop)
     return x
 
 
@@ -287,7 +324,8 @@ def _geometry(oc: OracleCfg, ncmp: int):
 
 
 def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Tensor],
-            quant: Optional[Callable] = None, keep_stages: bool = False):
+            quant: Optional[Callable] = None, keep_stages: bool = False, drop: Optional[int] = None,
+            p_obj: float = 0.2, p_mul: float = 0.2):
     """Conc{TEMP,SPAT,SEP}.forward (mdl_conc_single.py:68-127,
     mdl_conc_sep.py:131-217) for ImgGrnd / VidGrnd / VOGNet."""
     st = {}
@@ -300,7 +338,7 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
     # ---- language (a14-a16)
     tok = srl_arg_seq_to_sent_seq(words, inp["srl_arg_word_mask"], oc.vocab_size)
     lens = inp["srl_arg_word_mask_len"].reshape(B * nv)
-    full, hid = lang_encode(tok, lens, sd, oc.rnn_layers, quant)
+    full, hid = lang_encode(tok, lens, sd, oc.rnn_layers, quant, drop=drop)   # drop = seed of the train-mode masks (drop_mask)
     lang = retrieve_srl_args(full, inp["srl_arg_words_capture"],
                              inp["srl_arg_inds_msk"], sd, quant, stash=st if keep_stages else None)   # [B,nv,5,L]
     st.update(tokens=tok, lstm_full_output=full, final_hidden=hid, lang=lang)
@@ -334,7 +372,7 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
             bx = normalise_boxes(props5, oc.vid_w, oc.vid_h, 1.0).reshape(B * nc_v, NP, 5)
         obj_stash = {} if keep_stages else None
         x = transformer(x, bx, 1, sd, "obj_txf", "pe_obj_sub_enc.0",
-                        oc.obj_layers, oc.obj_heads, oc.obj_use_rel, quant, stash=obj_stash)
+                        oc.obj_layers, oc.obj_heads, oc.obj_use_rel, quant, stash=obj_stash, drop=drop, stack_id=1, p_drop=p_obj)
         if keep_stages:
             st.update(obj_tail_attn=obj_stash["tail_attn"], obj_tail_x=obj_stash["tail_x"], obj_tail_t=obj_stash["tail_t"],
                       obj_boxes=bx, obj_out_seq=x)
@@ -356,7 +394,7 @@ def forward(oc: OracleCfg, sd: Dict[str, torch.Tensor], inp: Dict[str, torch.Ten
             B * nc_v * nfrm, nppf, 5)
         mul_stash = {} if keep_stages else None
         x = transformer(x, bx, nsrl, sd, "mult_txf", "pe_mul_sub_enc.0",
-                        oc.mul_layers, oc.mul_heads, oc.mul_use_rel, quant, stash=mul_stash)
+                        oc.mul_layers, oc.mul_heads, oc.mul_use_rel, quant, stash=mul_stash, drop=drop, stack_id=2, p_drop=p_mul)
         if keep_stages:
             st.update(mul_out=x, mul_tail_attn=mul_stash["tail_attn"], mul_tail_x=mul_stash["tail_x"], mul_tail_t=mul_stash["tail_t"],
                       mul_boxes=bx)

@@ -637,3 +637,59 @@ def test_main_dist_cli_fit(capsys, tmp_path):
         assert hist2[0]["trn_loss"] == hist[1]["trn_loss"]
     else:
         assert hist2[0]["trn_loss"] < hist[1]["trn_loss"]
+
+
+@pytest.mark.parametrize("name", ["small/vog_spat", "small/vog_sep_r64", "small/vgrnd_temp", "full/cfg2_vog_spat_gt5_bs4"])
+def test_device_training_with_dropout_vs_oracle_with_the_same_masks(name):
+    """Train mode: LSTMEncoder's dropouts (embeddings, between the layers, output), the transformers' attn_drop on the
+    attention probabilities and on both sub-layer outputs - masks from the device's counter-based generator
+    (csrc/backward.hip::drop_scale, restated as oracle.drop_mask). The reference's masks come from torch's generator and
+    cannot be reproduced by anything else; what is pinned here is that forward AND backward use the masks consistently:
+    loss and all parameter gradients of one step equal autograd through the oracle run with the SAME masks, and two
+    Adam steps (a new seed per step) follow it."""
+    trn = importlib.import_module("vognet-pytorch_amd.train")
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    dev.update({k: torch.from_numpy(v).cuda() for k, v in tg.items()})
+    _, sd, _, _ = cases.build(name)
+    lr = 1e-4
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    tr = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=lr, dropout=True, dropout_seed=3)
+    oc = vo.OracleCfg.from_cfg(cfg, c["vocab"], c["nppf0"])
+    inp = vo.to_torch({**batch, **tg})
+    torch.set_num_threads(8)
+    p_obj, p_mul = float(cfg.mdl.obj_tx.attn_drop), float(cfg.mdl.mul_tx.attn_drop)
+    assert p_obj > 0 and p_mul > 0
+
+    def cpu_grads(sdt, seed):
+        res = vo.loss_forward(oc, vo.forward(oc, sdt, inp, drop=seed, p_obj=p_obj, p_mul=p_mul), inp,
+                              loss_lambda=float(cfg.loss.loss_lambda))
+        res["loss"].backward()
+        return float(res["loss"].detach())
+
+    # one step's loss and gradients, the masks of step 1
+    sdt = {k: v.clone().requires_grad_(True) for k, v in vo.to_torch(sd).items()}
+    l_cpu = cpu_grads(sdt, tr._step_seed())
+    ld, grads = tr.gradients(dev)
+    with torch.no_grad():                                   # dropout changes the loss visibly (it is really on)
+        l_eval = float(vo.loss_forward(oc, vo.forward(oc, vo.to_torch(sd), inp), inp, loss_lambda=float(cfg.loss.loss_lambda))["loss"])
+    assert abs(l_cpu - l_eval) > 1e-6 * abs(l_eval)          # (random-init logits are small: the loss moves in the 5th digit)
+    assert abs(float(ld["loss"]) - l_cpu) <= 2e-5 * abs(l_cpu), (float(ld["loss"]), l_cpu)
+    worst = 0.0
+    for k, gdev in grads.items():
+        ref = sdt[k].grad
+        scale = max(float(ref.abs().max()), 1e-12)
+        worst = max(worst, float((gdev.cpu() - ref).abs().max()) / scale)
+    assert worst <= 5e-3, worst
+    # two optimisation steps (seed changes per step) against torch Adam on the oracle
+    sdt = {k: v.clone().requires_grad_(True) for k, v in vo.to_torch(sd).items()}
+    opt = torch.optim.Adam(list(sdt.values()), lr=lr, betas=(0.9, 0.99))
+    dl, cl = [], []
+    for _ in range(2):
+        opt.zero_grad()
+        cl.append(cpu_grads(sdt, tr._step_seed()))
+        opt.step()
+        dl.append(float(tr.step(dev)["loss"]))
+    for a, b in zip(dl, cl):
+        assert abs(a - b) <= 1e-4 * abs(b), (dl, cl)
+    print(name, "dropout step: loss", float(ld["loss"]), l_cpu, "(eval-mode loss", l_eval, ") worst gradient error", worst, "losses", dl, cl)

@@ -96,7 +96,7 @@ class _Boxes:
         self.props, self.vid_w, self.vid_h, self.nfrm_div = props.contiguous(), float(vid_w), float(vid_h), float(nfrm_div)
 
 
-def _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=None, d_x=None, accumulate_dx=False, want_cat=False):
+def _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=None, d_x=None, accumulate_dx=False, want_cat=False, drop=None):
     lib = L.load()
     dev = x.device
     M, d = x.shape
@@ -129,12 +129,14 @@ def _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=None, d_x=None, accumula
         a.d_x, a.accumulate_dx = L.ptr(out["d_x"]), 1 if (accumulate_dx and d_x is not None) else 0
     a.scratch, a.scratch_bytes = L.ptr(scratch), nb
     a.S, a.N, a.n, a.d, a.n_heads = S, N, n, d, n_heads
+    if drop is not None and drop[0] > 0:                   # (p, seed, site of the layer): dropout on the probabilities
+        a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), int(drop[1]), int(drop[2])
     L.check(lib.vog_attn_f32(C.byref(a), L.stream_ptr()), "vog_attn_f32")
     out["_keepalive"] = keep
     return out
 
 
-def _tail_call(w, attn, x, head=None, d_y=None, want_y=False):
+def _tail_call(w, attn, x, head=None, d_y=None, want_y=False, drop=None):
     """head = (w_head dict {wl, bl, wl2}, d_mdl_outs, n_vid, nfrm, nppf, nsrl) or None (then d_y, or forward only)."""
     lib = L.load()
     dev = x.device
@@ -179,6 +181,8 @@ def _tail_call(w, attn, x, head=None, d_y=None, want_y=False):
         a.y_out = L.ptr(out["y"])
     a.scratch, a.scratch_bytes = L.ptr(scratch), nb
     a.M, a.d, a.dh = M, d, dh
+    if drop is not None and drop[0] > 0:                   # sites drop_site + 1 / + 2: the two sub-layer outputs
+        a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), int(drop[1]), int(drop[2])
     L.check(lib.vog_mul_tail_bwd(C.byref(a), L.stream_ptr()), "vog_mul_tail_bwd")
     out["_keepalive"] = keep
     return out
@@ -188,8 +192,16 @@ def _f32(sd, names, dev):
     return {k: sd[n].detach().to(dev, torch.float32).contiguous() for k, n in names.items()}
 
 
+STACK_ID = {"obj_txf": 1, "mult_txf": 2}      # dropout sites of a layer: 100 * stack + 10 * layer + {0, 1, 2}
+
+
+def _layer_drop(drop, stack, layer):
+    """drop = (p, seed) of a stack or None -> (p, seed, site of this layer)."""
+    return None if drop is None or drop[0] <= 0 else (drop[0], drop[1], 100 * STACK_ID[stack] + 10 * layer)
+
+
 def encoder_layer_forward(state_dict, stack: str, layer: int, pe_name, x: torch.Tensor, S: int, N: int, n: int,
-                          n_heads: int, boxes=None):
+                          n_heads: int, boxes=None, drop=None):
     """fp32 forward of one (Rel)EncoderLayer (the recomputation the backward starts from) -> (y [S*N, d], cat)."""
     dev = x.device
     w = _f32(state_dict, layer_param_names(stack, layer), dev)
@@ -198,13 +210,14 @@ def encoder_layer_forward(state_dict, stack: str, layer: int, pe_name, x: torch.
         pe = (state_dict[pe_name + ".weight"].detach().to(dev, torch.float32).contiguous(),
               state_dict[pe_name + ".bias"].detach().to(dev, torch.float32).contiguous())
     x = x.contiguous()
-    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes)
-    t = _tail_call(w, f["cat"], x)
+    ld = _layer_drop(drop, stack, layer)
+    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes, drop=ld)
+    t = _tail_call(w, f["cat"], x, drop=ld)
     return t["y"], f["cat"]
 
 
 def encoder_layer_backward(state_dict, stack: str, layer: int, pe_name, x: torch.Tensor, S: int, N: int, n: int,
-                           n_heads: int, boxes=None, d_y: torch.Tensor = None, head=None) -> Dict[str, torch.Tensor]:
+                           n_heads: int, boxes=None, d_y: torch.Tensor = None, head=None, drop=None) -> Dict[str, torch.Tensor]:
     """Backward of one whole (Rel)EncoderLayer on the device (code/transformer_code.py:128-203).
 
     x [S*N, d]: the layer's fp32 input. Either `d_y` [S*N, d] (gradient of the layer's output) or `head` =
@@ -219,14 +232,15 @@ def encoder_layer_backward(state_dict, stack: str, layer: int, pe_name, x: torch
         pe = (state_dict[pe_name + ".weight"].detach().to(dev, torch.float32).contiguous(),
               state_dict[pe_name + ".bias"].detach().to(dev, torch.float32).contiguous())
     x = x.contiguous()
-    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes)                         # recompute the concatenated heads
+    ld = _layer_drop(drop, stack, layer)                                       # train mode: (p, seed) -> the layer's masks
+    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes, drop=ld)                # recompute the concatenated heads
     hd = None
     if head is not None:
         hn = {"wl": "lin2.0.weight", "bl": "lin2.0.bias", "wl2": "lin2.2.weight", "bl2": "lin2.2.bias"}
         wh = _f32(state_dict, hn, dev)
         hd = (wh,) + tuple(head)
-    t = _tail_call(w, f["cat"], x, head=hd, d_y=d_y)
-    b = _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=t["d_attn"], d_x=t["d_x"], accumulate_dx=True)
+    t = _tail_call(w, f["cat"], x, head=hd, d_y=d_y, drop=ld)
+    b = _attn_call(w, pe, x, S, N, n, n_heads, boxes, d_cat=t["d_attn"], d_x=t["d_x"], accumulate_dx=True, drop=ld)
     out = {names[k]: t["g_" + k] for k in ("wo", "ln1g", "ln1b", "w1", "b1", "w2", "b2", "ln2g", "ln2b")}
     out.update({names[k]: b["g_" + k] for k in ("wq", "wk", "wv")})
     if head is not None:
@@ -302,19 +316,19 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, relu: bool, dy
 
 
 def stack_backward(state_dict, stack: str, n_layers: int, pe_name, x0: torch.Tensor, S: int, N: int, n: int, n_heads: int,
-                   boxes=None, d_y: torch.Tensor = None, head=None) -> Dict[str, torch.Tensor]:
+                   boxes=None, d_y: torch.Tensor = None, head=None, drop=None) -> Dict[str, torch.Tensor]:
     """(Rel)Transformer stack (code/transformer_code.py:227-279): fp32 forward recomputation layer by layer (each
     layer's input kept), then `encoder_layer_backward` from the last layer down. -> {parameter name: gradient,
     '_d_x': gradient of the stack input}. The box-bias Linear is shared by the layers: its gradient is summed."""
     xs = [x0.contiguous()]
     for l in range(n_layers - 1):
-        y, _ = encoder_layer_forward(state_dict, stack, l, pe_name, xs[-1], S, N, n, n_heads, boxes)
+        y, _ = encoder_layer_forward(state_dict, stack, l, pe_name, xs[-1], S, N, n, n_heads, boxes, drop=drop)
         xs.append(y)
     grads: Dict[str, torch.Tensor] = {}
     d = d_y
     for l in range(n_layers - 1, -1, -1):
         r = encoder_layer_backward(state_dict, stack, l, pe_name, xs[l], S, N, n, n_heads, boxes, d_y=d,
-                                   head=head if l == n_layers - 1 else None)
+                                   head=head if l == n_layers - 1 else None, drop=drop)
         d = r.pop("_d_x")
         for k, v in r.items():
             grads[k] = grads[k] + v if k in grads else v          # (torch add on two gradient tensors: pe_* only)
@@ -360,7 +374,7 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
     if g["mul_layers"] > 0:
         mb = _Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
         r = stack_backward(state_dict, "mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", acts["mul_x"], B * nc_v * nfrm, nsrl * nppf,
-                           nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl))
+                           nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl), drop=g.get("drop_mul"))
         d_mul = r.pop("_d_x")
         out.update(r)
     else:
@@ -382,7 +396,7 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
             S, N, fdiv = S0, NP, 1.0
         ob = _Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
         r = stack_backward(state_dict, "obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", acts["obj_x"], S, N, N, g["obj_heads"], ob,
-                           d_y=d_ps)
+                           d_y=d_ps, drop=g.get("drop_obj"))
         d_ps = r.pop("_d_x")
         out.update(r)
     out["_d_prop_seg"] = d_ps
@@ -409,7 +423,7 @@ def lang_param_names(layers: int) -> Dict[str, str]:
     return n
 
 
-def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: torch.Tensor = None, drop=None) -> Dict[str, torch.Tensor]:
     """The language side on the device in fp32 (`vog_lang_f32`): embedding, packed BiLSTM (back-propagation through
     time), lstm_out_feat_proj, srl_arg_words_out_enc. batch: the model's input dict (device int64 tensors
     srl_arg_words_ind [B, nv, nsrl, sl], srl_arg_word_mask [B, nv, ml], srl_arg_word_mask_len [B, nv],
@@ -453,6 +467,8 @@ def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: 
             for dr in range(2):
                 a.g_w_ih[l][dr], a.g_w_hh[l][dr] = L.ptr(g[f"weight_ih:{l}:{dr}"]), L.ptr(g[f"weight_hh:{l}:{dr}"])
                 a.g_b_ih[l][dr], a.g_b_hh[l][dr] = L.ptr(g[f"bias_ih:{l}:{dr}"]), L.ptr(g[f"bias_hh:{l}:{dr}"])
+    if drop is not None:                                   # train mode: (p_in, p_out, seed) of LSTMEncoder's dropouts
+        a.drop_in, a.drop_out, a.drop_seed = float(drop[0]), float(drop[1]), int(drop[2])
     nb = int(lib.vog_lang_f32_scratch_bytes(Bn, T, nsrl, E, R, layers, D, Lo))
     scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
     a.scratch, a.scratch_bytes = L.ptr(scratch), nb

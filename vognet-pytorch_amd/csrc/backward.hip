@@ -292,6 +292,33 @@ static int gemm_f32(const float* a, int64_t am, int64_t ak, const float* b, int6
   return gemm_f32_b(a, am, ak, 0, b, bk, bn, 0, c, ldc, 0, bias, relu, accum, M, N, K, 1, st);
 }
 
+// ---- train-mode dropout: counter-based masks, recomputed wherever they are needed (forward, backward): element idx of
+// site `site` is kept iff the top 32 bits of splitmix64(seed * 0x9E3779B97F4A7C15 + site * 0xBF58476D1CE4E5B9 + idx)
+// are >= p * 2^32; kept elements are scaled by 1 / (1 - p). The CPU oracle restates it (oracle/vog_oracle.py::drop_mask).
+struct Drop { unsigned long long seed; unsigned int site; unsigned int thr; float inv_keep; };   // thr == 0: off
+__device__ __forceinline__ float drop_scale(const Drop& d, unsigned long long idx) {
+  if (d.thr == 0) return 1.0f;
+  unsigned long long z = d.seed * 0x9E3779B97F4A7C15ull + (unsigned long long)d.site * 0xBF58476D1CE4E5B9ull + idx;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned int)(z >> 32) >= d.thr ? d.inv_keep : 0.0f;
+}
+static Drop make_drop(float p, unsigned long long seed, int site) {
+  Drop d{seed, (unsigned int)site, 0u, 1.0f};
+  if (p > 0.f) {
+    const double pd = (double)p;
+    d.thr = (unsigned int)(unsigned long long)(pd * 4294967296.0);
+    d.inv_keep = (float)(1.0 / (1.0 - pd));
+  }
+  return d;
+}
+// out[i] = in[i] * mask(i)
+__global__ void mask_mul_kernel(const float* in, float* out, Drop d, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * drop_scale(d, (unsigned long long)i);
+}
+
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -301,12 +328,16 @@ __device__ __forceinline__ float wsum(float v) {
 // ---- row-wise pieces -----------------------------------------------------------------------------
 // t = t + x (optional), stats[m] = (mean, rstd), y = (t - mean) * rstd * g + b      one wave per row
 __global__ __launch_bounds__(256) void ln_fwd_kernel(float* t, const float* x, const float* g, const float* b, float* y,
-                                                     float2* stats, int M, int d) {
+                                                     float2* stats, int M, int d, Drop dr) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   float* tr = t + (int64_t)row * d;
   float s = 0.f;
-  for (int i = lane; i < d; i += 64) { float v = tr[i]; if (x) { v += x[(int64_t)row * d + i]; tr[i] = v; } s += v; }
+  for (int i = lane; i < d; i += 64) {        // t = dropout(t) + x  (ResidualBlock: x + dropout(layer(x)))
+    float v = tr[i];
+    if (x) { v = v * drop_scale(dr, (unsigned long long)row * d + i) + x[(int64_t)row * d + i]; tr[i] = v; }
+    s += v;
+  }
   const float mean = wsum(s) / (float)d;
   float q = 0.f;
   for (int i = lane; i < d; i += 64) { const float c = tr[i] - mean; q += c * c; }
@@ -405,6 +436,7 @@ struct AttnRow {
   const float* w; const float* b;  // this head's Linear(5, H) row and bias entry (code/mdl_vog.py:446-451), device
   float* part;          // [S*N, 8] per-row sums of d bias . (box difference, 1) (ds)
   int S, N, n; float inv_scale;
+  Drop dr; int h, H;    // dropout on the probabilities: element ((s*H + h)*N + i)*N + j of the layer's site
 };
 
 __device__ __forceinline__ float box_z(const AttnRow& a, const float* bi, const float* bj) {
@@ -433,7 +465,13 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(AttnRow a) {
   for (int j = lane; j < a.N; j += 64) { const float e = expf(pr[j] - mx); pr[j] = e; sum += e; }
   sum = wsum(sum);
   const float inv = 1.0f / sum;
-  for (int j = lane; j < a.N; j += 64) pr[j] *= inv;
+  float* dr_ = a.D + (int64_t)row * a.N;
+  const unsigned long long base = (((unsigned long long)s * a.H + a.h) * a.N + i) * a.N;
+  for (int j = lane; j < a.N; j += 64) {
+    const float pv = pr[j] * inv;
+    pr[j] = pv;
+    if (a.dr.thr) dr_[j] = pv * drop_scale(a.dr, base + j);            // D := dropout(P), the operand of P V and of dV
+  }
 }
 
 // D[row] = P (dP - sum_j P dP) / scale  (= d (Q K^T) = d bias); part[row] = sum_j [z > 0] D (box_i - box_j, 1)
@@ -444,6 +482,8 @@ __global__ __launch_bounds__(256) void attn_ds_kernel(AttnRow a) {
   const float* pr = a.P + (int64_t)row * a.N;
   float* dr = a.D + (int64_t)row * a.N;
   float rs = 0.f;
+  const unsigned long long base = (((unsigned long long)s * a.H + a.h) * a.N + i) * a.N;
+  if (a.dr.thr) for (int j = lane; j < a.N; j += 64) dr[j] *= drop_scale(a.dr, base + j);   // d P = d dropout(P) * mask (own elements)
   for (int j = lane; j < a.N; j += 64) rs += pr[j] * dr[j];
   rs = wsum(rs);
   const float* bi = a.bx ? a.bx + ((int64_t)s * a.n + i % a.n) * 8 : nullptr;
@@ -570,11 +610,12 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
   auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
   // ---- recompute the forward in fp32
   VOG_TRY(gemm_f32(a->attn, d, 1, a->wo, 1, d, t, d, nullptr, 0, M, d, d, st));                    // a Wo^T   (Wo [d_out, d_in])
-  ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, t, a->x, a->ln1g, a->ln1b, x1, st1, M, d);   // t += x
+  const Drop dr1 = make_drop(a->drop_p, a->drop_seed, a->drop_site + 1), dr2 = make_drop(a->drop_p, a->drop_seed, a->drop_site + 2);
+  ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, t, a->x, a->ln1g, a->ln1b, x1, st1, M, d, dr1);   // t = drop(t) + x
   VOG_TRY(gemm_f32(x1, d, 1, a->w1, 1, d, pre1, H1, a->b1, 0, M, H1, d, st));                       // pre1 (relu applied on use)
   ::vog::launch(relu_bwd_kernel, blocks(n1), dim3(256), 0, st, pre1, pre1, df, n1);                  // df = relu(pre1) (reused as f)
   VOG_TRY(gemm_f32(df, H1, 1, a->w2, 1, H1, u, d, a->b2, 0, M, d, H1, st));                          // f W2^T + b2
-  ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, u, (const float*)x1, a->ln2g, a->ln2b, y, st2, M, d);   // u += x1
+  ::vog::launch(ln_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, u, (const float*)x1, a->ln2g, a->ln2b, y, st2, M, d, dr2);   // u = drop(u) + x1
   if (a->y_out) VOG_HIP(hipMemcpyAsync(a->y_out, y, (size_t)nd * 4, hipMemcpyDeviceToDevice, st));   // the layer's output
   if (fwd_only) { VOG_LAUNCH_CHECK(); return 0; }
   const float* dyp = a->d_y;
@@ -595,10 +636,12 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
                 (const float2*)st2, a->ln2g, du, tmp, (float*)nullptr, M, d);
   VOG_TRY(colsum(tmp, a->g_ln2g, part, M, d, st));
   VOG_TRY(colsum(dyp, a->g_ln2b, part, M, d, st));
-  // ---- FFN
-  VOG_TRY(gemm_f32(du, 1, d, df, H1, 1, a->g_w2, H1, nullptr, 0, d, H1, M, st));                     // d W2 = du^T f
-  VOG_TRY(colsum(du, a->g_b2, part, M, d, st));
-  VOG_TRY(gemm_f32(du, d, 1, a->w2, H1, 1, dpre1, H1, nullptr, 0, M, H1, d, st));                    // df = du W2
+  // ---- FFN (dum = the gradient behind the feed-forward sub-layer's dropout; du itself is the residual path)
+  const float* dum = du;
+  if (dr2.thr) { ::vog::launch(mask_mul_kernel, blocks(nd), dim3(256), 0, st, (const float*)du, dy, dr2, nd); dum = dy; }
+  VOG_TRY(gemm_f32(dum, 1, d, df, H1, 1, a->g_w2, H1, nullptr, 0, d, H1, M, st));                    // d W2 = du^T f
+  VOG_TRY(colsum(dum, a->g_b2, part, M, d, st));
+  VOG_TRY(gemm_f32(dum, d, 1, a->w2, H1, 1, dpre1, H1, nullptr, 0, M, H1, d, st));                   // df = du W2
   ::vog::launch(relu_bwd_kernel, blocks(n1), dim3(256), 0, st, (const float*)dpre1, (const float*)pre1, dpre1, n1);
   VOG_TRY(gemm_f32(dpre1, 1, H1, x1, d, 1, a->g_w1, d, nullptr, 0, H1, d, M, st));                   // d W1 = dpre1^T x1
   VOG_TRY(colsum(dpre1, a->g_b1, part, M, H1, st));
@@ -608,9 +651,11 @@ extern "C" int vog_mul_tail_bwd(const vog_tail_bwd_args* a, void* stream) {
                 (const float2*)st1, a->ln1g, dt, tmp, dy, M, d);                                       // dy := dx1 + du (summand of d beta)
   VOG_TRY(colsum(tmp, a->g_ln1g, part, M, d, st));
   VOG_TRY(colsum(dy, a->g_ln1b, part, M, d, st));
-  // ---- Wo and the two inputs
-  VOG_TRY(gemm_f32(dt, 1, d, a->attn, d, 1, a->g_wo, d, nullptr, 0, d, d, M, st));                   // d Wo = dt^T a
-  if (a->d_attn) VOG_TRY(gemm_f32(dt, d, 1, a->wo, d, 1, a->d_attn, d, nullptr, 0, M, d, d, st));    // da = dt Wo
+  // ---- Wo and the two inputs (dtm = the gradient behind the attention sub-layer's dropout)
+  const float* dtm = dt;
+  if (dr1.thr) { ::vog::launch(mask_mul_kernel, blocks(nd), dim3(256), 0, st, (const float*)dt, tmp, dr1, nd); dtm = tmp; }
+  VOG_TRY(gemm_f32(dtm, 1, d, a->attn, d, 1, a->g_wo, d, nullptr, 0, d, d, M, st));                  // d Wo = dt^T a
+  if (a->d_attn) VOG_TRY(gemm_f32(dtm, d, 1, a->wo, d, 1, a->d_attn, d, nullptr, 0, M, d, d, st));   // da = dt Wo
   if (a->d_x) VOG_HIP(hipMemcpyAsync(a->d_x, dt, (size_t)nd * 4, hipMemcpyDeviceToDevice, st));      // dx = dt
   VOG_LAUNCH_CHECK();
   return 0;
@@ -649,6 +694,7 @@ extern "C" int vog_attn_f32(const vog_attn_f32_args* a, void* stream) {
   if (rel)
     ::vog::launch(norm_boxes_kernel, dim3(ceil_div(S * n, 256)), dim3(256), 0, st, a->props, a->prop_stride, a->vid_w, a->vid_h,
                   a->nfrm_div, bx, S * n);
+  const Drop drp = make_drop(a->drop_p, a->drop_seed, a->drop_site);
   const int chunk = (d + H - 1) / H;                       // torch.chunk split sizes (transformer_code.py:66-67)
   const float inv_scale = 1.0f / sqrtf((float)d);          // scale = sqrt(d_model)
   const int64_t sx = (int64_t)N * d;
@@ -658,14 +704,15 @@ extern "C" int vog_attn_f32(const vog_attn_f32_args* a, void* stream) {
     // logits = Q_h K_h^T, then the softmax with the box bias
     VOG_TRY(gemm_f32_b(q + off, d, 1, sx, k + off, 1, d, sx, P, N, nn, nullptr, 0, 0, N, N, dh, S, st));
     AttnRow ar{P, D, rel ? bx : nullptr, rel ? a->pe_w + h * 5 : nullptr, rel ? a->pe_b + h : nullptr, bwd && rel ? part : nullptr,
-               S, N, n, inv_scale};
+               S, N, n, inv_scale, drp, h, H};
     ::vog::launch(attn_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, ar);
+    const float* Pd = drp.thr ? D : P;                                   // dropout(P) (D holds it until dP overwrites it)
     if (a->cat_out)
-      VOG_TRY(gemm_f32_b(P, N, 1, nn, v + off, d, 1, sx, a->cat_out + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));   // O_h = P V_h
+      VOG_TRY(gemm_f32_b(Pd, N, 1, nn, v + off, d, 1, sx, a->cat_out + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));  // O_h = drop(P) V_h
     if (!bwd) continue;
-    VOG_TRY(gemm_f32_b(a->d_cat + off, d, 1, sx, v + off, 1, d, sx, D, N, nn, nullptr, 0, 0, N, N, dh, S, st));       // dP = dO_h V_h^T
+    VOG_TRY(gemm_f32_b(Pd, 1, N, nn, a->d_cat + off, d, 1, sx, dv + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));     // dV_h = drop(P)^T dO_h
+    VOG_TRY(gemm_f32_b(a->d_cat + off, d, 1, sx, v + off, 1, d, sx, D, N, nn, nullptr, 0, 0, N, N, dh, S, st));       // d drop(P) = dO_h V_h^T
     ::vog::launch(attn_ds_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, ar);
-    VOG_TRY(gemm_f32_b(P, 1, N, nn, a->d_cat + off, d, 1, sx, dv + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));      // dV_h = P^T dO_h
     VOG_TRY(gemm_f32_b(D, N, 1, nn, k + off, d, 1, sx, dq + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));             // dQ_h = dS K_h
     VOG_TRY(gemm_f32_b(D, 1, N, nn, q + off, d, 1, sx, dk + off, d, sx, nullptr, 0, 0, N, dh, N, S, st));             // dK_h = dS^T Q_h
     if (rel) {
@@ -740,10 +787,10 @@ __global__ void lang_tokens_kernel(const int64_t* words, const int64_t* mask, in
   const int64_t m = mask[(int64_t)bn * mlen + t];
   tok[i] = m >= 0 ? words[(int64_t)bn * wlen + m] : V;
 }
-__global__ void embed_gather_kernel(const float* emb, const int64_t* tok, float* x, int rows, int E) {
+__global__ void embed_gather_kernel(const float* emb, const int64_t* tok, float* x, int rows, int E, Drop dr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)rows * E) return;
-  x[i] = emb[tok[i / E] * E + i % E];
+  x[i] = emb[tok[i / E] * E + i % E] * drop_scale(dr, (unsigned long long)i);      // F.dropout(x, dropout_in) (mdl_srl_utils.py:128)
 }
 // g_emb[v, c] = sum over the token positions holding v (fixed order)
 __global__ void embed_scatter_kernel(const float* dx, const int64_t* tok, float* g, int rows, int E, int nv) {
@@ -926,7 +973,8 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   // ---- forward recomputation
   ::vog::launch(lang_tokens_kernel, blocks(BT), dim3(256), 0, st, a->words_ind, a->word_mask, tok, Bn, T, a->words_len, a->mask_len,
                 a->vocab_size);
-  ::vog::launch(embed_gather_kernel, blocks((int64_t)BT * E), dim3(256), 0, st, a->emb, (const int64_t*)tok, x0, BT, E);
+  const Drop drop_emb = make_drop(a->drop_in, a->drop_seed, 1);
+  ::vog::launch(embed_gather_kernel, blocks((int64_t)BT * E), dim3(256), 0, st, a->emb, (const int64_t*)tok, x0, BT, E, drop_emb);
   for (int l = 0; l < NL; ++l) {
     const float* xin = l == 0 ? x0 : lout[l - 1];
     const int K = l == 0 ? E : 2 * R;
@@ -943,6 +991,10 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
         ::vog::launch(lstm_cell_fwd_kernel, blocks((int64_t)Bn * R), dim3(256), 0, st, ls);
       }
     }
+    // nn.LSTM's dropout between the layers / F.dropout on the encoder output (mdl_srl_utils.py:104, 150): in place - the
+    // recurrence reads its own state buffers, only the next layer / the projection read this tensor
+    const Drop dl = make_drop(a->drop_out, a->drop_seed, l < NL - 1 ? 2 + l : 10);
+    if (dl.thr) ::vog::launch(mask_mul_kernel, blocks((int64_t)BT * 2 * R), dim3(256), 0, st, (const float*)lout[l], lout[l], dl, (int64_t)BT * 2 * R);
   }
   VOG_TRY(gemm_f32(lout[NL - 1], 2 * R, 1, a->w_proj, 1, 2 * R, full, D, a->b_proj, 1, BT, D, 2 * R, st));   // relu(x W^T + b), every step
   ::vog::launch(argvec_gather_kernel, blocks((int64_t)Bn * nsrl * 2 * D), dim3(256), 0, st, (const float*)full, a->capture, enc, Bn,
@@ -978,6 +1030,8 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   for (int l = NL - 1; l >= 0; --l) {
     const float* xin = l == 0 ? x0 : lout[l - 1];
     const int K = l == 0 ? E : 2 * R;
+    const Drop dl = make_drop(a->drop_out, a->drop_seed, l < NL - 1 ? 2 + l : 10);
+    if (dl.thr) ::vog::launch(mask_mul_kernel, blocks((int64_t)BT * 2 * R), dim3(256), 0, st, (const float*)d_out, d_out, dl, (int64_t)BT * 2 * R);
     for (int dr = 0; dr < 2; ++dr) {
       VOG_CHECK_ARG(a->g_w_ih[l][dr] && a->g_w_hh[l][dr] && a->g_b_ih[l][dr] && a->g_b_hh[l][dr]);
       VOG_HIP(hipMemsetAsync(dGp, 0, (size_t)BT * G * 4, st));
@@ -1001,6 +1055,7 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
     }
     float* sw = d_out; d_out = d_in; d_in = sw;
   }
+  if (drop_emb.thr) ::vog::launch(mask_mul_kernel, blocks((int64_t)BT * E), dim3(256), 0, st, (const float*)d_out, d_out, drop_emb, (int64_t)BT * E);
   const int nv = a->vocab_size + 1;
   ::vog::launch(embed_scatter_kernel, blocks((int64_t)nv * E), dim3(256), 0, st, (const float*)d_out, (const int64_t*)tok, a->g_emb, BT, E, nv);
   VOG_LAUNCH_CHECK();

@@ -191,7 +191,7 @@ class TailBwdArgs(C.Structure):
                                       "g_wl", "g_bl", "g_wl2", "g_bl2", "scratch")]
                 + [("scratch_bytes", C.c_size_t)]
                 + [(n, c_i32) for n in ("M", "d", "dh", "dhead", "n_vid", "nfrm", "nppf", "nsrl", "no_head")]
-                + [("d_y", c_vp), ("y_out", c_vp)])
+                + [("d_y", c_vp), ("y_out", c_vp), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", c_i32)])
 
 
 class LinearF32Args(C.Structure):
@@ -211,7 +211,8 @@ class LangF32Args(C.Structure):
                 + [(n, c_vp) for n in ("w_proj", "b_proj", "w_arg", "b_arg", "d_lang_enc", "lang_enc_out", "full_out", "g_emb")]
                 + [("g_w_ih", _P42), ("g_w_hh", _P42), ("g_b_ih", _P42), ("g_b_hh", _P42)]
                 + [(n, c_vp) for n in ("g_w_proj", "g_b_proj", "g_w_arg", "g_b_arg", "scratch")]
-                + [("scratch_bytes", C.c_size_t), ("hid_out", c_vp)])
+                + [("scratch_bytes", C.c_size_t), ("hid_out", c_vp), ("drop_in", C.c_float), ("drop_out", C.c_float),
+                   ("drop_seed", C.c_uint64)])
 
 
 class AttnF32Args(C.Structure):
@@ -220,7 +221,8 @@ class AttnF32Args(C.Structure):
                 ("pe_w", c_vp), ("pe_b", c_vp), ("cat_out", c_vp),
                 ("g_wq", c_vp), ("g_wk", c_vp), ("g_wv", c_vp), ("g_pe_w", c_vp), ("g_pe_b", c_vp),
                 ("d_x", c_vp), ("accumulate_dx", c_i32), ("scratch", c_vp), ("scratch_bytes", C.c_size_t),
-                ("S", c_i32), ("N", c_i32), ("n", c_i32), ("d", c_i32), ("n_heads", c_i32)]
+                ("S", c_i32), ("N", c_i32), ("n", c_i32), ("d", c_i32), ("n_heads", c_i32),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", c_i32)]
 
 
 class Batch(C.Structure):

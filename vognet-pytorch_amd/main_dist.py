@@ -116,7 +116,8 @@ def main_dist(uid: str, **kwargs):
     if not (cfg.only_val or cfg.only_test):
         from . import train as TR
         model_file = Path(cfg.misc.tmp_path) / "models" / f"{uid}.pth"
-        tr = TR.FP32Trainer(cfg, comm, mdl.state_dict(), loss_fn, lr=float(cfg.train.lr))
+        # train mode (`self.mdl.train()`, utils/trn_utils.py:487): dropout on, masks from the device's own generator
+        tr = TR.FP32Trainer(cfg, comm, mdl.state_dict(), loss_fn, lr=float(cfg.train.lr), dropout=True, dropout_seed=0)
         if cfg.train.resume and model_file.exists():
             ck = torch.load(model_file.open("rb"), weights_only=False)
             tr.params.update({k: v.to(tr.dev, torch.float32).contiguous() for k, v in ck["model_state_dict"].items()})

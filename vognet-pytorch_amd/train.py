@@ -11,8 +11,10 @@ libvog_hip.so; torch tensors are device containers.
 
 This is the fp32 path that pins the MATH against autograd through the reference (every parameter gradient, three
 Adam steps); it shares no kernel with the 16-bit inference forward and is not tuned (one GEMM per BiLSTM time step).
-Covers ImgGrnd / VidGrnd / VOGNet with every conc_type. Not built: dropout (the reference trains with p = 0.1 masks drawn
-from torch's generator - a step here equals the reference's with the model in eval mode). For sep / svsq the verb head runs forward only:
+Covers ImgGrnd / VidGrnd / VOGNet with every conc_type. `dropout=True` is the reference's train mode (LSTMEncoder 0.1 / 0.1,
+attn_drop on attention probabilities and sub-layer outputs) with masks from a counter-based generator on the device - the
+reference's masks come from torch's generator, so a step is statistically, not bitwise, its step; with `dropout=False` a
+step equals the reference's with the model in eval mode. For sep / svsq the verb head runs forward only:
 the reference's `loss` excludes verb_loss (code/mdl_conc_sep.py:434-436).
 """
 from __future__ import annotations
@@ -29,7 +31,8 @@ from .engine import model_desc_from_cfg
 
 class FP32Trainer:
     def __init__(self, cfg, comm, state_dict: Dict[str, torch.Tensor], loss_fn, lr: Optional[float] = None,
-                 betas=(0.9, 0.99), eps: float = 1e-8, device: str = "cuda", process_group=None):
+                 betas=(0.9, 0.99), eps: float = 1e-8, device: str = "cuda", process_group=None, dropout: bool = False,
+                 dropout_seed: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("FP32Trainer needs a GPU (libvog_hip.so kernels; there is no CPU fallback)")
         self.lib = L.load()
@@ -47,6 +50,13 @@ class FP32Trainer:
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.num_it = 0
         self.pg = process_group
+        # train-mode dropout (`mdl.train()` in Learner.train_epoch): LSTMEncoder's 0.1 / 0.1 (utils/mdl_srl_utils.py:77), the
+        # transformers' cfg.mdl.{obj,mul}_tx.attn_drop on attention probabilities and sub-layer outputs; masks come from a
+        # counter-based generator seeded per step (csrc/backward.hip::drop_scale) - NOT torch's stream, so a step is
+        # statistically, not bitwise, the reference's. Off: a step equals the reference's in eval mode.
+        self.dropout, self.dropout_seed = bool(dropout), int(dropout_seed)
+        self.p_lstm = (0.1, 0.1)
+        self.p_obj, self.p_mul = float(cfg.mdl.obj_tx.attn_drop), float(cfg.mdl.mul_tx.attn_drop)
 
     # ---- geometry of one batch (Conc{TEMP,SPAT}: code/mdl_conc_single.py:24-37, 131-143)
     def _geo(self, batch):
@@ -62,13 +72,19 @@ class FP32Trainer:
             nc_v, nfrm, nppf = ncmp, d.nfrm0, d.nppf0
         name = self.cfg.mdl.name                       # ImgGrnd: encoders + lin2; VidGrnd: + obj_tx; VOGNet: + mul_tx (mdl_vog.py:286-744)
         has_obj = name == "vgrnd" or (name == "vog" and d.obj_to_use)
-        return dict(B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers if name == "vog" else 0,
+        seed = self._step_seed()
+        dr = dict(drop_obj=(self.p_obj, seed), drop_mul=(self.p_mul, seed), drop_lang=self.p_lstm + (seed,)) if self.dropout else {}
+        return dict(**dr, B=B, nc_v=nc_v, nfrm=nfrm, nppf=nppf, nsrl=d.nsrl, nppf0=d.nppf0, mul_layers=d.mul_layers if name == "vog" else 0,
                     mul_heads=d.mul_heads, mul_use_rel=bool(d.mul_use_rel), obj_layers=d.obj_layers if has_obj else 0, obj_heads=d.obj_heads,
                     obj_use_rel=bool(d.obj_use_rel), obj_one_frm=bool(d.obj_one_frm), vid_w=d.vid_w, vid_h=d.vid_h)
 
-    def _stack_forward(self, stack, n_layers, pe_name, x, S, N, n, heads, boxes):
+    def _step_seed(self) -> int:
+        """One seed per optimisation step (forward and backward of a step recompute the same masks from it)."""
+        return (self.dropout_seed * 1000003 + self.num_it + 1) & 0x7FFFFFFFFFFFFFFF
+
+    def _stack_forward(self, stack, n_layers, pe_name, x, S, N, n, heads, boxes, drop=None):
         for l in range(n_layers):
-            x, _ = BW.encoder_layer_forward(self.params, stack, l, pe_name, x, S, N, n, heads, boxes)
+            x, _ = BW.encoder_layer_forward(self.params, stack, l, pe_name, x, S, N, n, heads, boxes, drop=drop)
         return x
 
     def forward(self, batch):
@@ -80,7 +96,7 @@ class FP32Trainer:
         NP = nfrm * nppf
         BV = B * nc_v                                                   # model "videos" (sequence sets)
         T = int(batch["srl_arg_word_mask_len"].max())
-        lf = BW.language_backward(p, batch, T, self.desc.rnn_layers)
+        lf = BW.language_backward(p, batch, T, self.desc.rnn_layers, drop=g.get("drop_lang"))
         lang = lf["_lang_enc"]
         f32 = lambda k: batch[k].to(self.dev, torch.float32)
         prop_feat = f32("pad_region_feature").reshape(BV * NP, -1).contiguous()
@@ -99,7 +115,8 @@ class FP32Trainer:
             else:
                 S, N, fdiv = BV, NP, 1.0
             ob = BW._Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
-            obj_out = self._stack_forward("obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", obj_x, S, N, N, g["obj_heads"], ob)
+            obj_out = self._stack_forward("obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", obj_x, S, N, N, g["obj_heads"], ob,
+                                          drop=g.get("drop_obj"))
         msk = batch["srl_arg_inds_msk"].to(self.dev, torch.int64).contiguous()
         nv = msk.shape[1]
         assert nv in (1, nc_v), "language axis does not match conc_type"
@@ -113,7 +130,8 @@ class FP32Trainer:
         y = mul_x
         if g["mul_layers"] > 0:
             mb = BW._Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
-            y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb)
+            y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb,
+                                    drop=g.get("drop_mul"))
         M, dm = y.shape
         dhead = p["lin2.0.weight"].shape[0]
         scratch = torch.empty(M * dhead, dtype=torch.float32, device=self.dev)
@@ -143,7 +161,7 @@ class FP32Trainer:
         ld = self.loss_fn(out, batch)
         d_outs = self.loss_fn.backward(ld)
         grads = BW.visual_backward(self.params, g, acts, d_outs)
-        lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"])
+        lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"], drop=g.get("drop_lang"))
         grads.update(lg)
         return ld, {k: v for k, v in grads.items() if not k.startswith("_")}
 
