@@ -162,7 +162,12 @@ def _grad_worker(rank, world, port, q):
     grads = {"lin2.0.weight": torch.randn(8, 12, generator=g), "lin2.0.bias": torch.randn(8, generator=g),
              "mult_txf.encoder.layers.0.selfattn.layer.wo.weight": torch.randn(12, 12, generator=g),
              "_d_x": torch.full((3,), float(rank))}
-    n = D.all_reduce_grads(grads, bucket_bytes=400)          # small buckets: more than one collective
+    # two groups in flight at once, as the trainer issues them (visual side first, language side behind it)
+    ga = {k: v for k, v in grads.items() if k.startswith("lin2") or k.startswith("_")}
+    gb = {k: v for k, v in grads.items() if k.startswith("mult")}
+    fa = D.all_reduce_grads_begin(ga, bucket_bytes=400)      # small buckets: more than one collective
+    fb = D.all_reduce_grads_begin(gb, bucket_bytes=400)
+    n = fa() + fb()
     if rank == 0:
         q.put((n, {k: v.clone() for k, v in grads.items()}))
     D.synchronize()

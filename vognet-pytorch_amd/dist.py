@@ -197,19 +197,20 @@ def unpack_gathered(gathered: torch.Tensor, world: int, per_half: int, rows: int
     return w.permute(1, 0, 2, 3).reshape(n_valid * world * rows, -1)
 
 
-def all_reduce_grads(grads, bucket_bytes: int = 32 << 20, average: bool = True):
-    """Data-parallel gradient exchange of the training path (the reference wraps the model in
-    DistributedDataParallel, code/main_dist.py:72-85): the gradient tensors of `grads` (name -> tensor, e.g. what
-    `backward.mul_tail_backward` returns; keys starting with '_' are skipped) are flattened IN NAME ORDER into
-    buckets of at most `bucket_bytes` and every bucket is ONE in-place all-reduce (RCCL over xGMI with backend
-    "nccl", gloo on CPU), then divided by the world size. xGMI is point to point (7 links x ~153 GB/s per GPU), so a
-    ring all-reduce is per-link bound: few large buckets (default 32 MiB: 177 MB of fp32 parameters = 6 collectives)
-    instead of one per parameter. Buckets are issued asynchronously in order and waited for at the end, so the
-    copies of bucket k+1 overlap the collective of bucket k. Returns the number of collectives issued."""
+def all_reduce_grads_begin(grads, bucket_bytes: int = 32 << 20, average: bool = True):
+    """Start the data-parallel gradient exchange of the training path (the reference wraps the model in
+    DistributedDataParallel, code/main_dist.py:72-85) and return `finish()`: the gradient tensors of `grads` (name ->
+    tensor; keys starting with '_' are skipped) are flattened IN NAME ORDER into buckets of at most `bucket_bytes` and
+    every bucket is ONE asynchronous in-place all-reduce (RCCL over xGMI with backend "nccl", gloo on CPU). xGMI is
+    point to point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound: few large buckets (default 32
+    MiB: 177 MB of fp32 parameters = 6 collectives) instead of one per parameter. Nothing waits here: the caller goes on
+    computing (the trainer starts the exchange of the visual side's gradients and runs the language side's backward
+    meanwhile - the overlap DDP gets from its autograd hooks). `finish()` waits, divides by the world size, copies the
+    buckets back into the tensors of `grads` and returns the number of collectives."""
     names = sorted(k for k in grads if not k.startswith("_") and isinstance(grads[k], torch.Tensor))
     w = get_world_size()
     if w == 1 or not names:
-        return 0
+        return lambda: 0
     works, buckets, cur, cur_bytes = [], [], [], 0
     for n in names:
         t = grads[n]
@@ -226,13 +227,21 @@ def all_reduce_grads(grads, bucket_bytes: int = 32 << 20, average: bool = True):
         flat = torch.cat([grads[n].reshape(-1) for n in b])
         flats.append(flat)
         works.append(dist.all_reduce(flat, async_op=True))
-    for b, flat, wk in zip(buckets, flats, works):
-        wk.wait()
-        if average:
-            flat.div_(w)
-        off = 0
-        for n in b:
-            k = grads[n].numel()
-            grads[n].copy_(flat[off:off + k].view_as(grads[n]))
-            off += k
-    return len(buckets)
+
+    def finish():
+        for b, flat, wk in zip(buckets, flats, works):
+            wk.wait()
+            if average:
+                flat.div_(w)
+            off = 0
+            for n in b:
+                k = grads[n].numel()
+                grads[n].copy_(flat[off:off + k].view_as(grads[n]))
+                off += k
+        return len(buckets)
+    return finish
+
+
+def all_reduce_grads(grads, bucket_bytes: int = 32 << 20, average: bool = True):
+    """`all_reduce_grads_begin(...)()`: the whole exchange, blocking. Returns the number of collectives issued."""
+    return all_reduce_grads_begin(grads, bucket_bytes, average)()

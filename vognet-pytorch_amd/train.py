@@ -155,23 +155,32 @@ class FP32Trainer:
         acts = {"mul_x": mul_x, "obj_x": obj_x, "prop_feat": prop_feat, "seg_feat": seg_feat, "props": props, "inds_msk": msk, "T": T}
         return out, acts, g
 
-    def gradients(self, batch):
-        """-> (loss dict, {parameter name: gradient}) of one batch (no update)."""
+    def gradients(self, batch, exchange: bool = False):
+        """-> (loss dict, {parameter name: gradient}) of one batch (no update). exchange: average the gradients over the
+        ranks - the visual side's buckets are in flight while the language side's backward runs."""
         out, acts, g = self.forward(batch)
         ld = self.loss_fn(out, batch)
         d_outs = self.loss_fn.backward(ld)
         grads = BW.visual_backward(self.params, g, acts, d_outs)
+        gv = {k: v for k, v in grads.items() if not k.startswith("_")}
+        fin_v = None
+        if exchange:
+            from .dist import all_reduce_grads_begin
+            fin_v = all_reduce_grads_begin(gv)
         lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"], drop=g.get("drop_lang"))
-        grads.update(lg)
-        return ld, {k: v for k, v in grads.items() if not k.startswith("_")}
+        gl = {k: v for k, v in lg.items() if not k.startswith("_")}
+        if exchange:
+            fin_l = all_reduce_grads_begin(gl)
+            fin_v()
+            fin_l()
+        gv.update(gl)
+        return ld, gv
 
     def step(self, batch):
         """One `train_epoch` iteration: forward, loss, backward, (all-reduce,) Adam. -> the loss dict."""
-        ld, grads = self.gradients(batch)
-        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                   and torch.distributed.get_world_size() > 1):
-            from .dist import all_reduce_grads
-            all_reduce_grads(grads, average=True)
+        multi = self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                        and torch.distributed.get_world_size() > 1)
+        ld, grads = self.gradients(batch, exchange=multi)
         self.num_it += 1
         st = L.stream_ptr()
         for k in sorted(grads):
