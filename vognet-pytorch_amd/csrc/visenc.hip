@@ -70,7 +70,7 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
     if (a->defer_replicas && !can_copy) VOG_FAIL(-1, "vog_vis_encode: defer_replicas needs encode sizes and ldc %% 4 == 0");
     const bool split_rep = !a->defer_replicas && p.p[1].rep > 16 && can_copy;
     p.rep_first_only = (split_rep || a->defer_replicas) ? 1 : 0;
-    VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(nb * 2), dim3(512),
+    VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
                                                VisEncLeanBody<T16>::LDS, st, p));
     VOG_LAUNCH_CHECK();
     if (split_rep) {

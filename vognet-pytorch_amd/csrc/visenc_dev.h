@@ -130,7 +130,11 @@ struct VisEncLeanBody {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // item = (row block of 64, column half); tiles0 / tiles_all count 16-row tiles: 4 per block
     const int nb0 = (a.tiles0 + 3) >> 2, nb_all = nb0 + ((a.tiles_all - a.tiles0 + 3) >> 2);
-    const int blk = cx.bx >> 1, half = cx.bx & 1;
+    // the two column halves of a row block read the same 64 fp32 feature rows (512 KB): they sit 8 block ids apart, i.e.
+    // on the same XCD (block b is dealt to XCD b % 8), so the second read is served by that XCD's L2
+    // (2.1 x over-fetch at p100 with the halves on neighbouring XCDs)
+    const int grp = cx.bx >> 4, pos = cx.bx & 15;
+    const int blk = grp * 8 + (pos & 7), half = pos >> 3;
     if (blk >= nb_all) return;
     const bool second = blk >= nb0;
     const float* qx = second ? a.p[1].x : a.p[0].x;
