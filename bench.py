@@ -598,9 +598,12 @@ def main():
                            "usec_per_step": (ktimes.get("lstm_layer#0") or lstm_us[1]) / T if not fused_ih else None,
                            "note": "(bytes: W_hh + W_ih + layer input + gates / state, each read once per launch) "
                                    "latency bound by design, not bandwidth bound: T dependent steps per launch, each "
-                                   "one fabric round trip (self-validating tagged h words of all 32 workgroups of a "
-                                   "direction, the guide's allgather primitive: 2.4-3.0 us for 8 KB from 32 CUs) + LDS "
-                                   "+ 32 MFMAs per wave + gates; W_hh is read once and stays in registers (64 CUs). "
+                                   "one exchange of the Bn x R hidden vector among the 32 workgroups of a direction "
+                                   "(self-validating 16-bit values in one slot per step, a 16-byte write-through per "
+                                   "4 lanes and one 16-byte L1-bypassing load per thread: 1.3 us; 2.2 us per step with "
+                                   "the LDS staging, 32 MFMAs per wave and the gates); before them the layer's input "
+                                   "projection streams W_ih at the per-CU ingest rate (~40 GB/s from the Infinity "
+                                   "Cache); W_hh is read once and stays in registers (64 CUs). "
                                    "In the forward it shares its launch with the encoders / the obj_tx tail "
                                    "(csrc/pair.hip), which run on the other CUs"}
         res["roofline_mfma"] = roof_mfma
