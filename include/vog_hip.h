@@ -645,6 +645,10 @@ int64_t vog_score_head_f32_bwd_scratch_bytes(int M, int d, int dhead);
 int vog_score_head_f32_bwd(const float* x, const float* d_mdl_outs, const float* wl, const float* bl, const float* wl2,
                            float* g_wl, float* g_bl, float* g_wl2, float* g_bl2, float* d_x, void* scratch, size_t scratch_bytes,
                            int M, int d, int dhead, int n_vid, int nfrm, int nppf, int nsrl, void* stream);
+/* Switches of the training path. "bf16_gemm" = 1: the tile GEMMs of vog_*_f32 / vog_*_bwd round their operands to bf16 and
+ * use the 16-bit matrix instruction with fp32 accumulation (mixed precision: faster, gradients within ~1e-2 of the fp32
+ * ones); 0 (default): fp32 operands, the path pinned against autograd through the reference. Process-wide. */
+int vog_train_set_int(const char* name, int value);
 /* out[g, n] = mean over f of x[g, f, n] (the segment mean of the sep verb head, code/mdl_conc_sep.py:64-129) */
 int vog_row_mean_f32(const float* x, float* out, int G, int F, int N, void* stream);
 

@@ -14,7 +14,9 @@ sel = sel_mod.get_mdl_loss_eval(cfg)
 loss_fn = sel["loss"](cfg, comm)
 tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
 dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in {**batch, **tg}.items()}
-tr = trn.FP32Trainer(cfg, comm, {k: torch.from_numpy(v) for k, v in sd.items()}, loss_fn, lr=1e-4)
+BF16 = bool(int(os.environ.get("TRAIN_BF16", "0")))
+tr = trn.FP32Trainer(cfg, comm, {k: torch.from_numpy(v) for k, v in sd.items()}, loss_fn, lr=1e-4, bf16_gemm=BF16,
+                     dropout=bool(int(os.environ.get("TRAIN_DROPOUT", "0"))))
 for _ in range(3):
     tr.step(dev)
 torch.cuda.synchronize()
@@ -28,7 +30,7 @@ for _ in range(n):
     tr.forward(dev)
 torch.cuda.synchronize()
 df = (time.time() - t1) / n
-res = {"config": name, "ms_per_train_step": dt * 1e3, "ms_fp32_forward": df * 1e3, "queries_per_s_training": 4 / dt, "loss_after": float(ld["loss"]),
+res = {"config": name, "bf16_gemm": BF16, "ms_per_train_step": dt * 1e3, "ms_fp32_forward": df * 1e3, "queries_per_s_training": 4 / dt, "loss_after": float(ld["loss"]),
        "parameters": int(sum(v.numel() for v in tr.params.values()))}
 print(json.dumps(res))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -146,6 +146,109 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
       }
 }
 
+// ---- the same product with 16-bit operands (option `train_bf16`, off by default): A and B are rounded to bf16 on their way
+// into LDS and multiplied with v_mfma_f32_16x16x32_bf16 (fp32 accumulation, 16 x the rate of the fp32 matrix instruction).
+// Same tile, strides, batching, split-K and epilogue as gemm_f32_kernel (vector path only); K in chunks of 32.
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmF32 p) {
+  constexpr int TM = 128, TN = 64, TK = 32, LP = TK + 8;              // LP: row pitch in halfwords (80 B: 16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) unsigned short As[TM][LP];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[TN][LP];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 32;
+  const float* pa = p.a + (int64_t)blockIdx.z * p.sa;
+  const float* pb = p.b + (int64_t)blockIdx.z * p.sb;
+  float* pc = p.c + (int64_t)blockIdx.z * p.sc;
+  const int KL = p.kchunk ? (p.K - (int)blockIdx.z * p.kchunk < p.kchunk ? p.K - (int)blockIdx.z * p.kchunk : p.kchunk) : p.K;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool a_kfast = p.ak == 1, b_nfast = p.bn == 1;
+  float4 ra[4], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      int m, k;
+      if (a_kfast) { m = idx >> 3; k = (idx & 7) * 4; } else { k = idx >> 5; m = (idx & 31) * 4; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[e] = (gm < p.M && gk < KL) ? *reinterpret_cast<const float4*>(pa + (int64_t)gm * p.am + (int64_t)gk * p.ak)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + e * 256;
+      int n, k;
+      if (b_nfast) { k = idx >> 4; n = (idx & 15) * 4; } else { n = idx >> 3; k = (idx & 7) * 4; }
+      const int gn = n0 + n, gk = k0 + k;
+      rb[e] = (gn < p.N && gk < KL) ? *reinterpret_cast<const float4*>(pb + (int64_t)gk * p.bk + (int64_t)gn * p.bn)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      const unsigned short h0 = to16<BF16>(ra[e].x), h1 = to16<BF16>(ra[e].y), h2 = to16<BF16>(ra[e].z), h3 = to16<BF16>(ra[e].w);
+      if (a_kfast) {
+        const int m = idx >> 3, k = (idx & 7) * 4;
+        *reinterpret_cast<u16x4*>(&As[m][k]) = u16x4{h0, h1, h2, h3};
+      } else {
+        const int k = idx >> 5, m = (idx & 31) * 4;
+        As[m][k] = h0; As[m + 1][k] = h1; As[m + 2][k] = h2; As[m + 3][k] = h3;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + e * 256;
+      const unsigned short h0 = to16<BF16>(rb[e].x), h1 = to16<BF16>(rb[e].y), h2 = to16<BF16>(rb[e].z), h3 = to16<BF16>(rb[e].w);
+      if (b_nfast) {
+        const int k = idx >> 4, n = (idx & 15) * 4;
+        Bs[n][k] = h0; Bs[n + 1][k] = h1; Bs[n + 2][k] = h2; Bs[n + 3][k] = h3;
+      } else {
+        const int n = idx >> 3, k = (idx & 7) * 4;
+        *reinterpret_cast<u16x4*>(&Bs[n][k]) = u16x4{h0, h1, h2, h3};
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < KL; k0 += TK) {
+    park();
+    __syncthreads();
+    if (k0 + TK < KL) fetch(k0 + TK);
+    const int r = lane & 15, g8 = (lane >> 4) * 8;
+    u16x8 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u16x8*>(&As[wm + i * 16 + r][g8]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u16x8*>(&Bs[wn + j * 16 + r][g8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(fa[i], fb[j], acc[i][j]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + r, n = n0 + wn + j * 16 + (lane & 15);
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[n];
+          if (p.relu) v = v < 0.f ? 0.f : v;
+          float* dst = pc + (int64_t)m * p.ldc + n;
+          *dst = p.accum ? *dst + v : v;
+        }
+      }
+}
+
+static int g_train_bf16 = 0;      // vog_train_set_int("bf16_gemm", 1): 16-bit operands for the tile GEMMs of the training path
+
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // ---- C[M <= 16, N] = A[M, K] . W[N, K]^T (+ bias, relu, accumulate): the recurrent products of the BiLSTM (M = number of
@@ -276,14 +379,16 @@ static int gemm_f32_b(const float* a, int64_t am, int64_t ak, int64_t sa, const 
       q.c = part; q.ldc = N; q.bias = nullptr; q.relu = 0; q.accum = 0; q.kchunk = kchunk;
       q.sa = (int64_t)kchunk * ak; q.sb = (int64_t)kchunk * bk; q.sc = (int64_t)M * N;
       if (!(m4(q.sa) && m4(q.sb))) q.scalar = 1;
-      ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), S), dim3(256), 0, st, q);
+      if (g_train_bf16 && !q.scalar) ::vog::launch(gemm_bf16_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), S), dim3(256), 0, st, q);
+      else ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), S), dim3(256), 0, st, q);
       ::vog::launch(splitk_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, (const float*)part, S, c, ldc,
                     bias, relu, accum, M, N);
       VOG_LAUNCH_CHECK();
       return 0;
     }
   }
-  ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), batch), dim3(256), 0, st, p);
+  if (g_train_bf16 && !p.scalar) ::vog::launch(gemm_bf16_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), batch), dim3(256), 0, st, p);
+  else ::vog::launch(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 128), batch), dim3(256), 0, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -1209,4 +1314,10 @@ extern "C" int vog_score_head_f32_bwd(const float* x, const float* d_mdl_outs, c
   if (d_x) VOG_TRY(gemm_f32(dh, dhead, 1, wl, d, 1, d_x, d, nullptr, 0, M, d, dhead, st));
   VOG_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vog_train_set_int(const char* name, int value) {
+  VOG_CHECK_ARG(name);
+  if (strcmp(name, "bf16_gemm") == 0) { g_train_bf16 = value ? 1 : 0; return 0; }
+  VOG_FAIL(-1, "vog_train_set_int: unknown option %s", name);
 }

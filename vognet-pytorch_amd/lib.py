@@ -279,6 +279,7 @@ SYMBOLS = {
     "vog_score_head_f32": (c_i32, [c_vp] * 7 + [C.c_size_t] + [c_i32] * 7 + [c_vp]),
     "vog_adam_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, c_vp]),
     "vog_row_mean_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vog_train_set_int": (c_i32, [C.c_char_p, c_i32]),
     "vog_score_head_f32_bwd_scratch_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_score_head_f32_bwd": (c_i32, [c_vp] * 11 + [C.c_size_t] + [c_i32] * 7 + [c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),

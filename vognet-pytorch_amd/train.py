@@ -32,7 +32,7 @@ from .engine import model_desc_from_cfg
 class FP32Trainer:
     def __init__(self, cfg, comm, state_dict: Dict[str, torch.Tensor], loss_fn, lr: Optional[float] = None,
                  betas=(0.9, 0.99), eps: float = 1e-8, device: str = "cuda", process_group=None, dropout: bool = False,
-                 dropout_seed: int = 0):
+                 dropout_seed: int = 0, bf16_gemm: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("FP32Trainer needs a GPU (libvog_hip.so kernels; there is no CPU fallback)")
         self.lib = L.load()
@@ -54,6 +54,10 @@ class FP32Trainer:
         # transformers' cfg.mdl.{obj,mul}_tx.attn_drop on attention probabilities and sub-layer outputs; masks come from a
         # counter-based generator seeded per step (csrc/backward.hip::drop_scale) - NOT torch's stream, so a step is
         # statistically, not bitwise, the reference's. Off: a step equals the reference's in eval mode.
+        # mixed precision: the tile GEMMs round their operands to bf16 (fp32 accumulation, fp32 master weights, fp32 everything
+        # else); off = the fp32 path that is pinned against autograd through the reference. Process-wide switch of the library,
+        # set at every step.
+        self.bf16_gemm = bool(bf16_gemm)
         self.dropout, self.dropout_seed = bool(dropout), int(dropout_seed)
         self.p_lstm = (0.1, 0.1)
         self.p_obj, self.p_mul = float(cfg.mdl.obj_tx.attn_drop), float(cfg.mdl.mul_tx.attn_drop)
@@ -158,6 +162,7 @@ class FP32Trainer:
     def gradients(self, batch, exchange: bool = False):
         """-> (loss dict, {parameter name: gradient}) of one batch (no update). exchange: average the gradients over the
         ranks - the visual side's buckets are in flight while the language side's backward runs."""
+        L.check(self.lib.vog_train_set_int(b"bf16_gemm", 1 if self.bf16_gemm else 0), "vog_train_set_int")
         out, acts, g = self.forward(batch)
         ld = self.loss_fn(out, batch)
         d_outs = self.loss_fn.backward(ld)
@@ -174,6 +179,7 @@ class FP32Trainer:
             fin_v()
             fin_l()
         gv.update(gl)
+        L.check(self.lib.vog_train_set_int(b"bf16_gemm", 0), "vog_train_set_int")
         return ld, gv
 
     def step(self, batch):
