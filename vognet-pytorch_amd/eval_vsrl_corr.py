@@ -119,20 +119,25 @@ class Evaluator(torch.nn.Module):
         Here every batch's packed device records get the batch's metadata appended (same int64 row,
         exact for |id| < 2^53: carried as fp64 bit patterns in two fp32 words each) and travel through
         ONE all-gather per GATHER_EVERY batches (dist.RecordRing; a collective per batch plus seven for
-        the metadata cost 12-20 us per step each). Record order on rank 0 = (batch, rank, query), the
-        order of the reference's per-batch concatenation."""
+        the metadata cost 12-20 us per step each). Record order on rank 0 = (rank, batch, query): all of rank
+        0's records, then all of rank 1's, ... - the order in which the reference appends the per-rank files
+        (:131-137)."""
         model.eval()
-        results = []
+        world = D.get_world_size()
+        by_rank = [[] for _ in range(world)]
         losses = {}
         nums = 0
         ring = None
-        world = D.get_world_size()
         layout = {}
 
         def on_half(g, n_valid):
-            rows = D.unpack_gathered(g, world, self.GATHER_EVERY, layout["B"], n_valid)
             if not D.is_main_process():
                 return
+            per_rank = g.view(world, self.GATHER_EVERY, layout["B"], -1)[:, :n_valid]
+            for r in range(world):
+                unpack_rows(per_rank[r].reshape(n_valid * layout["B"], -1), by_rank[r])
+
+        def unpack_rows(rows, results):
             rec = rows[:, :layout["rw"]].contiguous()
             r = self.unpack(rec, layout["ncmp"], layout["nsrl"])
             cols = {"pred_boxes": r["boxes"], "pred_scores": r["scores"], "pred_cmp": r["indexs"]}
@@ -178,6 +183,7 @@ class Evaluator(torch.nn.Module):
             ring.push(row, torch.cuda.current_stream() if rec.is_cuda else None)
         if ring is not None:
             ring.flush()
+        results = [rec for r in range(world) for rec in by_rank[r]]
         val_loss = {k: (v / max(1, nums)).float() for k, v in losses.items()}
         if D.get_world_size() > 1:
             for k in sorted(val_loss):                 # as reduce_dict in the reference (utils/trn_utils.py:61-90)
