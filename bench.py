@@ -300,6 +300,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_dist.py: two ranks on the ONE GPU of the test box): device index and collective backend
+    if "VOG_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["VOG_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     # VOG_BENCH_FORCE_DIST=1: run the N > 1 exchange path (RCCL all-gather per step) with one rank too
     use_dist = world > 1 or bool(os.environ.get("VOG_BENCH_FORCE_DIST"))
@@ -314,7 +317,7 @@ def main():
             os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=os.environ.get("VOG_BENCH_BACKEND", "nccl"), init_method="env://")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1 and args.mode == "graph":
         # with a live multi-rank process group the engine keeps at most 3 forwards in flight (its lane book

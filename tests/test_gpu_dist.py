@@ -152,3 +152,33 @@ def test_two_rank_evaluator_merges_records_rank_major(tmp_path):
     # NewDistributedSampler pads the shorter shard by wrapping (utils/trn_utils.py:127-156): rank 1's last batch repeats batch 0
     assert [r["idx_vid"] for r in recs] == expect
     assert all(np.isfinite(v) and v > 0 for v in res[0].values())
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* from the environment),
+    with both ranks on the one GPU of this box and gloo instead of RCCL (test hooks VOG_BENCH_DEVICE / VOG_BENCH_BACKEND): the
+    N > 1 code path of the bench - record ring with a cross-rank gather, barrier + max-over-ranks timing, one JSON line from
+    rank 0 only, `value` = the queries of BOTH ranks. Two streams per rank keep the persistent BiLSTM kernels of the two
+    processes within the four the chip can hold."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VOG_BENCH_DEVICE="0", VOG_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "8",
+                                       "--streams", "2", "--no-cpu-baseline", "--no-train-extra", "--no-cobatch-extra"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 0 only
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 40 and d["scaling"] == "weak"
+    assert d["parity"]["ok"] and d["parity"]["non_finite_outputs_all_slots"] == 0
+    assert d["value"] == pytest.approx(2 * d["per_rank_value"]) and d["value"] > 50          # (gloo moves the records through the host: slow, functional only)
+    assert d["config"]["global_batch"] == 8
