@@ -19,7 +19,6 @@ the reference's `loss` excludes verb_loss (code/mdl_conc_sep.py:434-436).
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, Optional
 
 import torch
