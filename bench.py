@@ -731,8 +731,17 @@ def main():
                 ld = tr.step(tdev)
             torch.cuda.synchronize()
             dtt = (time.perf_counter() - t0) / nt
+            # the same with bf16-operand tile GEMMs (mixed precision option; fp32 accumulation and master weights)
+            tr.bf16_gemm = True
+            tr.step(tdev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nt):
+                tr.step(tdev)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t0) / nt
             res["training_step"] = {"ms_per_step": dtt * 1e3, "queries_per_s": w["B"] / dtt, "dtype": "f32", "steps_timed": nt,
-                                    "loss_first": l0, "loss_last": float(ld["loss"]),
+                                    "loss_first": l0, "loss_last": float(ld["loss"]), "ms_per_step_bf16_gemm": dtb * 1e3,
                                     "what": "train.FP32Trainer.step on the same batch: fp32 forward, vog_loss_fwd / _bwd, backward of both "
                                             "transformers, encoders, packed BiLSTM (BPTT), embedding, Adam (betas 0.9 / 0.99); pinned against "
                                             "autograd through the reference (tests/golden/bwd__*.npz)"}
