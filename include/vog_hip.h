@@ -618,6 +618,9 @@ typedef struct vog_lang_f32_args {
   /* train-mode dropout of LSTMEncoder (utils/mdl_srl_utils.py:104, 128, 150): drop_in on the embedded tokens (site 1),
    * drop_out behind every BiLSTM layer (site 2 + l between layers, 10 on the output); 0 = off */
   float drop_in, drop_out; unsigned long long drop_seed;
+  /* 1: `scratch` still holds the forward of an earlier call with the same inputs, weights and dropout seed (no other call used
+   * the buffer in between): the backward starts from those activations instead of recomputing them */
+  int reuse_forward;
 } vog_lang_f32_args;
 int64_t vog_lang_f32_scratch_bytes(int Bn, int T, int nsrl, int E, int R, int layers, int D, int L);
 int vog_lang_f32(const vog_lang_f32_args* a, void* stream);

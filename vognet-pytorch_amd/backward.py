@@ -217,7 +217,8 @@ def encoder_layer_forward(state_dict, stack: str, layer: int, pe_name, x: torch.
 
 
 def encoder_layer_backward(state_dict, stack: str, layer: int, pe_name, x: torch.Tensor, S: int, N: int, n: int,
-                           n_heads: int, boxes=None, d_y: torch.Tensor = None, head=None, drop=None) -> Dict[str, torch.Tensor]:
+                           n_heads: int, boxes=None, d_y: torch.Tensor = None, head=None, drop=None,
+                           cat: torch.Tensor = None) -> Dict[str, torch.Tensor]:
     """Backward of one whole (Rel)EncoderLayer on the device (code/transformer_code.py:128-203).
 
     x [S*N, d]: the layer's fp32 input. Either `d_y` [S*N, d] (gradient of the layer's output) or `head` =
@@ -233,7 +234,8 @@ def encoder_layer_backward(state_dict, stack: str, layer: int, pe_name, x: torch
               state_dict[pe_name + ".bias"].detach().to(dev, torch.float32).contiguous())
     x = x.contiguous()
     ld = _layer_drop(drop, stack, layer)                                       # train mode: (p, seed) -> the layer's masks
-    f = _attn_call(w, pe, x, S, N, n, n_heads, boxes, drop=ld)                # recompute the concatenated heads
+    # the concatenated heads: kept from the forward pass (`cat`) or recomputed
+    f = {"cat": cat.contiguous()} if cat is not None else _attn_call(w, pe, x, S, N, n, n_heads, boxes, drop=ld)
     hd = None
     if head is not None:
         hn = {"wl": "lin2.0.weight", "bl": "lin2.0.bias", "wl2": "lin2.2.weight", "bl2": "lin2.2.bias"}
@@ -315,20 +317,36 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, relu: bool, dy
     return out
 
 
+def stack_forward(state_dict, stack: str, n_layers: int, pe_name, x0: torch.Tensor, S: int, N: int, n: int, n_heads: int,
+                  boxes=None, drop=None):
+    """fp32 forward of a (Rel)Transformer stack -> (output, [input of every layer], [concatenated heads of every layer]):
+    what `stack_backward(..., kept=)` starts from instead of recomputing."""
+    xs, cats = [x0.contiguous()], []
+    for l in range(n_layers):
+        y, cat = encoder_layer_forward(state_dict, stack, l, pe_name, xs[-1], S, N, n, n_heads, boxes, drop=drop)
+        cats.append(cat)
+        xs.append(y)
+    return xs[-1], xs[:-1], cats
+
+
 def stack_backward(state_dict, stack: str, n_layers: int, pe_name, x0: torch.Tensor, S: int, N: int, n: int, n_heads: int,
-                   boxes=None, d_y: torch.Tensor = None, head=None, drop=None) -> Dict[str, torch.Tensor]:
+                   boxes=None, d_y: torch.Tensor = None, head=None, drop=None, kept=None) -> Dict[str, torch.Tensor]:
     """(Rel)Transformer stack (code/transformer_code.py:227-279): fp32 forward recomputation layer by layer (each
     layer's input kept), then `encoder_layer_backward` from the last layer down. -> {parameter name: gradient,
     '_d_x': gradient of the stack input}. The box-bias Linear is shared by the layers: its gradient is summed."""
-    xs = [x0.contiguous()]
-    for l in range(n_layers - 1):
-        y, _ = encoder_layer_forward(state_dict, stack, l, pe_name, xs[-1], S, N, n, n_heads, boxes, drop=drop)
-        xs.append(y)
+    cats = [None] * n_layers
+    if kept is not None:                                   # (layer inputs, concatenated heads) of `stack_forward`
+        xs, cats = kept
+    else:
+        xs = [x0.contiguous()]
+        for l in range(n_layers - 1):
+            y, _ = encoder_layer_forward(state_dict, stack, l, pe_name, xs[-1], S, N, n, n_heads, boxes, drop=drop)
+            xs.append(y)
     grads: Dict[str, torch.Tensor] = {}
     d = d_y
     for l in range(n_layers - 1, -1, -1):
         r = encoder_layer_backward(state_dict, stack, l, pe_name, xs[l], S, N, n, n_heads, boxes, d_y=d,
-                                   head=head if l == n_layers - 1 else None, drop=drop)
+                                   head=head if l == n_layers - 1 else None, drop=drop, cat=cats[l])
         d = r.pop("_d_x")
         for k, v in r.items():
             grads[k] = grads[k] + v if k in grads else v          # (torch add on two gradient tensors: pe_* only)
@@ -374,7 +392,8 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
     if g["mul_layers"] > 0:
         mb = _Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
         r = stack_backward(state_dict, "mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", acts["mul_x"], B * nc_v * nfrm, nsrl * nppf,
-                           nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl), drop=g.get("drop_mul"))
+                           nppf, g["mul_heads"], mb, head=(d_mdl_outs, B * nc_v, nfrm, nppf, nsrl), drop=g.get("drop_mul"),
+                           kept=acts.get("mul_kept"))
         d_mul = r.pop("_d_x")
         out.update(r)
     else:
@@ -396,7 +415,7 @@ def visual_backward(state_dict, geo: dict, acts: dict, d_mdl_outs: torch.Tensor)
             S, N, fdiv = S0, NP, 1.0
         ob = _Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
         r = stack_backward(state_dict, "obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", acts["obj_x"], S, N, N, g["obj_heads"], ob,
-                           d_y=d_ps, drop=g.get("drop_obj"))
+                           d_y=d_ps, drop=g.get("drop_obj"), kept=acts.get("obj_kept"))
         d_ps = r.pop("_d_x")
         out.update(r)
     out["_d_prop_seg"] = d_ps
@@ -423,7 +442,8 @@ def lang_param_names(layers: int) -> Dict[str, str]:
     return n
 
 
-def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: torch.Tensor = None, drop=None) -> Dict[str, torch.Tensor]:
+def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: torch.Tensor = None, drop=None,
+                      forward_scratch: torch.Tensor = None) -> Dict[str, torch.Tensor]:
     """The language side on the device in fp32 (`vog_lang_f32`): embedding, packed BiLSTM (back-propagation through
     time), lstm_out_feat_proj, srl_arg_words_out_enc. batch: the model's input dict (device int64 tensors
     srl_arg_words_ind [B, nv, nsrl, sl], srl_arg_word_mask [B, nv, ml], srl_arg_word_mask_len [B, nv],
@@ -470,9 +490,14 @@ def language_backward(state_dict, batch: dict, T: int, layers: int, d_lang_enc: 
     if drop is not None:                                   # train mode: (p_in, p_out, seed) of LSTMEncoder's dropouts
         a.drop_in, a.drop_out, a.drop_seed = float(drop[0]), float(drop[1]), int(drop[2])
     nb = int(lib.vog_lang_f32_scratch_bytes(Bn, T, nsrl, E, R, layers, D, Lo))
-    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    if forward_scratch is not None:                        # '_scratch' of the forward-only call on the same batch / weights / seed
+        assert d_lang_enc is not None and forward_scratch.numel() == nb
+        scratch, a.reuse_forward = forward_scratch, 1
+    else:
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
     a.scratch, a.scratch_bytes = L.ptr(scratch), nb
     L.check(lib.vog_lang_f32(C.byref(a), L.stream_ptr()), "vog_lang_f32")
+    out["_scratch"] = scratch
     out.update({names[k]: v for k, v in g.items()})
     out["_keepalive"] = [ints, w, scratch, d_lang_enc]
     return out

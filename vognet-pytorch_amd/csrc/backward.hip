@@ -1075,10 +1075,13 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   float* part = take((int64_t)CS_CHUNKS * (G > L ? G : L));
   float* dpre2 = take((int64_t)BT * D);
   float* whh_t = take((int64_t)G * R);
-  // ---- forward recomputation
+  const Drop drop_emb = make_drop(a->drop_in, a->drop_seed, 1);
+  // reuse_forward: `scratch` still holds the forward of an earlier call with the same inputs, weights and dropout seed
+  // (the trainer's forward pass): the backward starts from it instead of recomputing 2 T recurrent products per layer
+  if (!a->reuse_forward) {
+  // ---- forward (re)computation
   ::vog::launch(lang_tokens_kernel, blocks(BT), dim3(256), 0, st, a->words_ind, a->word_mask, tok, Bn, T, a->words_len, a->mask_len,
                 a->vocab_size);
-  const Drop drop_emb = make_drop(a->drop_in, a->drop_seed, 1);
   ::vog::launch(embed_gather_kernel, blocks((int64_t)BT * E), dim3(256), 0, st, a->emb, (const int64_t*)tok, x0, BT, E, drop_emb);
   for (int l = 0; l < NL; ++l) {
     const float* xin = l == 0 ? x0 : lout[l - 1];
@@ -1116,6 +1119,7 @@ extern "C" int vog_lang_f32(const vog_lang_f32_args* a, void* stream) {
   }
   if (a->lang_enc_out) VOG_HIP(hipMemcpyAsync(a->lang_enc_out, lenc, (size_t)Bn * nsrl * L * 4, hipMemcpyDeviceToDevice, st));
   if (a->full_out) VOG_HIP(hipMemcpyAsync(a->full_out, full, (size_t)BT * D * 4, hipMemcpyDeviceToDevice, st));
+  }
   if (!bwd) { VOG_LAUNCH_CHECK(); return 0; }
   VOG_CHECK_ARG(a->g_emb && a->g_w_proj && a->g_b_proj && a->g_w_arg && a->g_b_arg);
   // ---- srl_arg_words_out_enc

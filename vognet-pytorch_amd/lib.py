@@ -212,7 +212,7 @@ class LangF32Args(C.Structure):
                 + [("g_w_ih", _P42), ("g_w_hh", _P42), ("g_b_ih", _P42), ("g_b_hh", _P42)]
                 + [(n, c_vp) for n in ("g_w_proj", "g_b_proj", "g_w_arg", "g_b_arg", "scratch")]
                 + [("scratch_bytes", C.c_size_t), ("hid_out", c_vp), ("drop_in", C.c_float), ("drop_out", C.c_float),
-                   ("drop_seed", C.c_uint64)])
+                   ("drop_seed", C.c_uint64), ("reuse_forward", c_i32)])
 
 
 class AttnF32Args(C.Structure):

@@ -86,9 +86,9 @@ class FP32Trainer:
         return (self.dropout_seed * 1000003 + self.num_it + 1) & 0x7FFFFFFFFFFFFFFF
 
     def _stack_forward(self, stack, n_layers, pe_name, x, S, N, n, heads, boxes, drop=None):
-        for l in range(n_layers):
-            x, _ = BW.encoder_layer_forward(self.params, stack, l, pe_name, x, S, N, n, heads, boxes, drop=drop)
-        return x
+        """-> (output, kept = (layer inputs, concatenated heads) for the backward)."""
+        y, xs, cats = BW.stack_forward(self.params, stack, n_layers, pe_name, x, S, N, n, heads, boxes, drop=drop)
+        return y, (xs, cats)
 
     def forward(self, batch):
         """fp32 forward on the device -> ({'mdl_outs' [B, nc_v, nsrl, NP] (, 'vidf_outs' [B, ncmp])}, activations at the seams of
@@ -111,15 +111,15 @@ class FP32Trainer:
         obj_x = torch.empty(BV * NP, pe.shape[1] + se.shape[1], dtype=torch.float32, device=self.dev)
         L.check(lib.vog_concat_rows_f32(L.ptr(pe), pe.shape[1], 1, L.ptr(se), se.shape[1], g["nppf0"], L.ptr(obj_x), BV * NP, st),
                 "vog_concat_rows_f32")
-        obj_out = obj_x
+        obj_out, obj_kept, mul_kept = obj_x, None, None
         if g["obj_layers"] > 0:
             if g["obj_one_frm"]:
                 S, N, fdiv = BV * nfrm, nppf, float(nfrm)
             else:
                 S, N, fdiv = BV, NP, 1.0
             ob = BW._Boxes(props, g["vid_w"], g["vid_h"], fdiv) if g["obj_use_rel"] else None
-            obj_out = self._stack_forward("obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", obj_x, S, N, N, g["obj_heads"], ob,
-                                          drop=g.get("drop_obj"))
+            obj_out, obj_kept = self._stack_forward("obj_txf", g["obj_layers"], "pe_obj_sub_enc.0", obj_x, S, N, N, g["obj_heads"], ob,
+                                                    drop=g.get("drop_obj"))
         msk = batch["srl_arg_inds_msk"].to(self.dev, torch.int64).contiguous()
         nv = msk.shape[1]
         assert nv in (1, nc_v), "language axis does not match conc_type"
@@ -133,8 +133,8 @@ class FP32Trainer:
         y = mul_x
         if g["mul_layers"] > 0:
             mb = BW._Boxes(props, g["vid_w"], g["vid_h"], float(nfrm)) if g["mul_use_rel"] else None
-            y = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf, g["mul_heads"], mb,
-                                    drop=g.get("drop_mul"))
+            y, mul_kept = self._stack_forward("mult_txf", g["mul_layers"], "pe_mul_sub_enc.0", mul_x, BV * nfrm, nsrl * nppf, nppf,
+                                              g["mul_heads"], mb, drop=g.get("drop_mul"))
         M, dm = y.shape
         dhead = p["lin2.0.weight"].shape[0]
         scratch = torch.empty(M * dhead, dtype=torch.float32, device=self.dev)
@@ -155,7 +155,9 @@ class FP32Trainer:
                                             L.ptr(sv), BV, st), "vog_concat_rows_f32")
             h1 = BW.linear_f32(sv, p["seg_verb_classf.0.weight"], p["seg_verb_classf.0.bias"], True)["y"]
             out["vidf_outs"] = BW.linear_f32(h1, p["seg_verb_classf.2.weight"], p["seg_verb_classf.2.bias"], False)["y"].reshape(B, nc_v)
-        acts = {"mul_x": mul_x, "obj_x": obj_x, "prop_feat": prop_feat, "seg_feat": seg_feat, "props": props, "inds_msk": msk, "T": T}
+        # kept for the backward: the inputs and concatenated heads of every encoder layer, the language side's whole scratch
+        acts = {"mul_x": mul_x, "obj_x": obj_x, "prop_feat": prop_feat, "seg_feat": seg_feat, "props": props, "inds_msk": msk, "T": T,
+                "mul_kept": mul_kept, "obj_kept": obj_kept, "lang_scratch": lf["_scratch"]}
         return out, acts, g
 
     def gradients(self, batch, exchange: bool = False):
@@ -171,7 +173,8 @@ class FP32Trainer:
         if exchange:
             from .dist import all_reduce_grads_begin
             fin_v = all_reduce_grads_begin(gv)
-        lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"], drop=g.get("drop_lang"))
+        lg = BW.language_backward(self.params, batch, acts["T"], self.desc.rnn_layers, d_lang_enc=grads["_d_lang"], drop=g.get("drop_lang"),
+                                  forward_scratch=acts["lang_scratch"])
         gl = {k: v for k, v in lg.items() if not k.startswith("_")}
         if exchange:
             fin_l = all_reduce_grads_begin(gl)
