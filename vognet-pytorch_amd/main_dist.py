@@ -10,8 +10,8 @@ called as `eval_fn(mdl, loss_fn, dl, dl_name, rank=..., pred_path=<tmp_path>/pre
 forward -> device loss -> prediction records -> ONE cross-rank exchange per 16 batches (dist.RecordRing) ->
 rank 0 writes `<pred_path>/<dl_name>_0.pkl` and scores it when the annotation files of cfg.ds exist; the
 loss and metric dicts are printed like the reference prints them, followed by one JSON line.
-Without `only_val` / `only_test` it runs `Learner.fit` (code/main_dist.py:125 -> utils/trn_utils.py:701-775) through
-`train.fit`: per epoch the device training step (`train.FP32Trainer`: fp32 forward -> loss -> backward -> gradient
+Without `only_val` / `only_test` it builds `trn_utils.Learner` and runs `learn.fit` (code/main_dist.py:31-87, 125 ->
+utils/trn_utils.py:701-775): per epoch the device training step (`train.FP32Trainer`: fp32 forward -> loss -> backward -> gradient
 all-reduce -> Adam) over the training batches, then the validation flow above on the inference model carrying the
 new weights, and `<tmp_path>/models/<uid>.pth` in the reference's checkpoint layout; `--train.resume=True` loads
 it back (model + optimizer), as `Learner.load_model_dict`.
@@ -114,23 +114,17 @@ def main_dist(uid: str, **kwargs):
     # Learner.init_log_dirs (utils/trn_utils.py:341-368): <data.path = cfg.misc.tmp_path>/predictions/<uid>
     pred_path = Path(cfg.misc.tmp_path) / "predictions" / uid
     if not (cfg.only_val or cfg.only_test):
-        from . import train as TR
-        model_file = Path(cfg.misc.tmp_path) / "models" / f"{uid}.pth"
-        # train mode (`self.mdl.train()`, utils/trn_utils.py:487): dropout on, masks from the device's own generator
-        tr = TR.FP32Trainer(cfg, comm, mdl.state_dict(), loss_fn, lr=float(cfg.train.lr), dropout=True, dropout_seed=0)
-        if cfg.train.resume and model_file.exists():
-            ck = torch.load(model_file.open("rb"), weights_only=False)
-            tr.params.update({k: v.to(tr.dev, torch.float32).contiguous() for k, v in ck["model_state_dict"].items()})
-            if cfg.train.load_opt:
-                tr.load_optimizer_state_dict(ck["optimizer_state_dict"])
-        train_dl = synthetic_loader(cfg, comm, n_batches, rank, world, train=True)
-        valid_dl = synthetic_loader(cfg, comm, max(2, n_batches // 2), rank, world)
+        # learner_init + learn.fit (code/main_dist.py:31-87, 125)
+        from .trn_utils import DataWrap, Learner
+        data = DataWrap(path=cfg.misc.tmp_path, train_dl=synthetic_loader(cfg, comm, n_batches, rank, world, train=True),
+                        valid_dl=synthetic_loader(cfg, comm, max(2, n_batches // 2), rank, world))
+        learn = Learner(uid=uid, data=data, mdl=mdl, loss_fn=loss_fn, cfg=cfg, eval_fn=evl, comm=comm)
         t0 = time.time()
-        hist = TR.fit(tr, mdl, evl, train_dl, valid_dl, int(cfg.train.epochs), model_file, pred_path, rank=rank)
+        hist = learn.fit(epochs=int(cfg.train.epochs), lr=float(cfg.train.lr))
         torch.cuda.synchronize()
         if D.is_main_process():
-            print(json.dumps({"uid": uid, "world": world, "epochs": len(hist), "train_steps": tr.num_it, "seconds": time.time() - t0,
-                              "model_file": str(model_file), "history": hist}))
+            print(json.dumps({"uid": uid, "world": world, "epochs": len(hist), "train_steps": learn.trainer.num_it,
+                              "seconds": time.time() - t0, "model_file": str(learn.model_file), "history": hist}))
         return hist
     dl_name = "valid" if cfg.only_val else "test"
     dl = synthetic_loader(cfg, comm, n_batches, rank, world)

@@ -237,39 +237,3 @@ class SmoothenDict:
         for k in self.keys:
             self.mov[k] = self.beta * self.mov[k] + (1 - self.beta) * float(d[k])
             self.smooth[k] = self.mov[k] / (1 - self.beta ** self.n)
-
-
-def fit(trainer: FP32Trainer, mdl, evl, train_dl, valid_dl, epochs: int, model_file, pred_path, rank: int = 0,
-        log=print):
-    """`Learner.fit` (utils/trn_utils.py:701-775): per epoch one pass over the training loader (`train_epoch`), the
-    reference's validation flow on the inference model carrying the new weights (`Learner.validate` -> the evaluator:
-    16-bit HIP forward, device loss, records, metrics), and a checkpoint in the reference's layout whenever the first
-    metric improves. -> list of per-epoch dicts."""
-    import json
-    from . import dist as D
-    best_met, hist = -1.0, []
-    loss_keys, met_keys = trainer.loss_fn.loss_keys, evl.met_keys
-    for epoch in range(1, epochs + 1):
-        sm = SmoothenDict(loss_keys, 0.9)
-        for batch in train_dl:
-            batch = {k: v.to(trainer.dev) for k, v in batch.items()}
-            sm.add_value(trainer.step(batch))
-        D.synchronize()
-        mdl.load_state_dict(trainer.state_dict(), strict=False)
-        mdl.refresh_weights()
-        with torch.no_grad():
-            val_loss, val_acc = evl(mdl, trainer.loss_fn, valid_dl, "valid", rank=rank, pred_path=pred_path)
-        met = float(val_acc[met_keys[0]])
-        rec = {"epochs": epoch, **{"trn_" + k: sm.smooth[k] for k in loss_keys},
-               **{"val_" + k: float(val_loss[k]) for k in loss_keys}, **{"val_" + k: float(val_acc[k]) for k in met_keys}}
-        hist.append(rec)
-        if D.is_main_process():
-            log("  ".join(f"{k} {v:.4f}" if isinstance(v, float) else f"{k} {v}" for k, v in rec.items()))
-            if best_met < met or epoch == epochs and not model_file.exists():
-                best_met = max(best_met, met)
-                model_file.parent.mkdir(parents=True, exist_ok=True)
-                torch.save({"model_state_dict": {k: v.cpu() for k, v in trainer.state_dict().items()},
-                            "optimizer_state_dict": trainer.optimizer_state_dict(), "num_it": trainer.num_it, "num_epoch": epoch,
-                            "cfgtxt": json.dumps(trainer.cfg, default=str), "best_met": best_met}, model_file.open("wb"))
-        D.synchronize()
-    return hist
