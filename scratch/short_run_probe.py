@@ -15,7 +15,13 @@ NS = 4
 streams = [torch.cuda.Stream() for _ in range(NS)]
 slots = [eng.make_slot({k: torch.from_numpy(v) for k, v in synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=B.VOCAB, seed=2000 + s).items()}, graph=True)
          for s in range(NS)]
-def run(K, order="rr"):
+def spin_us(us):
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e6 < us:
+        pass
+
+
+def run(K, order="rr", stagger=0.0):
     torch.cuda.synchronize()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
@@ -25,6 +31,8 @@ def run(K, order="rr"):
     first = set()
     for i, u in enumerate(seq):
         if u not in first:
+            if first and stagger:
+                spin_us(stagger)
             ev0[u].record(streams[u]); first.add(u)
         slots[u].launch(streams[u])
         host.append((time.perf_counter() - t0) * 1e6)
@@ -36,8 +44,14 @@ def run(K, order="rr"):
     st = [ev0[0].elapsed_time(ev0[u]) * 1e3 for u in range(NS)]
     en = [ev0[0].elapsed_time(ev1[u]) * 1e3 for u in range(NS)]
     return dt, t_issue, host, st, en
-for K in (20, 20, 20, 40, 100):
-    for order in ("rr", "block"):
+for stg in (0, 15, 30, 50, 70):
+    res = []
+    for rep in range(5):
+        for _ in range(30): run(20)
+        res.append(run(20, "rr", stg)[0])
+    print(f"stagger {stg} us between the first launches: K=20 total {min(res):.0f} .. {max(res):.0f} us, median {sorted(res)[2]:.0f}")
+for K in (20,):
+    for order in ("rr",):
         for _ in range(30): run(20)
         dt, ti, host, st, en = run(K, order)
         print(f"K={K} {order}: total {dt:.0f} us ({dt/K:.1f}/step), host issued all after {ti:.0f} us; first 4 launches issued at {[round(h) for h in host[:4]]}; "

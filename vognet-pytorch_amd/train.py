@@ -164,6 +164,12 @@ class FP32Trainer:
         """-> (loss dict, {parameter name: gradient}) of one batch (no update). exchange: average the gradients over the
         ranks - the visual side's buckets are in flight while the language side's backward runs."""
         L.check(self.lib.vog_train_set_int(b"bf16_gemm", 1 if self.bf16_gemm else 0), "vog_train_set_int")
+        try:
+            return self._gradients(batch, exchange)
+        finally:                                            # (process-wide switch: never leave it on behind an exception)
+            self.lib.vog_train_set_int(b"bf16_gemm", 0)
+
+    def _gradients(self, batch, exchange):
         out, acts, g = self.forward(batch)
         ld = self.loss_fn(out, batch)
         d_outs = self.loss_fn.backward(ld)
@@ -181,7 +187,6 @@ class FP32Trainer:
             fin_v()
             fin_l()
         gv.update(gl)
-        L.check(self.lib.vog_train_set_int(b"bf16_gemm", 0), "vog_train_set_int")
         return ld, gv
 
     def step(self, batch):
