@@ -24,7 +24,8 @@ from oracle.make_golden_loss import targets_for
 
 BWD_CASES = ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16",
              "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2",
-             "full/cfg2_ragged", "small/vog_sep_cmpmsk"]      # sentences of different lengths at full size; masked-out videos
+             "full/cfg2_ragged", "small/vog_sep_cmpmsk",      # sentences of different lengths at full size; masked-out videos
+             "small/vog_spat_3layers", "small/vog_temp_objonefrm", "small/vog_spat_noobj", "small/vog_spat_norel"]   # the model's knobs
 N_SAMPLE = 4096
 
 
