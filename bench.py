@@ -40,6 +40,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "cfg2": dict(mdl="vog", conc="spat", exp="gt5", B=4, tx="bf16",
                  desc="VOGNet spat gt5 (obj_tx+mul_tx, use_rel) bs=4"),
+    # not a BASELINE config: four bs=4 requests served as ONE forward (what dynamic batching of the validation loop would run)
+    "cfg2x4": dict(mdl="vog", conc="spat", exp="gt5", B=16, tx="bf16",
+                   desc="VOGNet spat gt5 (obj_tx+mul_tx, use_rel) 4 x bs=4 in one forward"),
     "cfg3": dict(mdl="vog", conc="temp", exp="gt5", B=8, tx="bf16",
                  desc="VOGNet temp gt5 bs=8"),
     "cfg4": dict(mdl="vog", conc="spat", exp="p100", B=4, tx="bf16",
@@ -342,10 +345,10 @@ def main():
     for kv in args.set or []:            # engine switches for A/B runs, e.g. --set fused_pred=0 (defaults are what `value` is for)
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    cfg_id = int(args.workload[3:])
+    cfg_id = int(args.workload[3:4])
     aql = args.mode == "aql"
 
-    def measure(G, steps, warmup):
+    def measure(G, steps, warmup, batched=False):
         """K timed steps (one step = one batch of the workload) after W warm-up steps with G
         batches per language-encoder pass. Returns (seconds, slots, batches, in-flight count)."""
         Q, K, DEPTH = max(1, args.queues), max(1, args.interleave), 2
@@ -373,9 +376,10 @@ def main():
         else:
             assert steps % G == 0 and warmup % G == 0, "--steps / --warmup must be multiples of the co-batch size"
             for u in range(nunits * nsets):
-                grp = eng.make_group([{k: torch.from_numpy(v) for k, v in b.items()}
-                                      for b in batches[u * G:(u + 1) * G]], graph=(not args.no_graph) and not aql,
-                                     pred_rec=recbuf[u * G * w["B"]:(u + 1) * G * w["B"]])
+                mk = eng.make_batched if batched else eng.make_group
+                grp = mk([{k: torch.from_numpy(v) for k, v in b.items()}
+                          for b in batches[u * G:(u + 1) * G]], graph=(not args.no_graph) and not aql,
+                         pred_rec=recbuf[u * G * w["B"]:(u + 1) * G * w["B"]])
                 units.append(grp)
                 slots.extend(grp.slots)
         if aql:
@@ -466,6 +470,19 @@ def main():
                   "what": "the same strict per-batch path over 400 timed steps: `value` above is K = %d steps, whose fixed pipeline "
                           "fill / drain (~160 us per timed region) is %.0f %% of its time" % (args.steps, 100 * (1 - (dts / 400) / (dt / args.steps)))}
         del sl_s
+    # four bs=4 requests served as ONE forward (dynamic batching; `make_batched`): reported beside `value`, never instead of
+    # it - `value` is one bs=4 forward per launch sequence
+    batched4 = None
+    if G == 1 and world == 1 and not args.throughput_only and not args.no_graph and not aql and not args.no_cobatch_extra:
+        dtb, sl_b, _, n_b = measure(4, 400, 40, batched=True)
+        nfin = int(sum(int((~torch.isfinite(sl.out["mdl_outs_eval"])).sum().item()) for sl in sl_b))
+        batched4 = {"value": 400 * w["B"] / dtb if nfin == 0 else None, "unit": "queries/s", "ms_per_step": dtb / 400 * 1e3, "steps": 400,
+                    "warmup": 40, "requests_per_forward": 4, "forwards_in_flight": n_b // 4,
+                    "what": "400 timed steps (one step = one bs=%d request); four requests share one forward: every kernel of the chain "
+                            "is four times wider, the BiLSTM fills its 16 MFMA columns, a request costs a quarter of the launches; each "
+                            "request's outputs equal its stand-alone forward (tests/test_gpu_forward.py::"
+                            "test_batched_requests_match_standalone_forwards); Evaluator.forward uses it with cfg.hip.batch_requests" % w["B"]}
+        del sl_b
     # second, separately timed run of the same K steps: the language encoder of 4 in-flight batches as
     # one pass (reported beside `value`, never instead of it: `value` is the strict per-batch path)
     extra = None
@@ -530,6 +547,8 @@ def main():
         res["lang_cobatch4"] = extra
     if steady is not None:
         res["steady_state_400_steps"] = steady
+    if batched4 is not None:
+        res["requests_batched4"] = batched4
     # ---- roofline of the dominant kernel: HIP-event timing inside libvog_hip on this stream
     flops, total_flops = kernel_flops(w, T)
     executed_total = flops.pop("_executed_total")

@@ -425,6 +425,40 @@ def _group_members(name, n):
     return out
 
 
+@pytest.mark.parametrize("name,n", [("full/cfg2_vog_spat_gt5_bs4", 4), ("full/cfg2_ragged", 3), ("full/cfg5_vog_svsq_gt5_bs16", 2),
+                                    ("small/vog_temp", 4)])
+def test_batched_requests_match_standalone_forwards(name, n):
+    """`make_batched`: n requests served as ONE forward (their rows back to back in one slot). Rows never interact: every
+    member gets the outputs of its own stand-alone forward (same bound as the shared-language group: the fp32 summation order
+    of a GEMM row does not depend on M, but sentences of another request change T = the longest sentence, hence the BiLSTM
+    schedule of the padded steps), over graph replays."""
+    from tests.gpu_util import engine_mod, comm_for
+    members = _group_members(name, n)
+    cfg, sd, _, c = members[0]
+    eng = engine_mod.VogEngine(cfg, comm_for(c))
+    eng.load_state_dict(sd)
+    devs = [{k: torch.from_numpy(v).cuda() for k, v in m[2].items()} for m in members]
+    refs = []
+    for dv in devs:
+        o = eng.forward(dv)
+        refs.append({k: v.clone() for k, v in o.items() if isinstance(v, torch.Tensor)})
+    torch.cuda.synchronize()
+    bt = eng.make_batched(devs, graph=True)
+    ncmp = members[0][2]["new_srl_idxs"].shape[1]
+    exact = True
+    for rep in range(3):
+        bt.big.out["mdl_outs"].fill_(float("nan"))
+        outs = bt.launch()
+        torch.cuda.synchronize()
+        for m, (ref, out) in enumerate(zip(refs, outs)):
+            e = (ref["mdl_outs"] - out["mdl_outs"]).abs().max().item()
+            assert e <= 1.5e-3, (name, m, e)
+            exact &= e == 0.0
+            pa, pb = eng.unpack_pred(ref["pred_rec"], ncmp), eng.unpack_pred(out["pred_rec"].contiguous(), ncmp)
+            assert (pa["scores"] - pb["scores"]).abs().max().item() <= 4e-4, (name, m)
+    print(name, "batched == stand-alone bit for bit:", exact)
+
+
 @pytest.mark.parametrize("name,n", [("full/cfg2_vog_spat_gt5_bs4", 4), ("full/cfg2_ragged", 4),
                                     ("full/vog_sep_gt5_bs4_ragged", 2), ("full/cfg3_vog_temp_gt5_bs8", 2),
                                     ("full/cfg1_igrnd_spat_gt5_bs2", 3), ("small/vog_spat", 4),

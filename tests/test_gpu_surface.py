@@ -771,3 +771,24 @@ def test_learner_surface(tmp_path):
     for k, v in learn.trainer.state_dict().items():
         assert torch.equal(v, learn2.trainer.params[k]), k
     assert learn2.num_epoch == learn.num_epoch
+
+
+def test_evaluator_batches_requests(capsys, tmp_path):
+    """`cfg.hip.batch_requests = 4`: Evaluator.forward serves four loader batches as ONE forward (dynamic batching). Same
+    records in the same order, the same per-batch-averaged loss as one forward per loader batch - incl. a short tail batch
+    inside the last group."""
+    kw = {"mdl.name": "vog", "ds.conc_type": "spat", "mdl.obj_tx.use_rel": True, "mdl.mul_tx.use_rel": True, "train.bsv": 4,
+          "misc.tmp_path": str(tmp_path)}
+    main_mod.main_dist("b1", only_val=True, synthetic_batches=6, **kw)
+    r1 = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{\"uid\"")][-1])
+    main_mod.main_dist("b4", only_val=True, synthetic_batches=6, **{**kw, "hip.batch_requests": 4})
+    r4 = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{\"uid\"")][-1])
+    assert r1["queries"] == r4["queries"] == 23
+    for k in r1["val_loss"]:
+        assert abs(r1["val_loss"][k] - r4["val_loss"][k]) <= 2e-4 * abs(r1["val_loss"][k]), (k, r1["val_loss"], r4["val_loss"])
+    a = pickle.load(open(r1["pred_file"], "rb"))
+    b = pickle.load(open(r4["pred_file"], "rb"))
+    assert len(a) == len(b) == 23 and [x["idx_vid"] for x in a] == [x["idx_vid"] for x in b]
+    for x, y in zip(a, b):
+        assert np.abs(np.array(x["pred_scores"]) - np.array(y["pred_scores"])).max() <= 4e-4
+        assert x["pred_cmp"] == y["pred_cmp"] or np.abs(np.array(x["pred_scores"])).max() > 0      # (ties aside, the same choices)

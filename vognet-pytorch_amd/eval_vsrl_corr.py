@@ -154,16 +154,41 @@ class Evaluator(torch.nn.Module):
             n = len(cols["pred_boxes"])
             results.extend({k: v[i] for k, v in cols.items()} for i in range(n))
 
-        for batch in dl:
+        G = int(self.cfg.hip.get("batch_requests", 1)) if "hip" in self.cfg else 1
+
+        def batches():
+            """The loader's batches, `batch_requests` of them at a time as one (dynamic batching: rows never interact)."""
+            if G <= 1:
+                for bt in dl:
+                    yield bt, [next(iter(bt.values())).shape[0]]
+                return
+            pend = []
+            for bt in dl:
+                pend.append(bt)
+                if len(pend) == G:
+                    yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, [next(iter(p_.values())).shape[0] for p_ in pend]
+                    pend = []
+            if pend:
+                yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, [next(iter(p_.values())).shape[0] for p_ in pend]
+
+        for batch, sizes in batches():
             batch = {k: v.to(self.device) for k, v in batch.items()}
             b = next(iter(batch.values())).shape[0]
             with torch.no_grad():
                 out = model(batch)
                 if loss_fn is not None:
-                    ld = loss_fn(out, batch)
-                    for k, v in ld.items():
-                        losses[k] = losses.get(k, 0.0) + v.detach().double() * b
-                    nums += b
+                    # the loss of every loader batch on its own rows: the reference averages per-batch means (:113-127)
+                    lo = 0
+                    for sz in sizes:
+                        if len(sizes) == 1:
+                            ld = loss_fn(out, batch)
+                        else:
+                            ld = loss_fn({k: v[lo:lo + sz] for k, v in out.items() if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == b},
+                                         {k: v[lo:lo + sz] for k, v in batch.items()})
+                        for k, v in ld.items():
+                            losses[k] = losses.get(k, 0.0) + v.detach().double() * sz
+                        nums += sz
+                        lo += sz
             rec = self._records(out, batch)
             meta = [k for k in self.META_KEYS if k in batch]
             if ring is None:

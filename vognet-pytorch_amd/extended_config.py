@@ -148,7 +148,8 @@ _DEFAULTS: Dict[str, Any] = {
     "overfit_batch": False,
     # build-specific (not in the reference yaml): arithmetic type of the two
     # transformers' MFMA contractions ("bf16" | "f16"); fp32 accumulate always.
-    "hip": {"tx_dtype": "bf16", "use_graph": True},
+    # batch_requests: Evaluator.forward serves this many loader batches as ONE forward (dynamic batching; 1 = off)
+    "hip": {"tx_dtype": "bf16", "use_graph": True, "batch_requests": 1},
 }
 
 key_maps: Dict[str, str] = {}
