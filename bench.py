@@ -43,6 +43,8 @@ WORKLOADS = {
     # not a BASELINE config: four bs=4 requests served as ONE forward (what dynamic batching of the validation loop would run)
     "cfg2x4": dict(mdl="vog", conc="spat", exp="gt5", B=16, tx="bf16",
                    desc="VOGNet spat gt5 (obj_tx+mul_tx, use_rel) 4 x bs=4 in one forward"),
+    "cfg2x2": dict(mdl="vog", conc="spat", exp="gt5", B=8, tx="bf16", desc="VOGNet spat gt5, 2 x bs=4 in one forward"),
+    "cfg2x8": dict(mdl="vog", conc="spat", exp="gt5", B=32, tx="bf16", desc="VOGNet spat gt5, 8 x bs=4 in one forward"),
     "cfg3": dict(mdl="vog", conc="temp", exp="gt5", B=8, tx="bf16",
                  desc="VOGNet temp gt5 bs=8"),
     "cfg4": dict(mdl="vog", conc="spat", exp="p100", B=4, tx="bf16",
