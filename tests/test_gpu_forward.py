@@ -457,6 +457,20 @@ def test_batched_requests_match_standalone_forwards(name, n):
             pa, pb = eng.unpack_pred(ref["pred_rec"], ncmp), eng.unpack_pred(out["pred_rec"].contiguous(), ncmp)
             assert (pa["scores"] - pb["scores"]).abs().max().item() <= 4e-4, (name, m)
     print(name, "batched == stand-alone bit for bit:", exact)
+    # replay with the requests rotated by one position (update_member): outputs rotate with them - to the bound above, not bit
+    # for bit: the tail kernels rotate their k order by the row block's position on its XCD (fp32 summation order is a
+    # function of the position in the slot), 5e-4 on the logits at full size
+    if all(int(d_["srl_arg_word_mask_len"].max()) <= bt.big.T for d_ in devs):
+        first = [{k: v.clone() for k, v in o.items()} for o in outs]
+        for m in range(n):
+            bt.update_member(m, devs[(m + 1) % n])
+        outs = bt.launch()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for m in range(n):
+            worst = max(worst, (outs[m]["mdl_outs"] - first[(m + 1) % n]["mdl_outs"]).abs().max().item())
+        print(name, "rotated requests: max logit difference", worst)
+        assert worst <= 1.5e-3, (name, worst)
 
 
 @pytest.mark.parametrize("name,n", [("full/cfg2_vog_spat_gt5_bs4", 4), ("full/cfg2_ragged", 4),

@@ -460,6 +460,19 @@ class Batched:
         self.big.launch(stream)
         return self.out
 
+    def update_member(self, m: int, inp, check_lengths: bool = True):
+        """New inputs for request m (same shapes; sentence lengths <= the T the slot was captured with - the longest sentence of
+        the requests it was created from; capture with padded lengths when they vary)."""
+        lens = inp.get("srl_arg_word_mask_len") if check_lengths else None
+        if lens is not None:
+            mx = int((lens if isinstance(lens, torch.Tensor) else torch.as_tensor(lens)).max())
+            if mx > self.big.T:
+                raise ValueError(f"request has a sentence of {mx} tokens but this slot was captured with T = {self.big.T}")
+        view = self.slots[m].inp
+        for k, v in inp.items():
+            if k in view:
+                view[k].copy_(v if isinstance(v, torch.Tensor) else torch.from_numpy(v), non_blocking=True)
+
 
 class Group:
     """G batch slots + one shared language-encoder workspace + one graph / AQL program for all."""
