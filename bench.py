@@ -350,6 +350,12 @@ def main():
     cfg_id = int(args.workload[3:4])
     aql = args.mode == "aql"
 
+    # ONE set of streams for every measurement of this process. Which hardware queue a HIP stream lands on depends on the
+    # order in which ALL streams of the process were created and first used (scratch/dbg_streams2.py: the same 4-stream loop
+    # runs at 71 or 110 us per batch depending on whether the slots' capture streams were created between them; streams i and
+    # i + 4 of a run share a queue): the streams are created here, back to back, before any slot exists, and reused.
+    stream_pool = [torch.cuda.Stream(device=dev) for _ in range(16)]
+
     def measure(G, steps, warmup, batched=False):
         """K timed steps (one step = one batch of the workload) after W warm-up steps with G
         batches per language-encoder pass. Returns (seconds, slots, batches, in-flight count)."""
@@ -364,7 +370,7 @@ def main():
             b = synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=VOCAB,
                                  seed=1000 * cfg_id + rank * 64 + s)
             batches.append(b)
-            streams.append(torch.cuda.Stream(device=dev))
+            streams.append(stream_pool[s] if s < len(stream_pool) else torch.cuda.Stream(device=dev))
         # the prediction records of all batches in flight live in ONE buffer: the exchange step is
         # one all-gather per round of in-flight batches instead of one per batch
         ncmp_w = 1 if w["conc"] == "svsq" else 4
