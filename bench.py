@@ -353,7 +353,8 @@ def main():
     # ONE set of streams for every measurement of this process. Which hardware queue a HIP stream lands on depends on the
     # order in which ALL streams of the process were created and first used (scratch/dbg_streams2.py: the same 4-stream loop
     # runs at 71 or 110 us per batch depending on whether the slots' capture streams were created between them; streams i and
-    # i + 4 of a run share a queue): the streams are created here, back to back, before any slot exists, and reused.
+    # i + 4 of a run share a queue): the streams are created here, back to back, before any slot exists, and reused. (Picking
+    # them by a pairwise timing test was tried: what overlaps during the test does not reliably overlap afterwards.)
     stream_pool = [torch.cuda.Stream(device=dev) for _ in range(16)]
 
     def measure(G, steps, warmup, batched=False):

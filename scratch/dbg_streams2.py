@@ -22,3 +22,4 @@ def run(ns, create_first):
     print(f"{ns} streams, streams created {'first' if create_first else 'interleaved with slots'}: {us:.1f} us/batch; stream ids {[hex(s.cuda_stream)[-5:] for s in streams]}")
 for ns in (2, 3, 4):
     run(ns, True); run(ns, False)
+

@@ -645,3 +645,4 @@ def test_persistent_lstm_handoff_is_deterministic_under_load():
             for sl, ref, w in zip(slots, refs, last):
                 for k in ref[w]:
                     assert torch.equal(sl.out[k], ref[w][k]), (i, k)
+
