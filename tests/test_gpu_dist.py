@@ -100,12 +100,13 @@ def test_two_rank_training_equals_training_on_the_averaged_gradient():
     assert worst <= 1e-7, worst
 
 
-def _eval_worker(rank, world, port, name, tmp, q):
+def _eval_worker(rank, world, port, name, tmp, q, batch_requests=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     D = importlib.import_module("vognet-pytorch_amd.dist")
     cfg, sd, c, comm, sel, synth = _setup(name)
+    cfg.hip.batch_requests = batch_requests
     mdl = sel["mdl"](cfg=cfg, comm=comm)
     mdl.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     evl = sel["eval"](cfg, comm, torch.device("cuda", 0))
@@ -128,15 +129,17 @@ def _eval_worker(rank, world, port, name, tmp, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_evaluator_merges_records_rank_major(tmp_path):
+@pytest.mark.parametrize("batch_requests", [1, 2])
+def test_two_rank_evaluator_merges_records_rank_major(tmp_path, batch_requests):
     """`Evaluator.forward` on two ranks (HIP forward, device loss, record ring, cross-rank gather on device tensors): rank 0's
-    pickle holds every query of both ranks' shards, rank-major = the order the reference builds from its per-rank files."""
+    pickle holds every query of both ranks' shards, rank-major = the order the reference builds from its per-rank files - with
+    one forward per loader batch and with two loader batches per forward (`cfg.hip.batch_requests`, a short last group)."""
     import pickle
     name, world = "small/vog_spat", 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_eval_worker, args=(r, world, port, name, tmp_path, q)) for r in range(world)]
+    ps = [ctx.Process(target=_eval_worker, args=(r, world, port, name, tmp_path, q, batch_requests)) for r in range(world)]
     for p in ps:
         p.start()
     res = dict(q.get(timeout=300)[:2] for _ in range(world))
