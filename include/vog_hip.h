@@ -140,6 +140,11 @@ typedef struct vog_qkv_args {
    * M = 800, at twice its latency (the right trade with several forwards in flight). Needs
    * vog_qkv_rowblock_supported(3*H*dp, K); wqkv / ldw are not read. */
   const void* wqkv_p32;
+  /* row-block form as a consumer inside the encoders' launch (forward option chain_obj_qkv; csrc/pair.hip pair3_kernel):
+   * dep_flags = the done_flags of vog_visenc_args; a workgroup waits for the encoder workgroups that write its 64 rows
+   * (dep_nb0 = ceil(n_prop_rows / 64), dep_rep = nppf0, dep_nh0 / dep_nh1 = ceil(prop_enc / 128), ceil(seg_enc / 128)).
+   * NULL: no waiting. Set outside such a launch it is harmless (the flags are already up). */
+  const unsigned int* dep_flags; int dep_nb0, dep_rep, dep_nh0, dep_nh1;
 } vog_qkv_args;
 int vog_qkv_proj(const vog_qkv_args* a, void* stream);
 int vog_qkv_rowblock_supported(int n_out, int K);
@@ -292,6 +297,10 @@ typedef struct vog_visenc_args {
    * runs vog_seg_replicate (the forward does, so that the encoder kernel stays ONE launch and can share
    * the launch of a BiLSTM layer). */
   int defer_replicas;
+  /* lean form, optional: done_flags[(64-row block) * 2 + (128-column half)] (uint, zeroed by the caller before the launch) is
+   * set to 1 when that workgroup's rows are in memory, and the 16-bit copy is written through: lets consumers of the rows run
+   * in the same launch (vog_qkv_args.dep_flags). Blocks: ceil(n_prop_rows / 64) proposal blocks, then the segment blocks. */
+  unsigned int* done_flags;
 } vog_visenc_args;
 int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
 int vog_vis_encode(const vog_visenc_args* a, void* stream);

@@ -646,3 +646,35 @@ def test_persistent_lstm_handoff_is_deterministic_under_load():
                 for k in ref[w]:
                     assert torch.equal(sl.out[k], ref[w][k]), (i, k)
 
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8", "full/cfg5_vog_svsq_gt5_bs16",
+                                  "small/vog_spat", "small/vgrnd_sep"])
+def test_chained_obj_qkv_equals_separate_launches(name):
+    """chain_obj_qkv: obj_tx's layer-0 QKV projection (row-block form) runs INSIDE the BiLSTM layer 0 || encoders launch - its
+    workgroups wait on the done flags of the encoder workgroups that write their 64 rows (written through) - vs the same
+    kernels as separate launches: bit-identical, also over 400 graph replays on 4 streams (a consumer that read a row before
+    its producer had written it would show); and within the golden bounds."""
+    if not os.path.exists(cases.golden_path(name)):
+        pytest.skip("no golden for " + name)
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng.set_option("chain_obj_qkv", 1)
+    eng.set_option("enc_lean", 1)
+    eng.set_option("pair_launches", 0)                     # same kernels, every step its own launch
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("pair_launches", 1)
+    for _ in range(3):
+        b = eng.forward(dev)
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (name, k)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    slots = [eng.make_slot({k: v.cpu() for k, v in dev.items()}, graph=True) for _ in range(4)]
+    for it in range(400):
+        slots[it % 4].launch(streams[it % 4])
+    torch.cuda.synchronize()
+    for sl in slots:
+        assert torch.equal(sl.out["mdl_outs"], a["mdl_outs"]) and torch.equal(sl.out["pred_rec"], a["pred_rec"])
+    pred = eng.unpack_pred(b["pred_rec"], batch["new_srl_idxs"].shape[1])
+    g = np.load(cases.golden_path(name))
+    _check_against(name, b, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)

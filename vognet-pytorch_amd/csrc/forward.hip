@@ -29,6 +29,8 @@ int attn_head_pad(int dh);
 int tx_tail_supported(int d, int dh, int kwo);
 int64_t tx_tail_scratch_bytes(int M, int d);
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
+int pair_launch3(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
+                 const std::function<int(hipStream_t)>& fc, hipStream_t st, bool* fused);
 int pair_launch(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
                 hipStream_t st, bool* fused);
 
@@ -95,6 +97,8 @@ struct vog_ctx {
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
+  int chain_obj_qkv = 0;                // 1: obj_tx's QKV projection (row-block form) rides in the BiLSTM layer 0 || encoders launch,
+                                        // its blocks waiting for the encoder blocks that produce their rows (pair3_kernel)
   int fused_pred = 0;                   // 1: the prediction head runs in the score tail's launch (its last workgroup; txtail_dev.h).
                                         // Bit-identical and one launch less, but no faster (55.4 vs 55.8 k queries/s): off
   int fused_argvec = 0;                 // 1: argument vectors inside the language out-projection's launch (vog_argvec_tail): one
@@ -337,6 +341,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   }
   p.add("argvec_sync", 256);                          // arrival counter of the out-projection's argument-vector tail
   p.add("pred_sync", 256);                            // arrival counter of the score tail's prediction head
+  p.add("chain_flags", 1024);                         // done flags of the lean encoder workgroups (chain_obj_qkv)
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -409,7 +414,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
                      const float** out32, const void** out16,
                      const vog_vislang_args* structured = nullptr, const void* vis16 = nullptr,
                      bool last_needs_f32 = true, const vog_score_args* score = nullptr,
-                     const vog_pred_args* pred = nullptr, unsigned int* pred_counter = nullptr, bool* pred_done = nullptr) {
+                     const vog_pred_args* pred = nullptr, unsigned int* pred_counter = nullptr, bool* pred_done = nullptr,
+                     const vog_qkv_args* dep = nullptr) {
   const std::string n(nm);
   const vog_model_desc& d = c->d;
   const vog_dtype dt = (vog_dtype)d.tx_dtype;
@@ -428,6 +434,11 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     qa.q = ws.at<void>(n + "_q"); qa.k = ws.at<void>(n + "_k"); qa.vt = ws.at<void>(n + "_vt");
     qa.S = S; qa.N = N; qa.H = tw.H; qa.dp = tw.dp; qa.npad = npad; qa.K = tw.d; qa.dtype = dt;
     qa.wqkv_p32 = c->qkv_lean ? L.wqkv_p : nullptr;
+    if (dep && l == 0 && L.wqkv_p) {      // layer 0 rides in the encoders' launch: row-block form, waits for its rows' producers
+      qa.wqkv_p32 = L.wqkv_p;
+      qa.dep_flags = dep->dep_flags; qa.dep_nb0 = dep->dep_nb0; qa.dep_rep = dep->dep_rep; qa.dep_nh0 = dep->dep_nh0;
+      qa.dep_nh1 = dep->dep_nh1;
+    }
     const bool fact = structured && l == 0;
     if (fact) {
       // layer 0 of mul_tx: tokens are [vis[p] || lang[a]] -> project the two parts once each
@@ -569,6 +580,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // different programs)
   const bool fuse_prep = !shared && !lang_only;
   // one launch for both encoders + the concat, straight from the fp32 features (visenc.hip)
+  vog_qkv_args obj_dep{};               // chain_obj_qkv: the flags obj_tx's layer-0 QKV waits on (set with the encoders below)
   const bool enc_fused = c->fused_enc && c->w_prop_f && c->w_seg_f && !lang_only;
   auto make_visprep = [&]() {
     vog_visprep_args vp{};
@@ -762,6 +774,14 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       // so the encoder kernel stays one launch and can still share the BiLSTM layer's
       const bool rep_step = ve.lean && d.nppf0 > 16 && (d.seg_enc % 4) == 0 && (d.prop_enc % 4) == 0 && (g.d_obj % 4) == 0;
       ve.defer_replicas = rep_step ? 1 : 0;
+      // chain_obj_qkv: obj_tx's layer-0 QKV (row-block form) in the same launch, its workgroups waiting for the encoder
+      // workgroups that write their rows (flags zeroed by the prologue)
+      if (c->chain_obj_qkv && ve.lean && !rep_step && has_obj(d) && !c->obj.layers.empty() && c->obj.layers[0].wqkv_p &&
+          (ceil_div(Mp, 64) + ceil_div(Ms, 64)) * 2 <= 256) {
+        ve.done_flags = ws.at<unsigned int>("chain_flags");
+        obj_dep.dep_flags = ve.done_flags; obj_dep.dep_nb0 = ceil_div(Mp, 64); obj_dep.dep_rep = d.nppf0;
+        obj_dep.dep_nh0 = ceil_div(d.prop_enc, 128); obj_dep.dep_nh1 = ceil_div(d.seg_enc, 128);
+      }
       steps.push_back({"vis_enc", [=](hipStream_t st) { return vog_vis_encode(&ve, st); }});
       if (rep_step) steps.push_back({"seg_rep", [=](hipStream_t st) { return vog_seg_replicate(&ve, st); }});
     }
@@ -802,7 +822,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   const void* vis16 = ps16;
   if (has_obj(d))
     tx_steps(c, c->obj, "obj", g, ws, b, ps32, ps16, g.S_obj, g.N_obj, g.npad_obj, g.spv_obj, g.N_obj,
-             g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16);
+             g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16, nullptr, nullptr, true, nullptr, nullptr, nullptr,
+             nullptr, obj_dep.dep_flags ? &obj_dep : nullptr);
   // ---- vis || lang tokens in mul_tx order (a10, a11)
   vog_vislang_args va{};
   va.vis = vis32; va.lang = lang_vec; va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
@@ -920,10 +941,18 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         Step m = steps[i];
         auto fa = steps[q->ia].fn, fb = steps[q->ib].fn;
         m.name = steps[q->ia].name + "+" + steps[q->ib].name;
-        m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
+        int chained = -1;
+        if (c->chain_obj_qkv && steps[q->ib].name == "vis_enc" && q->it[0] >= 0 && steps[q->it[0]].name == "obj_qkv") {
+          auto fc = steps[q->it[0]].fn;
+          m.name += "+obj_qkv";
+          m.fn = [fa, fb, fc](hipStream_t st) { return pair_launch3(fa, fb, fc, st, nullptr); };
+          chained = 0;
+        } else {
+          m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
+        }
         out.push_back(m);
         for (int k = 0; k < 3; ++k)
-          if (q->it[k] >= 0) { Step t = steps[q->it[k]]; t.branch = m.branch; out.push_back(t); }
+          if (q->it[k] >= 0 && k != chained) { Step t = steps[q->it[k]]; t.branch = m.branch; out.push_back(t); }
       }
       steps.swap(out);
     }
@@ -1355,6 +1384,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_argvec") == 0) { c->fused_argvec = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_pred") == 0) { c->fused_pred = value ? 1 : 0; return 0; }
+  if (strcmp(name, "chain_obj_qkv") == 0) { c->chain_obj_qkv = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }

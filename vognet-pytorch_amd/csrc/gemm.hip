@@ -189,6 +189,11 @@ const void* kid_gemm_pipe_qkv(int dtype) {
                            : reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 2, EPI_QKV>);
 }
 
+const void* kid_qkv_rowblock(int dtype) {
+  return dtype == VOG_BF16 ? reinterpret_cast<const void*>(qkv_rowblock_kernel<BF16, 2>)
+                           : reinterpret_cast<const void*>(qkv_rowblock_kernel<F16, 2>);
+}
+
 int gemm_run(const vog_gemm_args* g, hipStream_t st) {
   VOG_CHECK_ARG(g && g->a && g->w && (g->c32 || g->c16));
   VOG_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0 && (g->K % 8) == 0);
@@ -235,6 +240,8 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
     if (!qkv_rowblock_supported(p.N, p.K))
       VOG_FAIL(-1, "row-block QKV: unsupported shape (K %% 128 == 0, 256 <= K <= 1024, (3*H*dp / 32) even)");
     p.w_p32 = (const unsigned short*)a->wqkv_p32;
+    p.dep_flags = a->dep_flags; p.dep_nb0 = a->dep_nb0; p.dep_rep = a->dep_rep; p.dep_nh0 = a->dep_nh0; p.dep_nh1 = a->dep_nh1;
+    if (a->dep_flags) VOG_CHECK_ARG(a->dep_rep >= 1 && a->dep_nb0 >= 1 && a->dep_nh0 >= 1 && a->dep_nh1 >= 1);
     static const int narrow = perf_env("VOG_QKV_NARROW") ? atoi(perf_env("VOG_QKV_NARROW")) : 0;
     const int nrb = ceil_div(p.M, 64);
     const size_t lds = QkvRowBlockBody<F16, 2>::lds_bytes(p.K);

@@ -41,6 +41,10 @@ struct GemmParams {
   // tail of the M <= 64 kernel (av_counter != nullptr; vog_argvec_tail): the argument vectors in the same launch
   unsigned int* av_counter; const int64_t* av_capture; const int64_t* av_msk; const float* av_w; const float* av_b;
   float* av_lang; int av_rows, av_T, av_nsrl, av_L;
+  // row-block QKV as a consumer inside the encoders' launch (dep_flags != nullptr): its rows are written by the lean encoder
+  // workgroups (visenc_dev.h: done_flags[block * 2 + half]); dep_nb0 = proposal row blocks, dep_rep = proposals per segment
+  // row, dep_nh0 / dep_nh1 = column halves of the proposal / segment encoder
+  const unsigned int* dep_flags; int dep_nb0, dep_rep, dep_nh0, dep_nh1;
 };
 
 template <typename T16, bool A_F32>

@@ -39,6 +39,25 @@ struct QkvRowBlockBody {
     const int cg = v / nrb, rb = v - cg * nrb;
     const int m0 = rb * 64;
     const int pitch = (p.K + 8) * 2;
+    if (p.dep_flags) {
+      // the rows of this block come from encoder workgroups of the SAME launch (dispatched before this one): wait for the
+      // 2 + (2 or 4) of them that write rows [m0, m0 + 64); bounded (a stuck producer shows as garbage, not as a hang)
+      if (tid == 0) {
+        const int mlast = (m0 + 63 < p.M ? m0 + 63 : p.M - 1);
+        const int s0 = (m0 / p.dep_rep) >> 6, s1 = (mlast / p.dep_rep) >> 6;
+        unsigned spins = 0;
+        auto wait = [&](int idx) {
+          while (__hip_atomic_load(p.dep_flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) break;
+          }
+        };
+        for (int h = 0; h < p.dep_nh0; ++h) wait(rb * 2 + h);
+        for (int sb = s0; sb <= s1; ++sb)
+          for (int h = 0; h < p.dep_nh1; ++h) wait((p.dep_nb0 + sb) * 2 + h);
+      }
+      __syncthreads();
+    }
     {
       const int cpr = p.K >> 3;
       const unsigned short* a = reinterpret_cast<const unsigned short*>(p.a);

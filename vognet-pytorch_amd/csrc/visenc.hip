@@ -63,6 +63,7 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
   p.tiles_all = p.tiles0 + ceil_div(p.p[1].M, 16);
   p.c32 = a->c32; p.c16 = (unsigned short*)a->c16; p.ldc = a->ldc;
   p.c16_bf16 = a->c16_dtype == VOG_BF16;
+  p.done_flags = a->lean ? a->done_flags : nullptr;
   if (a->lean) {
     const int nb = ceil_div(p.tiles0, 4) + ceil_div(p.tiles_all - p.tiles0, 4);
     // many replicas per segment row (p100: 100): the encoder kernel writes replica 0, a copy kernel the rest

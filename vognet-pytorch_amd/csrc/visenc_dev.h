@@ -13,6 +13,9 @@ struct VisEncParams {
   int tiles0, tiles_all;         // 16-row tiles of problem 0, of both
   float* c32; unsigned short* c16; int64_t ldc; int c16_bf16;
   int rep_first_only;            // 1: only replica j = 0 of every row is written here (seg_replicate_kernel writes the rest)
+  // lean form, optional: done_flags[block * 2 + column half] = 1 once that workgroup's rows are in memory (16-bit copy
+  // written through): consumers in the SAME launch (pair3_kernel: obj_tx's row-block QKV) wait on the flags of their rows
+  unsigned int* done_flags;
 };
 
 template <typename T16>
@@ -221,25 +224,33 @@ struct VisEncLeanBody {
       }
     }
     // D[row = 4*(lane>>4) + reg][col = lane & 15]
-    if (!n_ok) return;
     const int col = n0 + (lane & 15);
-    if (col >= qN) return;
-    const float b = qb[col];
+    if (n_ok && col < qN) {
+      const float b = qb[col];
 #pragma unroll
-    for (int mt = 0; mt < RB / 16; ++mt)
+      for (int mt = 0; mt < RB / 16; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + mt * 16 + (lane >> 4) * 4 + r;
-        if (row >= qM) continue;
-        const float o = fmaxf(acc[mt][r] + b, 0.f);
-        const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
-        const int nrep = a.rep_first_only ? 1 : qrep;
-        for (int j = 0; j < nrep; ++j) {
-          const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
-          if (a.c32) a.c32[off] = o;
-          if (a.c16) a.c16[off] = h;
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + mt * 16 + (lane >> 4) * 4 + r;
+          if (row >= qM) continue;
+          const float o = fmaxf(acc[mt][r] + b, 0.f);
+          const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+          const int nrep = a.rep_first_only ? 1 : qrep;
+          for (int j = 0; j < nrep; ++j) {
+            const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
+            if (a.c32) a.c32[off] = o;
+            if (a.c16) {
+              if (a.done_flags) __hip_atomic_store(&a.c16[off], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write through
+              else a.c16[off] = h;
+            }
+          }
         }
-      }
+    }
+    if (a.done_flags) {                                       // every thread of the workgroup gets here
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&a.done_flags[blk * 2 + half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 };
 

@@ -61,7 +61,8 @@ class QkvArgs(C.Structure):
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
                 ("K", c_i32), ("dtype", c_i32),
                 ("pl", c_vp), ("nsrl", c_i32), ("nppf", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32),
-                ("nc_v", c_i32), ("kv_visual_only", c_i32), ("npad_kv", c_i32), ("wqkv_p32", c_vp)]
+                ("nc_v", c_i32), ("kv_visual_only", c_i32), ("npad_kv", c_i32), ("wqkv_p32", c_vp),
+                ("dep_flags", c_vp), ("dep_nb0", c_i32), ("dep_rep", c_i32), ("dep_nh0", c_i32), ("dep_nh1", c_i32)]
 
 
 class AttnStructArgs(C.Structure):
@@ -135,7 +136,8 @@ class VisencArgs(C.Structure):
     _fields_ = [("prop", c_vp), ("seg", c_vp), ("w_prop_f", c_vp), ("w_seg_f", c_vp), ("b_prop", c_vp),
                 ("b_seg", c_vp), ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("c16_dtype", c_i32),
                 ("n_prop_rows", c_i32), ("nppf0", c_i32), ("prop_dim", c_i32), ("seg_dim", c_i32),
-                ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32), ("lean", c_i32), ("defer_replicas", c_i32)]
+                ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32), ("lean", c_i32), ("defer_replicas", c_i32),
+                ("done_flags", c_vp)]
 
 
 class LossArgs(C.Structure):
