@@ -142,7 +142,6 @@ struct LstmLayerParams {
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define VOG_RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // 16 bytes straight from the L2 (sc1: the CU's own L1 is bypassed - it is never refreshed by another
 // CU's stores). A compiler-visible buffer load (not inline asm): hipcc keeps its own vmcnt books.

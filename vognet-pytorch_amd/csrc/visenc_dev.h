@@ -225,26 +225,48 @@ struct VisEncLeanBody {
     }
     // D[row = 4*(lane>>4) + reg][col = lane & 15]
     const int col = n0 + (lane & 15);
+    const bool chained = a.done_flags != nullptr && a.c16 != nullptr && (a.ldc & 7) == 0 && (qcol0 & 7) == 0;
+    // chained form (consumers in the same launch): the 16-bit tile is parked in LDS and written THROUGH as 16-byte chunks
+    // (2-byte write-through stores, one per lane and element, cost more than the launch the chaining saves)
+    constexpr int TP = 128 + 8;                                // tile pitch in halfwords (272 B: 16-byte aligned rows)
+    unsigned short* tile = reinterpret_cast<unsigned short*>(smem);
+    if (chained) __syncthreads();                              // every wave is done reading the A images
     if (n_ok && col < qN) {
       const float b = qb[col];
 #pragma unroll
       for (int mt = 0; mt < RB / 16; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = m0 + mt * 16 + (lane >> 4) * 4 + r;
+          const int rl = mt * 16 + (lane >> 4) * 4 + r;
+          const int row = m0 + rl;
           if (row >= qM) continue;
           const float o = fmaxf(acc[mt][r] + b, 0.f);
           const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+          if (chained) tile[rl * TP + w * 16 + (lane & 15)] = h;
           const int nrep = a.rep_first_only ? 1 : qrep;
           for (int j = 0; j < nrep; ++j) {
             const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
             if (a.c32) a.c32[off] = o;
-            if (a.c16) {
+            if (a.c16 && !chained) {
               if (a.done_flags) __hip_atomic_store(&a.c16[off], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write through
               else a.c16[off] = h;
             }
           }
         }
+    }
+    if (chained) {
+      __syncthreads();
+      const int ncol_wg = (qN - half * 128) < 128 ? (qN - half * 128) : 128;     // columns this workgroup owns (multiple of 16)
+      const int cpr = ncol_wg >> 3;                                               // 16-byte chunks per row
+      const int nrep = a.rep_first_only ? 1 : qrep;
+      const int rows_wg = (qM - m0) < RB ? (qM - m0) : RB;
+      const int total = rows_wg * nrep * cpr;
+      for (int id = tid; id < total; id += THREADS) {
+        const int ch = id % cpr, rj = id / cpr, j = rj % nrep, rl = rj / nrep;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(tile + rl * TP + ch * 8);
+        u32x4* dst = reinterpret_cast<u32x4*>(a.c16 + ((int64_t)(m0 + rl) * qrep + j) * a.ldc + qcol0 + half * 128 + ch * 8);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+      }
     }
     if (a.done_flags) {                                       // every thread of the workgroup gets here
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
