@@ -167,7 +167,7 @@ class Evaluator(torch.nn.Module):
                 return
             pend = []
             for bt in dl:
-                pend.append(bt)
+                pend.append({k: v.to(self.device, non_blocking=True) for k, v in bt.items()})   # (concatenate on the device: 35 MB per group on the host cost 10 ms)
                 if len(pend) == G:
                     yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, [next(iter(p_.values())).shape[0] for p_ in pend]
                     pend = []
