@@ -182,7 +182,7 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(w, cfg, sd, batch, budget_s=24.0):
+def cpu_baseline(w, cfg, sd, batch, budget_s=30.0):
     """The CPU oracle (a validated port of the reference forward, oracle/vog_oracle.py: torch-CPU fp32
     ops, manual LSTM loops; "kind": "port" - the reference itself measured 43 queries/s on cfg 2 in the
     survey probe, this port 41-42) timed on this host on the same workload, as SURVEY.md 8(d) asks:
@@ -196,27 +196,34 @@ def cpu_baseline(w, cfg, sd, batch, budget_s=24.0):
     sdt, inp = vo.to_torch(sd), vo.to_torch(batch)
     tried = {}
     cands = sorted({min(8, ncpu), min(nphys, ncpu)})
+    WARM, TIMED = 5, 20                    # SURVEY.md 8(d) / BASELINE.md 3: >= 5 warm-up + >= 20 timed batches, median
     with torch.no_grad():
         for nt in cands:
             torch.set_num_threads(nt)
             t_start = time.time()
-            vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
+            share = budget_s / len(cands)
+            nwarm = 0
+            while nwarm < WARM and (nwarm == 0 or time.time() - t_start < share / 4):
+                vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
+                nwarm += 1
             times = []
-            while len(times) < 12 and time.time() - t_start < budget_s / len(cands):
+            while len(times) < TIMED and (not times or time.time() - t_start < share):
                 t0 = time.perf_counter()
                 vo.pred_head(oc, vo.forward(oc, sdt, inp), inp)
                 times.append(time.perf_counter() - t0)
-            if times:
-                tried[nt] = (float(np.median(times)), len(times))
+            tried[nt] = (float(np.median(times)), len(times), nwarm)
     if not tried:
         return {"value": None, "unit": "queries/s", "cores": ncpu, "kind": "port",
                 "sample": "no forward finished inside the time budget"}
     best = min(tried, key=lambda k: tried[k][0])
-    med, n = tried[best]
+    med, n, nwarm = tried[best]
     return {"value": w["B"] / med, "unit": "queries/s", "cores": best, "kind": "port",
             "cpu_model": cpu_model(), "physical_cores": nphys, "logical_cpus": ncpu,
             "by_threads": {str(k): w["B"] / v[0] for k, v in tried.items()},
-            "sample": f"{n} timed forwards of the same batch (bs={w['B']}) after 1 warm-up, median; "
+            "warmup_forwards": nwarm, "timed_forwards": n,
+            "sample": f"{n} timed forwards of the same batch (bs={w['B']}) after {nwarm} warm-up, median"
+                      + ("" if (n >= TIMED and nwarm >= WARM) else f" (the {budget_s:.0f} s budget ended the sample early: "
+                         f"protocol is {WARM} + {TIMED})") + "; "
                       f"threads tried: " + ", ".join(f"{k}: {w['B'] / v[0]:.1f} q/s" for k, v in tried.items()),
             "ms_per_batch": med * 1e3}
 
@@ -296,6 +303,12 @@ def main():
     ap.add_argument("--set", action="append", metavar="OPTION=INT", help="vog_ctx_set_int switch (A/B measurements)")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the side measurement of the fp32 training step")
     ap.add_argument("--kernel-iters", type=int, default=100)
+    ap.add_argument("--rotate-inputs", type=int, default=64,
+                    help="N > 0: also time the strict path with N distinct device-resident input sets cycling through the "
+                         "streams' workspaces (N x 8.7 MB of features > the 256 MB Infinity Cache at cfg 2), reported as "
+                         "`value_hbm_inputs` beside `value`; 0 = skip")
+    ap.add_argument("--rotate-main", action="store_true",
+                    help="apply --rotate-inputs to the main timed region too (A/B experiments with --throughput-only)")
     ap.add_argument("--throughput-only", action="store_true",
                     help="print '<queries/s> <us/step>' and exit (ablation experiments, scratch/ablate.sh)")
     args = ap.parse_args()
@@ -357,21 +370,25 @@ def main():
     # them by a pairwise timing test was tried: what overlaps during the test does not reliably overlap afterwards.)
     stream_pool = [torch.cuda.Stream(device=dev) for _ in range(16)]
 
-    def measure(G, steps, warmup, batched=False):
+    def measure(G, steps, warmup, batched=False, rotate=0):
         """K timed steps (one step = one batch of the workload) after W warm-up steps with G
-        batches per language-encoder pass. Returns (seconds, slots, batches, in-flight count)."""
+        batches per language-encoder pass. Returns (seconds, slots, batches, in-flight count).
+        rotate = R > 0 (graph mode, G = 1): R distinct device-resident input sets per stream are cycled through the
+        stream's workspace (slot j runs on stream j % streams and shares that stream's workspace), so that a forward's
+        features come from HBM, not from the Infinity Cache a 4-slot replay loop leaves them in."""
         Q, K, DEPTH = max(1, args.queues), max(1, args.interleave), 2
         if G > 1:
             K = 1
         nunits = Q * K * DEPTH if aql else max(1, args.streams)      # units in flight (slot or group)
-        nsets = 1
+        nsets = max(1, rotate) if (G == 1 and not aql) else 1
         nstreams = nunits * G * nsets                                 # batch buffers (in flight: nunits * G)
         slots, streams, batches, units = [], [], [], []
         for s in range(nstreams):
             b = synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=VOCAB,
                                  seed=1000 * cfg_id + rank * 64 + s)
             batches.append(b)
-            streams.append(stream_pool[s] if s < len(stream_pool) else torch.cuda.Stream(device=dev))
+            su = s % nunits if nsets > 1 else s
+            streams.append(stream_pool[su] if su < len(stream_pool) else torch.cuda.Stream(device=dev))
         # the prediction records of all batches in flight live in ONE buffer: the exchange step is
         # one all-gather per round of in-flight batches instead of one per batch
         ncmp_w = 1 if w["conc"] == "svsq" else 4
@@ -379,8 +396,9 @@ def main():
         if G == 1:
             for s_, b in enumerate(batches):
                 slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
-                                           graph=(not args.no_graph) and not aql, 
-                                           pred_rec=recbuf[s_ * w["B"]:(s_ + 1) * w["B"]]))
+                                           graph=(not args.no_graph) and not aql,
+                                           pred_rec=recbuf[s_ * w["B"]:(s_ + 1) * w["B"]],
+                                           share_ws_with=slots[s_ % nunits] if (nsets > 1 and s_ >= nunits) else None))
             units = slots
         else:
             assert steps % G == 0 and warmup % G == 0, "--steps / --warmup must be multiples of the co-batch size"
@@ -407,7 +425,7 @@ def main():
             if (aql and use_dist) else None
 
         def step(i):                       # graph mode: one unit (slot, or group of G batches) per call
-            u = i % nunits
+            u = i % (nunits * nsets)       # (rotation: unit u lives on stream u % nunits, see above)
             units[u].launch(streams[u])
             if ring is not None:
                 ring.push(recbuf[u * unit_rows:(u + 1) * unit_rows], streams[u])
@@ -466,7 +484,8 @@ def main():
         return dt, slots, batches, nunits * G
 
     G = max(1, args.cobatch)
-    dt, slots, batches, nstreams = measure(G, args.steps, args.warmup)
+    rot_sets = (args.rotate_inputs + max(1, args.streams) - 1) // max(1, args.streams) if args.rotate_inputs > 0 else 0
+    dt, slots, batches, nstreams = measure(G, args.steps, args.warmup, rotate=rot_sets if args.rotate_main else 0)
     T = slots[0].T
     Q, K = max(1, args.queues), (1 if G > 1 else max(1, args.interleave))
     # a short timed region (the driver's K = 20) carries a fixed ~160 us of pipeline fill and drain (4 forwards in flight,
@@ -479,6 +498,21 @@ def main():
                   "what": "the same strict per-batch path over 400 timed steps: `value` above is K = %d steps, whose fixed pipeline "
                           "fill / drain (~160 us per timed region) is %.0f %% of its time" % (args.steps, 100 * (1 - (dts / 400) / (dt / args.steps)))}
         del sl_s
+    # the same strict path with the inputs coming from HBM: N distinct input sets cycle through the streams' workspaces
+    hbm_inputs = None
+    if G == 1 and world == 1 and rot_sets > 1 and not aql and not args.no_graph and not args.throughput_only and not args.rotate_main:
+        ksteps = max(400, args.steps)
+        dth, sl_h, _, n_h = measure(G, ksteps, max(40, rot_sets * max(1, args.streams)), rotate=rot_sets)
+        nfin_h = int(sum(int((~torch.isfinite(sl.out["mdl_outs_eval"])).sum().item()) for sl in sl_h))
+        in_bytes = sum(v.numel() * v.element_size() for k, v in sl_h[0].inp.items())
+        hbm_inputs = {"value": ksteps * w["B"] / dth if nfin_h == 0 else None, "unit": "queries/s", "ms_per_step": dth / ksteps * 1e3,
+                      "steps": ksteps, "input_sets": len(sl_h), "input_bytes_per_set": in_bytes,
+                      "input_bytes_total": in_bytes * len(sl_h), "batches_in_flight": n_h,
+                      "what": "the strict per-batch path with %d distinct device-resident input sets (%.0f MB in total, the Infinity "
+                              "Cache holds 256 MB) cycling through the %d streams' workspaces: every forward reads its features "
+                              "from HBM; `value` replays %d slots whose 35 MB of features stay cache-resident"
+                              % (len(sl_h), in_bytes * len(sl_h) / 1e6, n_h, n_h)}
+        del sl_h
     # four bs=4 requests served as ONE forward (dynamic batching; `make_batched`): reported beside `value`, never instead of
     # it - `value` is one bs=4 forward per launch sequence
     batched4 = None
@@ -556,6 +590,9 @@ def main():
         res["lang_cobatch4"] = extra
     if steady is not None:
         res["steady_state_400_steps"] = steady
+    if hbm_inputs is not None:
+        res["value_hbm_inputs"] = hbm_inputs["value"]
+        res["hbm_inputs"] = hbm_inputs
     if batched4 is not None:
         res["requests_batched4"] = batched4
     # ---- roofline of the dominant kernel: HIP-event timing inside libvog_hip on this stream

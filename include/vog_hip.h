@@ -659,8 +659,12 @@ int vog_score_head_f32_bwd(const float* x, const float* d_mdl_outs, const float*
                            int M, int d, int dhead, int n_vid, int nfrm, int nppf, int nsrl, void* stream);
 /* Switches of the training path. "bf16_gemm" = 1: the tile GEMMs of vog_*_f32 / vog_*_bwd round their operands to bf16 and
  * use the 16-bit matrix instruction with fp32 accumulation (mixed precision: faster, gradients within ~1e-2 of the fp32
- * ones); 0 (default): fp32 operands, the path pinned against autograd through the reference. Process-wide. */
+ * ones); 0 (default): fp32 operands, the path pinned against autograd through the reference.
+ * The switch belongs to the CALLING THREAD (thread-local; no process-wide state): it selects the kernels of the vog_*_f32 /
+ * vog_*_bwd calls that thread issues afterwards. A trainer sets it at the top of every step (train.FP32Trainer), so two
+ * trainers with different settings - in one thread or in two - never see each other's choice. */
 int vog_train_set_int(const char* name, int value);
+int vog_train_get_int(const char* name, int* value);
 /* out[g, n] = mean over f of x[g, f, n] (the segment mean of the sep verb head, code/mdl_conc_sep.py:64-129) */
 int vog_row_mean_f32(const float* x, float* out, int G, int F, int N, void* stream);
 
@@ -768,6 +772,18 @@ int64_t vog_lang_workspace_bytes(const vog_ctx* c, int B_total, int ncmp, int T)
 int vog_lang_workspace_init(const vog_ctx* c, int B_total, int ncmp, int T, void* lang_ws, size_t bytes, void* stream);
 /* lb: only B, ncmp, T and the five srl_* word-level pointers are read */
 int vog_lang_forward(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t bytes, void* stream);
+/* LSTMEncoder.forward on its own (replaces /root/reference utils/mdl_srl_utils.py:114-169; SURVEY.md 8(b) `vog_bilstm_fwd`):
+ * token re-index (code/mdl_vog.py:67-95) + embedding + the packed 2-layer BiLSTM - both layers, both directions - on a
+ * language workspace (vog_lang_workspace_bytes / _init). `lb` as for vog_lang_forward. Outputs, plain fp32 rows:
+ * x_out [Bn, T, 2R] (zero past each sentence's length, like pad_packed_sequence) and final_hidden [Bn, 2R] =
+ * [h_fwd(last valid step) || h_bwd(first step)] of the top layer (what lang_encode feeds lstm_out_feat_proj,
+ * code/mdl_vog.py:262-283). The forward itself never calls this: it keeps the layer output in MFMA operand order for the
+ * projection that follows (vog_bilstm_layer x 2 inside vog_forward / vog_lang_forward). */
+int vog_bilstm_fwd(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t bytes, float* x_out, float* final_hidden,
+                   void* stream);
+/* the conversion at its end: 16-bit layer output (frag = 1: A-fragment order of the M <= 64 GEMM) -> plain fp32 rows */
+int vog_lstm_out_to_f32(const void* out16, int frag, int rows_x, int rows_f, int W, vog_dtype dtype, float* x, float* fin,
+                        void* stream);
 /* device pointers inside lang_ws: argument vectors [B_total*nvl*nsrl, lang_enc] and the final
  * hidden projection [B_total*nvl, lang_enc] */
 int vog_lang_outputs(const vog_ctx* c, int B_total, int ncmp, int T, void* lang_ws, float** lang,

@@ -176,3 +176,31 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         cls = pairs[cname]
         assert C.sizeof(cls) == int(size), (cname, C.sizeof(cls), size)
         assert getattr(cls, cls._fields_[-1][0]).offset == int(off), (cname, off)
+
+
+def test_training_switch_is_per_thread_not_process_state():
+    """vog_train_set_int("bf16_gemm") belongs to the calling thread (host-only check; the device side of it is
+    tests/test_gpu_surface.py::test_two_trainers_with_different_gemm_settings_in_one_process)."""
+    import threading
+    lib = L.load()
+
+    def get():
+        v = ctypes.c_int32(-1)
+        assert lib.vog_train_get_int(b"bf16_gemm", ctypes.byref(v)) == 0
+        return v.value
+
+    assert lib.vog_train_set_int(b"bf16_gemm", 1) == 0 and get() == 1
+    seen = {}
+
+    def other():
+        seen["before"] = get()
+        lib.vog_train_set_int(b"bf16_gemm", 0)
+        seen["after"] = get()
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == {"before": 0, "after": 0}
+    assert get() == 1                      # the other thread's write did not reach this one
+    assert lib.vog_train_set_int(b"bf16_gemm", 0) == 0 and get() == 0
+    assert lib.vog_train_set_int(b"no_such_switch", 1) != 0

@@ -792,3 +792,105 @@ def test_evaluator_batches_requests(capsys, tmp_path):
     for x, y in zip(a, b):
         assert np.abs(np.array(x["pred_scores"]) - np.array(y["pred_scores"])).max() <= 4e-4
         assert x["pred_cmp"] == y["pred_cmp"] or np.abs(np.array(x["pred_scores"])).max() > 0      # (ties aside, the same choices)
+
+
+def test_two_trainers_with_different_gemm_settings_in_one_process():
+    """`bf16_gemm` is not process state (round 3: a process-wide static in csrc/backward.hip): two trainers with different
+    settings, called alternately from one thread and at the same time from two threads, each reproduce what they compute alone,
+    bit for bit (the training path has no atomics), and the switch is off again for the thread behind every call."""
+    import ctypes
+    import threading
+    trn = importlib.import_module("vognet-pytorch_amd.train")
+    Lm = importlib.import_module("vognet-pytorch_amd.lib")
+    name = "small/vog_spat"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    dev.update({k: torch.from_numpy(v).cuda() for k, v in tg.items()})
+    _, sd, _, _ = cases.build(name)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    t32 = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=1e-4)
+    t16 = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=1e-4, bf16_gemm=True)
+    _, a32 = t32.gradients(dev)
+    _, a16 = t16.gradients(dev)
+    a32 = {k: v.clone() for k, v in a32.items()}
+    a16 = {k: v.clone() for k, v in a16.items()}
+    assert any(not torch.equal(a32[k], a16[k]) for k in a32)           # the settings do differ in what they compute
+    lib = Lm.load()
+
+    def flag():
+        v = ctypes.c_int32(-1)
+        assert lib.vog_train_get_int(b"bf16_gemm", ctypes.byref(v)) == 0
+        return v.value
+
+    for _ in range(2):                                                  # alternating in one thread
+        _, g16 = t16.gradients(dev)
+        assert flag() == 0
+        _, g32 = t32.gradients(dev)
+        for k in a32:
+            assert torch.equal(g32[k], a32[k]), k
+            assert torch.equal(g16[k], a16[k]), k
+    res, errs = {}, []
+
+    def work(tag, t, ref, other_on):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    _, g = t.gradients(dev)
+                    torch.cuda.current_stream().synchronize()
+                    for k in ref:
+                        assert torch.equal(g[k], ref[k]), (tag, k)
+            res[tag] = flag()
+        except Exception as e:                                         # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    th = [threading.Thread(target=work, args=("f32", t32, a32, True)), threading.Thread(target=work, args=("bf16", t16, a16, False))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert res == {"f32": 0, "bf16": 0}
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "small/vog_sep"])
+def test_bilstm_fwd_entry_point_matches_oracle_lstm_encoder(name):
+    """`vog_bilstm_fwd` (SURVEY 8(b) minimum export set): LSTMEncoder.forward on its own - re-index, embedding, both layers,
+    both directions - against the oracle's `lstm_encoder` (utils/mdl_srl_utils.py:114-169): padded outputs exactly 0 past
+    each sentence's length, final hidden = [h_fwd(last valid) || h_bwd(step 0)] of the top layer."""
+    import ctypes
+    from oracle import vog_oracle as vo
+    eng_mod = importlib.import_module("vognet-pytorch_amd.engine")
+    Lm = importlib.import_module("vognet-pytorch_amd.lib")
+    cfg, sd, batch, c = cases.build(name)
+    eng = eng_mod.VogEngine(cfg, comm_for(c))
+    eng.load_state_dict(sd)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    b, out, (B, ncmp, T) = eng.make_batch(dev)
+    lib = eng.lib
+    n = lib.vog_lang_workspace_bytes(eng.ctx, B, ncmp, T)
+    assert n > 0
+    ws = torch.empty(int(n), dtype=torch.uint8, device="cuda")
+    Lm.check(lib.vog_lang_workspace_init(eng.ctx, B, ncmp, T, ws.data_ptr(), ws.numel(), Lm.stream_ptr()), "init")
+    Bn = dev["srl_arg_words_ind"].shape[0] * dev["srl_arg_words_ind"].shape[1]
+    R = cfg.mdl.rnn.rnn_size
+    x = torch.full((Bn, T, 2 * R), float("nan"), device="cuda")
+    fin = torch.full((Bn, 2 * R), float("nan"), device="cuda")
+    for _ in range(2):                                                  # a second call on the same workspace: idempotent
+        Lm.check(lib.vog_bilstm_fwd(eng.ctx, ctypes.byref(b), ws.data_ptr(), ws.numel(), x.data_ptr(), fin.data_ptr(),
+                                    Lm.stream_ptr()), "vog_bilstm_fwd")
+    torch.cuda.synchronize()
+    oc = vo.OracleCfg.from_cfg(cfg, c["vocab"], c["nppf0"])
+    inp = vo.to_torch(batch)
+    sdt = vo.to_torch(sd)
+    lens = inp["srl_arg_word_mask_len"].reshape(-1)
+    with torch.no_grad():
+        tok = vo.srl_arg_seq_to_sent_seq(inp["srl_arg_words_ind"], inp["srl_arg_word_mask"], oc.vocab_size)
+        xr, fr = vo.lstm_encoder(tok[:, :T].contiguous(), lens, sdt, oc.rnn_layers)
+    xg, fg = x.cpu(), fin.cpu()
+    assert torch.isfinite(xg).all() and torch.isfinite(fg).all()
+    for bi in range(Bn):
+        assert (xg[bi, int(lens[bi]):] == 0).all()
+    ex, ef = (xg - xr).abs().max().item(), (fg - fr).abs().max().item()
+    print(name, "vog_bilstm_fwd: x abs err", ex, "final hidden abs err", ef)
+    assert ex < 4e-3 and ef < 4e-3            # f16 operands, fp32 cell state: |h| < 1

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmF32 p) {
       }
 }
 
-static int g_train_bf16 = 0;      // vog_train_set_int("bf16_gemm", 1): 16-bit operands for the tile GEMMs of the training path
+static thread_local int g_train_bf16 = 0;   // vog_train_set_int("bf16_gemm", 1), per calling thread: 16-bit operands for the tile GEMMs of the training path
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -1324,4 +1324,10 @@ extern "C" int vog_train_set_int(const char* name, int value) {
   VOG_CHECK_ARG(name);
   if (strcmp(name, "bf16_gemm") == 0) { g_train_bf16 = value ? 1 : 0; return 0; }
   VOG_FAIL(-1, "vog_train_set_int: unknown option %s", name);
+}
+
+extern "C" int vog_train_get_int(const char* name, int* value) {
+  VOG_CHECK_ARG(name && value);
+  if (strcmp(name, "bf16_gemm") == 0) { *value = g_train_bf16; return 0; }
+  VOG_FAIL(-1, "vog_train_get_int: unknown option %s", name);
 }

@@ -568,6 +568,31 @@ static int vis_prep_setup(const vog_visprep_args* a, int* cast_blocks, int* u_bl
 
 using namespace vog;
 
+namespace vog {
+// top BiLSTM layer's 16-bit output (A-fragment order or plain rows) -> plain fp32 rows: [rows_x, W] into x and the rows behind
+// them (the final states) into fin (vog_bilstm_fwd: the LSTMEncoder's own return values, utils/mdl_srl_utils.py:152-169)
+template <typename T16>
+__global__ __launch_bounds__(256) void lstm_out_f32_kernel(const unsigned short* __restrict__ o16, int frag, int rows_x, int rows_f,
+                                                           int W, float* __restrict__ x, float* __restrict__ fin) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)(rows_x + rows_f) * W) return;
+  const int r = (int)(i / W), k = (int)(i - (int64_t)r * W);
+  const float v = from16<T16>(o16[frag ? frag_a(r, k, W) : (int64_t)r * W + k]);
+  if (r < rows_x) x[(int64_t)r * W + k] = v;
+  else fin[(int64_t)(r - rows_x) * W + k] = v;
+}
+}  // namespace vog
+
+extern "C" int vog_lstm_out_to_f32(const void* out16, int frag, int rows_x, int rows_f, int W, vog_dtype dtype, float* x,
+                                   float* fin, void* stream) {
+  VOG_CHECK_ARG(out16 && x && fin && rows_x > 0 && rows_f > 0 && W > 0 && (!frag || (W % 32) == 0));
+  const int64_t n = (int64_t)(rows_x + rows_f) * W;
+  VOG_DISPATCH_DTYPE(dtype, ::vog::launch(vog::lstm_out_f32_kernel<T16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                          (hipStream_t)stream, (const unsigned short*)out16, frag, rows_x, rows_f, W, x, fin));
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vog_residual_layernorm(const float* x, const float* gamma, const float* beta,
                                       float* y32, void* y16, int rows, int d, vog_dtype dtype,
                                       void* stream) {

@@ -1265,6 +1265,27 @@ extern "C" int vog_lang_forward(vog_ctx* c, const vog_batch* lb, void* ws, size_
   return 0;
 }
 
+// LSTMEncoder.forward (utils/mdl_srl_utils.py:114-169) on its own: token re-index + embedding + the packed 2-layer BiLSTM,
+// both layers, both directions - the language chain of the forward up to (not including) lstm_out_feat_proj.
+extern "C" int vog_bilstm_fwd(vog_ctx* c, const vog_batch* lb, void* ws, size_t ws_bytes, float* x_out, float* final_hidden,
+                              void* stream) {
+  VOG_CHECK_ARG(c && lb && ws && x_out && final_hidden);
+  Plan plan;
+  std::vector<Step> steps;
+  VOG_TRY(build_steps(c, lb, ws, ws_bytes, plan, steps, true));
+  for (auto& s : steps) {
+    const bool lstm_part = s.name == "prep" || s.name == "lang_prep" || s.name.rfind("lstm_ih", 0) == 0 ||
+                           s.name == "lstm_layer" || s.name == "lstm_step";
+    if (lstm_part) VOG_TRY(s.fn((hipStream_t)stream));
+  }
+  const Geo g = make_geo(c->d, lb->B, lb->ncmp, lb->T);
+  WS w{(char*)ws, &plan};
+  const int top = c->d.rnn_layers - 1;
+  const bool ofrag = (g.Bn * g.T + g.Bn) <= 64;
+  return vog_lstm_out_to_f32(w.at<void>("lstm_out16_" + std::to_string(top)), ofrag ? 1 : 0, g.Bn * g.T, g.Bn, 2 * g.R,
+                             (vog_dtype)c->d.enc_dtype, x_out, final_hidden, stream);
+}
+
 namespace vog {
 // steps of a whole group: [language chain] + members' forwards; member_of[i] = -1 for language steps
 static int build_group(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes, const vog_batch* const* members,

@@ -86,6 +86,9 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
   if (fused) VOG_CHECK_ARG(a->xa && a->bias && a->K > 0 && (a->K % 256) == 0 && a->Bn * a->T <= 64);
   dim3 grid(a->R / 32, 2);
   hipStream_t st = (hipStream_t)stream;
+  // perf experiments only: a larger LDS claim per workgroup (prices what the footprint costs the other streams' kernels)
+  size_t lds_extra = 0;
+  if (const char* e = vog::perf_env("VOG_LSTM_LDS_EXTRA")) lds_extra = (size_t)atoi(e);
 #define VOG_LAUNCH_LAYER(KS)                                                                          \
   VOG_DISPATCH_DTYPE(a->dtype, {                                                                      \
     auto kern = vog::lstm_layer_kernel<T16, KS>;                                                      \
@@ -93,11 +96,11 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
     static bool attr_set = false;                                                                     \
     if (!attr_set) {                                                                                  \
       VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Body::LDS_MAX));   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));          \
       attr_set = true;                                                                                \
     }                                                                                                 \
     ::vog::launch(kern, grid, dim3(512),                                                              \
-                  fused ? Body::lds_fused(a->Bn, a->Bn * a->T) : Body::lds_plain(a->Bn), st, p);      \
+                  (fused ? Body::lds_fused(a->Bn, a->Bn * a->T) : Body::lds_plain(a->Bn)) + lds_extra, st, p); \
   })
   switch (a->R / 32) {
     case 1: VOG_LAUNCH_LAYER(1); break;

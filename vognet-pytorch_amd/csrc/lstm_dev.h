@@ -190,13 +190,16 @@ struct LstmLayerBody {
   // LDS: [gates of the fused input projection, kept for the whole recurrence]
   //      [union: layer-input chunks of the projection (2 x nct x 8 KiB) | h staging (2 x Bn x HS_LD x 2 B)] [16 B flags] [publish buffer]
   static constexpr int GX_PITCH = 20;                      // floats per column (16 + 4: spreads the banks)
-  static constexpr size_t GX_BYTES = (size_t)8 * 64 * GX_PITCH * 4;
+  // gates of the fused projection: [8 waves][column tiles x 16 columns][GX_PITCH] fp32, sized by the columns the layer
+  // really has (Bn*T <= 64): 30 KB instead of 40 at cfg 2, which puts the whole workgroup under half a CU's LDS
+  static constexpr size_t gx_bytes(int ncols) { return (size_t)8 * ((ncols + 15) / 16 * 16) * GX_PITCH * 4; }
+  static constexpr size_t GX_BYTES = gx_bytes(64);
   static constexpr size_t hs_bytes(int Bn) { return ((size_t)2 * Bn * HS_LD * 2 + 15) / 16 * 16; }
   static constexpr size_t xbuf_bytes(int ncols) { return (size_t)2 * ((ncols + 15) / 16) * 8 * 1024; }
   static constexpr size_t TAIL = 16 + 16 * 32 * 2;          // flags + the publish buffer [<= 16 sentences][32 units]
   static constexpr size_t lds_plain(int Bn) { return hs_bytes(Bn) + TAIL; }
   static constexpr size_t lds_fused(int Bn, int ncols) {
-    return GX_BYTES + (hs_bytes(Bn) > xbuf_bytes(ncols) ? hs_bytes(Bn) : xbuf_bytes(ncols)) + TAIL;
+    return gx_bytes(ncols) + (hs_bytes(Bn) > xbuf_bytes(ncols) ? hs_bytes(Bn) : xbuf_bytes(ncols)) + TAIL;
   }
   static constexpr size_t LDS_MAX = GX_BYTES + ((size_t)2 * 16 * HS_LD * 2 > (size_t)2 * 4 * 8 * 1024 ? (size_t)2 * 16 * HS_LD * 2 : (size_t)2 * 4 * 8 * 1024) + TAIL;
 
@@ -210,9 +213,10 @@ struct LstmLayerBody {
     const bool valid_b = b < p.Bn;
     const int len = valid_b ? (int)p.lens[b] : 0;
     const bool fused = p.wih != nullptr;
-    unsigned char* uni = smem + (fused ? GX_BYTES : 0);
-    unsigned short* hs = reinterpret_cast<unsigned short*>(uni);
     const int ncols = p.Bn * p.T;
+    const int gx_cols = (ncols + 15) / 16 * 16;
+    unsigned char* uni = smem + (fused ? gx_bytes(ncols) : 0);
+    unsigned short* hs = reinterpret_cast<unsigned short*>(uni);
     const size_t uni_bytes = fused ? (hs_bytes(p.Bn) > xbuf_bytes(ncols) ? hs_bytes(p.Bn) : xbuf_bytes(ncols)) : hs_bytes(p.Bn);
     unsigned int* flags = reinterpret_cast<unsigned int*>(uni + uni_bytes);   // [0] timeout seen, [1] direction shares an XCD
     unsigned short* pub = reinterpret_cast<unsigned short*>(uni + uni_bytes + 16);
@@ -231,7 +235,7 @@ struct LstmLayerBody {
     // fp32 round trip): every wave computes the gates of ITS 16 rows for all Bn*T (sentence, position)
     // columns: W_ih rows stream once through registers (K in chunks of 256), the layer input is
     // staged per chunk in LDS and shared by the 8 waves; the result stays in LDS for the recurrence.
-    float* gxl = reinterpret_cast<float*>(smem) + (size_t)wid * 64 * GX_PITCH;
+    float* gxl = reinterpret_cast<float*>(smem) + (size_t)wid * gx_cols * GX_PITCH;
     if (fused) {
       unsigned char* xch = uni;
       const int nct = (ncols + 15) >> 4;                                // <= 4 column tiles

@@ -250,8 +250,11 @@ class VogEngine:
     # ---- persistent slots (graph replay; what bench.py and the evaluator use) ----
     def make_slot(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
                   with_pred: bool = True, graph: Optional[bool] = None,
-                  pred_rec: Optional[torch.Tensor] = None) -> "Slot":
-        return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph, pred_rec)
+                  pred_rec: Optional[torch.Tensor] = None, share_ws_with: Optional["Slot"] = None) -> "Slot":
+        """`share_ws_with`: reuse another slot's workspace (same shapes). Only for slots that are launched on the SAME
+        stream one after the other (every forward re-initialises the state it needs in its prologue): N input sets
+        cycling through a few workspaces, the layout of a serving loop whose requests arrive in fresh buffers."""
+        return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph, pred_rec, share_ws_with)
 
     def aql_open(self, n_queues: int = 1) -> None:
         """Create the library's own hardware queues on this device (AQL submission path)."""
@@ -330,7 +333,7 @@ class Slot:
     Inputs live at fixed addresses (H2D copies land here directly), so one
     forward is a single hipGraphLaunch of ~50 kernel nodes."""
 
-    def __init__(self, eng: VogEngine, inp, T, with_pred, graph, pred_rec=None):
+    def __init__(self, eng: VogEngine, inp, T, with_pred, graph, pred_rec=None, share_ws_with=None):
         self.eng = eng
         self.epoch = eng.weights_epoch
         # the slot OWNS its input buffers (update_inputs / the device batch assembly write into them): a
@@ -343,9 +346,15 @@ class Slot:
         with torch.cuda.device(eng.device):
             self.batch, self.out, (self.B, self.ncmp, self.T) = eng.make_batch(self.inp, T, with_pred, pred_rec)
             n = eng.lib.vog_workspace_bytes(eng.ctx, self.B, self.ncmp, self.T)
-            self.ws = torch.empty(int(n), dtype=torch.uint8, device=eng.device)
-            L.check(eng.lib.vog_workspace_init(eng.ctx, self.B, self.ncmp, self.T, self.ws.data_ptr(),
-                                               self.ws.numel(), L.stream_ptr()), "vog_workspace_init")
+            if share_ws_with is not None:
+                o = share_ws_with
+                assert (o.B, o.ncmp, o.T) == (self.B, self.ncmp, self.T) and o.ws.numel() == int(n), \
+                    "a shared workspace needs slots of the same shape"
+                self.ws = o.ws
+            else:
+                self.ws = torch.empty(int(n), dtype=torch.uint8, device=eng.device)
+                L.check(eng.lib.vog_workspace_init(eng.ctx, self.B, self.ncmp, self.T, self.ws.data_ptr(),
+                                                   self.ws.numel(), L.stream_ptr()), "vog_workspace_init")
             self.graph = None
             self.aql = None
             if graph:

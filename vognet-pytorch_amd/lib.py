@@ -282,6 +282,9 @@ SYMBOLS = {
     "vog_adam_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, c_vp]),
     "vog_row_mean_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vog_train_set_int": (c_i32, [C.c_char_p, c_i32]),
+    "vog_train_get_int": (c_i32, [C.c_char_p, C.POINTER(c_i32)]),
+    "vog_bilstm_fwd": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp, c_vp, c_vp]),
+    "vog_lstm_out_to_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vog_score_head_f32_bwd_scratch_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "vog_score_head_f32_bwd": (c_i32, [c_vp] * 11 + [C.c_size_t] + [c_i32] * 7 + [c_vp]),
     "vog_bilstm_hx_bytes": (c_i64, [c_i32, c_i32, c_i32]),
