@@ -369,6 +369,20 @@ def main():
     # i + 4 of a run share a queue): the streams are created here, back to back, before any slot exists, and reused. (Picking
     # them by a pairwise timing test was tried: what overlaps during the test does not reliably overlap afterwards.)
     stream_pool = [torch.cuda.Stream(device=dev) for _ in range(16)]
+    if os.environ.get("VOG_PERF_EXPERIMENTS") and os.environ.get("VOG_BENCH_CU_MASK"):
+        # experiment only (no `value` is printed under VOG_PERF_EXPERIMENTS): streams restricted to a subset of the CUs
+        # (hipExtStreamCreateWithCUMask) - "is the 4-stream loop bound by CU time?" VOG_BENCH_CU_MASK = a 32-bit hex pattern
+        # repeated over the CU bit array (e.g. 77777777 = 3 of every 4 CUs), or per-stream patterns separated by ','
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        pats = [int(x, 16) for x in os.environ["VOG_BENCH_CU_MASK"].split(",")]
+        stream_pool = []
+        for i in range(16):
+            words = (ctypes.c_uint32 * 8)(*([pats[i % len(pats)]] * 8))
+            h = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+            assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
+            stream_pool.append(torch.cuda.ExternalStream(h.value, device=dev))
 
     def measure(G, steps, warmup, batched=False, rotate=0):
         """K timed steps (one step = one batch of the workload) after W warm-up steps with G

@@ -59,6 +59,14 @@ CASES["full/vog_sep_gt5_bs4_ragged"] = _case(
     {"mdl.name": "vog", "ds.conc_type": "sep", **REL}, B=4, ragged=True, dseed=11)
 CASES["full/cfg2_ragged"] = _case(
     {"mdl.name": "vog", "ds.conc_type": "spat", **REL}, B=4, ragged=True, dseed=12)
+# ---- the other model kinds / ablations the reference reports, at full size (round 4): VidGrnd (code/mdl_vog.py:412-523: obj_tx,
+# then lin2 straight on the [vis || lang] tokens) and VOGNet with 3-layer stacks (EXPTS.md:186-189, transformer_code.py:189-279:
+# layers >= 1 of mul_tx run the dense QKV / attention forms at d = 768, the shared box-bias Linear feeds every layer)
+CASES["full/vgrnd_spat_gt5_bs4"] = _case(
+    {"mdl.name": "vgrnd", "ds.conc_type": "spat", **REL}, B=4, ragged=True, dseed=13)
+CASES["full/vog_spat_gt5_bs4_3layers"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, "mdl.obj_tx.n_layers": 3, "mdl.mul_tx.n_layers": 3},
+    B=4, ragged=True, dseed=14, perturb_ln=True)
 # ---- every model x conc combination, shrunken dims, ragged sentences
 for _m in ("igrnd", "vgrnd", "vog"):
     for _c in ("spat", "temp", "sep", "svsq"):

@@ -25,7 +25,8 @@ from oracle.make_golden_loss import targets_for
 BWD_CASES = ["small/vog_spat", "small/vog_temp", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16",
              "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2",
              "full/cfg2_ragged", "small/vog_sep_cmpmsk",      # sentences of different lengths at full size; masked-out videos
-             "small/vog_spat_3layers", "small/vog_temp_objonefrm", "small/vog_spat_noobj", "small/vog_spat_norel"]   # the model's knobs
+             "small/vog_spat_3layers", "small/vog_temp_objonefrm", "small/vog_spat_noobj", "small/vog_spat_norel",   # the model's knobs
+             "full/vgrnd_spat_gt5_bs4", "full/vog_spat_gt5_bs4_3layers"]   # round 4: the other reported model kind / the 3-layer ablation at full size
 N_SAMPLE = 4096
 
 
@@ -145,5 +146,8 @@ def make(name: str):
 if __name__ == "__main__":
     if not ref_import.available():
         raise SystemExit("reference tree not present; goldens are generated in the build container")
+    import sys
+    pref = sys.argv[1] if len(sys.argv) > 1 else ""
     for n in BWD_CASES:
-        make(n)
+        if n.startswith(pref):
+            make(n)

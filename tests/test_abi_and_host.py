@@ -204,3 +204,21 @@ def test_training_switch_is_per_thread_not_process_state():
     assert get() == 1                      # the other thread's write did not reach this one
     assert lib.vog_train_set_int(b"bf16_gemm", 0) == 0 and get() == 0
     assert lib.vog_train_set_int(b"no_such_switch", 1) != 0
+
+
+def test_synthetic_loader_keeps_the_short_batch_last_on_its_rank():
+    """shard_indices wraps around, so on world = 4 with 10 validation batches rank 3 owns batches [9, 0, 1] - the
+    short tail batch must still be the LAST one it sees (a loader yields its tail last; the evaluator's ring is sized by
+    cfg.train.bsv, never by a short first batch)."""
+    cfg = ec.get_default_cfg()
+    comm = {"vocab_size": 200, "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1}, "num_prop_per_frm": ec.num_prop_per_frm(cfg)}
+    bs = int(cfg.train.bsv)
+    seen_short = 0
+    for rank in range(4):
+        idx = list(D.shard_indices(10, rank, 4))
+        if 9 in idx and idx[0] == 9:
+            dl = main_dist.synthetic_loader(cfg, comm, 10, rank, 4)
+            sizes = [int(b["num_cmp_msk"].shape[0]) for b in dl]
+            assert sizes[0] == bs and sizes[-1] == bs - 1 and sizes.count(bs - 1) == 1, sizes
+            seen_short += 1
+    assert seen_short >= 1

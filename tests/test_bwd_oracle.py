@@ -62,8 +62,10 @@ def test_oracle_autograd_equals_reference_autograd(name):
             worst = max(worst, check_fixture(g, k, sdt[n].grad.numpy(), tol=TOL))
     if "mul_tail_attn" in st:
         d = st["mul_tail_attn"].shape[-1]
-        worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=TOL))
-        worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=TOL))
+        # (activation gradients at a seam, like the ones below: behind three layers one flipped ReLU moved a row of d_x by
+        # 2.1e-3 of the tensor's largest entry at full size - fp32 summation order, reference vs oracle)
+        worst = max(worst, check_fixture(g, "d_attn", st["mul_tail_attn"].grad.reshape(-1, d).numpy(), tol=10 * TOL if name.startswith("full/") else TOL))
+        worst = max(worst, check_fixture(g, "d_x", st["mul_tail_t"].grad.reshape(-1, d).numpy(), tol=10 * TOL if name.startswith("full/") else TOL))
     # every parameter the loss reaches, and the gradients at the seams between the pieces of the backward
     n_par = 0
     for key in g.files:

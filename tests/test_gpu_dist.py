@@ -185,3 +185,46 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["parity"]["ok"] and d["parity"]["non_finite_outputs_all_slots"] == 0
     assert d["value"] == pytest.approx(2 * d["per_rank_value"]) and d["value"] > 50          # (gloo moves the records through the host: slow, functional only)
     assert d["config"]["global_batch"] == 8
+
+
+def _bcast_worker(rank, world, port, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    trn = importlib.import_module("vognet-pytorch_amd.train")
+    cfg, sd, c, comm, sel, synth = _setup(name)
+    # replicas that were NOT seeded alike: rank r starts from weights shifted by r (what torch.manual_seed(rank) does to an
+    # init that draws from torch's generator)
+    sd_r = {k: torch.from_numpy(v) + (0.01 * rank if np.issubdtype(v.dtype, np.floating) else 0) for k, v in sd.items()}
+    tr = trn.FP32Trainer(cfg, comm, sd_r, sel["loss"](cfg, comm), lr=1e-4)
+    before = float(next(iter(tr.params.values())).double().sum())
+    tr.broadcast_from_rank0()
+    dev = _rank_batch(synth, cfg, c, comm, rank, 2)
+    tr.step(dev)
+    torch.cuda.synchronize()
+    q.put((rank, before, {k: v.cpu().numpy() for k, v in tr.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_initial_weights_are_broadcast_from_rank0():
+    """the data-parallel path must not rely on identical seeding (DistributedDataParallel broadcasts rank 0's
+    parameters at construction, code/main_dist.py:72-85). Two ranks that start from DIFFERENT weights hold rank 0's after
+    `broadcast_from_rank0` and identical ones after a step on different batches."""
+    name = "small/vog_spat"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bcast_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, before, sd = q.get(timeout=300)
+        got[r] = (before, sd)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] != got[1][0]                       # they did start apart
+    for k in got[0][1]:
+        assert np.array_equal(got[0][1][k], got[1][1][k]), k

@@ -547,7 +547,8 @@ def test_device_full_backward_vs_reference_autograd(name):
 @pytest.mark.parametrize("name", ["small/vog_spat", "full/cfg2_vog_spat_gt5_bs4", "small/vog_sep_r64", "full/cfg5_vog_svsq_gt5_bs16",
                                   "small/igrnd_spat", "small/vgrnd_temp", "small/vgrnd_sep", "full/cfg1_igrnd_spat_gt5_bs2",
                                   "full/cfg2_ragged", "small/vog_sep_cmpmsk", "small/vog_spat_3layers", "small/vog_temp_objonefrm",
-                                  "small/vog_spat_noobj", "small/vog_spat_norel"])
+                                  "small/vog_spat_noobj", "small/vog_spat_norel",
+                                  "full/vgrnd_spat_gt5_bs4", "full/vog_spat_gt5_bs4_3layers"])
 def test_device_training_steps_vs_oracle_adam(name):
     """`FP32Trainer.step` x 3 on the device (fp32 forward with its own activations -> device loss -> loss gradient ->
     visual / language backward -> Adam, all C-ABI calls) against the same three steps on the CPU: autograd through
@@ -894,3 +895,32 @@ def test_bilstm_fwd_entry_point_matches_oracle_lstm_encoder(name):
     ex, ef = (xg - xr).abs().max().item(), (fg - fr).abs().max().item()
     print(name, "vog_bilstm_fwd: x abs err", ex, "final hidden abs err", ef)
     assert ex < 4e-3 and ef < 4e-3            # f16 operands, fp32 cell state: |h| < 1
+
+
+def test_optimizer_state_of_another_model_is_refused():
+    """Adam state is mapped by position; a state whose shape is not its parameter's must raise instead of letting
+    vog_adam_f32 walk a shorter m / v buffer. The repo's own checkpoint still round-trips."""
+    trn = importlib.import_module("vognet-pytorch_amd.train")
+    name = "small/vog_spat"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    dev.update({k: torch.from_numpy(v).cuda() for k, v in tg.items()})
+    _, sd, _, _ = cases.build(name)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    t = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=1e-4)
+    t.step(dev)
+    osd = t.optimizer_state_dict()
+    t2 = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=1e-4)
+    t2.load_optimizer_state_dict(osd)
+    assert t2.num_it == 1 and all(torch.equal(t2.m[k], t.m[k]) for k in t.m)
+    bad = {"state": {i: dict(s) for i, s in osd["state"].items()}, "param_groups": osd["param_groups"]}
+    i0 = next(iter(bad["state"]))
+    bad["state"][i0]["exp_avg"] = bad["state"][i0]["exp_avg"].reshape(-1)[:-1].clone()
+    t3 = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=1e-4)
+    with pytest.raises(ValueError):
+        t3.load_optimizer_state_dict(bad)
+    assert not t3.m                                     # nothing was half-loaded
+    swapped = {"state": {0: osd["state"][1], 1: osd["state"][0]}, "param_groups": osd["param_groups"]}
+    if tuple(osd["state"][0]["exp_avg"].shape) != tuple(osd["state"][1]["exp_avg"].shape):
+        with pytest.raises(ValueError):
+            t3.load_optimizer_state_dict(swapped)

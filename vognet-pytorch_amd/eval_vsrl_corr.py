@@ -195,15 +195,23 @@ class Evaluator(torch.nn.Module):
             rec = self._records(out, batch)
             meta = [k for k in self.META_KEYS if k in batch]
             if ring is None:
-                layout.update(B=rec.shape[0], rw=rec.shape[1], ncmp=batch["new_srl_idxs"].size(1),
+                # rows of one ring entry: the loader's batch size x the requests served per forward - not whatever this rank's
+                # FIRST batch happens to hold (a wrapped-around shard can start with the short tail batch), and the same on
+                # every rank (the all-gather's sizes must agree)
+                rows_ring = max(rec.shape[0], int(self.cfg.train.get("bsv", 0) or 0) * max(1, G))
+                if D.get_world_size() > 1:
+                    t = torch.tensor([rows_ring], dtype=torch.int64, device=rec.device)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    rows_ring = int(t.item())
+                layout.update(B=rows_ring, rw=rec.shape[1], ncmp=batch["new_srl_idxs"].size(1),
                               nsrl=out["mdl_outs_eval"].shape[2], meta=meta,
                               meta_w={k: int(batch[k].numel() // rec.shape[0]) for k in meta},
                               meta_1d={k: batch[k].dim() == 1 for k in meta})
                 width = rec.shape[1] + 2 * sum(layout["meta_w"].values()) + 1
-                ring = D.RecordRing(rec.shape[0], width, self.GATHER_EVERY, rec.device, on_half=on_half)
+                ring = D.RecordRing(rows_ring, width, self.GATHER_EVERY, rec.device, on_half=on_half)
             nb = rec.shape[0]
-            assert nb <= layout["B"], (f"batch of {nb} queries after a first batch of {layout['B']}: the exchange "
-                                       "ring is sized by the first batch (only the tail batch may be shorter)")
+            assert nb <= layout["B"], (f"batch of {nb} queries, the exchange ring holds {layout['B']} per entry "
+                                       "(cfg.train.bsv x cfg.hip.batch_requests, or the first batch if larger)")
             row = torch.cat([rec] + [batch[k].reshape(nb, -1).to(torch.float64).view(torch.float32) for k in meta]
                             + [torch.ones(nb, 1, dtype=torch.float32, device=rec.device)], dim=1)
             if nb < layout["B"]:

@@ -80,7 +80,11 @@ def synthetic_loader(cfg, comm, n_batches: int, rank: int, world: int, train: bo
     bs = int(cfg.train.bs if train else cfg.train.bsv)
     ct = cfg.ds.conc_type
     out = []
-    for i in D.shard_indices(n_batches, rank, world):
+    idx = list(D.shard_indices(n_batches, rank, world))
+    if not train and (n_batches - 1) in idx:
+        # shard_indices wraps around: the one short batch may not be the first a rank sees (a loader yields its tail last)
+        idx = [i for i in idx if i != n_batches - 1] + [n_batches - 1] * idx.count(n_batches - 1)
+    for i in idx:
         b = synth.make_batch(ct, bs, comm["num_prop_per_frm"], vocab_size=comm["vocab_size"], seed=1000 * i + (500000 if train else 0))
         b.update(synth.make_targets(b, ct, comm["num_prop_per_frm"], seed=i))
         ncmp = b["num_cmp_msk"].shape[1]

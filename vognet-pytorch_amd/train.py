@@ -54,8 +54,8 @@ class FP32Trainer:
         # counter-based generator seeded per step (csrc/backward.hip::drop_scale) - NOT torch's stream, so a step is
         # statistically, not bitwise, the reference's. Off: a step equals the reference's in eval mode.
         # mixed precision: the tile GEMMs round their operands to bf16 (fp32 accumulation, fp32 master weights, fp32 everything
-        # else); off = the fp32 path that is pinned against autograd through the reference. Process-wide switch of the library,
-        # set at every step.
+        # else); off = the fp32 path that is pinned against autograd through the reference. A per-thread switch of the library
+        # (vog_train_set_int), set at the top of every step.
         self.bf16_gemm = bool(bf16_gemm)
         self.dropout, self.dropout_seed = bool(dropout), int(dropout_seed)
         self.p_lstm = (0.1, 0.1)
@@ -205,6 +205,25 @@ class FP32Trainer:
                                           self.betas[1], self.eps, self.num_it, st), "vog_adam_f32")
         return ld
 
+    def broadcast_from_rank0(self, with_optimizer: bool = False) -> None:
+        """What DistributedDataParallel does at construction (code/main_dist.py:72-85): every rank starts from rank 0's
+        parameters (and Adam state, after a resume with load_opt) - replicas seeded differently would otherwise apply the
+        averaged gradient to different weights. Name order; a no-op without a multi-rank group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1):
+            return
+        for k in sorted(self.params):
+            dist.broadcast(self.params[k], src=0, group=self.pg)
+        if with_optimizer:
+            for k in sorted(self.params):
+                if k not in self.m:
+                    self.m[k], self.v[k] = torch.zeros_like(self.params[k]), torch.zeros_like(self.params[k])
+                dist.broadcast(self.m[k], src=0, group=self.pg)
+                dist.broadcast(self.v[k], src=0, group=self.pg)
+            t = torch.tensor([self.num_it], dtype=torch.int64, device=self.dev)
+            dist.broadcast(t, src=0, group=self.pg)
+            self.num_it = int(t.item())
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """The parameters under the reference's key names (load into the inference model with `load_state_dict`)."""
         return {k: v.clone() for k, v in self.params.items()}
@@ -219,12 +238,26 @@ class FP32Trainer:
                                                   "amsgrad": False, "params": list(range(len(keys)))}]}
 
     def load_optimizer_state_dict(self, osd):
+        """Adam state by POSITION in state-dict key order - torch.optim.Adam numbers `mdl.parameters()`, which for the reference's
+        modules is the order of `state_dict()` restricted to parameters. A state whose shape is not its parameter's (a
+        checkpoint of another mdl.name / conc_type, or of a model with other sizes) is refused: vog_adam_f32 walks m / v with
+        the parameter's element count."""
         keys = list(self.params)
+        new_m, new_v, num_it = {}, {}, self.num_it
         for i, stt in osd["state"].items():
+            if not 0 <= int(i) < len(keys):
+                raise ValueError(f"optimizer state for parameter #{i}, the model has {len(keys)}")
             k = keys[int(i)]
-            self.m[k] = stt["exp_avg"].to(self.dev, torch.float32).contiguous().clone()
-            self.v[k] = stt["exp_avg_sq"].to(self.dev, torch.float32).contiguous().clone()
-            self.num_it = int(stt["step"])
+            for nm in ("exp_avg", "exp_avg_sq"):
+                if tuple(stt[nm].shape) != tuple(self.params[k].shape):
+                    raise ValueError(f"optimizer state #{i} ({nm}) has shape {tuple(stt[nm].shape)}, parameter {k} has "
+                                     f"{tuple(self.params[k].shape)}: this checkpoint belongs to another model")
+            new_m[k] = stt["exp_avg"].to(self.dev, torch.float32).contiguous().clone()
+            new_v[k] = stt["exp_avg_sq"].to(self.dev, torch.float32).contiguous().clone()
+            num_it = int(stt["step"])
+        self.m.update(new_m)
+        self.v.update(new_v)
+        self.num_it = num_it
         g = osd["param_groups"][0]
         self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
 

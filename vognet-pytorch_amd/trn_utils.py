@@ -40,9 +40,21 @@ class Learner:
                          + [f"val_{k}" for k in self.met_keys])
         self.init_log_dirs()
         self.num_it, self.num_epoch, self.best_met = 0, 0, 0.0
-        self.trainer = FP32Trainer(cfg, self.comm, mdl.state_dict(), loss_fn, lr=float(cfg.train.lr), dropout=train_mode)
+        if bool(cfg.train.get("use_reduce_lr_plateau", False)):
+            # the reference steps ReduceLROnPlateau on the validation metric (utils/trn_utils.py:470-483, 760-763); its
+            # cfg.reduce_factor / cfg.patience are defined by no config - refuse instead of silently ignoring the flag
+            raise NotImplementedError("cfg.train.use_reduce_lr_plateau: the plateau scheduler is not implemented (constant LR only)")
+        # dropout masks: independent across ranks and runs (the reference draws from torch's per-process generator)
+        base_seed = int(torch.initial_seed()) & 0x7FFFFFFF
+        self.trainer = FP32Trainer(cfg, self.comm, mdl.state_dict(), loss_fn, lr=float(cfg.train.lr), dropout=train_mode,
+                                   dropout_seed=(base_seed * D.get_world_size() + self.rank) & 0x7FFFFFFF)
+        loaded_opt = False
         if cfg.train.resume:
-            self.load_model_dict(resume_path=cfg.train.resume_path, load_opt=cfg.train.load_opt)
+            loaded_opt = bool(self.load_model_dict(resume_path=cfg.train.resume_path, load_opt=cfg.train.load_opt)) and bool(cfg.train.load_opt)
+        # DistributedDataParallel broadcasts rank 0's parameters at construction: the replicas must not depend on seeding
+        self.trainer.broadcast_from_rank0(with_optimizer=loaded_opt)
+        if D.get_world_size() > 1:
+            self._sync_model()
 
     # ---- files (init_log_dirs / create_log_dirs, utils/trn_utils.py:341-379)
     def init_log_dirs(self):
@@ -82,6 +94,10 @@ class Learner:
                                     if k in self.trainer.params})
         if load_opt and "optimizer_state_dict" in ck:
             self.trainer.load_optimizer_state_dict(ck["optimizer_state_dict"])
+        # the iteration counter is restored on every load (utils/trn_utils.py:588-590), with or without the optimizer state:
+        # it also numbers the dropout masks, which must not restart
+        if "num_it" in ck:
+            self.trainer.num_it = self.num_it = int(ck["num_it"])
         self.num_epoch, self.best_met = int(ck.get("num_epoch", 0)), float(ck.get("best_met", 0.0))
         self._sync_model()
         return True
@@ -98,7 +114,13 @@ class Learner:
             sm.add_value(self.trainer.step(batch))
             self.num_it = self.trainer.num_it
         D.synchronize()
-        return dict(sm.smooth)
+        out = dict(sm.smooth)
+        if D.get_world_size() > 1:
+            # reduce_dict(average=True) over the ranks (utils/trn_utils.py:61-90, 527-530)
+            t = torch.tensor([out[k] for k in self.loss_keys], dtype=torch.float64, device=self.trainer.dev)
+            torch.distributed.all_reduce(t)
+            out = {k: float(v) / D.get_world_size() for k, v in zip(self.loss_keys, t.tolist())}
+        return out
 
     def validate(self, db=None, mb=None, write_to_file: bool = False):
         if db is None:
