@@ -26,9 +26,11 @@ def comm_for(c):
             "num_prop_per_frm": c["nppf0"]}
 
 
-def build_engine(name, tx_dtype="bf16"):
+def build_engine(name, tx_dtype=None):
+    """tx_dtype None: the package default (`auto`: bf16 for single-layer stacks, f16 for deeper ones)."""
     cfg, sd, batch, c = cases.build(name)
-    cfg.hip.tx_dtype = tx_dtype
+    if tx_dtype is not None:
+        cfg.hip.tx_dtype = tx_dtype
     eng = engine_mod.VogEngine(cfg, comm_for(c))
     eng.load_state_dict(sd)
     dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}

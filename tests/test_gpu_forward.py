@@ -76,7 +76,7 @@ def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
     return nflip
 
 
-def _run(name, tx_dtype="bf16", graph=False):
+def _run(name, tx_dtype=None, graph=False):
     eng, cfg, sd, batch, c, dev = build_engine(name, tx_dtype)
     before = {k: v.clone() for k, v in dev.items()}
     if graph:

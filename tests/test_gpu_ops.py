@@ -571,7 +571,10 @@ def test_pred_head_exact(conc, np0):
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("S,nfrm,nsrl,nppf,H,dh,dp,use_rel,lpv", [
     (8, 4, 5, 20, 3, 128, 128, 1, 0), (6, 3, 5, 7, 3, 16, 32, 1, 1), (4, 2, 5, 100, 2, 100, 128, 1, 0),
-    (4, 4, 3, 40, 1, 64, 64, 0, 0), (2, 1, 5, 400, 2, 128, 128, 1, 0)])
+    (4, 4, 3, 40, 1, 64, 64, 0, 0), (2, 1, 5, 400, 2, 128, 128, 1, 0),
+    # head dim 256 (mul_tx at full size): the E x F kernel of attn_struct_ef_dev.h (qvis = 1, several key blocks) with 13 / 4 /
+    # 2 key blocks, a partial last proposal block, language rows per video, no bias, fewer than 5 arguments
+    (3, 3, 5, 400, 3, 256, 256, 1, 0), (4, 2, 5, 100, 3, 256, 256, 1, 1), (2, 2, 4, 50, 2, 250, 256, 0, 0)])
 @pytest.mark.parametrize("qvis", [0, 1])
 def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, qvis):
     """Separable mul_tx layer-0 attention: token (a, p) has k = Kv[p] + Kl[a], v = Vv[p] + Vl[a]; the

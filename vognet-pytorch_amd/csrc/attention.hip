@@ -34,6 +34,7 @@
 #include "attention_dev.h"
 #include "attn_tile2_dev.h"
 #include "attn_struct_lds_dev.h"
+#include "attn_struct_ef_dev.h"
 
 namespace vog {
 
@@ -49,6 +50,25 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
   if (lds_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_LDS"); lds_form = e ? atoi(e) : 1; }
   constexpr int NF = (NDB * 32) / 16 + 2 * NDB;
   const size_t lds_res = (size_t)4 * NF * 1024 + ((size_t)p.npad_kv + (size_t)p.nsrl * 3 * NDB * 32) * sizeof(float);
+  // several visual key blocks, queries formed in the kernel: the E x F factorisation (attn_struct_ef_dev.h; head dim 128 / 256)
+  static int ef_form = -2;            // VOG_ATTN_STRUCT_EF=0 (perf experiments): the per-(a, p) kernels below
+  if (ef_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_EF"); ef_form = e ? atoi(e) : 1; }
+  if constexpr (NDB % 4 == 0) {
+    if (ef_form && p.q_visual && p.npad_kv > 32 && p.npad_kv <= 512 && p.nsrl <= EF_MAXA && !(p.dbg)) {
+      const size_t lds_ef = attn_struct_ef_lds<NDB>(p.nsrl, p.npad_kv);
+      if (lds_ef <= 150 * 1024) {
+        auto kern = attn_struct_ef_kernel<T16, NDB>;
+        static bool attr_ef = false;
+        if (!attr_ef) {
+          VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+          attr_ef = true;
+        }
+        ::vog::launch(kern, dim3(p.S * p.H * ((p.nppf + 31) / 32)), dim3(256), lds_ef, st, p);
+        VOG_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+  }
   if (p.npad_kv > 32 && lds_form && lds_res <= 150 * 1024) {
     auto kern = attn_struct_lds_kernel<T16, NDB>;
     static bool attr_sl = false;
@@ -60,7 +80,12 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
     VOG_LAUNCH_CHECK();
     return 0;
   }
-  if (p.npad_kv == 32) ::vog::launch((attn_struct1_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+  // lean form (<= 128 registers, four workgroups per CU) unless VOG_ATTN_STRUCT1_LEAN=0 (perf experiments): bit-identical
+  static int lean1 = -2;
+  if (lean1 == -2) { const char* e = perf_env("VOG_ATTN_STRUCT1_LEAN"); lean1 = e ? atoi(e) : 1; }
+  if (p.npad_kv == 32 && lean1 && (NDB % 1) == 0 && ((NDB * 32) / 16) % 2 == 0)
+    ::vog::launch((attn_struct1_lean_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+  else if (p.npad_kv == 32) ::vog::launch((attn_struct1_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
   else ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
@@ -159,6 +184,18 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
     ::vog::launch(kern, grid, dim3(256), lds, st, pt);
     VOG_LAUNCH_CHECK();
     return 0;
+  }
+  // <= 8 key blocks: the lean form (<= 128 registers, four workgroups per CU; VOG_ATTN_FRAG_LEAN=0 (perf experiments): the old one)
+  static int lean_f = -2;
+  if (lean_f == -2) { const char* e = perf_env("VOG_ATTN_FRAG_LEAN"); lean_f = e ? atoi(e) : 1; }
+  if constexpr (((NDB * 32) / 16) % 2 == 0) {
+    if (lean_f && p.npad <= 256) {
+      const size_t ldsl = (size_t)8 * 2 * 64 * 16 + (size_t)2 * 8 * 32 * sizeof(float) + (size_t)p.npad * sizeof(float);
+      dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
+      ::vog::launch((attn_frag_lean_kernel<T16, NDB>), grid, dim3(256), ldsl, st, p);
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
   }
   const size_t lds = ((size_t)2 * NDB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);
   if (lds > 150 * 1024) VOG_FAIL(-1, "rel_attention: sequence of %d tokens exceeds the LDS budget", p.N);

@@ -188,6 +188,143 @@ struct AttnFragBody {
 }
 };
 
+// ---- attn_frag under a quarter of a CU's registers (round 4; <= 8 key blocks, N <= 256: obj_tx at gt5). AttnFragBody keeps
+// K, Q, V^T of a key block and all NDB output accumulators per wave (368 registers at dp = 192: ONE 256-thread workgroup per
+// CU, 84 CUs for 12 us per forward at 5 % MFMA utilisation, and the 4-forward loop is bound by held CU time). Three phases,
+// two barriers: (1) the 4 waves split the KEY blocks: S^T tiles stay in registers (contraction walked two k-steps at a time),
+// block maxima to LDS; (2) softmax against the row maximum over ALL blocks (no running maximum, no accumulator rescale, no
+// merge of partial outputs): P^T fragments (16 bit, MFMA B-operand order) and block sums to LDS; (3) the waves split the
+// OUTPUT d-blocks: one accumulator per d-block, V^T fragments streamed from L2, P^T fragments from LDS. <= 128 registers:
+// four workgroups per CU.
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256, 4) void attn_frag_lean_kernel(AttnParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  constexpr int MAXKB = 8;
+  static_assert(KS % 2 == 0, "two k-steps per round");
+  extern __shared__ __attribute__((aligned(16))) unsigned char afl_smem[];
+  u16x8* Pl = reinterpret_cast<u16x8*>(afl_smem);                               // [MAXKB * 2][64] fragments
+  float* mloc = reinterpret_cast<float*>(afl_smem + MAXKB * 2 * 64 * 16);      // [MAXKB][32] block maxima
+  float* lloc = mloc + MAXKB * 32;                                              // [MAXKB][32] block sums
+  float* us = lloc + MAXKB * 32;                                                // [npad] bias precursor of every key
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int nqb = (p.N + 31) >> 5;
+  const int npair = p.S * p.H;
+  int pair, qb;
+  {   // as AttnFragBody: all query blocks of a (sequence, head) on ONE XCD (block b runs on XCD b % 8; speed only)
+    const int b = blockIdx.x;
+    const int full = (npair / 8) * 8;
+    const int grp = b / (8 * nqb);
+    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qb = (b >> 3) % nqb; }
+    else { const int r = b - full * nqb; pair = full + r / nqb; qb = r % nqb; }
+  }
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = qi < p.N;
+  const int nkb = nqb;
+  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
+  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + lane;
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
+    peb = p.pe_b[h];
+    for (int key = tid; key < p.npad; key += 256)
+      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
+  }
+  __syncthreads();
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+
+  // ---- phase 1: S^T tiles of this wave's key blocks (kb = wid, wid + 4), scaled logits kept in registers
+  f32x16 sacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kb = wid + 4 * i;
+    if (kb < nkb) {
+      const u16x8* Kb = Kf + (int64_t)kb * KS * 64;
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      u16x8 nq0 = Qf[0], nq1 = Qf[64], nk0 = Kb[0], nk1 = Kb[64];
+#pragma unroll 1
+      for (int ks = 0; ks < KS; ks += 2) {
+        const u16x8 q0 = nq0, q1 = nq1, k0 = nk0, k1 = nk1;
+        if (ks + 2 < KS) { nq0 = Qf[(ks + 2) * 64]; nq1 = Qf[(ks + 3) * 64]; nk0 = Kb[(ks + 2) * 64]; nk1 = Kb[(ks + 3) * 64]; }
+        s0 = mfma32<T16>(k0, q0, s0);
+        s1 = mfma32<T16>(k1, q1, s1);
+      }
+      float mblk = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + c32_row(r, lane);
+        float x = s0[r] + s1[r];
+        if (p.use_rel) x += fmaxf(uqp - us[key], 0.f);
+        x = key < p.N ? x * c2 : -1e30f;
+        sacc[i][r] = x;
+        mblk = fmaxf(mblk, x);
+      }
+      mblk = fmaxf(mblk, __shfl_xor(mblk, 32));
+      if (hi == 0) mloc[kb * 32 + ql] = mblk;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: probabilities against the row maximum over all key blocks; P^T fragments straight from the registers
+  float m = -1e30f;
+  for (int kb = 0; kb < nkb; ++kb) m = fmaxf(m, mloc[kb * 32 + ql]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kb = wid + 4 * i;
+    if (kb < nkb) {
+      float lsum = 0.f;
+      u16x8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[i][r] - m);
+        lsum += e;
+        pf[r >> 3][r & 7] = to16<T16>(e);
+      }
+      lsum += __shfl_xor(lsum, 32);
+      if (hi == 0) lloc[kb * 32 + ql] = lsum;
+      Pl[(kb * 2 + 0) * 64 + lane] = pf[0];
+      Pl[(kb * 2 + 1) * 64 + lane] = pf[1];
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: O^T d-blocks (db = wid, wid + 4, ...): V^T fragments from L2, P^T from LDS
+  float l = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) l += lloc[kb * 32 + ql];
+  const float inv_l = 1.0f / l;
+  for (int db = wid; db < NDB; db += 4) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    u16x8 v0 = Vf[(int64_t)(db * 2) * 64], v1 = Vf[(int64_t)(db * 2 + 1) * 64];
+    for (int kb = 0; kb < nkb; ++kb) {
+      const u16x8 a0 = v0, a1 = v1;
+      if (kb + 1 < nkb) {
+        v0 = Vf[((int64_t)(kb + 1) * NDB * 2 + db * 2) * 64];
+        v1 = Vf[((int64_t)(kb + 1) * NDB * 2 + db * 2 + 1) * 64];
+      }
+      o = mfma32<T16>(a0, Pl[(kb * 2 + 0) * 64 + lane], o);
+      o = mfma32<T16>(a1, Pl[(kb * 2 + 1) * 64 + lane], o);
+    }
+    if (q_ok) {
+      unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[g * 4 + e] * inv_l);
+        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
+      }
+    }
+  }
+}
+
 template <typename T16, int NDB>
 __global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char af_smem[];
@@ -803,6 +940,165 @@ __global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   VOG_ATS(5);
 #endif
+}
+
+// ---- the same kernel under half... a QUARTER of a CU's registers (round 4). attn_struct1_kernel holds Q, K and K_lang of the
+// whole head dimension at once (3 x KS fragments = 192 registers at dp = 256; 272 allocated): ONE 256-thread workgroup per CU,
+// and with 4 forwards in flight the chip is bound by the CU time its kernels hold (HSA_CU_MASK experiment) - this
+// kernel's 120 workgroups held 120 CUs for 13 us at 6 % MFMA utilisation. Here the contraction over the head dimension is
+// walked two k-steps at a time (the next pair's global fragments in flight), <= 128 registers: four workgroups share a CU and
+// their load latencies hide each other. Same MFMA order as attn_struct1_kernel (even / odd k-step chains): bit-identical.
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256, 4) void attn_struct1_lean_kernel(AttnStructParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  static_assert(KS % 2 == 0, "two k-steps per round");
+  extern __shared__ __attribute__((aligned(16))) float ssm[];
+  float* us = ssm;                                   // [32] bias precursor of the visual keys
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int Nq = p.nsrl * p.nppf;
+  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
+  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qb = qg * 4 + wid;
+  const bool wave_ok = qb < nqb;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = wave_ok && qi < Nq;
+  const int hd = p.H * DP, ldp = 3 * hd;
+  const int vid = s / p.nfrm;
+  const int lv = p.lpv ? vid : vid / p.ncv;
+  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
+  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)p.npad_kv * DP;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.kv + kvbase) + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vv + kvbase) + lane;
+  float* pls = ssm + 32;                             // [nsrl][3][DP]
+  {
+    const int per_row = 3 * DP / 4;                  // float4 per argument
+    for (int i = tid; i < p.nsrl * per_row; i += 256) {
+      const int a = i / per_row, c = i - a * per_row;
+      const int part = c / (DP / 4), dd4 = c - part * (DP / 4);
+      *reinterpret_cast<float4*>(&pls[(a * 3 + part) * DP + dd4 * 4]) =
+          *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + part * hd + dd4 * 4);
+    }
+  }
+  const int qbs = wave_ok ? qb : 0;
+  int qa = 0, qp = 0;
+  const unsigned short* qv = p.q + kvbase;
+  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + ((int64_t)s * p.H + h) * (int64_t)p.npad_q * DP) + (int64_t)qbs * KS * 64 + lane;
+  if (p.q_visual) {
+    const int t = qbs * 32 + ql;
+    qa = t / p.nppf;
+    qp = t - qa * p.nppf;
+    qa = qa < p.nsrl ? qa : p.nsrl - 1;              // tokens past the end are never stored
+  }
+  auto load_q = [&](int ks) -> u16x8 {
+    return p.q_visual ? *reinterpret_cast<const u16x8*>(qv + frag_qk(qp, ks * 16 + hi * 8, DP)) : Qf[ks * 64];
+  };
+  u16x8 nq0 = load_q(0), nq1 = load_q(1), nk0 = Kf[0], nk1 = Kf[64];
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
+    peb = p.pe_b[h];
+    if (tid < 32) us[tid] = tid < p.nppf ? p.u[(u_base + tid) * p.H + h] : 0.f;
+    if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
+  }
+  __syncthreads();
+  if (!wave_ok) return;
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+  f32x16 sv, sl;
+  {
+    f32x16 s1, l1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = 0.f; s1[r] = 0.f; sl[r] = 0.f; l1[r] = 0.f; }
+    const float* qlr = pls + (qa * 3 + 0) * DP + hi * 8;
+    const bool a_ok = ql < p.nsrl;
+    const float* kr = pls + ((a_ok ? ql : 0) * 3 + 1) * DP + hi * 8;
+    auto add_ql = [&](u16x8 v, int ks) -> u16x8 {       // q(a, p) = Qv[p] + Ql[a]
+      if (!p.q_visual) return v;
+      const float4 l0 = *reinterpret_cast<const float4*>(qlr + ks * 16);
+      const float4 l1_ = *reinterpret_cast<const float4*>(qlr + ks * 16 + 4);
+      return u16x8{to16<T16>(from16<T16>(v[0]) + l0.x), to16<T16>(from16<T16>(v[1]) + l0.y),
+                   to16<T16>(from16<T16>(v[2]) + l0.z), to16<T16>(from16<T16>(v[3]) + l0.w),
+                   to16<T16>(from16<T16>(v[4]) + l1_.x), to16<T16>(from16<T16>(v[5]) + l1_.y),
+                   to16<T16>(from16<T16>(v[6]) + l1_.z), to16<T16>(from16<T16>(v[7]) + l1_.w)};
+    };
+    auto load_kl = [&](int ks) -> u16x8 {               // language K fragment: lane = key a
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
+      return u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
+                   to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 2) {
+      const u16x8 q0 = add_ql(nq0, ks), q1 = add_ql(nq1, ks + 1), k0 = nk0, k1 = nk1;
+      if (ks + 2 < KS) {                                  // the next round's global fragments
+        nq0 = load_q(ks + 2); nq1 = load_q(ks + 3);
+        nk0 = Kf[(ks + 2) * 64]; nk1 = Kf[(ks + 3) * 64];
+      }
+      const u16x8 kl0 = load_kl(ks), kl1 = load_kl(ks + 1);
+      sv = mfma32<T16>(k0, q0, sv);
+      sl = mfma32<T16>(kl0, q0, sl);
+      s1 = mfma32<T16>(k1, q1, s1);
+      l1 = mfma32<T16>(kl1, q1, l1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] += s1[r]; sl[r] += l1[r]; }
+  }
+  // ---- two independent softmaxes, probabilities normalised before P.V (as attn_struct1_kernel)
+  u16x8 pv_[2], pl_[2];
+  {
+    float mv = -1e30f, ml = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = c32_row(r, lane);
+      float x = sv[r];
+      if (p.use_rel) x += fmaxf(uqp - us[key], 0.f);
+      x = key < p.nppf ? x * c2 : -1e30f;
+      const float y = key < p.nsrl ? sl[r] * c2 : -1e30f;
+      sv[r] = x; sl[r] = y;
+      mv = fmaxf(mv, x); ml = fmaxf(ml, y);
+    }
+    mv = fmaxf(mv, __shfl_xor(mv, 32));
+    ml = fmaxf(ml, __shfl_xor(ml, 32));
+    float lv_ = 0.f, ll = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = __builtin_amdgcn_exp2f(sv[r] - mv); lv_ += sv[r];
+      sl[r] = __builtin_amdgcn_exp2f(sl[r] - ml); ll += sl[r];
+    }
+    lv_ += __shfl_xor(lv_, 32);
+    ll += __shfl_xor(ll, 32);
+    const float iv = 1.0f / lv_, il = 1.0f / ll;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pv_[ks][j] = to16<T16>(sv[ks * 8 + j] * iv);
+        pl_[ks][j] = to16<T16>(sl[ks * 8 + j] * il);
+      }
+  }
+  // ---- output, one d-block at a time
+  const int nksl = p.nsrl > 16 ? 2 : 1;
+#pragma unroll 2
+  for (int db = 0; db < NDB; ++db) {
+    const u16x8 v0 = Vf[(db * 2) * 64], v1 = Vf[(db * 2 + 1) * 64];
+    u16x8 w0;                                        // language V fragment from the staged rows
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = 8 * (j >> 2) + 4 * hi + (j & 3);
+      w0[j] = key < p.nsrl ? to16<T16>(pls[(key * 3 + 2) * DP + db * 32 + ql]) : (unsigned short)0;
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    o = mfma32<T16>(v0, pv_[0], o);
+    o = mfma32<T16>(v1, pv_[1], o);
+    o = mfma32<T16>(w0, pl_[0], o);
+    if (nksl > 1) o = mfma32<T16>(struct_load_vl<T16>(p, db, 1, lane, plr, hd, ldp), pl_[1], o);
+    if (q_ok) struct_store<T16>(p, o, db, (int64_t)s * Nq + qi, h, DP, hi);
+  }
 }
 
 // ---- general form: flash loop over the visual key blocks (p100), then the language block

@@ -110,6 +110,7 @@ struct vog_ctx {
                                         // (47.9 k vs 49.1 k queries/s with 4 forwards in flight), so off by default
   int enc_lean = -1;                    // -1: lean form exactly when the encoders share a BiLSTM layer's launch
   int pair_launches = 1;                // step i of the language chain shares a launch with step i of the visual chain (pair.hip)
+  int pair_mask = 7;                    // which of the three pairs are formed: 1 BiLSTM layer 0 + encoders, 2 layer 1 + obj tail, 4 out-projection + mul QKV
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
   float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
   float *w_sv0 = nullptr, *b_sv0 = nullptr, *w_sv2 = nullptr, *b_sv2 = nullptr;
@@ -907,7 +908,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     std::vector<Plan2> plans;
     bool ok = true;
     int prev_vis = -1;
+    int wi = -1;
     for (auto& w : want) {
+      ++wi;
+      if (!((c->pair_mask >> wi) & 1)) continue;       // this pair stays two launches (its visual step keeps its place)
       Plan2 q{find(w.lang, w.occ), find(w.vis, 0), {-1, -1, -1}};
       // every visual step only moves EARLIER (its producers sit in earlier pairs) and the visual chain
       // keeps its own order; any missing piece (other model variants / shapes) leaves the rest unpaired
@@ -922,6 +926,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       prev_vis = last;
       plans.push_back(q);
     }
+    if (plans.empty()) ok = false;
     if (ok) {
       // nothing else of the visual chain may sit between the moved steps (it would be overtaken)
       std::vector<int> moved;
@@ -1407,6 +1412,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "fused_pred") == 0) { c->fused_pred = value ? 1 : 0; return 0; }
   if (strcmp(name, "chain_obj_qkv") == 0) { c->chain_obj_qkv = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
+  if (strcmp(name, "pair_mask") == 0) { c->pair_mask = value & 7; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }
   if (strcmp(name, "qkv_lean") == 0) { c->qkv_lean = value ? 1 : 0; return 0; }

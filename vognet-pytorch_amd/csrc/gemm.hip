@@ -172,7 +172,14 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
       else ::vog::launch((gemm_skinny<T16, false, 8, 2>), grid, dim3(256), lds2, st, p);
     } else {
       dim3 grid(ncol, ncol < 128 ? ceil_div(p.M, 16) : 1);
-      if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), lds1, st, p);
+      // short K (a wave owns <= 2 k-steps: the language half of mul_tx's layer-0 QKV, K = 256): the 2-deep register chunk
+      // - 84 instead of 192 registers (the 8-deep form loads six zero fragments per operand), i.e. 4 instead of 2
+      // workgroups per CU for the 144 workgroups of that launch. Same k order per wave: bit-identical.
+      const bool shortk = p.K / 32 <= 8 && !p.av_counter;
+      if (shortk) {
+        if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
+        else ::vog::launch((gemm_skinny<T16, false, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
+      } else if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), lds1, st, p);
       else ::vog::launch((gemm_skinny<T16, false, 8, 1>), grid, dim3(256), lds1, st, p);
     }
     VOG_LAUNCH_CHECK();

@@ -579,7 +579,10 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
 // SK_CH = k-steps (of 32) per register chunk. The W panel is the HBM-bound stream of this
 // kernel: with K = 2048 a wave owns 16 k-steps, and all 16 of its weight fragments are
 // requested before anything else (one round trip instead of two).
-template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4>
+// TAIL = false: the body without the argument-vector tail (vog_argvec_tail) - what shares a launch with the QKV GEMM
+// (pair.hip): the tail's row gather costs ~50 registers, and a pair kernel allocates the maximum of its halves for EVERY
+// workgroup (200 registers halved the occupancy of the 516 QKV workgroups riding with the 64 of the out-projection).
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true>
 struct GemmSkinnyBody {
   using Params = GemmParams;
   static constexpr int THREADS = KW * 64;
@@ -691,7 +694,7 @@ struct GemmSkinnyBody {
   // was measured first and cost more than the launch it removes - inside a pair launch the L2 write-back
   // also flushes the Q / K / V fragments the partner GEMM is writing (212 vs 205 us per forward).
   // The wait is bounded: on a timeout the share is written as NaN.
-  if (p.av_counter) {
+  if constexpr (TAIL) if (p.av_counter) {
     __syncthreads();
     __shared__ unsigned int av_flag;
     if (tid == 0) {
@@ -719,10 +722,10 @@ struct GemmSkinnyBody {
 }
 };
 
-template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4>
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-  GemmSkinnyBody<T16, A_F32, SK_CH, NT, KW>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, sk_smem);
+  GemmSkinnyBody<T16, A_F32, SK_CH, NT, KW, TAIL>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, sk_smem);
 }
 
 }  // namespace vog

@@ -147,7 +147,9 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
   static std::map<std::pair<const void*, const void*>, PairFn> r;
   static std::once_flag once;
   std::call_once(once, [] {
-    using SkinnyIh = GemmSkinnyBody<F16, false, 8, 1, 4>;
+    // the out-projection next to the QKV GEMM: 4-deep register chunk, no argument-vector tail = 128 registers, so that the
+    // pair keeps the QKV workgroups' 4 per CU (the stand-alone kernel's 8-deep form has 200; same k order: bit-identical)
+    using SkinnyIh = GemmSkinnyBody<F16, false, 4, 1, 4, false>;
     using Lstm = LstmLayerBody<F16, 32>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_f16()}] = &launch_pair<Lstm, VisEncBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16()}] = &launch_pair<Lstm, VisEncLeanBody<F16>>;

@@ -20,6 +20,42 @@ from . import lib as L
 FWD_KEYS = ("pad_proposals", "pad_region_feature", "seg_feature_for_frms")
 
 
+class PackedStaging:
+    """Host -> device staging of a batch as ONE copy. The tensors of a batch (per-video items for the assembler, word-level
+    language arrays, ...) live back to back, 256-byte aligned, in ONE pinned host buffer and in one device buffer of the same
+    layout; `host[k]` / `dev[k]` are views. `upload()` is a single asynchronous H2D copy of the used bytes on the current
+    stream (13 per-key `copy_` calls measured 8.9 GB/s on the driver's box in round 3: every call pays its own launch and
+    its own sub-MB transfer; the link wants one large one). The loader side fills `host[k]` in place (`fill`, or writes
+    straight into the views), so nothing is concatenated on the host."""
+
+    def __init__(self, spec: Dict[str, torch.Tensor], device: Optional[torch.device] = None):
+        """spec: name -> example tensor / array (shape and dtype are taken from it; its values are copied in)."""
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        ex = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(v)) for k, v in spec.items()}
+        self.layout, off = {}, 0
+        for k, v in ex.items():
+            nb = v.numel() * v.element_size()
+            self.layout[k] = (off, nb, tuple(v.shape), v.dtype)
+            off += (nb + 255) // 256 * 256
+        self.nbytes = off
+        self.hbuf = torch.empty(off, dtype=torch.uint8).pin_memory()
+        self.dbuf = torch.empty(off, dtype=torch.uint8, device=self.device)
+        self.host = {k: self.hbuf[o:o + nb].view(dt).view(*shp) for k, (o, nb, shp, dt) in self.layout.items()}
+        self.dev = {k: self.dbuf[o:o + nb].view(dt).view(*shp) for k, (o, nb, shp, dt) in self.layout.items()}
+        self.fill(ex)
+
+    def fill(self, items: Dict[str, torch.Tensor]) -> "PackedStaging":
+        for k, v in items.items():
+            if k in self.host:
+                self.host[k].copy_(v if isinstance(v, torch.Tensor) else torch.from_numpy(v))
+        return self
+
+    def upload(self) -> Dict[str, torch.Tensor]:
+        """ONE async copy on the current stream; returns the device views (valid once the stream reaches this point)."""
+        self.dbuf.copy_(self.hbuf, non_blocking=True)
+        return self.dev
+
+
 class DeviceBatchAssembler:
     def __init__(self, cfg, comm):
         self.conc_type = cfg.ds.conc_type

@@ -162,6 +162,9 @@ class RecordRing:
                     done.record(self.gather_stream)
                 self.work[h] = done
                 self.read_done[h] = done
+                if self.world > 1 or os.environ.get("VOG_FORCE_MULTI_RANK_LANES") == "1":
+                    dev = self.ring[h].device
+                    _PENDING_COLLECTIVE[dev.index if dev.index is not None else torch.cuda.current_device()] = done
             else:
                 self._gather(h)
                 self.work[h] = True
@@ -188,6 +191,17 @@ class RecordRing:
         first = self.half                          # older half first: push order
         for h in (first, 1 - first):
             self._settle(h)
+
+
+# ---- collectives and the persistent BiLSTM share the CUs ---------------------------------------------------------------
+# The event behind the most recent cross-rank gather of a device (RecordRing._send). engine._lane_enter makes the LAST forward
+# lane wait for it before its next forward, so a collective never shares the chip with more than 3 forwards (4 persistent
+# BiLSTM layer kernels fill the 256 CUs; a resident RCCL kernel waiting for its peers would leave one of them short).
+_PENDING_COLLECTIVE = {}
+
+
+def pending_collective(dev_index: int):
+    return _PENDING_COLLECTIVE.get(int(dev_index))
 
 
 def unpack_gathered(gathered: torch.Tensor, world: int, per_half: int, rows: int, n_valid: int) -> torch.Tensor:

@@ -147,9 +147,11 @@ _DEFAULTS: Dict[str, Any] = {
     "run_final_val": True,
     "overfit_batch": False,
     # build-specific (not in the reference yaml): arithmetic type of the two
-    # transformers' MFMA contractions ("bf16" | "f16"); fp32 accumulate always.
+    # transformers' MFMA contractions ("auto" | "bf16" | "f16"); fp32 accumulate always. "auto" = bf16 for
+    # single-layer stacks (the reference default, BASELINE.json config 2), f16 when a stack has more layers
+    # (engine.model_desc_from_cfg: the 1e-3 bound against the full-size 3-layer golden).
     # batch_requests: Evaluator.forward serves this many loader batches as ONE forward (dynamic batching; 1 = off)
-    "hip": {"tx_dtype": "bf16", "use_graph": True, "batch_requests": 1},
+    "hip": {"tx_dtype": "auto", "use_graph": True, "batch_requests": 1},
 }
 
 key_maps: Dict[str, str] = {}
