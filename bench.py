@@ -119,6 +119,10 @@ def kernel_flops(w, T):
     if w["mdl"] == "vog":
         executed["mul_qkv"] = f["mul_pv"] + f["mul_pl"]
         executed["mul_attn"] = f["mul_attn"] * (nppf + 5) / float(N_mul)
+        if nppf > 32:
+            # several visual key blocks: the E x F form (csrc/attn_struct_ef_dev.h) also shares Q.K^T among the 5 arguments of
+            # a proposal (half of the attention FLOPs are Q.K^T: 1/5 of that half; P.V keeps its size)
+            executed["mul_attn"] *= 0.5 * (1.0 / 5.0) + 0.5
     total_exec = sum(executed.values()) + lstm + f["lstm_outproj"]
     f["_executed_total"] = total_exec
     f["_executed_mul_attn"] = executed.get("mul_attn", 0.0)
@@ -632,13 +636,18 @@ def main():
     pmc = pmc_traffic(args.workload + ("" if persistent else "_lstm_steps")) or {}
     cands = [k for k in flops if ktimes.get(k) and flops[k] > 0]
     mfma_dom = max(cands, key=lambda k: ktimes[k])
-    ach = flops[mfma_dom] / (ktimes[mfma_dom] * 1e-6) / 1e12
+    # FLOPs of the dominant kernel: what it EXECUTES where that is less than the dense formulation (mul_attn)
+    fl_dom = executed_mul_attn if mfma_dom == "mul_attn" else flops[mfma_dom]
+    ach = fl_dom / (ktimes[mfma_dom] * 1e-6) / 1e12
     # row-block kernels occupy ceil(rows / 64) CUs, not the chip: also quote the fraction of THEIR CUs' peak
     roof_mfma = {"bound": "mfma", "kernel": mfma_dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                  "traffic": (pmc.get("kernels", {}).get(mfma_dom) or {}).get("bytes_per_launch"),
-                 "usec_per_launch": ktimes[mfma_dom], "flops_per_launch": flops[mfma_dom],
+                 "usec_per_launch": ktimes[mfma_dom], "flops_per_launch": fl_dom,
                  "launches_per_forward": 1}
+    if mfma_dom == "mul_attn":
+        roof_mfma["frac_dense_equivalent"] = flops[mfma_dom] / (ktimes[mfma_dom] * 1e-6) / 1e12 / PEAK_MFMA_TFLOPS
+        roof_mfma["note"] = "executed FLOPs (separable attention); the dense-equivalent fraction is quoted beside it only"
     if mfma_dom in ("mul_tail", "obj_tail"):
         nppf0 = 5 if w["exp"] == "gt5" else 100
         ncmp = 1 if w["conc"] == "svsq" else 4
@@ -672,6 +681,10 @@ def main():
                            "traffic": (pmc.get("kernels", {}).get("lstm_layer") or {}).get("bytes_per_launch"),
                            "usec_per_launch": us_launch, "bytes_per_launch": nbytes, "launches_per_forward": 2,
                            "input_projection_in_kernel": bool(fused_ih),
+                           "bytes_source": "Infinity Cache (MALL), not HBM: the 88 MB of 16-bit weights stay resident in the 256 MB "
+                                           "cache between launches (the PMC `traffic` is the L2's memory-side request counter, which "
+                                           "counts cache hits too); `peak` is the HBM figure the bench contract names - read `frac` as "
+                                           "a weight-stream rate against the HBM peak, not as HBM utilisation",
                            "share_of_forward_kernel_time": 2 * us_launch / max(1e-9, sum(
                                ktimes[k] for k in ("prep", "lstm_ih0", "lstm_layer#0", "lstm_ih1", "lstm_layer#1",
                                                    "lstm_outproj", "argvec", "mul_pl", "vis_enc", "obj_qkv", "obj_attn",
@@ -717,16 +730,16 @@ def main():
                                        "(separable attention, exact); MFMA tile padding is not counted as work"}
     if ktimes.get("mul_attn"):
         ka = (pmc.get("kernels", {}).get("mul_attn") or {})
+        ach_x = executed_mul_attn / (ktimes["mul_attn"] * 1e-6) / 1e12
+        ach_d = flops["mul_attn"] / (ktimes["mul_attn"] * 1e-6) / 1e12
         res["roofline_mul_attn"] = {"bound": "mfma", "kernel": "mul_attn (separable)", "usec_per_launch": ktimes["mul_attn"],
-                                    "flops_dense": flops["mul_attn"], "flops_executed": executed_mul_attn,
-                                    "achieved": flops["mul_attn"] / (ktimes["mul_attn"] * 1e-6) / 1e12,
-                                    "achieved_executed": executed_mul_attn / (ktimes["mul_attn"] * 1e-6) / 1e12,
-                                    "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": flops["mul_attn"] / (ktimes["mul_attn"] * 1e-6) / 1e12 / PEAK_MFMA_TFLOPS,
-                                    "frac_executed": executed_mul_attn / (ktimes["mul_attn"] * 1e-6) / 1e12 / PEAK_MFMA_TFLOPS,
+                                    "flops_executed": executed_mul_attn, "flops_dense_equivalent": flops["mul_attn"],
+                                    "achieved": ach_x, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_x / PEAK_MFMA_TFLOPS,
+                                    "achieved_dense_equivalent": ach_d, "frac_dense_equivalent": ach_d / PEAK_MFMA_TFLOPS,
                                     "mfma_busy": ka.get("mfma_util_of_occupied_cus"),
-                                    "note": "dense-equivalent FLOPs flatter a kernel that skips 3/4 of the keys: "
-                                            "`frac_executed` and the measured MFMA-busy fraction of its CUs are the honest figures"}
+                                    "note": "`frac` counts the FLOPs the kernel executes (separable softmax: nppf + nsrl instead of "
+                                            "nsrl * nppf keys per query; at p100 also Q.K^T shared by the 5 arguments of a proposal); "
+                                            "the dense-equivalent figure flatters a kernel that skips work and is quoted beside it only"}
     for blk in ("roofline", "roofline_mfma"):
         if blk in res and res[blk].get("kernel") in pmc.get("kernels", {}):
             res[blk]["mfma_busy"] = pmc["kernels"][res[blk]["kernel"]].get("mfma_util_of_occupied_cus")

@@ -54,16 +54,27 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
   static int ef_form = -2;            // VOG_ATTN_STRUCT_EF=0 (perf experiments): the per-(a, p) kernels below
   if (ef_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_EF"); ef_form = e ? atoi(e) : 1; }
   if constexpr (NDB % 4 == 0) {
-    if (ef_form && p.q_visual && p.npad_kv > 32 && p.npad_kv <= 512 && p.nsrl <= EF_MAXA && !(p.dbg)) {
-      const size_t lds_ef = attn_struct_ef_lds<NDB>(p.nsrl, p.npad_kv);
+    if (ef_form && p.q_visual && p.npad_kv > 32 && p.npad_kv <= 512 && p.nsrl == EF_MAXA && !(p.dbg)) {
+      const size_t lds_ef = attn_struct_ef_lds<NDB>(p.npad_kv);
       if (lds_ef <= 150 * 1024) {
-        auto kern = attn_struct_ef_kernel<T16, NDB>;
-        static bool attr_ef = false;
-        if (!attr_ef) {
-          VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-          attr_ef = true;
+        const dim3 grid_ef(p.S * p.H * ((p.nppf + 31) / 32));
+        if (ef_form != 3) {           // 256 registers, two workgroups per CU whose phases overlap (141 vs 244 us at cfg 4)
+          auto kern = attn_struct_ef_kernel<T16, NDB, 2>;
+          static bool attr_ef2 = false;
+          if (!attr_ef2) {
+            VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_ef2 = true;
+          }
+          ::vog::launch(kern, grid_ef, dim3(256), lds_ef, st, p);
+        } else {                      // (VOG_ATTN_STRUCT_EF=3, perf experiments: up to 512 registers, one workgroup per CU)
+          auto kern = attn_struct_ef_kernel<T16, NDB, 1>;
+          static bool attr_ef = false;
+          if (!attr_ef) {
+            VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_ef = true;
+          }
+          ::vog::launch(kern, grid_ef, dim3(256), lds_ef, st, p);
         }
-        ::vog::launch(kern, dim3(p.S * p.H * ((p.nppf + 31) / 32)), dim3(256), lds_ef, st, p);
         VOG_LAUNCH_CHECK();
         return 0;
       }

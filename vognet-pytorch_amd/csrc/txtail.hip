@@ -89,6 +89,12 @@ int tx_tail_run(const vog_tx_tail_args* a, hipStream_t st) {
   p.y32 = a->y32; p.y16 = (unsigned short*)a->y16;
   p.y16_bf16 = (a->y16_dtype < 0 ? (int)a->dtype : a->y16_dtype) == VOG_BF16;
   p.M = a->M;
+  {
+    // many row blocks per XCD (>= 4 rounds of workgroups): stream the activation rows past L2's retention
+    // (VOG_TAIL_NT = 0 / 1 forces it off / on, perf experiments)
+    static const int nt_env = perf_env("VOG_TAIL_NT") ? atoi(perf_env("VOG_TAIL_NT")) : -1;
+    p.nt_rows = nt_env >= 0 ? nt_env : (a->M >= 4 * 256 * 64 ? 1 : 0);
+  }
   const bool score = a->score != nullptr;
   if (score) {
     VOG_CHECK_ARG(a->wl_p && a->bl && a->score->w2 && a->score->b2 && a->score->arg_msk && a->score->cmp_msk &&

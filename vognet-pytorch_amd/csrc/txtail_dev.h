@@ -17,6 +17,7 @@ struct TailParams {
   // prediction head in the same launch (pred_counter != nullptr; SCORE kernels): the workgroup that arrives last runs it
   vog_pred_args pred; int64_t pred_rec_bytes; unsigned int* pred_counter;
   int M;
+  int nt_rows;   // non-temporal loads of the attention rows (large M)
   int dbgf;      // perf experiments only, read by the DBG & 4 instantiation: 1 no residual, 2 no attention staging, 4 no LayerNorm, 8 no outputs
 };
 
@@ -199,8 +200,11 @@ struct TxTailBody {
       const int r = idx / cpr, c = idx - r * cpr;
       int m = m0 + r;
       m = m < p.M ? m : p.M - 1;
-      const uint4 v = *reinterpret_cast<const uint4*>(p.attn16 + (int64_t)m * p.KWO + c * 8);
-      *reinterpret_cast<uint4*>(X + r * p1 + c * 16) = v;
+      // (read once: with p.nt_rows the load is non-temporal, so that at many row blocks per XCD - 156 at cfg 4 - the streamed
+      // activation rows do not displace the 2.75 MB of weights every workgroup of the XCD re-reads from its L2)
+      const u32x4* src = reinterpret_cast<const u32x4*>(p.attn16 + (int64_t)m * p.KWO + c * 8);
+      const u32x4 v = p.nt_rows ? __builtin_nontemporal_load(src) : *src;
+      *reinterpret_cast<u32x4*>(X + r * p1 + c * 16) = v;
     }
     for (int i = tid; i < D / 4; i += 512) {
       reinterpret_cast<float4*>(vec1)[i] = reinterpret_cast<const float4*>(p.ln1g)[i];
