@@ -778,17 +778,22 @@ def main():
                 lang_keys = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", "srl_arg_words_capture",
                              "srl_arg_inds_msk", "num_cmp_msk")
                 stg = [dls.PackedStaging({**{k: it[k].cpu() for k in dls.FWD_KEYS},
-                                          **{k: slots[u].inp[k].cpu() for k in lang_keys}}, dev) for u in range(ns)]
+                                          **{k: slots[u].inp[k].cpu() for k in lang_keys}}, dev, n_dev=2) for u in range(ns)]
+                # H2D copies on their own streams (they overlap the forwards of every slot); VOG_BENCH_COPY_STREAMS of them
+                # (default 2: an 8.5 MB copy carries ~150 us of fixed latency on one stream - 27.7 GB/s back to back, 56 GB/s
+                # for the 133 MB copies of cfg 4)
+                ncs = max(1, int(os.environ.get("VOG_BENCH_COPY_STREAMS", "2")))
+                copy_sts = [torch.cuda.Stream(device=dev) for _ in range(ncs)]
                 dsts = [{k: slots[u].inp[k] for k in dls.FWD_KEYS} for u in range(ns)]
                 sts = stream_pool[:ns] if len(stream_pool) >= ns else [torch.cuda.Stream(device=dev) for _ in range(ns)]
 
                 def fed_step(i):
                     u = i % ns
                     with torch.cuda.stream(sts[u]):
-                        d = stg[u].upload()
+                        d = stg[u].upload_on(copy_sts[u % ncs])
                         asm({k: d[k] for k in dls.FWD_KEYS}, out=dsts[u], with_loss_keys=False)
-                        for k in lang_keys:
-                            slots[u].inp[k].copy_(d[k], non_blocking=True)
+                        torch._foreach_copy_([slots[u].inp[k] for k in lang_keys], [d[k] for k in lang_keys], non_blocking=True)
+                        stg[u].release()
                         slots[u].launch(sts[u])
 
                 fsteps = max(200, args.steps)
@@ -805,8 +810,9 @@ def main():
                     "h2d_bytes_per_step": stg[0].nbytes, "h2d_copies_per_step": 1,
                     "achieved_h2d_gbs": stg[0].nbytes * fsteps / dtf / 1e9,
                     "what": "same path, inputs in pinned host memory at the start of every step: ONE async H2D copy of a packed "
-                            "staging buffer (raw per-video items + language arrays, dat_loader_simple.PackedStaging) + device-side "
-                            "assembly + forward, per slot on its own stream; %d timed steps" % fsteps}
+                            "staging buffer (raw per-video items + language arrays, dat_loader_simple.PackedStaging) on a copy "
+                            "stream into one of two device buffers per slot, then device-side assembly + forward on the slot's "
+                            "own stream; %d timed steps" % fsteps}
         except Exception as e:          # never fail the bench line on the side measurement
             res["batch_assembly"] = {"error": str(e)}
     if world == 1 and not args.no_train_extra and cfg.mdl.name == "vog" and w["conc"] in ("temp", "spat") and not args.throughput_only:

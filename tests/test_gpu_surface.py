@@ -931,3 +931,29 @@ def test_packed_staging_one_copy_feeds_the_assembler(conc):
         assert np.array_equal(got, g[k].astype(got.dtype)), k
     for k, v in it.items():
         assert np.array_equal(st.dev[k].cpu().numpy(), v), k
+
+
+def test_packed_staging_copy_stream_double_buffer():
+    """`upload_on` (copy stream, two device buffers): three batches in a row, each assembled from the buffer its copy landed
+    in, while the next copy is already issued - every result equals the assembly of ITS items (no copy overtakes a reader)."""
+    conc = "spat"
+    it = mga.items()
+    asm = dls.DeviceBatchAssembler(_asm_cfg(conc), {"num_prop_per_frm": mga.SHAPE["nppf0"]})
+    st = dls.PackedStaging({k: np.zeros_like(v) for k, v in it.items()}, n_dev=2)
+    cs = torch.cuda.Stream()
+    outs, refs = [], []
+    for i in range(3):
+        cur = {k: (v + (i if v.dtype.kind == "f" else 0)).astype(v.dtype) for k, v in it.items()}
+        torch.cuda.current_stream().synchronize() if i == 0 else None
+        cs.synchronize()                                  # the host buffer is free again (its previous copy has left it)
+        st.fill(cur)
+        d = st.upload_on(cs)
+        res = asm(d, with_loss_keys=False)
+        st.release()
+        outs.append({k: res[k].clone() for k in dls.FWD_KEYS})
+        ref = asm({k: torch.from_numpy(v).cuda() for k, v in cur.items()}, with_loss_keys=False)
+        refs.append({k: ref[k].clone() for k in dls.FWD_KEYS})
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        for k in dls.FWD_KEYS:
+            assert torch.equal(o[k], r[k]), k

@@ -105,7 +105,7 @@ struct vog_ctx {
                                         // launch less, but the in-launch arrival wait costs more than the boundary it removes
                                         // (210.6 vs 205.2 us per forward, 72.6 vs 70.6 us per batch with 4 in flight): off
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
-  int qkv_lean = 0;                     // 1: row-block QKV projections (qkvrb_dev.h) where the shape allows: ~1/3 of the
+  int qkv_lean = -1;                    // -1: auto (row-block form from 8192 visual rows: +1.5 % at cfg 4, neutral / negative at gt5); 1: row-block QKV projections (qkvrb_dev.h) where the shape allows: ~1/3 of the
                                         // busy-CU time of the tiled GEMM at twice its latency; measured neutral at cfg 2
                                         // (47.9 k vs 49.1 k queries/s with 4 forwards in flight), so off by default
   int enc_lean = -1;                    // -1: lean form exactly when the encoders share a BiLSTM layer's launch
@@ -434,7 +434,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     qa.x16 = cur16; qa.ldx = tw.d; qa.wqkv = L.wqkv; qa.ldw = tw.d;
     qa.q = ws.at<void>(n + "_q"); qa.k = ws.at<void>(n + "_k"); qa.vt = ws.at<void>(n + "_vt");
     qa.S = S; qa.N = N; qa.H = tw.H; qa.dp = tw.dp; qa.npad = npad; qa.K = tw.d; qa.dtype = dt;
-    qa.wqkv_p32 = c->qkv_lean ? L.wqkv_p : nullptr;
+    const bool qkv_rb = c->qkv_lean > 0 || (c->qkv_lean < 0 && g.rows_obj >= 8192);
+    qa.wqkv_p32 = qkv_rb ? L.wqkv_p : nullptr;
     if (dep && l == 0 && L.wqkv_p) {      // layer 0 rides in the encoders' launch: row-block form, waits for its rows' producers
       qa.wqkv_p32 = L.wqkv_p;
       qa.dep_flags = dep->dep_flags; qa.dep_nb0 = dep->dep_nb0; qa.dep_rep = dep->dep_rep; qa.dep_nh0 = dep->dep_nh0;
@@ -451,7 +452,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       const float* plang = ws.at<float>(n + "_pl");
       const int npad_kv = (int)round_up64(sv.nppf, 32);
       qs.N = sv.nppf; qs.npad = npad_kv;
-      qs.wqkv_p32 = c->qkv_lean ? L.wqkv_pv : nullptr;
+      qs.wqkv_p32 = qkv_rb ? L.wqkv_pv : nullptr;
       steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_qkv_proj(&qs, st); }});
       vog_attn_struct_args sa{};
       sa.q_visual = 1;
@@ -1415,7 +1416,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "pair_mask") == 0) { c->pair_mask = value & 7; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }
-  if (strcmp(name, "qkv_lean") == 0) { c->qkv_lean = value ? 1 : 0; return 0; }
+  if (strcmp(name, "qkv_lean") == 0) { c->qkv_lean = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 

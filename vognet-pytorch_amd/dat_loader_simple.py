@@ -28,8 +28,10 @@ class PackedStaging:
     its own sub-MB transfer; the link wants one large one). The loader side fills `host[k]` in place (`fill`, or writes
     straight into the views), so nothing is concatenated on the host."""
 
-    def __init__(self, spec: Dict[str, torch.Tensor], device: Optional[torch.device] = None):
-        """spec: name -> example tensor / array (shape and dtype are taken from it; its values are copied in)."""
+    def __init__(self, spec: Dict[str, torch.Tensor], device: Optional[torch.device] = None, n_dev: int = 1):
+        """spec: name -> example tensor / array (shape and dtype are taken from it; its values are copied in).
+        n_dev = 2: two device buffers used alternately (`upload` flips), so that the copy of batch i + 1 - issued on a
+        copy stream - runs while the forward of batch i still reads its own (`upload_on`)."""
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         ex = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(v)) for k, v in spec.items()}
         self.layout, off = {}, 0
@@ -39,9 +41,13 @@ class PackedStaging:
             off += (nb + 255) // 256 * 256
         self.nbytes = off
         self.hbuf = torch.empty(off, dtype=torch.uint8).pin_memory()
-        self.dbuf = torch.empty(off, dtype=torch.uint8, device=self.device)
+        self.dbufs = [torch.empty(off, dtype=torch.uint8, device=self.device) for _ in range(max(1, int(n_dev)))]
         self.host = {k: self.hbuf[o:o + nb].view(dt).view(*shp) for k, (o, nb, shp, dt) in self.layout.items()}
-        self.dev = {k: self.dbuf[o:o + nb].view(dt).view(*shp) for k, (o, nb, shp, dt) in self.layout.items()}
+        self.devs = [{k: b[o:o + nb].view(dt).view(*shp) for k, (o, nb, shp, dt) in self.layout.items()} for b in self.dbufs]
+        self.dbuf, self.dev = self.dbufs[0], self.devs[0]
+        self._cur = 0
+        self._ready = [None] * len(self.dbufs)       # event: the copy into buffer b has landed
+        self._free = [None] * len(self.dbufs)        # event: the consumer of buffer b is done reading it
         self.fill(ex)
 
     def fill(self, items: Dict[str, torch.Tensor]) -> "PackedStaging":
@@ -52,8 +58,35 @@ class PackedStaging:
 
     def upload(self) -> Dict[str, torch.Tensor]:
         """ONE async copy on the current stream; returns the device views (valid once the stream reaches this point)."""
-        self.dbuf.copy_(self.hbuf, non_blocking=True)
-        return self.dev
+        b = self._cur
+        self._cur = (b + 1) % len(self.dbufs)
+        self.dbufs[b].copy_(self.hbuf, non_blocking=True)
+        return self.devs[b]
+
+    def upload_on(self, copy_stream: "torch.cuda.Stream", consumer: Optional["torch.cuda.Stream"] = None):
+        """The same copy on `copy_stream` (so it overlaps whatever the consumer stream is still running - a copy issued on
+        the forward's own stream waits for the previous forward there: 11.5 k instead of 26 k queries/s at cfg 2), into the
+        next device buffer. The consumer stream (default: the current one) waits for the copy; call `release()` on it once
+        the kernels that read the views are enqueued, so the buffer's next copy waits for them. Returns the device views."""
+        b = self._cur
+        self._cur = (b + 1) % len(self.dbufs)
+        cons = consumer if consumer is not None else torch.cuda.current_stream(self.device)
+        if self._free[b] is not None:
+            copy_stream.wait_event(self._free[b])
+        with torch.cuda.stream(copy_stream):
+            self.dbufs[b].copy_(self.hbuf, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        self._ready[b] = ev
+        cons.wait_event(ev)
+        self._last = b
+        return self.devs[b]
+
+    def release(self, consumer: Optional["torch.cuda.Stream"] = None) -> None:
+        cons = consumer if consumer is not None else torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cons)
+        self._free[self._last] = ev
 
 
 class DeviceBatchAssembler:
