@@ -437,8 +437,12 @@ def main():
         # it runs on the process group's own (5th) stream, which shares a hardware queue with one of
         # the four forward streams and drags that stream's chain behind the collective's dependencies.
         unit_rows = G * w["B"]
-        per_half = max(nunits, (32 // nunits) * nunits)           # unit launches per half ring
-        ring = D.RecordRing(unit_rows, recbuf.shape[1], per_half, dev) if use_dist else None
+        per_half = max(nunits, (64 // nunits) * nunits)           # unit launches per half ring (64: the last lane waits for a gather once per half)
+        # (VOG_FORCE_MULTI_RANK_LANES=1 with one rank: the half-ring copy stands in for the collective, so that the event-gated
+        # fourth lane of engine._lane_enter is exercised and priced on one GPU)
+        forced_lanes = os.environ.get("VOG_FORCE_MULTI_RANK_LANES") == "1"
+        ring = D.RecordRing(unit_rows, recbuf.shape[1], per_half, dev,
+                            on_half=(lambda g_, n_: None) if forced_lanes else None) if use_dist else None
         gathered_aql = torch.empty((world * recbuf.shape[0], recbuf.shape[1]), dtype=torch.float32, device=dev) \
             if (aql and use_dist) else None
 
@@ -602,7 +606,7 @@ def main():
                    "weights": "seeded default-init-like, vocab 5000",
                    "launches_per_forward": "see kernels_usec: steps joined by '+' share one launch (csrc/pair.hip)",
                    "parallelism": f"dp{world} (replicated weights; prediction records of every batch staged in a "
-                                  f"device ring, one RCCL all-gather per 32 batches)"},
+                                  f"device ring, one RCCL all-gather per 64 batches)"},
     }
     if extra:
         res["lang_cobatch4"] = extra

@@ -144,22 +144,31 @@ class RecordRing:
             dst.copy_(rec)
         self.n = n + 1
         if self.n == self.per_half:
-            self._send()
+            self._send(st if self.cuda else None)
 
-    def _send(self):
+    def _send(self, pushing_stream=None):
         h = self.half
         self.count[h] = self.n
         if self.world > 1 or self.on_half is not None:
             if self.cuda:
+                # Multi-rank: the collective is issued IN the stream that staged the half's last rows (with 4 forward streams
+                # that is always the same one: the last lane). A stream of its own is a 5th stream on 4 hardware queues: while
+                # the gather waits for the other lanes' in-flight forwards it blocks the queue it shares with one of them
+                # (measured with the policy forced on one GPU: 0.92 of the no-exchange rate; in the lane's own stream only
+                # that lane waits, once per half).
+                multi = self.world > 1 or os.environ.get("VOG_FORCE_MULTI_RANK_LANES") == "1"
+                gs = pushing_stream if (multi and pushing_stream is not None) else self.gather_stream
                 for s in self._streams:            # the collective runs behind every stream that staged rows
+                    if s.cuda_stream == gs.cuda_stream:
+                        continue
                     ev = torch.cuda.Event()
                     ev.record(s)
-                    self.gather_stream.wait_event(ev)
+                    gs.wait_event(ev)
                 self._streams = set()
-                with torch.cuda.stream(self.gather_stream):
+                with torch.cuda.stream(gs):
                     self._gather(h)
                     done = torch.cuda.Event()
-                    done.record(self.gather_stream)
+                    done.record(gs)
                 self.work[h] = done
                 self.read_done[h] = done
                 if self.world > 1 or os.environ.get("VOG_FORCE_MULTI_RANK_LANES") == "1":
@@ -185,7 +194,7 @@ class RecordRing:
     def flush(self):
         """Send a partially filled half and settle everything (end of the loop)."""
         if self.n:
-            self._send()
+            self._send(None)
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.gather_stream)
         first = self.half                          # older half first: push order

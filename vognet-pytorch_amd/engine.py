@@ -67,9 +67,9 @@ def model_desc_from_cfg(cfg, comm) -> L.ModelDesc:
 # BOOK: every forward it issues (slot / group launch, eager call) belongs to one of N lanes - a stream
 # gets the next lane the first time it is seen - and a lane remembers the stream that used it last: a
 # launch from another stream first waits for that stream (`wait_stream`), so the forwards of a lane are
-# serialised on the GPU whatever the caller does and at most N layer kernels are ever resident. N = 4, or 3
-# while a process group with more than one rank exists (one kernel's worth of CUs stays free for the
-# collective). Streams that keep to themselves (bench.py: one slot per stream; the evaluator: one stream)
+# serialised on the GPU whatever the caller does and at most N layer kernels are ever resident. N = 4; while
+# a cross-rank gather is pending the last lane yields to it (`_max_inflight`, `dist.pending_collective`).
+# Streams that keep to themselves (bench.py: one slot per stream; the evaluator: one stream)
 # never wait. (AQL programs run on the library's own queues: aql.hip has its own guard.)
 _LANE_BOOK: Dict[int, Dict[int, "torch.cuda.Stream"]] = {}
 _STREAM_LANE: Dict[int, Dict[int, int]] = {}
