@@ -150,9 +150,16 @@ def test_evaluator_forward_loop_and_pickle(tmp_path):
     assert set(val_acc) == set(evl.met_keys) and set(val_loss) == set(loss_fn.loss_keys)
     gl = np.load(mgl.loss_path(name))
     assert abs(float(val_loss["loss"]) - float(gl["loss"])) <= 2e-3 * float(gl["loss"])
-    recs = pickle.load(open(tmp_path / "valid_0.pkl", "rb"))
+    raw = open(tmp_path / "valid_0.pkl", "rb").read()
+    recs = pickle.loads(raw)
     B = batch["num_cmp_msk"].shape[0]
     assert len(recs) == 3 * B and set(recs[0]) == REF_RECORD_KEYS
+    # the file is what the reference's `pickle.dump(list of per-query dicts of Python lists)` writes, byte for byte (the
+    # evaluator never builds the lists: fast_pickle.dumps_records; format pinned in tests/test_fast_pickle.py)
+    assert pickle.dumps(recs, protocol=4) == raw
+    assert list(recs[0]) == ["pred_boxes", "pred_scores", "pred_cmp", "idx_vid", "idx_verbs", "idx_sent", "cmp_msk", "targ_cmp",
+                             "perm", "perm_inv"]
+    assert isinstance(recs[0]["pred_boxes"][0][0][0][0], float) and isinstance(recs[0]["idx_vid"], int)
     g = np.load(cases.golden_path(name))
     for k in range(3):                                         # every batch, in loader order
         got = np.array([r["pred_scores"] for r in recs[k * B:(k + 1) * B]])

@@ -396,7 +396,9 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
       const int pq = pb * 32 + q;
       if (pq < p.nppf) {
         unsigned short* orow = p.out + ((int64_t)s * Nq + (int64_t)a * p.nppf + pq) * ((int64_t)p.H * DP) + (int64_t)h * DP + db0 * 32 + ch * 8;
-        *reinterpret_cast<u16x8*>(orow) = u16x8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        // (non-temporal: 123 MB of output at cfg 4 that the next kernel reads from memory anyway - it must not displace
+        // the K / V^T fragments the 13 proposal blocks of a (sequence, head) re-read from L2)
+        __builtin_nontemporal_store(u16x8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]}, reinterpret_cast<u16x8*>(orow));
       }
     }
   }

@@ -246,10 +246,13 @@ struct TxTailBody {
         const bool in_lang = p.res_vis && n >= p.rv_dv;       // wave-uniform per (i): dv % 32 == 0
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (!((DBG & 4) && (p.dbgf & 1))) r = *reinterpret_cast<const float4*>(in_lang ? lp[rb] + (n - p.rv_dv) : rp[rb] + n);
-          acc[i][rb][4 * g + 0] = r.x; acc[i][rb][4 * g + 1] = r.y;
-          acc[i][rb][4 * g + 2] = r.z; acc[i][rb][4 * g + 3] = r.w;
+          f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!((DBG & 4) && (p.dbgf & 1))) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(in_lang ? lp[rb] + (n - p.rv_dv) : rp[rb] + n);
+            r = p.nt_rows ? __builtin_nontemporal_load(src) : *src;      // (streamed once at large M, like the attention rows)
+          }
+          acc[i][rb][4 * g + 0] = r[0]; acc[i][rb][4 * g + 1] = r[1];
+          acc[i][rb][4 * g + 2] = r[2]; acc[i][rb][4 * g + 3] = r[3];
         }
       }
   }
