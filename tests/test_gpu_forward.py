@@ -14,6 +14,7 @@ reference fp32 CPU forward):
 Budget: bf16 operands in the two transformers, f16 elsewhere, fp32 accumulate
 — oracle-simulated at 4.5e-4 (tests/test_quant_budget.py).
 """
+import importlib
 import os
 
 import numpy as np
@@ -678,3 +679,28 @@ def test_chained_obj_qkv_equals_separate_launches(name):
     pred = eng.unpack_pred(b["pred_rec"], batch["new_srl_idxs"].shape[1])
     g = np.load(cases.golden_path(name))
     _check_against(name, b, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+def test_slots_sharing_a_workspace_on_one_stream():
+    """`make_slot(share_ws_with=...)` (bench.py --rotate-inputs: N input sets cycling through a stream's workspace): slots that
+    share a workspace and are launched one after the other on ONE stream give exactly what slots with their own workspaces
+    give, in any interleaving (every forward re-initialises the state it needs in its prologue)."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    synth = importlib.import_module("vognet-pytorch_amd.synth")
+    bs = [synth.make_batch("spat", 4, c["nppf0"], vocab_size=c["vocab"], seed=900 + i) for i in range(3)]
+    T = max(int(b["srl_arg_word_mask_len"].max()) for b in bs)
+    own = [eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()}, T=T, graph=True) for b in bs]
+    sh = [eng.make_slot({k: torch.from_numpy(v) for k, v in bs[0].items()}, T=T, graph=True)]
+    sh += [eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()}, T=T, graph=True, share_ws_with=sh[0]) for b in bs[1:]]
+    assert sh[1].ws.data_ptr() == sh[0].ws.data_ptr() == sh[2].ws.data_ptr()
+    st = torch.cuda.Stream()
+    for s in own:
+        s.launch(st)
+    for order in ([0, 1, 2], [2, 0, 1, 1, 0, 2]):
+        for i in order:
+            sh[i].launch(st)
+        st.synchronize()
+        for i in range(3):
+            for k in ("mdl_outs", "mdl_outs_eval", "pred_rec"):
+                assert torch.equal(sh[i].out[k], own[i].out[k]), (order, i, k)
