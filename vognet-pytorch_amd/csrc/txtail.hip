@@ -35,8 +35,7 @@ namespace vog {
 template <typename T16, int NB, bool SCORE, int DBG = 0>
 static int launch_tail(const TailParams& p, hipStream_t st) {
   constexpr int D = NB * 256, DH = D / 2;
-  const int xcols = p.KWO > D ? p.KWO : D;
-  const size_t lds = (size_t)64 * (xcols + 8) * 2 + (size_t)64 * (DH + 8) * 2 + (512 + 3 * D + DH) * sizeof(float);
+  const size_t lds = TxTailBody<T16, F16, NB, SCORE, DBG>::lds_bytes(p.KWO);
   auto kern = tx_tail_kernel<T16, F16, NB, SCORE, DBG>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -46,6 +45,23 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
   }
   if (lds > 160 * 1024) VOG_FAIL(-1, "fused encoder tail: %zu bytes of LDS needed", lds);
   ::vog::launch(kern, dim3(ceil_div(p.M, 64)), dim3(512), lds, st, p);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+
+// 32-row workgroups, two per CU (TxTailBody<..., RB = 1>)
+template <typename T16, int NB, bool SCORE>
+static int launch_tail32(const TailParams& p, hipStream_t st) {
+  using Body = TxTailBody<T16, F16, NB, SCORE, 0, 1>;
+  const size_t lds = Body::lds_bytes(p.KWO);
+  auto kern = tx_tail32_kernel<T16, F16, NB, SCORE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (lds > 160 * 1024) VOG_FAIL(-1, "fused encoder tail (32 rows): %zu bytes of LDS needed", lds);
+  ::vog::launch(kern, dim3(ceil_div(p.M, 32)), dim3(512), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -131,6 +147,14 @@ int tx_tail_run(const vog_tx_tail_args* a, hipStream_t st) {
       if (dbg == 3) return launch_tail<BF16, 3, true, 3>(p, st);
       if (dbg == 4) return launch_tail<BF16, 3, true, 4>(p, st);
     }
+  }
+  // VOG_TAIL_ROWS32=1 (perf experiments): the mul_tx (d = 768) tail as 32-row workgroups, two per CU. Measured in round 4
+  // (profiles/round4_tail_32rows.md): 327 -> 434 us at cfg 4, cfg 2 59.0 -> 50.7 k queries/s - the kernel is bound by the
+  // weight bytes a CU ingests per row, which this form doubles. Off.
+  static const int rows32 = perf_env("VOG_TAIL_ROWS32") ? atoi(perf_env("VOG_TAIL_ROWS32")) : 0;
+  if (rows32 && !g_pair_capture && a->d == 768) {
+    if (score) { VOG_DISPATCH_DTYPE(a->dtype, return (launch_tail32<T16, 3, true>(p, st))); }
+    else { VOG_DISPATCH_DTYPE(a->dtype, return (launch_tail32<T16, 3, false>(p, st))); }
   }
   if (a->d == 512) VOG_TAIL(2);
   else VOG_TAIL(3);

@@ -33,8 +33,8 @@ struct TailParams {
 //    found in L2 by the other seven (in lock-step every workgroup took the ~2 us fabric miss on
 //    every line: kernel boundaries leave the XCD L2s cold). The fp32 summation order depends on the
 //    row block only, so results stay bit-reproducible.
-template <typename TT, int NBW, int PF, bool ZERO, int DBG = 0>
-__device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][2], const unsigned short* __restrict__ wp,
+template <typename TT, int NBW, int PF, bool ZERO, int DBG = 0, int RB = 2>
+__device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][RB], const unsigned short* __restrict__ wp,
                                           int blk0, int blk_step, int KS, int rot,
                                           const unsigned char* xl, int pitch, int lane) {
   constexpr int KST = (DBG & 1) ? 0 : 64;     // DBG 1 (perf experiments): every weight load hits the block's first KiB
@@ -45,7 +45,7 @@ __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][2], const unsigned 
     wb[i] = reinterpret_cast<const u16x8*>(wp + ((int64_t)(blk0 + i * blk_step) * KS) * 512) + lane;
     if constexpr (ZERO) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][rb][r] = 0.f;
     }
@@ -60,20 +60,23 @@ __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][2], const unsigned 
     for (int i = 0; i < NBW; ++i) wq[j][i] = wb[i][k * KST];
   }
   const unsigned char* x0 = xl + ml * pitch + hi * 16;
-  const unsigned char* x1 = x0 + 32 * pitch;
-  u16x8 xf0 = *reinterpret_cast<const u16x8*>(x0 + kk(0) * 32), xf1 = *reinterpret_cast<const u16x8*>(x1 + kk(0) * 32);
+  u16x8 xf[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) xf[rb] = *reinterpret_cast<const u16x8*>(x0 + rb * 32 * pitch + kk(0) * 32);
   auto step = [&](int j, int t, bool refill) {
     const int kn = kk(t + 1);                  // next k-step's activations (t + 1 == KS wraps to `rot`: in bounds)
-    const u16x8 n0 = *reinterpret_cast<const u16x8*>(x0 + kn * 32);
-    const u16x8 n1 = *reinterpret_cast<const u16x8*>(x1 + kn * 32);
+    u16x8 nx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) nx[rb] = *reinterpret_cast<const u16x8*>(x0 + rb * 32 * pitch + kn * 32);
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-      if constexpr (DBG & 2) {                 // DBG 2: no matrix work (keeps the operands live)
-        acc[i][0][0] += __builtin_bit_cast(float, (unsigned)wq[j][i][0] | ((unsigned)xf0[0] << 16));
-        acc[i][1][0] += __builtin_bit_cast(float, (unsigned)wq[j][i][1] | ((unsigned)xf1[0] << 16));
-      } else {
-        acc[i][0] = mfma32<TT>(wq[j][i], xf0, acc[i][0]);
-        acc[i][1] = mfma32<TT>(wq[j][i], xf1, acc[i][1]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        if constexpr (DBG & 2) {               // DBG 2: no matrix work (keeps the operands live)
+          acc[i][rb][0] += __builtin_bit_cast(float, (unsigned)wq[j][i][rb] | ((unsigned)xf[rb][0] << 16));
+        } else {
+          acc[i][rb] = mfma32<TT>(wq[j][i], xf[rb], acc[i][rb]);
+        }
       }
     }
     if (refill) {
@@ -81,7 +84,8 @@ __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][2], const unsigned 
 #pragma unroll
       for (int i = 0; i < NBW; ++i) wq[j][i] = wb[i][kl * KST];
     }
-    xf0 = n0; xf1 = n1;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) xf[rb] = nx[rb];
     __builtin_amdgcn_sched_barrier(0);
   };
   int t = 0;
@@ -98,48 +102,61 @@ __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][2], const unsigned 
 // LayerNorm over n of the swapped accumulator tile of the whole workgroup (D columns spread over the
 // 8 waves): two-pass statistics as layernorm_kernel (mean, then sum of squared deviations); gamma / beta
 // come from LDS (prefetched at kernel start: no dependent global round trip in the epilogue).
-template <int NB>
-__device__ __forceinline__ void tail_ln(f32x16 (&acc)[NB][2], const float* gamma_l, const float* beta_l,
+template <int NB, int RB = 2>
+__device__ __forceinline__ void tail_ln(f32x16 (&acc)[NB][RB], const float* gamma_l, const float* beta_l,
                                         float* red, int w, int lane, int nblk0) {
+  constexpr int RW = 32 * RB;                  // rows of the workgroup (red: [8 waves][RW])
   constexpr int D = NB * 256;
   int ml = lane & 31, hi = lane >> 5;
   // opaque copies: keeps hipcc from sharing the 16 exchange addresses between the two LayerNorms of
   // the kernel (it kept them live - spilled - across two GEMM stages instead of re-deriving them)
   asm volatile("" : "+v"(ml), "+v"(hi));
-  float s[2] = {0.f, 0.f};
+  float s[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) s[rb] = 0.f;
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[rb] += acc[i][rb][r];
-  s[0] += __shfl_xor(s[0], 32); s[1] += __shfl_xor(s[1], 32);
-  if (hi == 0) { red[w * 64 + ml] = s[0]; red[w * 64 + 32 + ml] = s[1]; }
-  __syncthreads();
-  float mean[2], rstd[2];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RB; ++rb) s[rb] += __shfl_xor(s[rb], 32);
+  if (hi == 0) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) red[w * RW + rb * 32 + ml] = s[rb];
+  }
+  __syncthreads();
+  float mean[RB], rstd[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
     float t = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) t += red[ww * 64 + rb * 32 + ml];
+    for (int ww = 0; ww < 8; ++ww) t += red[ww * RW + rb * 32 + ml];
     mean[rb] = t / (float)D;
   }
-  float q[2] = {0.f, 0.f};
+  float q[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) q[rb] = 0.f;
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float dd = acc[i][rb][r] - mean[rb]; q[rb] += dd * dd; }
-  q[0] += __shfl_xor(q[0], 32); q[1] += __shfl_xor(q[1], 32);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) q[rb] += __shfl_xor(q[rb], 32);
   __syncthreads();                              // every wave has read the sums
-  if (hi == 0) { red[w * 64 + ml] = q[0]; red[w * 64 + 32 + ml] = q[1]; }
+  if (hi == 0) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) red[w * RW + rb * 32 + ml] = q[rb];
+  }
   __syncthreads();
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RB; ++rb) {
     float t = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) t += red[ww * 64 + rb * 32 + ml];
+    for (int ww = 0; ww < 8; ++ww) t += red[ww * RW + rb * 32 + ml];
     rstd[rb] = 1.0f / sqrtf(t / (float)D + 1e-5f);
   }
 #pragma unroll
@@ -150,7 +167,7 @@ __device__ __forceinline__ void tail_ln(f32x16 (&acc)[NB][2], const float* gamma
       const float4 gm = *reinterpret_cast<const float4*>(gamma_l + n);
       const float4 bt = *reinterpret_cast<const float4*>(beta_l + n);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
         acc[i][rb][4 * g + 0] = (acc[i][rb][4 * g + 0] - mean[rb]) * rstd[rb] * gm.x + bt.x;
         acc[i][rb][4 * g + 1] = (acc[i][rb][4 * g + 1] - mean[rb]) * rstd[rb] * gm.y + bt.y;
         acc[i][rb][4 * g + 2] = (acc[i][rb][4 * g + 2] - mean[rb]) * rstd[rb] * gm.z + bt.z;
@@ -170,22 +187,39 @@ __device__ __forceinline__ u16x4 cvt4(float a, float b, float c, float d) {
 
 __device__ __forceinline__ float tail_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0>
+// RB = row blocks of 32 per workgroup. 2 (default): 64 rows, one workgroup per CU (162 KB of LDS at d = 768). 1 (round 4, the
+// "<= 80 KB / <= 128 VGPR" form round 3's verdict asked to be measured): 32 rows, the LayerNorm / bias vectors read from
+// memory instead of LDS (76 KB), so that two workgroups share a CU and overlap each other's stage boundaries - at twice the
+// weight bytes per row through the CU's vector memory path.
+template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0, int RB = 2>
 struct TxTailBody {
   using Params = TailParams;
   static constexpr int THREADS = 512;
+  static constexpr int ROWS = 32 * RB;
+  static constexpr size_t lds_bytes(int kwo) {
+    const int D_ = NB * 256, DH_ = D_ / 2, xcols = kwo > D_ ? kwo : D_;
+    return (size_t)ROWS * (xcols + 8) * 2 + (size_t)ROWS * (DH_ + 8) * 2 + (size_t)8 * ROWS * sizeof(float) +
+           (RB == 2 ? (size_t)(3 * D_ + DH_) * sizeof(float) : 0);
+  }
   static __device__ __forceinline__ void run(const TailParams& p, const BlockCtx& cx, unsigned char* smem) {
   constexpr int D = NB * 256, DH = D / 2;
   constexpr int NB1 = NB == 3 ? 2 : 1;              // FFN1 n-blocks per wave (DH/32 = 8 or 12 over 8 waves)
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = cx.bx * 64;
+  const int m0 = cx.bx * ROWS;
   const int xcols = p.KWO > D ? p.KWO : D;
   unsigned char* X = smem;
-  unsigned char* Y = X + 64 * (xcols + 8) * 2;
-  float* red = reinterpret_cast<float*>(Y + 64 * (DH + 8) * 2);      // [8 waves][64 rows]
-  float* vec2 = red + 512;                          // ln2 gamma, ln2 beta, b2 [D each], b1 [DH]
-  float* vec1 = reinterpret_cast<float*>(Y);        // ln1 gamma, ln1 beta [D each]: parked in Y until FFN1 writes it
+  unsigned char* Y = X + ROWS * (xcols + 8) * 2;
+  float* red = reinterpret_cast<float*>(Y + ROWS * (DH + 8) * 2);    // [8 waves][ROWS rows]
+  float* vec2 = red + 8 * ROWS;                     // ln2 gamma, ln2 beta, b2 [D each], b1 [DH]  (RB == 2 only)
+  float* vec1 = reinterpret_cast<float*>(Y);        // ln1 gamma, ln1 beta [D each]: parked in Y until FFN1 writes it (RB == 2 only)
+  // the epilogue vectors: staged in LDS (RB == 2) or read where they are (RB == 1: L1 / L2 hits, 10 KB less LDS)
+  const float* g1p = RB == 2 ? vec1 : p.ln1g;
+  const float* b1np = RB == 2 ? vec1 + D : p.ln1b;
+  const float* g2p = RB == 2 ? vec2 : p.ln2g;
+  const float* b2np = RB == 2 ? vec2 + D : p.ln2b;
+  const float* fb2p = RB == 2 ? vec2 + 2 * D : p.b2;
+  const float* fb1p = RB == 2 ? vec2 + 3 * D : p.b1;
   const int p1 = (p.KWO + 8) * 2, pD = (D + 8) * 2, pH = (DH + 8) * 2;
   // position of this workgroup among the ones that share its XCD's L2 (block b runs on XCD b % 8;
   // speed only): staggers the k order of the weight streams
@@ -196,7 +230,7 @@ struct TxTailBody {
   // round trip: no epilogue below waits for a global load.
   {
     const int cpr = ((DBG & 4) && (p.dbgf & 2)) ? 0 : (p.KWO >> 3);
-    for (int idx = tid; idx < 64 * cpr; idx += 512) {
+    for (int idx = tid; idx < ROWS * cpr; idx += 512) {
       const int r = idx / cpr, c = idx - r * cpr;
       int m = m0 + r;
       m = m < p.M ? m : p.M - 1;
@@ -206,22 +240,24 @@ struct TxTailBody {
       const u32x4 v = p.nt_rows ? __builtin_nontemporal_load(src) : *src;
       *reinterpret_cast<u32x4*>(X + r * p1 + c * 16) = v;
     }
-    for (int i = tid; i < D / 4; i += 512) {
-      reinterpret_cast<float4*>(vec1)[i] = reinterpret_cast<const float4*>(p.ln1g)[i];
-      reinterpret_cast<float4*>(vec1 + D)[i] = reinterpret_cast<const float4*>(p.ln1b)[i];
-      reinterpret_cast<float4*>(vec2)[i] = reinterpret_cast<const float4*>(p.ln2g)[i];
-      reinterpret_cast<float4*>(vec2 + D)[i] = reinterpret_cast<const float4*>(p.ln2b)[i];
-      reinterpret_cast<float4*>(vec2 + 2 * D)[i] = reinterpret_cast<const float4*>(p.b2)[i];
+    if constexpr (RB == 2) {
+      for (int i = tid; i < D / 4; i += 512) {
+        reinterpret_cast<float4*>(vec1)[i] = reinterpret_cast<const float4*>(p.ln1g)[i];
+        reinterpret_cast<float4*>(vec1 + D)[i] = reinterpret_cast<const float4*>(p.ln1b)[i];
+        reinterpret_cast<float4*>(vec2)[i] = reinterpret_cast<const float4*>(p.ln2g)[i];
+        reinterpret_cast<float4*>(vec2 + D)[i] = reinterpret_cast<const float4*>(p.ln2b)[i];
+        reinterpret_cast<float4*>(vec2 + 2 * D)[i] = reinterpret_cast<const float4*>(p.b2)[i];
+      }
+      for (int i = tid; i < DH / 4; i += 512)
+        reinterpret_cast<float4*>(vec2 + 3 * D)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     }
-    for (int i = tid; i < DH / 4; i += 512)
-      reinterpret_cast<float4*>(vec2 + 3 * D)[i] = reinterpret_cast<const float4*>(p.b1)[i];
   }
-  int mrow[2];
-  f32x16 acc[NB][2];
+  int mrow[RB];
+  f32x16 acc[NB][RB];
   {
-    const float* rp[2]; const float* lp[2];
+    const float* rp[RB]; const float* lp[RB];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
       mrow[rb] = m0 + rb * 32 + ml;
       const int mc = mrow[rb] < p.M ? mrow[rb] : p.M - 1;
       if (p.res_vis) {
@@ -245,7 +281,7 @@ struct TxTailBody {
         const int n = (w * NB + i) * 32 + 8 * g + 4 * hi;
         const bool in_lang = p.res_vis && n >= p.rv_dv;       // wave-uniform per (i): dv % 32 == 0
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
           f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
           if (!((DBG & 4) && (p.dbgf & 1))) {
             const f32x4* src = reinterpret_cast<const f32x4*>(in_lang ? lp[rb] + (n - p.rv_dv) : rp[rb] + n);
@@ -259,8 +295,8 @@ struct TxTailBody {
   __syncthreads();
 
   // ---- stage 1: x + attn Wo^T, LayerNorm
-  tail_gemm<T16, NB, NB == 3 ? 4 : 6, false, DBG>(acc, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, p1, lane);
-  if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB>(acc, vec1, vec1 + D, red, w, lane, w * NB);
+  tail_gemm<T16, NB, NB == 3 ? 4 : 6, false, DBG, RB>(acc, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, p1, lane);
+  if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB, RB>(acc, g1p, b1np, red, w, lane, w * NB);
   // x1 stays in the accumulator registers through FFN1 (which accumulates elsewhere) and becomes,
   // with b2 added, the initial accumulator of FFN2: the fp32 residual stream never leaves registers.
   // Its 16-bit copy = FFN1 operand (X is free: every wave is past stage 1, LayerNorm took barriers).
@@ -271,9 +307,9 @@ struct TxTailBody {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = (w * NB + i) * 32 + 8 * g + 4 * hix;
-      const float4 b = *reinterpret_cast<const float4*>(vec2 + 2 * D + n);
+      const float4 b = *reinterpret_cast<const float4*>(fb2p + n);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
         *reinterpret_cast<u16x4*>(X + (rb * 32 + mlx) * pD + n * 2) =
             cvt4<T16>(acc[i][rb][4 * g], acc[i][rb][4 * g + 1], acc[i][rb][4 * g + 2], acc[i][rb][4 * g + 3]);
         acc[i][rb][4 * g + 0] += b.x; acc[i][rb][4 * g + 1] += b.y;
@@ -287,15 +323,15 @@ struct TxTailBody {
   // waves 0-3 own two blocks (w, w + 8), waves 4-7 one - a wave-uniform choice of instantiation
   // (no per-block conditions inside the pipelined loop)
   {
-    const float* b1l = vec2 + 3 * D;
-    auto ffn1_epi = [&](const f32x16 (&h)[2], int blk) {
+    const float* b1l = fb1p;
+    auto ffn1_epi = [&](const f32x16 (&h)[RB], int blk) {
       const int mlx = fresh(ml), hix = fresh(hi);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = blk * 32 + 8 * g + 4 * hix;
         const float4 b = *reinterpret_cast<const float4*>(b1l + n);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
           *reinterpret_cast<u16x4*>(Y + (rb * 32 + mlx) * pH + n * 2) =
               cvt4<T16>(relu_nan(h[rb][4 * g] + b.x), relu_nan(h[rb][4 * g + 1] + b.y),
                         relu_nan(h[rb][4 * g + 2] + b.z), relu_nan(h[rb][4 * g + 3] + b.w));
@@ -304,24 +340,24 @@ struct TxTailBody {
     const int rot = (xpos * (D >> 4)) >> 3;
     // (two blocks = two passes over K with one accumulator pair: 64 fewer live registers than one
     // pass with two pairs, which spilled x1; the extra LDS operand reads are free here)
-    f32x16 hacc[1][2];
-    tail_gemm<T16, 1, 4, true, DBG>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane);
+    f32x16 hacc[1][RB];
+    tail_gemm<T16, 1, 4, true, DBG, RB>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane);
     ffn1_epi(hacc[0], w);
     if (NB1 == 2 && w < 4) {
-      tail_gemm<T16, 1, 4, true, DBG>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane);
+      tail_gemm<T16, 1, 4, true, DBG, RB>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane);
       ffn1_epi(hacc[0], w + 8);
     }
   }
   __syncthreads();
 
   // ---- stage 3: (x1 + b2) + W2 hidden, LayerNorm
-  tail_gemm<T16, NB, NB == 3 ? 4 : 8, false, DBG>(acc, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, pH, lane);
-  if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB>(acc, vec2, vec2 + D, red, w, lane, w * NB);
+  tail_gemm<T16, NB, NB == 3 ? 4 : 8, false, DBG, RB>(acc, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, pH, lane);
+  if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB, RB>(acc, g2p, b2np, red, w, lane, w * NB);
   const int mlo = fresh(ml), hio = fresh(hi);
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = (w * NB + i) * 32 + 8 * g + 4 * hio;
@@ -347,7 +383,7 @@ struct TxTailBody {
       hb[g] = *reinterpret_cast<const float4*>(p.bl + n);
       hw[g] = *reinterpret_cast<const float4*>(p.wl2 + n);
     }
-    if (tid < 64) {
+    if (tid < ROWS) {
       const int64_t row0 = (int64_t)m0 + tid;
       const int64_t row = row0 < p.M ? row0 : p.M - 1;
       const vog_score_args& a = p.sc;      // same index arithmetic as score_kernel (elementwise.hip)
@@ -371,24 +407,30 @@ struct TxTailBody {
   if constexpr (SCORE) {
     __syncthreads();
     // ---- stage 4: lin2.0 + ReLU, lin2.2 as a row dot product, inverse regroup + masks
-    f32x16 sacc[1][2];
-    tail_gemm<TH, 1, 8, true, DBG>(sacc, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, X, pD, lane);
-    float part[2] = {0.f, 0.f};
+    f32x16 sacc[1][RB];
+    tail_gemm<TH, 1, 8, true, DBG, RB>(sacc, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, X, pD, lane);
+    float part[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) part[rb] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 b = hb[g], ww = hw[g];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
         part[rb] += relu_nan(sacc[0][rb][4 * g] + b.x) * ww.x + relu_nan(sacc[0][rb][4 * g + 1] + b.y) * ww.y +
                     relu_nan(sacc[0][rb][4 * g + 2] + b.z) * ww.z + relu_nan(sacc[0][rb][4 * g + 3] + b.w) * ww.w;
     }
-    part[0] += __shfl_xor(part[0], 32); part[1] += __shfl_xor(part[1], 32);
-    if (hi == 0) { red[w * 64 + ml] = part[0]; red[w * 64 + 32 + ml] = part[1]; }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) part[rb] += __shfl_xor(part[rb], 32);
+    if (hi == 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) red[w * ROWS + rb * 32 + ml] = part[rb];
+    }
     __syncthreads();
-    if (tid < 64 && (int64_t)m0 + tid < p.M) {
+    if (tid < ROWS && (int64_t)m0 + tid < p.M) {
       float logit = p.bl2[0];
 #pragma unroll
-      for (int ww = 0; ww < 8; ++ww) logit += red[ww * 64 + tid];
+      for (int ww = 0; ww < 8; ++ww) logit += red[ww * ROWS + tid];
       p.sc.outs[o_idx] = logit;
       const float ev = tail_sigmoid(logit) * am * cm;
       if (p.pred_counter) __hip_atomic_store(&p.sc.outs_eval[o_idx], ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write through
@@ -419,6 +461,13 @@ template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0>
 __global__ __launch_bounds__(512) void tx_tail_kernel(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tt_smem[];
   TxTailBody<T16, TH, NB, SCORE, DBG>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, tt_smem);
+}
+
+// the 32-row form: <= 128 registers (4 waves per SIMD), two workgroups per CU
+template <typename T16, typename TH, int NB, bool SCORE>
+__global__ __launch_bounds__(512, 4) void tx_tail32_kernel(TailParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tt32_smem[];
+  TxTailBody<T16, TH, NB, SCORE, 0, 1>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, tt32_smem);
 }
 
 }  // namespace vog
