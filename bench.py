@@ -346,6 +346,8 @@ def main():
         # engine._lane_enter / dist.RecordRing - between collectives all 4 forwards are in flight)
         args.streams = min(args.streams, eng_mod._max_inflight())
     dev = torch.device("cuda", local_rank)
+    # the rank's host side on its GPU's NUMA node (a launcher's numactl; VOG_BENCH_NUMA_BIND=0: leave the affinity alone)
+    numa_node = D.bind_host_to_device_node(local_rank) if os.environ.get("VOG_BENCH_NUMA_BIND", "1") == "1" else None
 
     w = WORKLOADS[args.workload]
     cfg = make_cfg(w)
@@ -593,7 +595,7 @@ def main():
         # or a failed parity check make the timing meaningless
         "value": value if (parity["ok"] and not experiments) else None, "unit": "queries/s",
         "parity": parity,
-        "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1, "per_rank_value": value / world,
+        "n_gpus": world, "host_numa_node": numa_node, "rccl_ranks": dist.get_world_size() if use_dist else 1, "per_rank_value": value / world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": w["tx"], "data": "synthetic",
@@ -791,8 +793,16 @@ def main():
                 dsts = [{k: slots[u].inp[k] for k in dls.FWD_KEYS} for u in range(ns)]
                 sts = stream_pool[:ns] if len(stream_pool) >= ns else [torch.cuda.Stream(device=dev) for _ in range(ns)]
 
+                zero_copy = os.environ.get("VOG_BENCH_ZERO_COPY", "0") == "1"
+
                 def fed_step(i):
                     u = i % ns
+                    if zero_copy:
+                        with torch.cuda.stream(sts[u]):
+                            asm({k: stg[u].host[k] for k in dls.FWD_KEYS}, out=dsts[u], with_loss_keys=False)
+                            torch._foreach_copy_([slots[u].inp[k] for k in lang_keys], [stg[u].host[k] for k in lang_keys], non_blocking=True)
+                            slots[u].launch(sts[u])
+                        return
                     with torch.cuda.stream(sts[u]):
                         d = stg[u].upload_on(copy_sts[u % ncs])
                         asm({k: d[k] for k in dls.FWD_KEYS}, out=dsts[u], with_loss_keys=False)
@@ -817,6 +827,50 @@ def main():
                             "staging buffer (raw per-video items + language arrays, dat_loader_simple.PackedStaging) on a copy "
                             "stream into one of two device buffers per slot, then device-side assembly + forward on the slot's "
                             "own stream; %d timed steps" % fsteps}
+                if os.environ.get("VOG_BENCH_FED_GRAPH", "1") == "1":
+                    # the same again with the feed INSIDE each slot's graph (engine.FedPipeline / Slot.feed_from): per step ONE
+                    # transfer of the packed staging buffer (copy engine, copy stream) and ONE graph launch = device-side assembly +
+                    # word-level arrays + forward; two fed slots per stream, one copy stream per forward stream.
+                    # VOG_BENCH_FED_VIA = zero_copy | dma_node: the graph reads the pinned buffer itself / starts with a memcpy node
+                    # (4 slots; both measured slower: profiles/round4_host_fed.md)
+                    via = os.environ.get("VOG_BENCH_FED_VIA", "device")
+                    fed_per_stream = max(1, int(os.environ.get("VOG_BENCH_FED_SLOTS_PER_STREAM", "2")))
+                    spec = {k: v.clone() for k, v in stg[0].host.items()}
+                    fed_bytes = stg[0].nbytes
+                    if via == "device":
+                        del stg
+                        pipe = eng_mod.FedPipeline(eng, dict(slots[0].inp), spec, asm, streams=ns, slots_per_stream=fed_per_stream,
+                                                      stream_pool=sts,
+                                                      copy_streams={"own": "own", "old": copy_sts}.get(os.environ.get("VOG_BENCH_FED_COPY", ""), None))
+                        nfs, fcs = len(pipe.slots), len(pipe.copy_streams)
+
+                        def fedg_step(i):
+                            pipe.submit()
+                    else:
+                        fstg = stg if via == "zero_copy" else [dls.PackedStaging(spec, dev, n_dev=1) for _ in range(ns)]
+                        for u in range(ns):
+                            slots[u].feed_from(fstg[u], asm, via=via)
+                        nfs, fcs = ns, 0
+
+                        def fedg_step(i):
+                            slots[i % ns].launch(sts[i % ns])
+
+                    for i in range(max(args.warmup, 2 * nfs)):
+                        fedg_step(i)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(fsteps):
+                        fedg_step(i)
+                    torch.cuda.synchronize()
+                    dtg = time.perf_counter() - t0
+                    res["batch_assembly"]["measured_host_fed_graph"] = {
+                        "queries_per_s": w["B"] * fsteps / dtg, "us_per_step": dtg / fsteps * 1e6,
+                        "host_link_bytes_per_step": fed_bytes, "achieved_host_link_gbs": fed_bytes * fsteps / dtg / 1e9,
+                        "form": via, "fed_slots": nfs, "copy_streams": fcs,
+                        "what": "engine.FedPipeline: per step ONE copy-engine transfer of the packed pinned staging buffer (raw per-video "
+                                "items + word-level arrays) and ONE graph launch whose first two kernels assemble the batch on the "
+                                "device, then the forward; 2 fed slots per stream, a copy stream per forward stream; %d timed steps "
+                                "(inputs in pinned host memory at the start of every step)" % fsteps}
         except Exception as e:          # never fail the bench line on the side measurement
             res["batch_assembly"] = {"error": str(e)}
     if world == 1 and not args.no_train_extra and cfg.mdl.name == "vog" and w["conc"] in ("temp", "spat") and not args.throughput_only:

@@ -487,6 +487,14 @@ typedef struct vog_assemble_args {
 } vog_assemble_args;
 int vog_assemble_batch(const vog_assemble_args* a, void* stream);
 
+/* Byte ranges src -> dst in ONE launch (16-byte aligned pointers, any length, <= VOG_MAX_COPY_SEGS ranges). The sources may be
+ * pinned host memory (hipHostMalloc / torch pin_memory: mapped into the device's address space): the kernel then reads over the
+ * host link - the reference's `batch[k].to(device)` of the small per-batch arrays (code/utils/trn_utils.py:478, :562) without
+ * one DMA transfer, and one transfer's fixed latency, per array. vog_assemble_batch accepts pinned-host *_in pointers the same way. */
+#define VOG_MAX_COPY_SEGS 24
+typedef struct vog_copy_seg { const void* src; void* dst; size_t bytes; } vog_copy_seg;
+int vog_copy_segments(const vog_copy_seg* segs, int n, void* stream);
+
 /* Loss of one batch on the device: LossB_TEMP / LossB_SPAT
  * (code/mdl_conc_single.py:180-433) and LossB_SEP (code/mdl_conc_sep.py:220-447) with the IoU targets of
  * utils/box_utils.py:61-118: target[b,v,a,r] = max_k(IoU(prop r, gt box srl_boxes[b,v,a,k]) * mask *
@@ -733,6 +741,16 @@ typedef struct vog_graph vog_graph;
 int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
                       void* stream, vog_graph** out);
 int vog_graph_launch(vog_graph* g, void* stream);
+/* The same graph with the batch's way onto the device in front of the forward ("fed" graph): one host -> device DMA transfer
+ * (memcpy node) of dma->bytes if dma != NULL, then vog_assemble_batch(asm_args) if asm_args != NULL, then
+ * vog_copy_segments(segs, nseg) if nseg > 0, then the forward - so that a step of a host-fed loop is ONE hipGraphLaunch: the
+ * loader writes the next batch into pinned host memory at fixed addresses. Two forms: zero copy (dma == NULL; asm_args' *_in
+ * pointers and the segments' sources ARE the pinned host buffer, the kernels read it over the host link: no transfer set-up
+ * latency, ~40 GB/s) and DMA (the packed host buffer goes to a device staging buffer first, the kernels read that: the copy
+ * engine's ~55 GB/s on large batches). The caller must not rewrite the host buffer before the launch that reads it has
+ * completed. */
+int vog_graph_capture_fed(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, const vog_copy_seg* dma,
+                          const vog_assemble_args* asm_args, const vog_copy_seg* segs, int nseg, void* stream, vog_graph** out);
 /* Integer options of a context. ("graph_dag", the language chain as a parallel graph branch, was
  * removed: lower throughput with batches in flight and unstable in the runtime; setting it to 1 fails.)
  * "lstm_persistent" (default 1; env VOG_LSTM_PERSISTENT presets it): use vog_bilstm_layer instead

@@ -3,7 +3,8 @@ rocprofv3's vgpr column reports half of the allocated registers for wave64 kerne
 import re, subprocess, sys, glob, os
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vognet-pytorch_amd", "csrc")
 pat = sys.argv[1] if len(sys.argv) > 1 else "."
-for co in sorted(glob.glob(os.path.join(here, "libvog_hip.*.co"))):
+cos = [a for a in sys.argv[2:]] or sorted(glob.glob(os.path.join(here, "libvog_hip.*.co")))
+for co in cos:
     txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
     for blk in txt.split("  - .agpr_count:")[1:]:
         g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk)

@@ -6,6 +6,8 @@ d = tempfile.mkdtemp()
 kw = {"mdl.name": "vog", "ds.conc_type": "spat", "mdl.obj_tx.use_rel": True, "mdl.mul_tx.use_rel": True, "train.bsv": 4, "misc.tmp_path": d,
       "hip.batch_requests": int(os.environ.get("BR", "1"))}
 m.main_dist("w", only_val=True, synthetic_batches=8, **kw)
+if os.environ.get("NOPROF") == "1":
+    m.main_dist("u", only_val=True, synthetic_batches=128, **kw); m.main_dist("u", only_val=True, synthetic_batches=128, **kw); sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 m.main_dist("v", only_val=True, synthetic_batches=128, **kw)
 pr.disable()

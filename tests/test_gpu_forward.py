@@ -22,7 +22,7 @@ import pytest
 import torch
 
 from oracle import cases
-from tests.gpu_util import build_engine, oracle_run, rel_err
+from tests.gpu_util import L, build_engine, oracle_run, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -602,6 +602,123 @@ def test_slot_replay_with_new_inputs(name):
     again = check(batch_a, "A again")
     for k in keys:
         assert torch.equal(again[k], first[k]), k
+
+
+@pytest.mark.parametrize("via", ["zero_copy", "dma_node", "device"])
+@pytest.mark.parametrize("name", ["full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8"])
+def test_fed_slot_reads_the_batch_from_pinned_host_memory(name, via):
+    """`Slot.feed_from` (vog_graph_capture_fed): the graph's first kernels read the per-video items and the word-level arrays
+    of the batch from a pinned staging buffer (zero copy), assemble / copy them into the slot's inputs, then run the forward -
+    one launch per step (`dma_node`: the graph starts with one transfer of the packed buffer and the kernels read the device
+    copy; `device`: the caller uploads the packed buffer on a copy stream, the graph reads the device copy). Two different batches written into the SAME host buffer one after the other: every replay equals the
+    eager forward on the device-assembled batch bit for bit; the assembled inputs equal the oracle's assembly."""
+    import importlib
+    dls = importlib.import_module("vognet-pytorch_amd.dat_loader_simple")
+    synth = importlib.import_module("vognet-pytorch_amd.synth")
+    from oracle import vog_oracle as vo
+    eng, cfg, sd, batch_a, c, dev_a = build_engine(name)
+    batch_b = _variant(name, 41)
+    T = int(max(batch_a["srl_arg_word_mask_len"].max(), batch_b["srl_arg_word_mask_len"].max()))
+    slot = eng.make_slot(dev_a, T=T, graph=True)
+    conc = cfg.ds.conc_type
+    B = batch_a["num_cmp_msk"].shape[0]
+    asm = dls.DeviceBatchAssembler(cfg, {"num_prop_per_frm": c["nppf0"]})
+    lang_keys = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", "srl_arg_words_capture",
+                 "srl_arg_inds_msk", "num_cmp_msk")
+    items = [synth.make_items(B, 4, c["nppf0"], seed=s) for s in (23, 29)]
+    stg = dls.PackedStaging({**{k: np.zeros_like(items[0][k]) for k in dls.FWD_KEYS},
+                             **{k: np.zeros_like(batch_a[k]) for k in lang_keys}})
+    slot.feed_from(stg, asm, via=via)
+    cs = torch.cuda.Stream()
+    assert set(slot.fed_keys) == set(dls.FWD_KEYS) | set(lang_keys)
+    keys = ("mdl_outs", "mdl_outs_eval", "pred_rec")
+    outs = []
+    for it, lang in zip(items, (batch_b, batch_a)):
+        stg.fill({k: it[k] for k in dls.FWD_KEYS})
+        stg.fill({k: lang[k] for k in lang_keys})
+        if via == "device":
+            stg.upload_on(cs)
+        out = slot.launch()
+        if via == "device":
+            stg.release()
+        slot.consumed().synchronize()
+        got = {k: out[k].clone() for k in keys}
+        ref_asm = vo.assemble_batch(it, conc, 10, c["nppf0"])
+        full = dict(batch_a)
+        full.update({k: lang[k] for k in lang_keys})
+        full.update({k: ref_asm[k] for k in dls.FWD_KEYS})
+        for k in dls.FWD_KEYS + lang_keys:
+            assert np.array_equal(slot.inp[k].cpu().numpy(), full[k]), k
+        ref = eng.forward({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in full.items()}, T=T)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), k
+        assert torch.isfinite(got["mdl_outs"]).all()
+        outs.append(got)
+    assert not torch.equal(outs[0]["mdl_outs"], outs[1]["mdl_outs"])
+
+
+def test_fed_pipeline_serves_a_stream_of_batches():
+    """`engine.FedPipeline` (2 streams x 2 fed slots): 10 different batches written into the staging buffers in turn, one transfer
+    + one launch each; every result equals the eager forward on the oracle-assembled batch bit for bit, in submission order."""
+    import importlib
+    dls = importlib.import_module("vognet-pytorch_amd.dat_loader_simple")
+    synth = importlib.import_module("vognet-pytorch_amd.synth")
+    engine_mod = importlib.import_module("vognet-pytorch_amd.engine")
+    from oracle import vog_oracle as vo
+    name = "full/cfg2_ragged"
+    eng, cfg, sd, batch_a, c, dev_a = build_engine(name)
+    variants = [batch_a, _variant(name, 41), _variant(name, 7)]
+    T = int(max(b["srl_arg_word_mask_len"].max() for b in variants))
+    B = batch_a["num_cmp_msk"].shape[0]
+    asm = dls.DeviceBatchAssembler(cfg, {"num_prop_per_frm": c["nppf0"]})
+    lang_keys = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", "srl_arg_words_capture",
+                 "srl_arg_inds_msk", "num_cmp_msk")
+    it0 = synth.make_items(B, 4, c["nppf0"], seed=1)
+    spec = {**{k: np.zeros_like(it0[k]) for k in dls.FWD_KEYS}, **{k: np.zeros_like(batch_a[k]) for k in lang_keys}}
+    pipe = engine_mod.FedPipeline(eng, dev_a, spec, asm, streams=2, slots_per_stream=2, T=T)
+    assert len(pipe.slots) == 4 and pipe.slots[2].ws.data_ptr() == pipe.slots[0].ws.data_ptr()
+    keys = ("mdl_outs", "mdl_outs_eval", "pred_rec")
+    got, fulls = [], []
+    for i in range(10):
+        it = synth.make_items(B, 4, c["nppf0"], seed=100 + i)
+        lang = variants[i % 3]
+        st = pipe.next_staging()
+        st.fill({k: it[k] for k in dls.FWD_KEYS})
+        st.fill({k: lang[k] for k in lang_keys})
+        sl = pipe.submit()
+        with torch.cuda.stream(pipe.stream_of(sl)):            # collect on the slot's stream: the slot is reused 4 batches later
+            got.append({k: sl.out[k].clone() for k in keys})
+        full = dict(batch_a)
+        full.update({k: lang[k] for k in lang_keys})
+        full.update({k: vo.assemble_batch(it, cfg.ds.conc_type, 10, c["nppf0"])[k] for k in dls.FWD_KEYS})
+        fulls.append(full)
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    for i, (g, full) in enumerate(zip(got, fulls)):
+        ref = eng.forward({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in full.items()}, T=T)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(g[k], ref[k]), (i, k)
+    assert not torch.equal(got[0]["mdl_outs"], got[1]["mdl_outs"])
+
+
+def test_copy_segments_odd_lengths_and_host_sources():
+    """vog_copy_segments: several byte ranges in one launch, lengths that are no multiple of 16, sources in pinned host memory
+    and in device memory."""
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    sizes = [16, 4096, 100003, 7, 33]
+    srcs = [torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8)) for n in sizes]
+    held = [t.pin_memory() if i % 2 == 0 else t.cuda() for i, t in enumerate(srcs)]
+    dsts = [torch.zeros(n + 16, dtype=torch.uint8, device="cuda") for n in sizes]
+    arr = (L.CopySeg * len(sizes))()
+    for i, (h, d, n) in enumerate(zip(held, dsts, sizes)):
+        arr[i].src, arr[i].dst, arr[i].bytes = h.data_ptr(), d.data_ptr(), n
+    L.check(lib.vog_copy_segments(arr, len(sizes), L.stream_ptr()), "vog_copy_segments")
+    torch.cuda.synchronize()
+    for s_, d, n in zip(srcs, dsts, sizes):
+        assert torch.equal(d[:n].cpu(), s_) and int(d[n:].sum()) == 0, n
 
 
 def test_persistent_lstm_handoff_is_deterministic_under_load():

@@ -940,6 +940,39 @@ def test_packed_staging_one_copy_feeds_the_assembler(conc):
         assert np.array_equal(st.dev[k].cpu().numpy(), v), k
 
 
+@pytest.mark.parametrize("hold", [1, 4])
+def test_device_prefetcher_hands_out_every_batch_once_and_intact(hold):
+    """`DevicePrefetcher`: 40 batches (small arrays packed into one transfer, a large one on its own, a short tail batch of
+    another shape in the middle and at the end), copies issued ahead on a copy stream into a ring of persistent buffers. The
+    consumer keeps the last `hold` batches it was handed and reads them late (a kernel queue in front): every batch arrives
+    once, in order, with its own values, and a buffer set is never rewritten while the consumer may still read it."""
+    rng = np.random.default_rng(3)
+    def mk(i, b):
+        return {"big": torch.from_numpy(rng.standard_normal((b, 40000)).astype(np.float32)).pin_memory(),
+                "ids": torch.full((b, 3), i, dtype=torch.int64).pin_memory(),
+                "msk": torch.from_numpy(rng.integers(0, 2, (b, 5, 7)).astype(np.uint8)),          # pageable on purpose
+                "len": torch.arange(b, dtype=torch.int64) + i}
+    batches = [mk(i, 2 if i in (17, 39) else 4) for i in range(40)]
+    held, sums = [], []
+    busy = torch.randn(2048, 2048, device="cuda")
+    n = 0
+    for dbt, hbt in dls.DevicePrefetcher(batches, "cuda", depth=2, hold=hold):
+        assert hbt is batches[n] and all(v.is_cuda for v in dbt.values()) and list(dbt) == list(hbt)
+        held.append((n, dbt))
+        held = held[-hold:]
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                       # the consumer's stream runs behind the host
+        for j, d in held:                                   # late reads of everything the consumer may still hold
+            sums.append((j, d["big"].double().sum(), d["ids"].sum(), d["msk"].long().sum(), d["len"].sum()))
+        n += 1
+    assert n == 40
+    torch.cuda.synchronize()
+    for j, a, b_, c, d in sums:
+        h = batches[j]
+        assert abs(float(a) - float(h["big"].double().sum())) < 1e-6 * h["big"].numel()
+        assert int(b_) == int(h["ids"].sum()) and int(c) == int(h["msk"].long().sum()) and int(d) == int(h["len"].sum()), j
+
+
 def test_packed_staging_copy_stream_double_buffer():
     """`upload_on` (copy stream, two device buffers): three batches in a row, each assembled from the buffer its copy landed
     in, while the next copy is already issued - every result equals the assembly of ITS items (no copy overtakes a reader)."""

@@ -99,7 +99,42 @@ __global__ __launch_bounds__(256) void assemble_gt_kernel(vog_assemble_args a) {
   }
 }
 
+// byte ranges src -> dst, one launch: blockIdx.y = segment, the blocks of a segment stride over its 16-byte chunks.
+// The sources may be PINNED HOST memory (mapped into the device's address space): the loads then cross the host link,
+// which wants many 16-byte requests in flight and nothing else - no staging copy, no DMA set-up latency.
+struct CopySegs { vog_copy_seg s[VOG_MAX_COPY_SEGS]; };
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs cs) {
+  const vog_copy_seg sg = cs.s[blockIdx.y];
+  const size_t n16 = sg.bytes >> 4;
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(sg.src);
+  u32x4* d4 = reinterpret_cast<u32x4*>(sg.dst);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) d4[i] = s4[i];
+  if (blockIdx.x == 0) {
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(sg.src);
+    unsigned char* db = reinterpret_cast<unsigned char*>(sg.dst);
+    for (size_t i = (n16 << 4) + threadIdx.x; i < sg.bytes; i += 256) db[i] = sb[i];
+  }
+}
+
 }  // namespace vog
+
+extern "C" int vog_copy_segments(const vog_copy_seg* segs, int n, void* stream) {
+  using namespace vog;
+  VOG_CHECK_ARG(n >= 0 && n <= VOG_MAX_COPY_SEGS && (n == 0 || segs));
+  if (n == 0) return 0;
+  CopySegs cs;
+  size_t mx = 0;
+  for (int i = 0; i < n; ++i) {
+    VOG_CHECK_ARG(segs[i].src && segs[i].dst && ((uintptr_t)segs[i].src & 15) == 0 && ((uintptr_t)segs[i].dst & 15) == 0);
+    cs.s[i] = segs[i];
+    mx = segs[i].bytes > mx ? segs[i].bytes : mx;
+  }
+  size_t gx = (mx + 4095) / 4096;                          // one 16-byte chunk per thread for the largest segment ...
+  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);               // ... up to 1024 blocks (4 MB in flight per pass)
+  ::vog::launch(copy_segments_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, cs);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int vog_assemble_batch(const vog_assemble_args* a, void* stream) {
   using namespace vog;

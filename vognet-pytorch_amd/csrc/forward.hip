@@ -1347,9 +1347,10 @@ struct vog_graph {
   hipGraphExec_t exec = nullptr;
 };
 
-extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
-                                 void* stream, vog_graph** out) {
+static int graph_capture_impl(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, const vog_copy_seg* dma,
+                              const vog_assemble_args* asm_args, const vog_copy_seg* segs, int nseg, void* stream, vog_graph** out) {
   VOG_CHECK_ARG(c && b && ws && out && stream);
+  VOG_CHECK_ARG(nseg >= 0 && nseg <= VOG_MAX_COPY_SEGS && (nseg == 0 || segs));
   Plan plan;
   std::vector<Step> steps;
   VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
@@ -1360,7 +1361,15 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
   // Steps that can run side by side share a launch instead: csrc/pair.hip.)
   VOG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int rc = 0;
+  // fed graph: the batch's way onto the device first (kernel nodes reading pinned host memory at fixed addresses)
+  if (dma && dma->bytes) {
+    hipError_t de = hipMemcpyAsync(dma->dst, dma->src, dma->bytes, hipMemcpyHostToDevice, st);
+    if (de != hipSuccess) { rc = -(int)de - 1000; vog::set_error("hipMemcpyAsync (fed graph): %s", hipGetErrorString(de)); }
+  }
+  if (rc == 0 && asm_args) rc = vog_assemble_batch(asm_args, st);
+  if (rc == 0 && nseg > 0) rc = vog_copy_segments(segs, nseg, st);
   for (auto& s : steps) {
+    if (rc != 0) break;
     if (s.branch < 0) continue;          // join marker (AQL row bookkeeping)
     rc = s.fn(st);
     if (rc != 0) break;
@@ -1375,6 +1384,17 @@ extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_
   if (e != hipSuccess) { (void)hipGraphDestroy(g); delete vg; VOG_FAIL(-(int)e - 1000, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
   *out = vg;
   return 0;
+}
+
+extern "C" int vog_graph_capture(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
+                                 void* stream, vog_graph** out) {
+  return graph_capture_impl(c, b, ws, ws_bytes, nullptr, nullptr, nullptr, 0, stream, out);
+}
+
+extern "C" int vog_graph_capture_fed(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, const vog_copy_seg* dma,
+                                     const vog_assemble_args* asm_args, const vog_copy_seg* segs, int nseg, void* stream,
+                                     vog_graph** out) {
+  return graph_capture_impl(c, b, ws, ws_bytes, dma, asm_args, segs, nseg, stream, out);
 }
 
 extern "C" int vog_group_graph_capture(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes,

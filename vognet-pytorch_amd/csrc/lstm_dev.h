@@ -399,7 +399,10 @@ struct LstmLayerBody {
         // group AHEAD of the MFMAs that use them (two register sets; the scheduling fences keep hipcc from
         // folding the groups back into read-2 / wait / MFMA-2, which exposes the LDS latency 16 times per
         // step: 0.95 us of a 3 us step in round 2)
-        constexpr int G = KSTEPS < 8 ? KSTEPS : 8;
+#ifndef VOG_LSTM_G
+#define VOG_LSTM_G 8
+#endif
+        constexpr int G = KSTEPS < VOG_LSTM_G ? KSTEPS : VOG_LSTM_G;
         u16x8 fa[G], fb[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) fa[j] = *reinterpret_cast<const u16x8*>(hrow + j * 32);
@@ -497,8 +500,11 @@ struct LstmLayerBody {
   }
 };
 
+#ifndef VOG_LSTM_KATTR
+#define VOG_LSTM_KATTR
+#endif
 template <typename T16, int KSTEPS>
-__global__ __launch_bounds__(512) void lstm_layer_kernel(LstmLayerParams p) {
+__global__ __launch_bounds__(512) VOG_LSTM_KATTR void lstm_layer_kernel(LstmLayerParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
   LstmLayerBody<T16, KSTEPS>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, lstm_smem);
 }

@@ -121,6 +121,9 @@ __global__ __launch_bounds__(512) void vis_enc_kernel(VisEncParams a) {
 // order) per K chunk of 256, the 8 waves own 16 columns each and stream their weight fragments once.
 // 32 workgroups, ~1 MB through each CU: ~25 us (proposals) / ~37 us (segments), ~900 CU*us.
 // ---------------------------------------------------------------------------------------------------
+#ifndef VOG_VE_G
+#define VOG_VE_G 8
+#endif
 template <typename T16>
 struct VisEncLeanBody {
   using Params = VisEncParams;
@@ -188,25 +191,29 @@ struct VisEncLeanBody {
       // them (the scheduling fences keep hipcc from folding this into read-2 / wait / MFMA-2, which exposes
       // the LDS latency 16 times per chunk)
       const unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
-      u16x8 fa[8], fb[8];
+      // units of VG k-steps: unit u = (row tile u / UPT, k-steps (u % UPT) * VG ...); VG = 4 keeps the whole body under
+      // 192 registers, which is what lets a <= 128-register workgroup of another stream share the CU when this body
+      // rides in the BiLSTM layer's launch (the pair kernel allocates the maximum of its two bodies)
+      constexpr int VG = VOG_VE_G, UPT = 8 / VG, NU = (RB / 16) * UPT;
+      u16x8 fa[VG], fb[VG];
+      auto rd = [&](u16x8 (&f)[VG], int u) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) fa[ks] = *reinterpret_cast<const u16x8*>(img + ((0 * (KC / 32) + ks) * 64 + lane) * 16);
+        for (int j = 0; j < VG; ++j)
+          f[j] = *reinterpret_cast<const u16x8*>(img + (((u / UPT) * (KC / 32) + (u % UPT) * VG + j) * 64 + lane) * 16);
+      };
+      rd(fa, 0);
 #pragma unroll
-      for (int mt = 0; mt < RB / 16; mt += 2) {
+      for (int u = 0; u < NU; u += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fb, u + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) fb[ks] = *reinterpret_cast<const u16x8*>(img + (((mt + 1) * (KC / 32) + ks) * 64 + lane) * 16);
+        for (int j = 0; j < VG; ++j) acc[u / UPT] = mfma16<T16>(fa[j], q[(u % UPT) * VG + j], acc[u / UPT]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < NU) rd(fa, u + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc[mt] = mfma16<T16>(fa[ks], q[ks], acc[mt]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (mt + 2 < RB / 16) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ++ks) fa[ks] = *reinterpret_cast<const u16x8*>(img + (((mt + 2) * (KC / 32) + ks) * 64 + lane) * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc[mt + 1] = mfma16<T16>(fb[ks], q[ks], acc[mt + 1]);
+        for (int j = 0; j < VG; ++j) acc[(u + 1) / UPT] = mfma16<T16>(fb[j], q[((u + 1) % UPT) * VG + j], acc[(u + 1) / UPT]);
       }
     };
     // (fence-free barriers: __syncthreads() would wait for the next chunk's loads, issued just above it)

@@ -89,6 +89,127 @@ class PackedStaging:
         self._free[self._last] = ev
 
 
+class DevicePrefetcher:
+    """`for dev_batch, host_batch in DevicePrefetcher(loader, device, depth, hold)`: the loader's batches (dicts of CPU tensors)
+    as device batches whose host -> device copies were issued `depth` batches ahead on a copy stream, so that they overlap the
+    forwards of the batches in front of them and the loop never waits for a copy it has just issued (the reference's
+    `batch[k].to(device)` per key and batch, code/utils/trn_utils.py:478 / :562, is a blocking copy per key: 1.2 ms per
+    cfg-2 batch, 6 forwards' worth).
+
+    The copies land in persistent device buffers (a ring of depth + hold + 1 sets per batch shape; a batch of another shape -
+    the short tail batch - gets a set of its own); a set is rewritten only after the consumer's stream has passed the point
+    where it gave the batch back: the consumer may keep using the last `hold` batches it was handed (dynamic batching
+    concatenates `hold` of them), nothing older. Batches that already live on the device pass through untouched.
+    Pinned host tensors make the copies asynchronous; pageable ones still work (staged by the runtime)."""
+
+    def __init__(self, loader, device, depth: int = 2, hold: int = 1):
+        self.loader, self.device = loader, torch.device(device)
+        self.depth, self.hold = max(1, int(depth)), max(1, int(hold))
+
+    def __iter__(self):
+        dev = self.device
+        if dev.type != "cuda":
+            for bt in self.loader:
+                yield bt, bt
+            return
+        from collections import deque
+        cs = torch.cuda.Stream(device=dev)
+        nring = self.depth + self.hold + 1
+        ring: list = [None] * nring
+        given = {}                                   # batch number -> event on the consumer's stream behind its use
+        pending = deque()
+        n = 0
+
+        SMALL = 64 << 10        # tensors below this travel together: one pinned buffer, ONE transfer (a transfer costs ~8 us of
+                                # copy-engine time whatever its size: 20 KB-sized arrays per batch were 40 % of a cfg-2 batch's copies)
+
+        def make_set(bt, sig):
+            small = [k for k, v in bt.items() if v.numel() * v.element_size() < SMALL]
+            e = {"sig": sig, "bufs": {k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in bt.items() if k not in small},
+                 "small": small}
+            if small:
+                off, lay = 0, {}
+                for k in small:
+                    v = bt[k]
+                    nb = v.numel() * v.element_size()
+                    lay[k] = (off, nb)
+                    off += (nb + 255) // 256 * 256
+                e["hpack"] = [torch.empty(off, dtype=torch.uint8).pin_memory() for _ in range(2)]     # filled alternately:
+                e["hfree"] = [None, None]                                                             # a buffer is rewritten once its transfer is done
+                e["dpack"] = torch.empty(off, dtype=torch.uint8, device=dev)
+                e["hviews"] = [{k: h[o:o + nb].view(bt[k].dtype).view(bt[k].shape) for k, (o, nb) in lay.items()} for h in e["hpack"]]
+                for k, (o, nb) in lay.items():
+                    e["bufs"][k] = e["dpack"][o:o + nb].view(bt[k].dtype).view(bt[k].shape)
+                e["turn"] = 0
+            e["bufs"] = {k: e["bufs"][k] for k in bt}           # the loader's key order
+            return e
+
+        def issue(bt):
+            nonlocal n
+            if any(v.is_cuda for v in bt.values()):
+                pending.append((bt, bt, None))
+                n += 1
+                return
+            sig = tuple((k, tuple(v.shape), v.dtype) for k, v in bt.items())
+            e = ring[n % nring]
+            cur = torch.cuda.current_stream(dev)
+            if e is None or e["sig"] != sig:
+                # new buffers come from the consumer stream's pool: whatever used that memory before is ordered on that stream
+                e = make_set(bt, sig)
+                ring[n % nring] = e
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                cs.wait_event(ev)
+            else:
+                m = n - nring + self.hold - 1          # the batch whose hand-back frees this set
+                if m in given:
+                    cs.wait_event(given[m])
+            small = e["small"]
+            if small:
+                t = e["turn"]
+                e["turn"] = 1 - t
+                if e["hfree"][t] is not None:
+                    e["hfree"][t].synchronize()        # (two uses of this set ago: long done)
+                hv = e["hviews"][t]
+                for k in small:
+                    hv[k].copy_(bt[k])
+            with torch.cuda.stream(cs):
+                for k, v in bt.items():
+                    if not small or k not in hv:
+                        e["bufs"][k].copy_(v, non_blocking=True)
+                if small:
+                    e["dpack"].copy_(e["hpack"][t], non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(cs)
+                if small:
+                    e["hfree"][t] = ready
+            pending.append((e["bufs"], bt, ready))
+            n += 1
+
+        def hand_out():
+            dbt, hbt, ready = pending.popleft()
+            if ready is not None:
+                torch.cuda.current_stream(dev).wait_event(ready)
+            return dbt, hbt
+
+        j = 0
+        for bt in self.loader:
+            issue(bt)
+            if len(pending) > self.depth:
+                yield hand_out()
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                given[j] = ev
+                given.pop(j - 2 * nring, None)
+                j += 1
+        while pending:
+            yield hand_out()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            given[j] = ev
+            j += 1
+
+
 class DeviceBatchAssembler:
     def __init__(self, cfg, comm):
         self.conc_type = cfg.ds.conc_type
@@ -100,13 +221,29 @@ class DeviceBatchAssembler:
 
     def __call__(self, items: Dict[str, torch.Tensor], out: Optional[Dict[str, torch.Tensor]] = None,
                  with_loss_keys: bool = True) -> Dict[str, torch.Tensor]:
-        """items: device tensors with leading axes [B, ncmp]. `out`: optional existing destination tensors
-        (e.g. `slot.inp`) for any of the produced keys; missing ones are allocated."""
+        a, out = self.args(items, out, with_loss_keys)
+        L.check(self.lib.vog_assemble_batch(C.byref(a), L.stream_ptr()), "vog_assemble_batch")
+        return out
+
+    def args(self, items: Dict[str, torch.Tensor], out: Optional[Dict[str, torch.Tensor]] = None,
+             with_loss_keys: bool = True):
+        """The vog_assemble_args of this call and the destination dict, without launching (a fed slot captures the launch
+        into its graph: `engine.Slot.feed_from`).
+        items: device tensors with leading axes [B, ncmp] - or PINNED host tensors (zero copy: pinned memory is mapped
+        into the device's address space, the kernels read it over the host link, so the batch needs no DMA of its own and
+        none of a copy's fixed latency; `out` must then name the destination tensors, which also fixes the device).
+        `out`: optional existing destination tensors (e.g. `slot.inp`) for any of the produced keys; missing ones are
+        allocated."""
         P = items["pad_proposals"]
-        assert P.is_cuda and P.dtype == torch.float32 and P.dim() == 4 and P.shape[-1] == 7
+        assert (P.is_cuda or P.is_pinned()) and P.dtype == torch.float32 and P.dim() == 4 and P.shape[-1] == 7
         B, ncmp, NPv, _ = P.shape
         assert NPv == self.nfrm0 * self.nppf0
-        dev = P.device
+        if P.is_cuda:
+            dev = P.device
+        else:
+            assert out and "pad_region_feature" in out, "pinned host items: pass the destination tensors in `out`"
+            dev = out["pad_region_feature"].device
+            assert all(items[k].is_pinned() for k in ("pad_region_feature", "seg_feature_for_frms")), "host items must be pinned"
         R, S = items["pad_region_feature"], items["seg_feature_for_frms"]
         out = dict(out or {})
 
@@ -142,6 +279,5 @@ class DeviceBatchAssembler:
         a.B, a.ncmp, a.nfrm0, a.nppf0 = B, ncmp, self.nfrm0, self.nppf0
         a.prop_dim, a.seg_dim = R.shape[-1], S.shape[-1]
         a.conc_type, a.vid_w = L.CONC_TYPE[self.conc_type], self.vid_w
-        L.check(self.lib.vog_assemble_batch(C.byref(a), L.stream_ptr()), "vog_assemble_batch")
         out["_keepalive"] = keep
-        return out
+        return a, out

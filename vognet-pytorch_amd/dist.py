@@ -51,6 +51,40 @@ def init_from_env(backend: str = "nccl"):
     dist.init_process_group(backend=backend, init_method="env://")
 
 
+def _parse_cpulist(txt: str):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_host_to_device_node(dev_index: int = 0):
+    """Run this process on the CPUs of the NUMA node its GPU hangs off (what `numactl --cpunodebind` per rank does in a
+    launcher script; torchrun does not). Pinned staging buffers are then allocated on that node (first touch) and host -> device
+    transfers do not cross the socket interconnect: on the 2-socket MI355X boxes the host-fed rate of one and the same binary
+    varied 17.8 - 21.7 k queries/s from run to run without it. Returns the node, or None when the topology cannot be read
+    (the affinity is then left alone). Call it before anything allocates pinned memory."""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bus = "%04x:%02x:%02x.0" % (int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(p.pci_device_id))
+        with open(f"/sys/bus/pci/devices/{bus}/numa_node") as f:
+            node = int(f.read())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """[start, stop) of this rank's contiguous slice; every rank gets
     ceil(n/world) items, the tail wraps around to the first items

@@ -392,6 +392,78 @@ class Slot:
                 self.graph = g
                 torch.cuda.synchronize()
 
+    def feed_from(self, staging, assembler=None, via: str = "zero_copy", part: Optional[int] = None) -> "Slot":
+        """Make this slot HOST-FED: re-capture its graph with the batch's way onto the device in front of the forward
+        (vog_graph_capture_fed), reading `staging.host` - a `dat_loader_simple.PackedStaging`'s pinned host views - at fixed
+        addresses over the host link. A step of the loop is then ONE `launch()`: the loader writes batch i + 1 into
+        `staging.host[k]` (after the launch that read batch i has completed: `consumed()`), nothing is copied, staged or
+        assembled by separate calls. With `assembler` (a `DeviceBatchAssembler`, SPAT / TEMP) the per-video items
+        (`FWD_KEYS`) go through vog_assemble_batch into the slot's concatenated input buffers; every other key that the slot
+        and the staging buffer share (same byte size) is copied by vog_copy_segments.
+        `via`: "zero_copy" (above); "dma_node": the graph starts with ONE host -> device memcpy node of the packed buffer into
+        `staging.dbuf` and the kernels read the device views (measured no faster than zero copy: 42 GB/s at p100, the runtime
+        executes the node with a copy kernel); "device": the graph reads the device views and the CALLER moves the packed
+        buffer with the copy engine on a copy stream (`staging.upload_on(copy_stream, consumer=stream)`, `launch(stream)`,
+        `staging.release(stream)`; the staging buffer must have ONE device buffer, n_dev = 1): 55 GB/s on large batches and
+        the copy of a slot's next batch overlaps the other slots' forwards.
+        `part`: the staging buffer holds SEVERAL batches (every tensor with a leading axis over them) and this slot reads
+        batch `part`: one transfer then feeds a group of slots - a transfer costs ~80 us whatever its size (8.5 MB cfg-2
+        batches one per transfer: 36 GB/s; four per transfer: the link's 50+).
+        (reference: the `.to(device)` of every batch tensor, code/utils/trn_utils.py:478 / :562, and the SPAT / TEMP
+        concatenation of the collate step, code/dat_loader_simple.py:380-520)"""
+        assert self.graph is not None, "feed_from needs a graph slot"
+        eng = self.eng
+        asm_keys = ()
+        a = None
+        assert via in ("zero_copy", "dma_node", "device")
+        assert via == "zero_copy" or len(staging.dbufs) == 1, "the graph reads ONE device buffer: PackedStaging(n_dev=1)"
+        src = staging.host if via == "zero_copy" else staging.dev
+        if part is not None:
+            src = {k: v[part] for k, v in src.items()}
+        dseg = None
+        if via == "dma_node":
+            dseg = L.CopySeg()
+            dseg.src, dseg.dst, dseg.bytes = staging.hbuf.data_ptr(), staging.dbuf.data_ptr(), staging.nbytes
+        if assembler is not None:
+            from .dat_loader_simple import FWD_KEYS
+            asm_keys = FWD_KEYS
+            a, _ = assembler.args({k: src[k] for k in FWD_KEYS}, out={k: self.inp[k] for k in FWD_KEYS},
+                                  with_loss_keys=False)
+        segs = []
+        for k, h in src.items():
+            if k in asm_keys or k not in self.inp:
+                continue
+            d = self.inp[k]
+            nb = h.numel() * h.element_size()
+            assert d.numel() * d.element_size() == nb and d.dtype == h.dtype, f"staging['{k}'] does not match the slot's input"
+            segs.append((h.data_ptr(), d.data_ptr(), nb))
+        assert len(segs) <= L.MAX_COPY_SEGS
+        arr = (L.CopySeg * max(1, len(segs)))()
+        for i, (sp_, dp_, nb) in enumerate(segs):
+            arr[i].src, arr[i].dst, arr[i].bytes = sp_, dp_, nb
+        with torch.cuda.device(eng.device):
+            torch.cuda.synchronize()
+            cap = torch.cuda.Stream(device=eng.device)
+            g = C.c_void_p()
+            L.check(eng.lib.vog_graph_capture_fed(eng.ctx, C.byref(self.batch), self.ws.data_ptr(), self.ws.numel(),
+                                                  C.byref(dseg) if dseg is not None else None,
+                                                  C.byref(a) if a is not None else None, arr, len(segs),
+                                                  cap.cuda_stream, C.byref(g)), "vog_graph_capture_fed")
+            eng.lib.vog_graph_destroy(self.graph)
+            self.graph = g
+            torch.cuda.synchronize()
+        self.feed = staging
+        self.fed_keys = tuple(asm_keys) + tuple(k for k in src if k in self.inp and k not in asm_keys)
+        self._consumed = None
+        return self
+
+    def consumed(self, stream: Optional[torch.cuda.Stream] = None) -> "torch.cuda.Event":
+        """Fed slots: an event that fires when everything launched on `stream` so far (hence the last `launch()` there, and
+        its reads of the staging buffer) has completed; the loader waits for it before it writes the next batch."""
+        ev = torch.cuda.Event()
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.eng.device))
+        return ev
+
     # ---- AQL path (include/vog_hip.h "AQL programs") ------------------------------------------
     def build_aql(self, split_chains: bool = True) -> "Slot":
         """Record this slot's forward as an AQL program (pre-built dispatch packets)."""
@@ -453,6 +525,148 @@ class Slot:
                 self.eng.lib.vog_graph_destroy(self.graph)
         except Exception:
             pass
+
+
+def _shares_hw_queue(a: "torch.cuda.Stream", b: "torch.cuda.Stream", scratch: torch.Tensor, spin_cycles: int, spin_s: float) -> bool:
+    """Do two HIP streams sit on the same hardware queue? A spin kernel on `a`, then a tiny kernel on `b`: on a shared queue
+    the second one is dispatched behind the first (the runtime deals its streams onto 4 hardware queues)."""
+    import time
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(spin_cycles)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(b):
+        scratch.add_(1)
+        ev = torch.cuda.Event()
+        ev.record(b)
+    ev.synchronize()
+    dt = time.perf_counter() - t0
+    a.synchronize()
+    return dt > 0.5 * spin_s
+
+
+def paired_copy_streams(streams, device, candidates: int = 16):
+    """One copy stream per forward stream ON THE SAME HARDWARE QUEUE (None where no candidate matched). An event recorded on a copy
+    stream is a barrier packet in that stream's hardware queue until the transfer has landed; everything behind it in the queue
+    waits - harmless when that is the forward that needs the transfer anyway, 30 % of the host-fed rate when it is another
+    slot's forward (cfg 2: 20.7 k queries/s with aligned pairs, 14.9 k misaligned, 19.6 k with the transfers on the forward
+    streams themselves; profiles/round4_host_fed.md)."""
+    import time
+    with torch.cuda.device(device):
+        scratch = torch.zeros(64, device=device)
+        cyc = 1_000_000
+        torch.cuda._sleep(cyc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        torch.cuda._sleep(cyc)
+        torch.cuda.synchronize()
+        spin_s = time.perf_counter() - t0
+        cands = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+        out, used = [], set()
+        for fs in streams:
+            hit = None
+            for i, c in enumerate(cands):
+                if i in used:
+                    continue
+                if _shares_hw_queue(fs, c, scratch, cyc, spin_s) and _shares_hw_queue(fs, c, scratch, cyc, spin_s):
+                    hit = i
+                    break
+            if hit is not None:
+                used.add(hit)
+            out.append(cands[hit] if hit is not None else None)
+    return out
+
+
+class FedPipeline:
+    """The host-fed serving / validation loop as an object: `streams` forward streams x `slots_per_stream` fed slots
+    (`Slot.feed_from(..., via="device")`), every slot with its own packed pinned staging buffer and device copy, one copy stream
+    per forward stream. Per batch:
+
+        st = pipe.next_staging()        # pinned host views of the slot that is next in turn; its previous transfer has left it
+        st.fill(raw_batch)              # (or write into st.host[k] in place)
+        slot = pipe.submit()            # ONE transfer (copy engine) + ONE graph launch: assembly + word arrays + forward
+        ... slot.out is valid once `pipe.done(slot)` has fired (stream order on `pipe.stream_of(slot)`)
+
+    Two slots per stream: the transfer of a slot's next batch never waits for that slot's previous forward (a copy queue
+    waiting for a compute queue cost 60 us per step at cfg 2); one copy stream per forward stream: no transfer queues behind
+    another slot's. 21.6 k queries/s at cfg 2 and 24.5 k at cfg 3 from pinned host memory (link: 46 / 52 GB/s), 1.70 k at
+    cfg 4 (56.6 GB/s = the link); profiles/round4_host_fed.md. The slots of a stream share one workspace.
+    (reference: the loop body `batch = {k: v.to(device)}; out = mdl(batch)` of code/utils/trn_utils.py:478-485, :562-570
+    behind the collate step's SPAT / TEMP concatenation, code/dat_loader_simple.py:380-520)"""
+
+    def __init__(self, eng: VogEngine, example_inp, spec, assembler=None, streams: int = 4, slots_per_stream: int = 2,
+                 T: Optional[int] = None, with_pred: bool = True, pred_rec=None, stream_pool=None, copy_streams=None):
+        from .dat_loader_simple import PackedStaging
+        self.eng = eng
+        dev = eng.device
+        self.n_streams, self.per = int(streams), max(1, int(slots_per_stream))
+        n = self.n_streams * self.per
+        self.streams = list(stream_pool[:self.n_streams]) if stream_pool else [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        # copy_streams: "own" = the transfer is issued on the slot's forward stream (no cross-stream events at all)
+        #               default: a copy stream per forward stream on the same hardware queue (`paired_copy_streams`)
+        self.copy_own = isinstance(copy_streams, str) and copy_streams == "own"
+        if self.copy_own:
+            self.copy_streams = []
+        elif copy_streams:
+            self.copy_streams = list(copy_streams)
+        else:
+            self.copy_streams = paired_copy_streams(self.streams, dev)
+            if any(c is None for c in self.copy_streams):
+                self.copy_own, self.copy_streams = True, []
+        self.slots, self.stagings = [], []
+        with torch.cuda.device(dev):
+            for j in range(n):
+                rec = None if pred_rec is None else pred_rec[j]
+                sl = eng.make_slot(example_inp, T=T, with_pred=with_pred, graph=True, pred_rec=rec,
+                                   share_ws_with=self.slots[j % self.n_streams] if j >= self.n_streams else None)
+                st = PackedStaging(spec, dev, n_dev=1)
+                sl.feed_from(st, assembler, via="device")
+                self.slots.append(sl)
+                self.stagings.append(st)
+        self._done = [None] * n
+        self._i = 0
+
+    def next_staging(self):
+        """The staging buffer of the slot that `submit()` will launch next. Blocks (host) until the transfer that last read its
+        host side has completed - 2 x streams batches ago: never in steady state."""
+        st = self.stagings[self._i % len(self.slots)]
+        ev = st._ready[0]
+        if ev is not None:
+            ev.synchronize()
+        return st
+
+    def stream_of(self, slot: "Slot") -> "torch.cuda.Stream":
+        return self.streams[self.slots.index(slot) % self.n_streams]
+
+    def submit(self) -> "Slot":
+        j = self._i % len(self.slots)
+        self._i += 1
+        u = j % self.n_streams
+        st, sl, fs = self.stagings[j], self.slots[j], self.streams[u]
+        if self.copy_own:
+            with torch.cuda.stream(fs):
+                st.dbuf.copy_(st.hbuf, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(fs)
+            st._ready[0] = ev
+            sl.launch(fs)
+            ev2 = torch.cuda.Event()
+            ev2.record(fs)
+            self._done[j] = ev2
+            return sl
+        st.upload_on(self.copy_streams[u % len(self.copy_streams)], consumer=fs)
+        sl.launch(fs)
+        st.release(fs)
+        self._done[j] = st._free[0]
+        return sl
+
+    def done(self, slot: "Slot"):
+        """Event behind the slot's last forward (its outputs are complete, its device staging buffer is free)."""
+        return self._done[self.slots.index(slot)]
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
 
 
 LANG_KEYS = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", "srl_arg_words_capture",

@@ -118,15 +118,22 @@ class Evaluator(torch.nn.Module):
         record format (:247-273) and returns (loss dict, metric dict).
 
         Exchange: the reference pickles per-rank predictions and rank 0 re-reads the files (:125-140).
-        Here every batch's packed device records get the batch's metadata appended (same int64 row,
-        exact for |id| < 2^53: carried as fp64 bit patterns in two fp32 words each) and travel through
-        ONE all-gather per GATHER_EVERY batches (dist.RecordRing; a collective per batch plus seven for
-        the metadata cost 12-20 us per step each). Record order on rank 0 = (rank, batch, query): all of rank
-        0's records, then all of rank 1's, ... - the order in which the reference appends the per-rank files
-        (:131-137)."""
+        Here every batch's packed device records travel through ONE all-gather per GATHER_EVERY batches
+        (dist.RecordRing; a collective per batch costs 12-20 us per step) and the batches' metadata (ids,
+        masks, permutations: int64, known on the HOST before the batch is uploaded) stays on the host and
+        is exchanged once, at the end. Record order on rank 0 = (rank, batch, query): all of rank 0's
+        records, then all of rank 1's, ... - the order in which the reference appends the per-rank files
+        (:131-137).
+
+        Host side of the loop: the batches are uploaded `depth` batches ahead on a copy stream
+        (dat_loader_simple.DevicePrefetcher) and the longest sentence is taken from the host copy of the
+        lengths, so that no step of the loop waits for the device (the per-key blocking `.to(device)` and the
+        `.item()` of the reference's loop cost 1.5 ms per cfg-2 batch)."""
+        from .dat_loader_simple import DevicePrefetcher
         model.eval()
         world = D.get_world_size()
-        by_rank = [[] for _ in range(world)]
+        rec_rows = [[] for _ in range(world)]          # rank 0: per rank, the gathered record rows of every half (numpy)
+        meta_rows = []                                 # this rank: per ring entry, int64 [rows_ring, W + 1] (last column: real row)
         losses = {}
         nums = 0
         ring = None
@@ -135,53 +142,44 @@ class Evaluator(torch.nn.Module):
         def on_half(g, n_valid):
             if not D.is_main_process():
                 return
-            per_rank = g.view(world, self.GATHER_EVERY, layout["B"], -1)[:, :n_valid]
+            # ONE device-to-host copy of the gathered rows; everything else is host-side slicing
+            host = g.view(world, self.GATHER_EVERY, layout["B"], -1)[:, :n_valid].detach().cpu().numpy()
             for r in range(world):
-                unpack_rows(per_rank[r].reshape(n_valid * layout["B"], -1), by_rank[r])
-
-        def unpack_rows(rows, results):
-            # ONE device-to-host copy of the gathered rows; everything below is host-side slicing (a copy and a handful of
-            # small device ops per column cost 27 ms per half: more than the 16 forwards it describes)
-            rows = rows.detach().cpu()
-            rec = rows[:, :layout["rw"]].contiguous()
-            r = self.unpack(rec, layout["ncmp"], layout["nsrl"])
-            cols = {"pred_boxes": r["boxes"], "pred_scores": r["scores"], "pred_cmp": r["indexs"]}
-            off = layout["rw"]
-            for k in layout["meta"]:
-                w = layout["meta_w"][k]
-                m = rows[:, off:off + 2 * w].contiguous().view(torch.float64).to(torch.int64)
-                cols[self.META_NAMES[k]] = m[:, 0] if layout["meta_1d"][k] else m
-                off += 2 * w
-            # the last column marks real rows: a short batch (validation loaders keep the tail,
-            # drop_last=is_train, utils/trn_utils.py:200-203) is padded to the ring's row count
-            keep = rows[:, off] > 0.5
-            # kept as numpy columns; the reference's per-query dicts of Python lists (eval_vsrl_corr.py:247-273) are never
-            # built: rank 0 writes their pickle bytes directly at the end (fast_pickle.dumps_records, byte-identical;
-            # `tolist` + `pickle.dumps` of 512 queries cost 170 ms = a 3 k queries/s ceiling for the whole validation loop)
-            results.append({k: v[keep].numpy() for k, v in cols.items()})
+                rec_rows[r].append(host[r].reshape(n_valid * layout["B"], -1))
 
         G = int(self.cfg.hip.get("batch_requests", 1)) if "hip" in self.cfg else 1
+        dev = torch.device(self.device)
+
+        def host_T(bts):
+            """Longest sentence of the group from the host copies of the lengths (None: they live on the device)."""
+            ls = [bt.get("srl_arg_word_mask_len") for bt in bts]
+            if any(l is None or l.is_cuda for l in ls):
+                return None
+            return max(int(l.max()) for l in ls)
 
         def batches():
-            """The loader's batches, `batch_requests` of them at a time as one (dynamic batching: rows never interact)."""
-            if G <= 1:
-                for bt in dl:
-                    yield bt, [next(iter(bt.values())).shape[0]]
-                return
-            pend = []
-            for bt in dl:
-                pend.append({k: v.to(self.device, non_blocking=True) for k, v in bt.items()})   # (concatenate on the device: 35 MB per group on the host cost 10 ms)
+            """(device batch, host batches, sizes): the loader's batches, `batch_requests` of them at a time as one
+            (dynamic batching: rows never interact; concatenated on the device: 35 MB per group on the host cost 10 ms)."""
+            pend, hosts = [], []
+            for dbt, hbt in DevicePrefetcher(dl, dev, depth=2, hold=max(1, G)):
+                if dev.type != "cuda" or not all(v.is_cuda for v in dbt.values()):
+                    dbt = {k: v.to(dev) for k, v in dbt.items()}
+                if G <= 1:
+                    yield dbt, [hbt], [next(iter(dbt.values())).shape[0]]
+                    continue
+                pend.append(dbt)
+                hosts.append(hbt)
                 if len(pend) == G:
-                    yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, [next(iter(p_.values())).shape[0] for p_ in pend]
-                    pend = []
+                    yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, hosts, [next(iter(p_.values())).shape[0] for p_ in pend]
+                    pend, hosts = [], []
             if pend:
-                yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, [next(iter(p_.values())).shape[0] for p_ in pend]
+                yield {k: torch.cat([p_[k] for p_ in pend], dim=0) for k in pend[0]}, hosts, [next(iter(p_.values())).shape[0] for p_ in pend]
 
-        for batch, sizes in batches():
-            batch = {k: v.to(self.device) for k, v in batch.items()}
+        for batch, hosts, sizes in batches():
             b = next(iter(batch.values())).shape[0]
             with torch.no_grad():
-                out = model(batch)
+                T = host_T(hosts) if getattr(model, "supports_T_hint", False) else None
+                out = model(batch, T=T) if T is not None else model(batch)
                 if loss_fn is not None:
                     # the loss of every loader batch on its own rows: the reference averages per-batch means (:113-127)
                     lo = 0
@@ -210,19 +208,61 @@ class Evaluator(torch.nn.Module):
                               nsrl=out["mdl_outs_eval"].shape[2], meta=meta,
                               meta_w={k: int(batch[k].numel() // rec.shape[0]) for k in meta},
                               meta_1d={k: batch[k].dim() == 1 for k in meta})
-                width = rec.shape[1] + 2 * sum(layout["meta_w"].values()) + 1
-                ring = D.RecordRing(rows_ring, width, self.GATHER_EVERY, rec.device, on_half=on_half)
+                ring = D.RecordRing(rows_ring, rec.shape[1], self.GATHER_EVERY, rec.device, on_half=on_half)
             nb = rec.shape[0]
             assert nb <= layout["B"], (f"batch of {nb} queries, the exchange ring holds {layout['B']} per entry "
                                        "(cfg.train.bsv x cfg.hip.batch_requests, or the first batch if larger)")
-            row = torch.cat([rec] + [batch[k].reshape(nb, -1).to(torch.float64).view(torch.float32) for k in meta]
-                            + [torch.ones(nb, 1, dtype=torch.float32, device=rec.device)], dim=1)
+            # metadata of the entry's rows from the HOST batches (a device-resident loader batch is read back: a sync per batch)
+            m = np.zeros((layout["B"], sum(layout["meta_w"].values()) + 1), dtype=np.int64)
+            lo = 0
+            for hbt, sz in zip(hosts, sizes):
+                off = 0
+                for k in meta:
+                    w = layout["meta_w"][k]
+                    m[lo:lo + sz, off:off + w] = hbt[k].detach().cpu().numpy().reshape(sz, w)
+                    off += w
+                lo += sz
+            m[:nb, -1] = 1                             # real rows: a short batch (validation loaders keep the tail,
+            meta_rows.append(m)                        # drop_last=is_train, utils/trn_utils.py:200-203) is padded to the ring's rows
+            row = rec
             if nb < layout["B"]:
-                row = torch.cat([row, row.new_zeros(layout["B"] - nb, row.shape[1])], dim=0)
+                row = torch.cat([rec, rec.new_zeros(layout["B"] - nb, rec.shape[1])], dim=0)
             ring.push(row, torch.cuda.current_stream() if rec.is_cuda else None)
         if ring is not None:
             ring.flush()
-        chunks = [c for r in range(world) for c in by_rank[r]]          # (rank, batch) order: the reference's merge order
+        # the metadata of every rank on rank 0: one exchange for the whole loop
+        meta_all = None
+        if meta_rows:
+            mine = np.stack(meta_rows)                 # [entries, rows_ring, W + 1]
+            if world > 1:
+                t = torch.from_numpy(mine).to(dev)
+                cnt = torch.tensor([t.shape[0], -t.shape[0]], dtype=torch.int64, device=dev)
+                torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MAX)
+                assert int(cnt[0]) == -int(cnt[1]), "every rank must run the same number of validation batches (DistributedSampler pads)"
+                outl = [torch.empty_like(t) for _ in range(world)]
+                torch.distributed.all_gather(outl, t)
+                meta_all = [o.cpu().numpy() for o in outl] if D.is_main_process() else None
+            else:
+                meta_all = [mine]
+        # kept as numpy columns; the reference's per-query dicts of Python lists (eval_vsrl_corr.py:247-273) are never
+        # built: rank 0 writes their pickle bytes directly (fast_pickle.dumps_records, byte-identical;
+        # `tolist` + `pickle.dumps` of 512 queries cost 170 ms = a 3 k queries/s ceiling for the whole validation loop)
+        chunks = []                                    # (rank, batch) order: the reference's merge order
+        if D.is_main_process() and meta_all is not None:
+            for r in range(world):
+                rows = np.concatenate(rec_rows[r], axis=0) if rec_rows[r] else np.zeros((0, layout["rw"]), np.float32)
+                mr = meta_all[r].reshape(-1, meta_all[r].shape[-1])
+                assert rows.shape[0] == mr.shape[0], (rows.shape, mr.shape)
+                keep = mr[:, -1] > 0
+                u = self.unpack(torch.from_numpy(np.ascontiguousarray(rows[keep])), layout["ncmp"], layout["nsrl"])
+                cols = {"pred_boxes": u["boxes"].numpy(), "pred_scores": u["scores"].numpy(), "pred_cmp": u["indexs"].numpy()}
+                off = 0
+                for k in layout["meta"]:
+                    w = layout["meta_w"][k]
+                    mk = mr[keep][:, off:off + w]
+                    cols[self.META_NAMES[k]] = np.ascontiguousarray(mk[:, 0] if layout["meta_1d"][k] else mk)
+                    off += w
+                chunks.append(cols)
         merged = {k: np.concatenate([c[k] for c in chunks], axis=0) for k in chunks[0]} if chunks else {}
         val_loss = {k: (v / max(1, nums)).float() for k, v in losses.items()}
         if D.get_world_size() > 1:

@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvog_hip.so")
+# VOG_HIP_LIB: an experiment hook (scratch/build_variant.sh builds variants of the library with other compile-time knobs)
+LIB_PATH = os.environ.get("VOG_HIP_LIB") or os.path.join(_HERE, "csrc", "libvog_hip.so")
 
 VOG_BF16, VOG_F16 = 0, 1
 MDL_KIND = {"igrnd": 0, "vgrnd": 1, "vog": 2}
@@ -157,6 +158,13 @@ class AssembleArgs(C.Structure):
                 ("B", c_i32), ("ncmp", c_i32), ("nfrm0", c_i32), ("nppf0", c_i32), ("prop_dim", c_i32),
                 ("seg_dim", c_i32), ("G", c_i32), ("nv", c_i32), ("nsrl", c_i32), ("nbox", c_i32),
                 ("conc_type", c_i32), ("vid_w", c_f32)]
+
+
+class CopySeg(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("bytes", C.c_size_t)]
+
+
+MAX_COPY_SEGS = 24
 
 
 class PredcmpArgs(C.Structure):
@@ -316,6 +324,9 @@ SYMBOLS = {
     "vog_forward": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp]),
     "vog_workspace_stage": (c_i32, [c_vp, c_i32, c_i32, c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "vog_graph_capture": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_vp, C.POINTER(c_vp)]),
+    "vog_graph_capture_fed": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.POINTER(CopySeg), C.POINTER(AssembleArgs),
+                                      C.POINTER(CopySeg), c_i32, c_vp, C.POINTER(c_vp)]),
+    "vog_copy_segments": (c_i32, [C.POINTER(CopySeg), c_i32, c_vp]),
     "vog_ctx_set_int": (c_i32, [c_vp, C.c_char_p, c_i32]),
     "vog_graph_launch": (c_i32, [c_vp, c_vp]),
     "vog_graph_destroy": (c_i32, [c_vp]),

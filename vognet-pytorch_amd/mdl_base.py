@@ -9,7 +9,7 @@ libvog_hip.so (engine.py). There is no torch compute on the path.
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -159,13 +159,18 @@ class AnetBaseMdl(nn.Module):
             self._uploaded_version = ver
         return self._engine
 
-    def forward(self, inp: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    supports_T_hint = True
+
+    def forward(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """`forward(inp) -> {'mdl_outs', 'mdl_outs_eval'[, 'vidf_outs',
         'fin_scores_loss', 'fin_scores']}` as Conc{TEMP,SPAT,SEP}.forward
         (mdl_conc_single.py:68-127; mdl_conc_sep.py:131-217). Inputs are
         borrowed and NOT modified (the reference overwrites srl_arg_word_mask).
-        Adds '_pred_rec': packed prediction records of the evaluator head."""
-        out = self.engine().forward(inp, with_pred=True)
+        Adds '_pred_rec': packed prediction records of the evaluator head.
+        `T`: the longest sentence of the batch if the caller already knows it (from the HOST copy of
+        `srl_arg_word_mask_len`); without it the length is read back from the device as in the reference
+        (mdl_vog.py:257 `.max().item()`), which drains the stream once per batch."""
+        out = self.engine().forward(inp, T=T, with_pred=True)
         res = {k: v for k, v in out.items() if not k.startswith("_") and k != "pred_rec"}
         res["_pred_rec"] = out["pred_rec"]
         return res
