@@ -399,8 +399,12 @@ struct LstmLayerBody {
         // group AHEAD of the MFMAs that use them (two register sets; the scheduling fences keep hipcc from
         // folding the groups back into read-2 / wait / MFMA-2, which exposes the LDS latency 16 times per
         // step: 0.95 us of a 3 us step in round 2)
+        // Group size 2 (round 4; 8 before): the layer kernel allocates 190 registers instead of 238, i.e. 2 x 192 of a SIMD lane's
+        // 512 - what is left holds one wave of a <= 128-register workgroup, so the lean kernels of OTHER forwards share the 64 CUs a
+        // layer holds for 35-45 us (+8 % at 128 CUs, +2 % single stream, neutral at 256 CUs / 4 streams; same accumulation order:
+        // even k-steps -> acc0, odd -> acc1, bit-identical). profiles/round4_cu_bound_experiments.md, section 7
 #ifndef VOG_LSTM_G
-#define VOG_LSTM_G 8
+#define VOG_LSTM_G 2
 #endif
         constexpr int G = KSTEPS < VOG_LSTM_G ? KSTEPS : VOG_LSTM_G;
         u16x8 fa[G], fb[G];

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void vis_enc_kernel(VisEncParams a) {
 // 32 workgroups, ~1 MB through each CU: ~25 us (proposals) / ~37 us (segments), ~900 CU*us.
 // ---------------------------------------------------------------------------------------------------
 #ifndef VOG_VE_G
-#define VOG_VE_G 8
+#define VOG_VE_G 4
 #endif
 template <typename T16>
 struct VisEncLeanBody {
