@@ -13,3 +13,4 @@ m.main_dist("v", only_val=True, synthetic_batches=128, **kw)
 pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:6000])
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_callees("eval_vsrl_corr.py:.*forward"); print(s.getvalue()[:9000])

@@ -156,7 +156,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
              "vog_attn_struct_args": L.AttnStructArgs, "vog_visprep_args": L.VisprepArgs,
              "vog_lstm_step_args": L.LstmStepArgs, "vog_lstm_layer_args": L.LstmLayerArgs,
              "vog_vislang_args": L.VislangArgs, "vog_score_args": L.ScoreArgs,
-             "vog_predcmp_args": L.PredcmpArgs, "vog_pred_args": L.PredArgs, "vog_tx_tail_args": L.TxTailArgs, "vog_encoder_layer_args": L.EncoderLayerArgs, "vog_visenc_args": L.VisencArgs, "vog_loss_args": L.LossArgs, "vog_tail_bwd_args": L.TailBwdArgs, "vog_attn_f32_args": L.AttnF32Args, "vog_linear_f32_args": L.LinearF32Args, "vog_lang_f32_args": L.LangF32Args, "vog_assemble_args": L.AssembleArgs,
+             "vog_predcmp_args": L.PredcmpArgs, "vog_pred_args": L.PredArgs, "vog_tx_tail_args": L.TxTailArgs, "vog_encoder_layer_args": L.EncoderLayerArgs, "vog_visenc_args": L.VisencArgs, "vog_loss_args": L.LossArgs, "vog_tail_bwd_args": L.TailBwdArgs, "vog_attn_f32_args": L.AttnF32Args, "vog_linear_f32_args": L.LinearF32Args, "vog_lang_f32_args": L.LangF32Args, "vog_assemble_args": L.AssembleArgs, "vog_copy_seg": L.CopySeg,
              "vog_model_desc": L.ModelDesc, "vog_batch": L.Batch}
     gcc = shutil.which("gcc")
     assert gcc, "gcc is part of the image"
@@ -222,3 +222,22 @@ def test_synthetic_loader_keeps_the_short_batch_last_on_its_rank():
             assert sizes[0] == bs and sizes[-1] == bs - 1 and sizes.count(bs - 1) == 1, sizes
             seen_short += 1
     assert seen_short >= 1
+
+
+def test_cpulist_parser_and_numa_binding_without_a_gpu():
+    """dist.bind_host_to_device_node: the sysfs cpulist syntax, and no GPU / no topology -> None with the affinity untouched."""
+    D = importlib.import_module("vognet-pytorch_amd.dist")
+    assert D._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert D._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    assert D.bind_host_to_device_node(0) is None
+    assert os.sched_getaffinity(0) == before
+
+
+def test_device_prefetcher_is_transparent_on_cpu():
+    """Without a GPU the prefetcher hands the loader's batches through, in order."""
+    import torch
+    dls = importlib.import_module("vognet-pytorch_amd.dat_loader_simple")
+    dl = [{"a": torch.full((2, 3), i)} for i in range(5)]
+    got = [(d["a"][0, 0].item(), h is dl[i]) for i, (d, h) in enumerate(dls.DevicePrefetcher(dl, "cpu", depth=2, hold=3))]
+    assert got == [(i, True) for i in range(5)]
