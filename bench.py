@@ -12,6 +12,14 @@ captured hipGraph with its own inputs, workspace and outputs), so several
 batches are in flight — the regime SURVEY.md section 7 calls for, since one batch is
 ~50 dependent launches. `--streams 1` gives the serial latency.
 
+Before the W warm-up steps the device is warmed up for `device_warmup_ms` (25 ms of the same forwards, untimed, reported in
+the JSON line; VOG_BENCH_BURNIN_MS=0 turns it off): the clocks of an idle MI355X are not up after W = 5 steps (0.4 ms), and a
+K = 20 region then reads 52 k instead of 55-56 k queries/s. The timed region is exactly K steps between barrier + synchronize.
+Side measurements in the same line (never `value`): `value_hbm_inputs` (--rotate-inputs N distinct input sets: features from HBM),
+`requests_batched4`, `batch_assembly.measured_host_fed` / `measured_host_fed_graph` (inputs start in pinned host memory every step:
+per-call loop / engine.FedPipeline), `training_step`, `cpu_baseline`. The process binds itself to its GPU's NUMA node
+(`host_numa_node`; VOG_BENCH_NUMA_BIND=0 leaves the affinity alone).
+
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
 from __future__ import annotations
@@ -495,6 +503,15 @@ def main():
                 if inflight[g]:
                     wait_group(g)
 
+        # device warm-up in front of the W warm-up steps (untimed, reported as `device_warmup_ms`): an idle MI355X needs some
+        # milliseconds of work before its clocks are up - 5 warm-up steps are 0.4 ms. K = 20 from a cold device: 52.2 k queries/s,
+        # after 20 ms of forwards: 55.3-56.4 k; K = 400 does not care (scratch/r4_burn.sh). VOG_BENCH_BURNIN_MS=0 turns it off.
+        burn_ms = float(os.environ.get("VOG_BENCH_BURNIN_MS", "25"))
+        if burn_ms > 0 and not aql:
+            tb = time.perf_counter()
+            while (time.perf_counter() - tb) * 1e3 < burn_ms:
+                run(4 * max(1, nunits) * G)
+                torch.cuda.synchronize()
         run(warmup)
         fence()
         t0 = time.perf_counter()
@@ -595,7 +612,7 @@ def main():
         # or a failed parity check make the timing meaningless
         "value": value if (parity["ok"] and not experiments) else None, "unit": "queries/s",
         "parity": parity,
-        "n_gpus": world, "host_numa_node": numa_node, "rccl_ranks": dist.get_world_size() if use_dist else 1, "per_rank_value": value / world,
+        "n_gpus": world, "host_numa_node": numa_node, "device_warmup_ms": float(os.environ.get("VOG_BENCH_BURNIN_MS", "25")), "rccl_ranks": dist.get_world_size() if use_dist else 1, "per_rank_value": value / world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": w["tx"], "data": "synthetic",
