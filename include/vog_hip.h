@@ -181,8 +181,11 @@ typedef struct vog_attn_args {
    * dims <= 192 run attn_tile2_kernel (64 queries per wave, softmax against a fixed per-row reference
    * overlapped with the MFMAs; csrc/attn_tile2_dev.h); the flag is cleared, raised by the kernel if a
    * row left the safe range of that formulation, and a second (normally empty) launch of the
-   * running-maximum kernel redoes the call when it was raised. NULL: running-maximum kernel only. */
+   * running-maximum kernel redoes the call when it was raised. NULL: running-maximum kernel only.
+   * guard_precleared != 0: the caller guarantees *guard_flag == 0 on entry (vog_forward keeps the flags in the workspace
+   * region its prologue zero-fills), so the clearing launch is skipped. */
   int* guard_flag;
+  int guard_precleared;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
 

@@ -168,7 +168,8 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_t2 = true;
       }
-      ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: recorded by the AQL path too)
+      if (!p.guard_precleared)
+        ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: recorded by the AQL path too)
       dim3 grid(ceil_div(p.N, 256) * p.H * p.S);
       ::vog::launch(kern, grid, dim3(512), lds2, st, p);
       VOG_LAUNCH_CHECK();
@@ -251,7 +252,7 @@ int attn_run(const vog_attn_args* a, hipStream_t st) {
   p.u = a->u; p.pe_b = a->pe_b;
   p.S = a->S; p.N = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad; p.use_rel = a->use_rel;
   p.n_box = a->n_box; p.seq_per_vid = a->seq_per_vid; p.NP = a->NP; p.inv_scale = a->inv_scale;
-  p.guard = a->guard_flag;
+  p.guard = a->guard_flag; p.guard_precleared = a->guard_precleared;
   VOG_DISPATCH_DTYPE(a->dtype, return attn_dispatch<T16>(p, st));
   return 0;
 }

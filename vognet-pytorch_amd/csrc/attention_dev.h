@@ -13,6 +13,7 @@ struct AttnParams {
   float inv_scale;
   int* guard;       // attn_tile2_kernel: set to 1 when its fixed-reference softmax left its safe range;
                     // attn_tile_kernel: when non-null, run only if *guard != 0 (fallback pass)
+  int guard_precleared;   // host side only: *guard is already 0 (no clearing launch)
 };
 
 template <typename T16, int NDB>

@@ -343,6 +343,8 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   p.add("argvec_sync", 256);                          // arrival counter of the out-projection's argument-vector tail
   p.add("pred_sync", 256);                            // arrival counter of the score tail's prediction head
   p.add("chain_flags", 1024);                         // done flags of the lean encoder workgroups (chain_obj_qkv)
+  p.add("obj_guard", 256);                            // vog_attn_args.guard_flag of the two stacks (long-sequence attention): zeroed
+  p.add("mul_guard", 256);                            // with the rest of this region, so the attention needs no clearing launch
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -365,7 +367,6 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
     const std::string n(nm);
     p.add(n + "_u", g.rows_obj * tw.H * 4);
-    p.add(n + "_guard", 256);                 // vog_attn_args.guard_flag (long-sequence attention)
     p.add(n + "_q", (int64_t)S * tw.H * tw.dp * npad * 2);      // fragment order, npad = N up to 32
     p.add(n + "_k", (int64_t)S * tw.H * tw.dp * npad * 2);
     p.add(n + "_vt", (int64_t)S * tw.H * tw.dp * npad * 2);
@@ -471,6 +472,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.use_rel = tw.use_rel; aa.n_box = n_box; aa.seq_per_vid = spv; aa.NP = g.NP;
     aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
     aa.guard_flag = ws.at<int>(n + "_guard");
+    aa.guard_precleared = 1;
     if (!fact)
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
     const bool last = l == tw.n_layers - 1;

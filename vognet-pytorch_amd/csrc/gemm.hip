@@ -249,7 +249,11 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
     p.w_p32 = (const unsigned short*)a->wqkv_p32;
     p.dep_flags = a->dep_flags; p.dep_nb0 = a->dep_nb0; p.dep_rep = a->dep_rep; p.dep_nh0 = a->dep_nh0; p.dep_nh1 = a->dep_nh1;
     if (a->dep_flags) VOG_CHECK_ARG(a->dep_rep >= 1 && a->dep_nb0 >= 1 && a->dep_nh0 >= 1 && a->dep_nh1 >= 1);
-    static const int narrow = perf_env("VOG_QKV_NARROW") ? atoi(perf_env("VOG_QKV_NARROW")) : 0;
+    // 256 instead of 512 columns per workgroup (84 instead of 146 registers: two or three workgroups share a CU and overlap their
+    // staging / streaming / epilogue phases) from 8192 rows: cfg 4 67.2 -> 58.8 and 82.2 -> 74.2 us, 5285 -> 5360 queries/s;
+    // at the few hundred rows of gt5 the wide form holds fewer CUs. VOG_QKV_NARROW = 0 / 1 forces (perf experiments).
+    static const int narrow_env = perf_env("VOG_QKV_NARROW") ? atoi(perf_env("VOG_QKV_NARROW")) : -1;
+    const int narrow = narrow_env >= 0 ? narrow_env : (p.M >= 8192 && !a->dep_flags ? 1 : 0);
     const int nrb = ceil_div(p.M, 64);
     const size_t lds = QkvRowBlockBody<F16, 2>::lds_bytes(p.K);
 #define VOG_QKVRB(NBWV)                                                                                        \

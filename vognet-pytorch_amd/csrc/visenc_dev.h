@@ -124,11 +124,21 @@ __global__ __launch_bounds__(512) void vis_enc_kernel(VisEncParams a) {
 #ifndef VOG_VE_G
 #define VOG_VE_G 4
 #endif
-template <typename T16>
+#ifndef VOG_VE_BOTH
+#define VOG_VE_BOTH 0
+#endif
+// BOTH (round 4, measured and left OFF): ONE workgroup computes both 128-column halves of its 64 rows from the same staged A
+// images - the fp32 rows cross the CU's vector memory path once instead of twice (1.5 instead of 2 MB per row block); the blocks
+// that used to own the second halves exit at once. Half as many workgroups, each a longer dependent chain: cfg 4 72 -> 94 us,
+// a cfg-2 forward alone 201 -> 218 us, 57.5 -> 55.5 k queries/s (scratch/r4_ve.sh): the kernel is bound by the latency of a
+// workgroup's chunk loop and by how many of them run side by side, not by ingest bytes. Per chunk: half 0 with the weight set loaded
+// during the previous unit, half 1 with the set loaded during half 0; accumulation order per column unchanged (bit-identical).
+template <typename T16, bool BOTH = (VOG_VE_BOTH != 0)>
 struct VisEncLeanBody {
   using Params = VisEncParams;
   static constexpr int THREADS = 512;
   static constexpr int RB = 64, KC = 256;
+  static constexpr int NH = BOTH ? 2 : 1;
   static constexpr size_t LDS = (size_t)2 * (RB / 16) * (KC / 32) * 1024;       // two A-chunk images (fragment order)
 
   static __device__ __forceinline__ void run(const VisEncParams& a, const BlockCtx& cx, unsigned char* smem) {
@@ -140,8 +150,9 @@ struct VisEncLeanBody {
     // on the same XCD (block b is dealt to XCD b % 8), so the second read is served by that XCD's L2
     // (2.1 x over-fetch at p100 with the halves on neighbouring XCDs)
     const int grp = cx.bx >> 4, pos = cx.bx & 15;
-    const int blk = grp * 8 + (pos & 7), half = pos >> 3;
+    const int blk = grp * 8 + (pos & 7), half0 = pos >> 3;
     if (blk >= nb_all) return;
+    if (BOTH && half0 != 0) return;
     const bool second = blk >= nb0;
     const float* qx = second ? a.p[1].x : a.p[0].x;
     const unsigned short* qw = second ? a.p[1].w : a.p[0].w;
@@ -150,16 +161,23 @@ struct VisEncLeanBody {
     const int qK = second ? a.p[1].K : a.p[0].K, qrep = second ? a.p[1].rep : a.p[0].rep;
     const int qcol0 = second ? a.p[1].col0 : a.p[0].col0;
     const int m0 = (second ? blk - nb0 : blk) * RB;
-    const int n0 = half * 128 + w * 16;                      // this wave's 16 columns
-    if (half * 128 >= qN) return;
-    const bool n_ok = n0 < qN;
+    if (half0 * 128 >= qN) return;
+    const int nh = BOTH ? (qN > 128 ? 2 : 1) : 1;            // halves this workgroup computes
     const int ksteps = qK >> 5, nchunk = qK / KC;            // K % 256 == 0
-    const u16x8* wf = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok ? n0 : 0) >> 4) * ksteps) * 64 + lane;
+    int n0[NH]; bool n_ok[NH]; const u16x8* wf[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      n0[h] = (half0 + h) * 128 + w * 16;                    // this wave's 16 columns of half h
+      n_ok[h] = n0[h] < qN;
+      wf[h] = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok[h] ? n0[h] : 0) >> 4) * ksteps) * 64 + lane;
+    }
     // A staging: thread -> (row, 8-column piece): 32 pieces per row and chunk, 16 rows per pass, 4 passes
     const int pr = tid >> 5, pc = tid & 31;
-    f32x4 acc[RB / 16];
+    f32x4 acc[NH][RB / 16];
 #pragma unroll
-    for (int mt = 0; mt < RB / 16; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int mt = 0; mt < RB / 16; ++mt) acc[h][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 xa[4][2];
     u16x8 wq[2][8];
     auto load_a = [&](int c) {
@@ -182,18 +200,17 @@ struct VisEncLeanBody {
         *reinterpret_cast<u16x8*>(img + ((ps * (KC / 32) + ks) * 64 + kgp * 16 + pr) * 16) = h;
       }
     };
-    auto load_w = [&](u16x8 (&q)[8], int c) {
+    auto load_w = [&](u16x8 (&q)[8], int c, int h) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) q[ks] = wf[(c * 8 + ks) * 64];
+      for (int ks = 0; ks < 8; ++ks) q[ks] = wf[h][(c * 8 + ks) * 64];
     };
-    auto mfmas = [&](const u16x8 (&q)[8], int c) {
-      // A fragments of a row tile (8 k-steps) are requested together, one tile AHEAD of the MFMAs that use
-      // them (the scheduling fences keep hipcc from folding this into read-2 / wait / MFMA-2, which exposes
-      // the LDS latency 16 times per chunk)
+    auto mfmas = [&](const u16x8 (&q)[8], int c, f32x4 (&ac)[RB / 16]) {
+      // A fragments come from LDS in units of VG k-steps, one unit AHEAD of the MFMAs that use them (the scheduling fences
+      // keep hipcc from folding this into read-2 / wait / MFMA-2, which exposes the LDS latency 16 times per chunk).
+      // unit u = (row tile u / UPT, k-steps (u % UPT) * VG ...); VG = 4 keeps the whole body under 192 registers, which is
+      // what lets a <= 128-register workgroup of another stream share the CU when this body rides in the BiLSTM layer's
+      // launch (the pair kernel allocates the maximum of its two bodies)
       const unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
-      // units of VG k-steps: unit u = (row tile u / UPT, k-steps (u % UPT) * VG ...); VG = 4 keeps the whole body under
-      // 192 registers, which is what lets a <= 128-register workgroup of another stream share the CU when this body
-      // rides in the BiLSTM layer's launch (the pair kernel allocates the maximum of its two bodies)
       constexpr int VG = VOG_VE_G, UPT = 8 / VG, NU = (RB / 16) * UPT;
       u16x8 fa[VG], fb[VG];
       auto rd = [&](u16x8 (&f)[VG], int u) {
@@ -208,77 +225,99 @@ struct VisEncLeanBody {
         rd(fb, u + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < VG; ++j) acc[u / UPT] = mfma16<T16>(fa[j], q[(u % UPT) * VG + j], acc[u / UPT]);
+        for (int j = 0; j < VG; ++j) ac[u / UPT] = mfma16<T16>(fa[j], q[(u % UPT) * VG + j], ac[u / UPT]);
         __builtin_amdgcn_sched_barrier(0);
         if (u + 2 < NU) rd(fa, u + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < VG; ++j) acc[(u + 1) / UPT] = mfma16<T16>(fb[j], q[((u + 1) % UPT) * VG + j], acc[(u + 1) / UPT]);
+        for (int j = 0; j < VG; ++j) ac[(u + 1) / UPT] = mfma16<T16>(fb[j], q[((u + 1) % UPT) * VG + j], ac[(u + 1) / UPT]);
       }
     };
     // (fence-free barriers: __syncthreads() would wait for the next chunk's loads, issued just above it)
-    load_a(0); load_w(wq[0], 0);
-    for (int c = 0; c < nchunk; c += 2) {
-      store_a(c);                                            // image (c & 1) was last read two chunks ago
-      if (c + 1 < nchunk) { load_a(c + 1); load_w(wq[1], c + 1); }
-      lds_barrier();
-      mfmas(wq[0], c);
-      if (c + 1 < nchunk) {
-        store_a(c + 1);
-        if (c + 2 < nchunk) { load_a(c + 2); load_w(wq[0], c + 2); }
+    if constexpr (!BOTH) {
+      load_a(0); load_w(wq[0], 0, 0);
+      for (int c = 0; c < nchunk; c += 2) {
+        store_a(c);                                            // image (c & 1) was last read two chunks ago
+        if (c + 1 < nchunk) { load_a(c + 1); load_w(wq[1], c + 1, 0); }
         lds_barrier();
-        mfmas(wq[1], c + 1);
+        mfmas(wq[0], c, acc[0]);
+        if (c + 1 < nchunk) {
+          store_a(c + 1);
+          if (c + 2 < nchunk) { load_a(c + 2); load_w(wq[0], c + 2, 0); }
+          lds_barrier();
+          mfmas(wq[1], c + 1, acc[0]);
+        }
+      }
+    } else {
+      // units (chunk c, half h): weight set u & 1; the set of unit u + 1 is in flight while unit u computes
+      load_a(0); load_w(wq[0], 0, 0);
+      for (int c = 0; c < nchunk; ++c) {
+        store_a(c);                                            // image (c & 1) was last read two chunks ago
+        if (c + 1 < nchunk) load_a(c + 1);
+        if (nh == 2) load_w(wq[1], c, NH - 1);
+        lds_barrier();
+        mfmas(wq[0], c, acc[0]);
+        if (c + 1 < nchunk) load_w(wq[0], c + 1, 0);
+        if (nh == 2) mfmas(wq[1], c, acc[NH - 1]);
       }
     }
     // D[row = 4*(lane>>4) + reg][col = lane & 15]
-    const int col = n0 + (lane & 15);
     const bool chained = a.done_flags != nullptr && a.c16 != nullptr && (a.ldc & 7) == 0 && (qcol0 & 7) == 0;
     // chained form (consumers in the same launch): the 16-bit tile is parked in LDS and written THROUGH as 16-byte chunks
     // (2-byte write-through stores, one per lane and element, cost more than the launch the chaining saves)
     constexpr int TP = 128 + 8;                                // tile pitch in halfwords (272 B: 16-byte aligned rows)
     unsigned short* tile = reinterpret_cast<unsigned short*>(smem);
-    if (chained) __syncthreads();                              // every wave is done reading the A images
-    if (n_ok && col < qN) {
-      const float b = qb[col];
 #pragma unroll
-      for (int mt = 0; mt < RB / 16; ++mt)
+    for (int h = 0; h < NH; ++h) {
+      if (h >= nh) break;
+      const int half = half0 + h;
+      const int col = n0[h] + (lane & 15);
+      if (chained) __syncthreads();                            // every wave is done reading the A images / the previous half's tile
+      if (n_ok[h] && col < qN) {
+        const float b = qb[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rl = mt * 16 + (lane >> 4) * 4 + r;
-          const int row = m0 + rl;
-          if (row >= qM) continue;
-          const float o = fmaxf(acc[mt][r] + b, 0.f);
-          const unsigned short h = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
-          if (chained) tile[rl * TP + w * 16 + (lane & 15)] = h;
-          const int nrep = a.rep_first_only ? 1 : qrep;
-          for (int j = 0; j < nrep; ++j) {
-            const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
-            if (a.c32) a.c32[off] = o;
-            if (a.c16 && !chained) {
-              if (a.done_flags) __hip_atomic_store(&a.c16[off], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write through
-              else a.c16[off] = h;
+        for (int mt = 0; mt < RB / 16; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = mt * 16 + (lane >> 4) * 4 + r;
+            const int row = m0 + rl;
+            if (row >= qM) continue;
+            const float o = fmaxf(acc[h][mt][r] + b, 0.f);
+            const unsigned short hv = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+            if (chained) tile[rl * TP + w * 16 + (lane & 15)] = hv;
+            const int nrep = a.rep_first_only ? 1 : qrep;
+            for (int j = 0; j < nrep; ++j) {
+              const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
+              if (a.c32) a.c32[off] = o;
+              if (a.c16 && !chained) {
+                if (a.done_flags) __hip_atomic_store(&a.c16[off], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write through
+                else a.c16[off] = hv;
+              }
             }
           }
+      }
+      if (chained) {
+        __syncthreads();
+        const int ncol_wg = (qN - half * 128) < 128 ? (qN - half * 128) : 128;     // columns of this half (multiple of 16)
+        const int cpr = ncol_wg >> 3;                                               // 16-byte chunks per row
+        const int nrep = a.rep_first_only ? 1 : qrep;
+        const int rows_wg = (qM - m0) < RB ? (qM - m0) : RB;
+        const int total = rows_wg * nrep * cpr;
+        for (int id = tid; id < total; id += THREADS) {
+          const int ch = id % cpr, rj = id / cpr, j = rj % nrep, rl = rj / nrep;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tile + rl * TP + ch * 8);
+          u32x4* dst = reinterpret_cast<u32x4*>(a.c16 + ((int64_t)(m0 + rl) * qrep + j) * a.ldc + qcol0 + half * 128 + ch * 8);
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
         }
-    }
-    if (chained) {
-      __syncthreads();
-      const int ncol_wg = (qN - half * 128) < 128 ? (qN - half * 128) : 128;     // columns this workgroup owns (multiple of 16)
-      const int cpr = ncol_wg >> 3;                                               // 16-byte chunks per row
-      const int nrep = a.rep_first_only ? 1 : qrep;
-      const int rows_wg = (qM - m0) < RB ? (qM - m0) : RB;
-      const int total = rows_wg * nrep * cpr;
-      for (int id = tid; id < total; id += THREADS) {
-        const int ch = id % cpr, rj = id / cpr, j = rj % nrep, rl = rj / nrep;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(tile + rl * TP + ch * 8);
-        u32x4* dst = reinterpret_cast<u32x4*>(a.c16 + ((int64_t)(m0 + rl) * qrep + j) * a.ldc + qcol0 + half * 128 + ch * 8);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
       }
     }
     if (a.done_flags) {                                       // every thread of the workgroup gets here
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(&a.done_flags[blk * 2 + half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        for (int h = 0; h < nh; ++h)
+          __hip_atomic_store(&a.done_flags[blk * 2 + half0 + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 };
