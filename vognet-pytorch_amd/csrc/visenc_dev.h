@@ -124,6 +124,9 @@ __global__ __launch_bounds__(512) void vis_enc_kernel(VisEncParams a) {
 #ifndef VOG_VE_G
 #define VOG_VE_G 4
 #endif
+#ifndef VOG_VE_KC
+#define VOG_VE_KC 256
+#endif
 #ifndef VOG_VE_BOTH
 #define VOG_VE_BOTH 0
 #endif
@@ -137,9 +140,12 @@ template <typename T16, bool BOTH = (VOG_VE_BOTH != 0)>
 struct VisEncLeanBody {
   using Params = VisEncParams;
   static constexpr int THREADS = 512;
-  static constexpr int RB = 64, KC = 256;
+  static constexpr int RB = 64, KC = VOG_VE_KC;
+  static constexpr int KSC = KC / 32;                       // k-steps per chunk
+  static constexpr int PIECES = KC / 8, RPP = THREADS / PIECES, NPASS = RB / RPP;   // A staging: 8-float pieces per row, rows per pass
   static constexpr int NH = BOTH ? 2 : 1;
-  static constexpr size_t LDS = (size_t)2 * (RB / 16) * (KC / 32) * 1024;       // two A-chunk images (fragment order)
+  static constexpr size_t LDS = (size_t)2 * (RB / 16) * (KC / 32) * 1024 > (size_t)RB * (128 + 8) * 2
+                                    ? (size_t)2 * (RB / 16) * (KC / 32) * 1024 : (size_t)RB * (128 + 8) * 2;   // two A-chunk images (fragment order) | the chained epilogue's tile
 
   static __device__ __forceinline__ void run(const VisEncParams& a, const BlockCtx& cx, unsigned char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,19 +177,19 @@ struct VisEncLeanBody {
       n_ok[h] = n0[h] < qN;
       wf[h] = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok[h] ? n0[h] : 0) >> 4) * ksteps) * 64 + lane;
     }
-    // A staging: thread -> (row, 8-column piece): 32 pieces per row and chunk, 16 rows per pass, 4 passes
-    const int pr = tid >> 5, pc = tid & 31;
+    // A staging: thread -> (row, 8-column piece): PIECES pieces per row and chunk, RPP rows per pass, NPASS passes
+    const int pr = tid / PIECES, pc = tid % PIECES;
     f32x4 acc[NH][RB / 16];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int mt = 0; mt < RB / 16; ++mt) acc[h][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 xa[4][2];
-    u16x8 wq[2][8];
+    float4 xa[NPASS][2];
+    u16x8 wq[2][KSC];
     auto load_a = [&](int c) {
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        int m = m0 + ps * 16 + pr;
+      for (int ps = 0; ps < NPASS; ++ps) {
+        int m = m0 + ps * RPP + pr;
         m = m < qM ? m : qM - 1;
         const float* src = qx + (int64_t)m * qK + c * KC + pc * 8;
         xa[ps][0] = *reinterpret_cast<const float4*>(src);
@@ -191,32 +197,33 @@ struct VisEncLeanBody {
       }
     };
     auto store_a = [&](int c) {      // -> fragment order [m tile][k-step][lane = kgroup*16 + m%16][8 halfwords]
-      unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
+      unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * KSC * 1024;
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
+      for (int ps = 0; ps < NPASS; ++ps) {
         const u16x8 h = {to16<T16>(xa[ps][0].x), to16<T16>(xa[ps][0].y), to16<T16>(xa[ps][0].z), to16<T16>(xa[ps][0].w),
                          to16<T16>(xa[ps][1].x), to16<T16>(xa[ps][1].y), to16<T16>(xa[ps][1].z), to16<T16>(xa[ps][1].w)};
         const int ks = pc >> 2, kgp = pc & 3;
-        *reinterpret_cast<u16x8*>(img + ((ps * (KC / 32) + ks) * 64 + kgp * 16 + pr) * 16) = h;
+        const int rl = ps * RPP + pr;                          // row of the block: tile rl / 16, row rl % 16 of the tile
+        *reinterpret_cast<u16x8*>(img + (((rl >> 4) * KSC + ks) * 64 + kgp * 16 + (rl & 15)) * 16) = h;
       }
     };
-    auto load_w = [&](u16x8 (&q)[8], int c, int h) {
+    auto load_w = [&](u16x8 (&q)[KSC], int c, int h) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) q[ks] = wf[h][(c * 8 + ks) * 64];
+      for (int ks = 0; ks < KSC; ++ks) q[ks] = wf[h][(c * KSC + ks) * 64];
     };
-    auto mfmas = [&](const u16x8 (&q)[8], int c, f32x4 (&ac)[RB / 16]) {
+    auto mfmas = [&](const u16x8 (&q)[KSC], int c, f32x4 (&ac)[RB / 16]) {
       // A fragments come from LDS in units of VG k-steps, one unit AHEAD of the MFMAs that use them (the scheduling fences
       // keep hipcc from folding this into read-2 / wait / MFMA-2, which exposes the LDS latency 16 times per chunk).
       // unit u = (row tile u / UPT, k-steps (u % UPT) * VG ...); VG = 4 keeps the whole body under 192 registers, which is
       // what lets a <= 128-register workgroup of another stream share the CU when this body rides in the BiLSTM layer's
       // launch (the pair kernel allocates the maximum of its two bodies)
-      const unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * (KC / 32) * 1024;
-      constexpr int VG = VOG_VE_G, UPT = 8 / VG, NU = (RB / 16) * UPT;
+      const unsigned char* img = smem + (size_t)(c & 1) * (RB / 16) * KSC * 1024;
+      constexpr int VG = VOG_VE_G < KSC ? VOG_VE_G : KSC, UPT = KSC / VG, NU = (RB / 16) * UPT;
       u16x8 fa[VG], fb[VG];
       auto rd = [&](u16x8 (&f)[VG], int u) {
 #pragma unroll
         for (int j = 0; j < VG; ++j)
-          f[j] = *reinterpret_cast<const u16x8*>(img + (((u / UPT) * (KC / 32) + (u % UPT) * VG + j) * 64 + lane) * 16);
+          f[j] = *reinterpret_cast<const u16x8*>(img + (((u / UPT) * KSC + (u % UPT) * VG + j) * 64 + lane) * 16);
       };
       rd(fa, 0);
 #pragma unroll
