@@ -509,9 +509,16 @@ def main():
         burn_ms = float(os.environ.get("VOG_BENCH_BURNIN_MS", "25"))
         if burn_ms > 0 and not aql:
             tb = time.perf_counter()
-            while (time.perf_counter() - tb) * 1e3 < burn_ms:
+            while True:
                 run(4 * max(1, nunits) * G)
                 torch.cuda.synchronize()
+                stop = (time.perf_counter() - tb) * 1e3 >= burn_ms
+                if use_dist:                     # every rank runs the same number of rounds (the exchange ring's collectives must pair up)
+                    t = torch.tensor([1 if stop else 0], device=dev, dtype=torch.int32)
+                    dist.broadcast(t, src=0)
+                    stop = bool(int(t.item()))
+                if stop:
+                    break
         run(warmup)
         fence()
         t0 = time.perf_counter()
