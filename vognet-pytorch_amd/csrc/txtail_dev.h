@@ -3,6 +3,10 @@
 #include "common.h"
 #include "pred_dev.h"
 
+#ifndef VOG_TAIL_PF1
+#define VOG_TAIL_PF1 4      // k-steps of weight prefetch in the FFN1 stage (one 32-column block per wave); 8 measured: 84 more bytes of scratch in the mul tail, 0.5-1 % slower at cfg 2 and cfg 4 (scratch/r4_pf.sh)
+#endif
+
 namespace vog {
 
 struct TailParams {
@@ -341,10 +345,10 @@ struct TxTailBody {
     // (two blocks = two passes over K with one accumulator pair: 64 fewer live registers than one
     // pass with two pairs, which spilled x1; the extra LDS operand reads are free here)
     f32x16 hacc[1][RB];
-    tail_gemm<T16, 1, 4, true, DBG, RB>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane);
+    tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane);
     ffn1_epi(hacc[0], w);
     if (NB1 == 2 && w < 4) {
-      tail_gemm<T16, 1, 4, true, DBG, RB>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane);
+      tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane);
       ffn1_epi(hacc[0], w + 8);
     }
   }
