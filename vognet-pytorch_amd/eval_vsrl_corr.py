@@ -135,6 +135,7 @@ class Evaluator(torch.nn.Module):
         rec_rows = [[] for _ in range(world)]          # rank 0: per rank, the gathered record rows of every half (numpy)
         meta_rows = []                                 # this rank: per ring entry, int64 [rows_ring, W + 1] (last column: real row)
         losses = {}
+        loss_log = []
         nums = 0
         ring = None
         layout = {}
@@ -189,8 +190,9 @@ class Evaluator(torch.nn.Module):
                         else:
                             ld = loss_fn({k: v[lo:lo + sz] for k, v in out.items() if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == b},
                                          {k: v[lo:lo + sz] for k, v in batch.items()})
-                        for k, v in ld.items():
-                            losses[k] = losses.get(k, 0.0) + v.detach().double() * sz
+                        # (kept as 0-dim device tensors and reduced ONCE behind the loop: a running `+= v.double() * sz` is three
+                        # tiny launches per key and batch)
+                        loss_log.append(({k: v.detach() for k, v in ld.items()}, sz))
                         nums += sz
                         lo += sz
             rec = self._records(out, batch)
@@ -264,6 +266,10 @@ class Evaluator(torch.nn.Module):
                     off += w
                 chunks.append(cols)
         merged = {k: np.concatenate([c[k] for c in chunks], axis=0) for k in chunks[0]} if chunks else {}
+        if loss_log:
+            wts = torch.tensor([float(sz) for _, sz in loss_log], dtype=torch.float64, device=loss_log[0][0]["loss"].device)
+            for k in loss_log[0][0]:
+                losses[k] = (torch.stack([d[k] for d, _ in loss_log]).double() * wts).sum()
         val_loss = {k: (v / max(1, nums)).float() for k, v in losses.items()}
         if D.get_world_size() > 1:
             for k in sorted(val_loss):                 # as reduce_dict in the reference (utils/trn_utils.py:61-90)
