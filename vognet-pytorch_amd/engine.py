@@ -554,9 +554,15 @@ def paired_copy_streams(streams, device, candidates: int = 16):
     import time
     with torch.cuda.device(device):
         scratch = torch.zeros(64, device=device)
-        cyc = 1_000_000
-        torch.cuda._sleep(cyc)
-        torch.cuda.synchronize()
+        cyc = 200_000
+        for _ in range(2):                         # calibrate the spin to ~0.4 ms (the counter's rate differs between parts)
+            torch.cuda._sleep(cyc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            torch.cuda._sleep(cyc)
+            torch.cuda.synchronize()
+            spin_s = time.perf_counter() - t0
+            cyc = max(20_000, min(50_000_000, int(cyc * 4e-4 / max(spin_s, 1e-6))))
         t0 = time.perf_counter()
         torch.cuda._sleep(cyc)
         torch.cuda.synchronize()
