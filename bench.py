@@ -194,20 +194,47 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(w, cfg, sd, batch, budget_s=30.0):
+_ORIG_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None     # before any NUMA binding
+
+
+def _set_affinity_all_threads(mask):
+    """sched_setaffinity on EVERY thread of the process (torch's intra-op pool threads keep the mask they were created with)."""
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), mask)
+            except OSError:
+                pass
+    except Exception:
+        pass
+
+
+def cpu_baseline(w, cfg, sd, batch, budget_s=14.0):
     """The CPU oracle (a validated port of the reference forward, oracle/vog_oracle.py: torch-CPU fp32
     ops, manual LSTM loops; "kind": "port" - the reference itself measured 43 queries/s on cfg 2 in the
     survey probe, this port 41-42) timed on this host on the same workload, as SURVEY.md 8(d) asks:
-    N = 8 threads AND N = all physical cores, CPU model stated. `value` is the better of the two and
-    `cores` the thread count it used (the forward is a chain of small GEMMs, M = 4..4000: more
-    threads is not faster)."""
+    8 / 16 / 32 threads AND every CPU this process is ALLOWED to run on (sched_getaffinity as the process started - the
+    NUMA binding of the GPU measurement is lifted for this leg and restored after it; round 4 timed 128 threads inside a
+    one-node mask: 0.22 queries/s), CPU model stated. `value` is the best of them and `cores` the thread count it used (the
+    forward is a chain of small GEMMs, M = 4..4000: more threads is not faster)."""
     from oracle import vog_oracle as vo
-    ncpu = os.cpu_count() or 1
-    nphys = physical_cores()
+    bound = os.sched_getaffinity(0) if _ORIG_AFFINITY is not None else None
+    if _ORIG_AFFINITY is not None:
+        _set_affinity_all_threads(_ORIG_AFFINITY)
+    try:
+        return _cpu_baseline(vo, w, cfg, sd, batch, budget_s)
+    finally:
+        if bound is not None:
+            _set_affinity_all_threads(bound)
+
+
+def _cpu_baseline(vo, w, cfg, sd, batch, budget_s):
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nphys = min(physical_cores(), ncpu)
     oc = vo.OracleCfg.from_cfg(cfg, VOCAB, ec.num_prop_per_frm(cfg))
     sdt, inp = vo.to_torch(sd), vo.to_torch(batch)
     tried = {}
-    cands = sorted({min(8, ncpu), min(nphys, ncpu)})
+    cands = sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), nphys})
     WARM, TIMED = 5, 20                    # SURVEY.md 8(d) / BASELINE.md 3: >= 5 warm-up + >= 20 timed batches, median
     with torch.no_grad():
         for nt in cands:
@@ -230,7 +257,7 @@ def cpu_baseline(w, cfg, sd, batch, budget_s=30.0):
     best = min(tried, key=lambda k: tried[k][0])
     med, n, nwarm = tried[best]
     return {"value": w["B"] / med, "unit": "queries/s", "cores": best, "kind": "port",
-            "cpu_model": cpu_model(), "physical_cores": nphys, "logical_cpus": ncpu,
+            "cpu_model": cpu_model(), "physical_cores": nphys, "logical_cpus": ncpu, "allowed_cpus": ncpu,
             "by_threads": {str(k): w["B"] / v[0] for k, v in tried.items()},
             "warmup_forwards": nwarm, "timed_forwards": n,
             "sample": f"{n} timed forwards of the same batch (bs={w['B']}) after {nwarm} warm-up, median"
@@ -309,6 +336,8 @@ def main():
     ap.add_argument("--no-cobatch-extra", action="store_true",
                     help="skip the second timed run that reports the co-batched language encoder (G=4) "
                          "beside the strict per-batch figure")
+    ap.add_argument("--cobatch-extra", action="store_true",
+                    help="also time round 2's shared language encoder (4 in-flight batches per BiLSTM pass): `lang_cobatch4`")
     ap.add_argument("--no-split", action="store_true", help="aql: one kernel per row (no lang/vis row sharing)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -398,7 +427,7 @@ def main():
             assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
             stream_pool.append(torch.cuda.ExternalStream(h.value, device=dev))
 
-    def measure(G, steps, warmup, batched=False, rotate=0):
+    def measure(G, steps, warmup, batched=False, rotate=0, eng=eng):
         """K timed steps (one step = one batch of the workload) after W warm-up steps with G
         batches per language-encoder pass. Returns (seconds, slots, batches, in-flight count).
         rotate = R > 0 (graph mode, G = 1): R distinct device-resident input sets per stream are cycled through the
@@ -546,6 +575,28 @@ def main():
                   "what": "the same strict per-batch path over 400 timed steps: `value` above is K = %d steps, whose fixed pipeline "
                           "fill / drain (~160 us per timed region) is %.0f %% of its time" % (args.steps, 100 * (1 - (dts / 400) / (dt / args.steps)))}
         del sl_s
+    # the same strict path with f16 transformers (`cfg.hip.tx_dtype = auto`, the package default since round 5: same MFMA rate,
+    # three more mantissa bits - it holds the 1e-3 bound to wq / wk x 12 where bf16 leaves it at x 8)
+    f16_tx = None
+    if G == 1 and world == 1 and w["tx"] == "bf16" and not args.throughput_only and not aql and not args.no_graph:
+        cfg_h = make_cfg(dict(w, tx="auto"))
+        eng_h = eng_mod.VogEngine(cfg_h, comm)
+        eng_h.load_state_dict(sd)
+        eng_h.set_option("lstm_persistent", int(persistent))
+        for kv in args.set or []:
+            k_, v_ = kv.split("=")
+            eng_h.set_option(k_, int(v_))
+        assert eng_h.precise is None and eng_h.desc.tx_dtype == eng_mod.L.VOG_F16
+        dth_, sl_h16, _, n_h16 = measure(G, 400, 40, eng=eng_h)
+        par_h = check_parity(w, cfg_h, sd, batches[0], sl_h16[0], eng_h)
+        ref_ms = (steady["ms_per_step"] if steady is not None else dt / args.steps * 1e3)
+        f16_tx = {"value": 400 * w["B"] / dth_ if par_h["ok"] else None, "unit": "queries/s", "ms_per_step": dth_ / 400 * 1e3,
+                  "steps": 400, "warmup": 40, "batches_in_flight": n_h16, "attention_sharpness": eng_h.sharpness,
+                  "ratio_vs_bf16_same_protocol": ref_ms / (dth_ / 400 * 1e3) if steady is not None or args.steps >= 200 else None,
+                  "parity": {k_: par_h[k_] for k_ in ("ok", "rel_err_mdl_outs_eval", "rel_err_pred_scores", "abs_err_logits")},
+                  "what": "the same strict per-batch path, 400 timed steps, f16 operands in obj_tx / mul_tx (the package default; "
+                          "`value` is bf16 as BASELINE.json's config names it)"}
+        del sl_h16, eng_h
     # the same strict path with the inputs coming from HBM: N distinct input sets cycle through the streams' workspaces
     hbm_inputs = None
     if G == 1 and world == 1 and rot_sets > 1 and not aql and not args.no_graph and not args.throughput_only and not args.rotate_main:
@@ -577,12 +628,16 @@ def main():
     # second, separately timed run of the same K steps: the language encoder of 4 in-flight batches as
     # one pass (reported beside `value`, never instead of it: `value` is the strict per-batch path)
     extra = None
-    if G == 1 and not args.no_cobatch_extra and not args.throughput_only and not args.no_graph \
-            and args.steps % 4 == 0 and args.warmup % 4 == 0:
-        dt4, slots4, _, n4 = measure(4, args.steps, args.warmup)
+    if not args.cobatch_extra:
+        extra = {"value": None, "skipped": "opt-in since round 5 (--cobatch-extra): round 2's shared language encoder is slower "
+                                           "than four requests per forward (`requests_batched4`), which replaced it"}
+    elif G == 1 and not args.no_cobatch_extra and not args.throughput_only and not args.no_graph:
+        # (K and W rounded up to multiples of the group size: the driver's --warmup 5 used to drop this block silently)
+        k4, w4 = (args.steps + 3) // 4 * 4, (args.warmup + 3) // 4 * 4
+        dt4, slots4, _, n4 = measure(4, k4, w4)
         assert np.isfinite(float(slots4[0].out["mdl_outs_eval"].sum().item()))
-        extra = {"value": world * args.steps * w["B"] / dt4, "unit": "queries/s", "ms_per_step": dt4 / args.steps * 1e3,
-                 "batches_in_flight": n4, "steps": args.steps, "warmup": args.warmup,
+        extra = {"value": world * k4 * w["B"] / dt4, "unit": "queries/s", "ms_per_step": dt4 / k4 * 1e3,
+                 "batches_in_flight": n4, "steps": k4, "warmup": w4,
                  "what": "same K steps, same per-batch inputs/outputs; the BiLSTM language encoder of 4 in-flight "
                          "batches runs as one pass (W_hh streamed once per recurrent step for the 16 sentences "
                          "instead of once per batch), transformers/heads per batch as before; every batch's "
@@ -638,6 +693,8 @@ def main():
         res["lang_cobatch4"] = extra
     if steady is not None:
         res["steady_state_400_steps"] = steady
+    if f16_tx is not None:
+        res["f16_transformers"] = f16_tx
     if hbm_inputs is not None:
         res["value_hbm_inputs"] = hbm_inputs["value"]
         res["hbm_inputs"] = hbm_inputs

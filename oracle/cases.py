@@ -36,10 +36,10 @@ REL = {"mdl.obj_tx.use_rel": True, "mdl.mul_tx.use_rel": True}
 
 
 def _case(over, B, nppf0=5, vocab=5000, ragged=False, wseed=1, dseed=3,
-          perturb_ln=False, ncmp=4, arg_lens=None, cmp_msk=None):
+          perturb_ln=False, ncmp=4, arg_lens=None, cmp_msk=None, sharp=None, feat="normal"):
     return dict(over=over, B=B, nppf0=nppf0, vocab=vocab, ragged=ragged,
                 wseed=wseed, dseed=dseed, perturb_ln=perturb_ln, ncmp=ncmp,
-                arg_lens=arg_lens, cmp_msk=cmp_msk)
+                arg_lens=arg_lens, cmp_msk=cmp_msk, sharp=sharp, feat=feat)
 
 
 CASES: Dict[str, dict] = {}
@@ -119,6 +119,46 @@ CASES["small/edge_temp_cmpmsk"] = _case({**_SM, "ds.conc_type": "temp"}, B=2, vo
                                         perturb_ln=True, dseed=45, cmp_msk=[[1, 1, 0, 0], [1, 1, 1, 0]])
 
 
+# ---- round 5: weights / features away from the random-init regime. With torch-default-init weights the attention
+# logits have std ~0.016 (softmax ~uniform, transformer_code.py:141-155); a trained checkpoint (EXPTS.md:95-189,
+# utils/trn_utils.py:534-614) does not. `sharp = (qk, pe)`: wq / wk of every obj_txf / mult_txf layer x qk (logits x qk^2:
+# x8 -> std ~1, x16 -> std ~4), pe_*_sub_enc (the box-bias Linear(5, H)) x pe; LayerNorm gains / biases perturbed.
+# `feat = "relu_heavy"`: non-negative heavy-tailed features (what fc6 / ReLU'd I3D activations look like: ~half zeros,
+# log-normal tail), mean ~0.5.
+_SPAT2 = {"mdl.name": "vog", "ds.conc_type": "spat", **REL}
+CASES["full/cfg2_sharp8"] = _case(_SPAT2, B=4, ragged=True, dseed=51, perturb_ln=True, sharp=(8.0, 4.0))
+CASES["full/cfg2_sharp12"] = _case(_SPAT2, B=4, ragged=True, dseed=58, perturb_ln=True, sharp=(12.0, 4.0))   # edge of the f16 envelope
+CASES["full/cfg2_sharp16"] = _case(_SPAT2, B=4, ragged=True, dseed=52, perturb_ln=True, sharp=(16.0, 4.0))
+CASES["full/cfg2_relu_heavy"] = _case(_SPAT2, B=4, ragged=True, dseed=53, perturb_ln=True, sharp=(8.0, 4.0),
+                                      feat="relu_heavy")
+CASES["full/cfg3_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "temp", **REL}, B=8, ragged=True, dseed=54,
+                                  perturb_ln=True, sharp=(8.0, 4.0), feat="relu_heavy")
+CASES["full/cfg5_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "svsq", **REL}, B=16, ragged=True, dseed=55,
+                                  perturb_ln=True, sharp=(8.0, 4.0))
+for _c in ("spat", "temp", "sep", "svsq"):
+    CASES[f"small/sharp8_vog_{_c}"] = _case(
+        {"mdl.name": "vog", "ds.conc_type": _c, **REL, **SMALL_DIMS},
+        B=2, vocab=50, ragged=True, perturb_ln=True, dseed=56, sharp=(8.0, 4.0), feat="relu_heavy")
+CASES["small/sharp16_vgrnd_spat"] = _case(
+    {"mdl.name": "vgrnd", "ds.conc_type": "spat", **REL, **SMALL_DIMS},
+    B=2, vocab=50, ragged=True, perturb_ln=True, dseed=57, sharp=(16.0, 4.0))
+
+
+def sharpen_state_dict(sd, qk: float, pe: float):
+    for k in list(sd):
+        if k.endswith("selfattn.layer.wq.weight") or k.endswith("selfattn.layer.wk.weight"):
+            sd[k] = (sd[k] * np.float32(qk)).astype(np.float32)
+        elif k.startswith("pe_obj_sub_enc.") or k.startswith("pe_mul_sub_enc."):
+            sd[k] = (sd[k] * np.float32(pe)).astype(np.float32)
+    return sd
+
+
+def relu_heavy(x: np.ndarray, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(30_011 + seed)
+    tail = np.exp(0.75 * rng.standard_normal(x.shape, dtype=np.float32))
+    return (np.maximum(x, 0.0) * tail).astype(np.float32)
+
+
 def build(name: str):
     """-> (cfg, state_dict(np), batch(np), case)."""
     c = CASES[name]
@@ -135,6 +175,11 @@ def build(name: str):
         cfg.ds.conc_type, c["B"], c["nppf0"], ncmp=c["ncmp"], vocab_size=c["vocab"],
         prop_dim=cfg.mdl.prop_feat_dim, seg_dim=cfg.mdl.seg_feat_dim,
         seed=c["dseed"], ragged=c["ragged"], num_cmp_msk=msk, arg_lens=c.get("arg_lens"))
+    if c.get("sharp"):
+        sharpen_state_dict(sd, *c["sharp"])
+    if c.get("feat", "normal") == "relu_heavy":
+        batch["pad_region_feature"] = relu_heavy(batch["pad_region_feature"], c["dseed"])
+        batch["seg_feature_for_frms"] = relu_heavy(batch["seg_feature_for_frms"], c["dseed"] + 1)
     return cfg, sd, batch, c
 
 

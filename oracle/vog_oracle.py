@@ -256,10 +256,12 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
     (mdl_vog.py:482-488). scale = sqrt(d_model)."""
     S, N, d = x.shape
     p = f"{prefix}.selfattn.layer."
-    xq = _q(quant, scope, x)
-    q = xq @ _q(quant, scope, sd[p + "wq.weight"]).t()
-    k = xq @ _q(quant, scope, sd[p + "wk.weight"]).t()
-    v = xq @ _q(quant, scope, sd[p + "wv.weight"]).t()
+    # sub-scopes (round 5): a quant hook may treat the pieces of a layer differently ("tx.qk" = the Q.K^T operands ...);
+    # hooks that only know "tx" look at scope.split(".")[0]
+    xq = _q(quant, scope + ".proj", x)
+    q = xq @ _q(quant, scope + ".proj", sd[p + "wq.weight"]).t()
+    k = xq @ _q(quant, scope + ".proj", sd[p + "wk.weight"]).t()
+    v = xq @ _q(quant, scope + ".proj", sd[p + "wv.weight"]).t()
     scale = math.sqrt(d)
     heads = []
     off = 0
@@ -267,7 +269,7 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
     for h, dh in enumerate(chunk_sizes(d, n_heads)):
         qh, kh, vh = (t[..., off:off + dh] for t in (q, k, v))
         off += dh
-        qh, kh = _q(quant, scope, qh, kh)
+        qh, kh = _q(quant, scope + ".qk", qh, kh)
         logits = qh @ kh.transpose(1, 2)
         if use_rel:
             bh = box_bias_head(boxes, sd[pe_name + ".weight"][h],
@@ -278,22 +280,23 @@ def encoder_layer(x, boxes, nsrl, sd, prefix, pe_name, n_heads, use_rel,
         attn = torch.softmax(logits / scale, dim=-1)
         if pm is not None:
             attn = attn * pm[:, h]                          # self.dropout(F.softmax(...)) (transformer_code.py:50,153)
-        attn, vh = _q(quant, scope, attn, vh)
+        attn = _q(quant, scope + ".p", attn)
+        vh = _q(quant, scope + ".v", vh)
         heads.append(attn @ vh)
     cat = torch.cat(heads, dim=-1)
     if stash is not None:            # the two inputs of the layer's tail (backward fixtures, oracle/make_golden_bwd.py)
         stash["tail_attn"] = cat
         stash["tail_x"] = x
-    a = _q(quant, scope, cat) @ _q(quant, scope, sd[p + "wo.weight"]).t()
+    a = _q(quant, scope + ".wo", cat) @ _q(quant, scope + ".wo", sd[p + "wo.weight"]).t()
     t = x + _drop(drop, site0 + 1, a, p_drop)               # ResidualBlock: x + dropout(layer(x)) (transformer_code.py:31)
     if stash is not None:
         stash["tail_t"] = t          # its gradient = the gradient of the layer input THROUGH THE TAIL (residual path)
     x1 = layer_norm(t, sd[f"{prefix}.selfattn.layernorm.weight"],
                     sd[f"{prefix}.selfattn.layernorm.bias"])
     f = f"{prefix}.feedforward.layer."
-    hdn = torch.relu(_q(quant, scope, x1) @ _q(quant, scope, sd[f + "linear1.weight"]).t()
+    hdn = torch.relu(_q(quant, scope + ".ffn", x1) @ _q(quant, scope + ".ffn", sd[f + "linear1.weight"]).t()
                      + sd[f + "linear1.bias"])
-    y = _q(quant, scope, hdn) @ _q(quant, scope, sd[f + "linear2.weight"]).t() + sd[f + "linear2.bias"]
+    y = _q(quant, scope + ".ffn", hdn) @ _q(quant, scope + ".ffn", sd[f + "linear2.weight"]).t() + sd[f + "linear2.bias"]
     y = _drop(drop, site0 + 2, y, p_drop)
     return layer_norm(x1 + y, sd[f"{prefix}.feedforward.layernorm.weight"],
                       sd[f"{prefix}.feedforward.layernorm.bias"])

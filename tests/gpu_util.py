@@ -27,7 +27,7 @@ def comm_for(c):
 
 
 def build_engine(name, tx_dtype=None):
-    """tx_dtype None: the package default (`auto`: bf16 for single-layer stacks, f16 for deeper ones)."""
+    """tx_dtype None: the package default (`auto`: f16 kernels inside their envelope, the fp32 path beyond; engine.py)."""
     cfg, sd, batch, c = cases.build(name)
     if tx_dtype is not None:
         cfg.hip.tx_dtype = tx_dtype

@@ -86,13 +86,14 @@ def test_two_rank_training_equals_training_on_the_averaged_gradient():
         for r in range(world):
             assert abs(float(gs[r][0]["loss"]) - got[r][0][it]) <= 1e-6 * abs(got[r][0][it])
         tr.num_it += 1
+        tr.adam_step += 1
         for k in sorted(gs[0][1]):
             g = ((gs[0][1][k] + gs[1][1][k]) / world).contiguous()
             p = tr.params[k]
             if k not in tr.m:
                 tr.m[k], tr.v[k] = torch.zeros_like(p), torch.zeros_like(p)
             L.check(tr.lib.vog_adam_f32(L.ptr(p), L.ptr(g), L.ptr(tr.m[k]), L.ptr(tr.v[k]), p.numel(), tr.lr, tr.betas[0], tr.betas[1],
-                                        tr.eps, tr.num_it, L.stream_ptr()), "vog_adam_f32")
+                                        tr.eps, tr.adam_step, L.stream_ptr()), "vog_adam_f32")
     torch.cuda.synchronize()
     worst = 0.0
     for k, v in tr.state_dict().items():

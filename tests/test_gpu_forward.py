@@ -11,9 +11,12 @@ reference fp32 CPU forward):
     reference's top-2 proposals of that frame are within 2e-3 of each other
     (a flip there is inside the score tolerance, SURVEY.md hard-part 2).
   * indexs: same rule (arg-max over videos).
-Budget: bf16 operands in the two transformers, f16 elsewhere, fp32 accumulate
-— oracle-simulated at 4.5e-4 (tests/test_quant_budget.py).
+Budget (round 5): `cfg.hip.tx_dtype = auto` = f16 operands everywhere (oracle-simulated at 1.8e-4 on cfg 2, 5.7e-4 at the edge
+of its envelope, wq / wk x 12), the fp32 path beyond (`precise.py`); bf16 transformers (what BASELINE.json's config 2 names and
+bench.py times) are selectable and hold the bound only for near-uniform attention: 4.5e-4 simulated at random-init scale, 2e-3 at
+wq / wk x 8 (tests/test_quant_budget.py, DESIGN.md section 2 "envelope").
 """
+import ctypes
 import importlib
 import os
 
@@ -22,12 +25,15 @@ import pytest
 import torch
 
 from oracle import cases
-from tests.gpu_util import L, build_engine, oracle_run, rel_err
+from tests.gpu_util import L, build_engine, engine_mod, oracle_run, rel_err
 
 pytestmark = pytest.mark.gpu
 
 FULL = [n for n in cases.CASES if n.startswith("full/") and "p100" not in n]
 SMALL = [n for n in cases.CASES if n.startswith("small/")]
+SHARP = [n for n in cases.CASES if cases.CASES[n].get("sharp")]
+# random-init scale, single-layer stacks: the cases bf16 transformers are specified for (3-layer stacks: 1.0-1.1e-3 measured)
+BF16_OK = [n for n in FULL if n not in SHARP and "3layers" not in n]
 
 
 def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
@@ -108,6 +114,61 @@ def test_forward_small_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
+@pytest.mark.parametrize("name", BF16_OK)
+def test_forward_full_bf16_vs_reference_golden(name):
+    """bf16 transformers - BASELINE.json's config 2 as written, the operand type bench.py times - inside their envelope."""
+    out, pred, g, _ = _run(name, tx_dtype="bf16")
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+def test_precision_plan_follows_attention_sharpness():
+    """`auto` (round 5): f16 kernels inside their envelope, the fp32 path beyond it, decided per checkpoint in load_state_dict
+    from the weights alone (engine.attention_sharpness); explicit requests are honoured, with a warning outside the envelope."""
+    import warnings
+    E = engine_mod
+    seen = {}
+    for name in ("full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp12", "full/cfg2_sharp16"):
+        eng, *_ = build_engine(name)
+        seen[name] = (eng.sharpness, eng.precise is not None)
+        assert eng.desc.tx_dtype == L.VOG_F16
+    print(seen)
+    assert seen["full/cfg2_vog_spat_gt5_bs4"][0] < 1 and not seen["full/cfg2_vog_spat_gt5_bs4"][1]
+    assert E.BF16_SHARPNESS_MAX < seen["full/cfg2_sharp8"][0] < E.F16_SHARPNESS_MAX and not seen["full/cfg2_sharp8"][1]
+    assert seen["full/cfg2_sharp12"][0] < E.F16_SHARPNESS_MAX and not seen["full/cfg2_sharp12"][1]
+    assert seen["full/cfg2_sharp16"][0] > E.F16_SHARPNESS_MAX and seen["full/cfg2_sharp16"][1]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng, *_ = build_engine("full/cfg2_sharp8", "bf16")
+        assert eng.precise is None and eng.desc.tx_dtype == L.VOG_BF16
+        assert any("envelope" in str(x.message) for x in w)
+    eng, *_ = build_engine("full/cfg2_vog_spat_gt5_bs4", "f32")
+    assert eng.precise is not None
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg5_vog_svsq_gt5_bs16", "full/cfg3_vog_temp_gt5_bs8",
+                                  "full/cfg1_igrnd_spat_gt5_bs2", "small/vgrnd_sep", "small/vog_sep_cmpmsk", "small/vog_spat_3layers"])
+def test_forward_fp32_path_vs_reference_golden(name):
+    """tx_dtype = f32: the precise path (fp32 kernels of csrc/backward.hip + the exact heads) through the same engine surface,
+    eager and from a graph slot - an order of magnitude inside the bound."""
+    out, pred, g, _ = _run(name, tx_dtype="f32")
+    _check_against(name, out, pred, g, None, tol_rel=5e-5, tol_logit=1e-4)
+    out, pred, g, _ = _run(name, tx_dtype="f32", graph=True)
+    _check_against(name, out, pred, g, None, tol_rel=5e-5, tol_logit=1e-4)
+
+
+def test_bf16_leaves_the_bound_where_f16_holds_it():
+    """The envelope is real: at wq / wk x 8 (attention logit std ~1.7) bf16 transformers miss 1e-3 on the reference golden
+    while the default plan holds it (the reason `auto` no longer picks bf16)."""
+    name = "full/cfg2_sharp8"
+    out, pred, g, _ = _run(name, tx_dtype="bf16")
+    nz = g["mdl_outs_eval"] != 0
+    e_bf = float(rel_err(out["mdl_outs_eval"].cpu().numpy()[nz], g["mdl_outs_eval"][nz]).max())
+    out, pred, g, _ = _run(name)
+    e_h = float(rel_err(out["mdl_outs_eval"].cpu().numpy()[nz], g["mdl_outs_eval"][nz]).max())
+    print(f"{name}: bf16 {e_bf:.2e}  auto {e_h:.2e}")
+    assert e_h < 1e-3 < e_bf
+
+
 @pytest.mark.parametrize("name", ["full/cfg2_ragged", "small/vog_spat_r128", "small/vog_sep_r64"])
 def test_forward_persistent_lstm_layer(name):
     """The opt-in one-launch-per-layer LSTM (cross-workgroup hand-off through agent-scope
@@ -185,7 +246,15 @@ def test_argvec_tail_equals_separate_launch(name, pair):
     eng.set_option("fused_argvec", 0)
     a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
     eng.set_option("fused_argvec", 1)
+    B, ncmp = batch["srl_arg_words_ind"].shape[0], batch["new_srl_idxs"].shape[1]
+    T = int(batch["srl_arg_word_mask_len"].max())
+    nb = eng.lib.vog_workspace_bytes(eng.ctx, B, ncmp, T)
     for _ in range(3):                                   # (replays: the arrival counter is re-zeroed by the prologue)
+        # poison the argument vectors left by the previous run: `lang` lies outside the region the prologue re-zeroes, so a
+        # fused run that never wrote them (round 4: the paired out-projection body has no tail) would pass on stale values
+        off, sz = ctypes.c_int64(), ctypes.c_int64()
+        L.check(eng.lib.vog_workspace_stage(eng.ctx, B, ncmp, T, b"lang", ctypes.byref(off), ctypes.byref(sz)), "stage lang")
+        eng.workspace(B, ncmp, T)[off.value: off.value + sz.value].view(torch.float32).fill_(float("nan"))
         b = eng.forward(dev)
         torch.cuda.synchronize()
         for k in a:

@@ -779,6 +779,34 @@ def test_learner_surface(tmp_path):
     for k, v in learn.trainer.state_dict().items():
         assert torch.equal(v, learn2.trainer.params[k]), k
     assert learn2.num_epoch == learn.num_epoch
+    assert learn2.trainer.num_it == 6 and learn2.trainer.adam_step == 6         # load_opt: Adam's step comes with m / v
+
+    # resume WITHOUT the optimizer state (the reference's defaults: resume = True, load_opt = False, utils/trn_utils.py:594-605):
+    # the Learner's iteration counter is restored, Adam starts fresh - step 0, m = v = 0. (a restored step count
+    # against zero moments switched the bias correction off: first update ~3.2 x lr.) The first update after the resume must be
+    # torch.optim.Adam's first update from that checkpoint.
+    cfg3, sel3, mdl3, evl3, _, _, _ = _build(name)
+    assert not cfg3.train.load_opt
+    learn3 = tu.Learner(uid="L0", data=data, mdl=mdl3, loss_fn=sel3["loss"](cfg3, comm), cfg=cfg3, eval_fn=evl3, comm=comm)
+    tr3 = learn3.trainer
+    assert tr3.num_it == 6 and tr3.adam_step == 0 and not tr3.m
+    before = {k: v.clone() for k, v in tr3.params.items()}
+    dev_b = {k: v.cuda() for k, v in one.items()}
+    _, grads = tr3.gradients(dev_b)
+    grads = {k: v.clone() for k, v in grads.items()}
+    tr3.step(dev_b)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, g in grads.items():
+        p = torch.nn.Parameter(before[k].clone())
+        opt = torch.optim.Adam([p], lr=tr3.lr, betas=tr3.betas, eps=tr3.eps)
+        p.grad = g.clone()
+        opt.step()
+        upd_ref = (p.detach() - before[k])
+        upd = tr3.params[k] - before[k]
+        worst = max(worst, float((upd - upd_ref).abs().max()) / max(float(upd_ref.abs().max()), 1e-12))
+    print("first update after a resume without optimizer state vs torch.optim.Adam: worst relative deviation", worst)
+    assert worst < 1e-3, worst
 
 
 def test_evaluator_batches_requests(capsys, tmp_path):
@@ -906,7 +934,7 @@ def test_optimizer_state_of_another_model_is_refused():
     osd = t.optimizer_state_dict()
     t2 = trn.FP32Trainer(cfg, comm_for(c), sd_torch(sd), loss_fn, lr=1e-4)
     t2.load_optimizer_state_dict(osd)
-    assert t2.num_it == 1 and all(torch.equal(t2.m[k], t.m[k]) for k in t.m)
+    assert t2.adam_step == 1 and t2.num_it == 0 and all(torch.equal(t2.m[k], t.m[k]) for k in t.m)
     bad = {"state": {i: dict(s) for i, s in osd["state"].items()}, "param_groups": osd["param_groups"]}
     i0 = next(iter(bad["state"]))
     bad["state"][i0]["exp_avg"] = bad["state"][i0]["exp_avg"].reshape(-1)[:-1].clone()

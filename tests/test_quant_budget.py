@@ -14,7 +14,7 @@ def _scheme(tx, rest):
     m = {"tx": tx, "enc": rest, "lstm": rest, "head": rest}
 
     def q(scope, x):
-        return x.to(m[scope]).to(torch.float32)
+        return x.to(m[scope.split(".")[0]]).to(torch.float32)
     return q
 
 

@@ -143,6 +143,19 @@ static int launch_pair(const LaunchRecord& ra, const LaunchRecord& rb, hipStream
   return 0;
 }
 
+// The paired out-projection body is compiled WITHOUT the argument-vector tail (128 registers, see below): a recorded launch
+// that carries one (fused_argvec = 1: GemmParams::av_counter) must not be paired, or `lang` would never be written.
+// Declined pairs run back to back (pair_launch).
+static constexpr int kPairDeclined = 1;
+template <typename A, typename B>
+static int launch_pair_no_argvec(const LaunchRecord& ra, const LaunchRecord& rb, hipStream_t st) {
+  GemmParams pa;
+  if (ra.arg_bytes != sizeof(pa)) VOG_FAIL(-1, "pair launch: recorded launches do not match the registered bodies");
+  memcpy(&pa, ra.args, sizeof(pa));
+  if (pa.av_counter != nullptr) return kPairDeclined;
+  return launch_pair<A, B>(ra, rb, st);
+}
+
 static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
   static std::map<std::pair<const void*, const void*>, PairFn> r;
   static std::once_flag once;
@@ -157,8 +170,8 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_F16)}] = &launch_pair<Lstm, TxTailBody<F16, F16, 2, false, 0>>;
-    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
-    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
+    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
+    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
   });
   return r;
 }
@@ -179,8 +192,11 @@ int pair_launch(const std::function<int(hipStream_t)>& fa, const std::function<i
   if (na == 1 && recs.size() == 2) {
     auto it = registry().find({recs[0].host_fn, recs[1].host_fn});
     if (it != registry().end()) {
-      if (fused) *fused = true;
-      return it->second(recs[0], recs[1], st);
+      const int prc = it->second(recs[0], recs[1], st);
+      if (prc != kPairDeclined) {
+        if (fused) *fused = prc == 0;
+        return prc;
+      }
     }
   }
   VOG_TRY(fa(st));

@@ -27,13 +27,13 @@ def model_desc_from_cfg(cfg, comm) -> L.ModelDesc:
     m = cfg.mdl
     hip = cfg.get("hip", {}) if hasattr(cfg, "get") else {}
     tx = hip.get("tx_dtype", "auto") if hasattr(hip, "get") else "auto"
-    if tx == "auto":
-        # bf16 transformers (what BASELINE.json's config 2 names) hold the 1e-3 bound with the reference's default
-        # single-layer stacks (5.8e-4 at cfg 2); operand rounding adds up over layers: with the 3-layer stacks of the
-        # ablations (EXPTS.md:186-189) bf16 measured 1.0-1.1e-3 against the full-size reference golden
-        # (full/vog_spat_gt5_bs4_3layers), f16 - three more mantissa bits, same MFMA rate - stays well inside
-        deep = max(int(m.obj_tx.n_layers), int(m.mul_tx.n_layers)) > 1
-        tx = "f16" if deep else "bf16"
+    if tx in ("auto", "f32"):
+        # f16 transformers by default (round 5): same MFMA rate as bf16 on gfx950, three more mantissa bits. bf16 holds the
+        # 1e-3 bound only while attention is near-uniform (random-init weights; fails at wq / wk x 8, logit std ~ 1); f16 holds
+        # to x 12 ("envelope"). Past that `auto` routes forwards through the fp32 kernels
+        # (`precise.PreciseForward`, decided per checkpoint in `load_state_dict` from `attention_sharpness`); "f32" forces it.
+        # bf16 stays selectable (`cfg.hip.tx_dtype = "bf16"`: what BASELINE.json's config 2 names, what bench.py times).
+        tx = "f16"
     d = L.ModelDesc()
     d.mdl_kind = L.MDL_KIND[m.name]
     d.conc_type = L.CONC_TYPE[cfg.ds.conc_type]
@@ -57,6 +57,56 @@ def model_desc_from_cfg(cfg, comm) -> L.ModelDesc:
     d.tx_dtype = L.DTYPE[tx]
     d.enc_dtype = L.VOG_F16
     return d
+
+
+# ---- how sharp can this checkpoint's attention get (round 5) -----------------------------------------------
+# logits = x Wq_h^T Wk_h x'^T / sqrt(d) (code/transformer_code.py:141-155, scale = sqrt(d_model)). For inputs with mean square
+# r2 per feature their standard deviation is ~ ||Wq_h^T Wk_h||_F / sqrt(d) * r2. r2 of a layer's input: LayerNorm output
+# (mean(g^2) + mean(b^2)) for every layer behind a LayerNorm - mul_tx layer 0 reads obj_tx's output -; 0.25 for obj_tx layer 0,
+# which reads the ReLU'd encoder outputs (measured 0.13-0.3 on synthetic and heavy-tailed features). Softmax turns an ABSOLUTE
+# logit error into a RELATIVE probability error and 16-bit operands make a logit error proportional to this scale, so the
+# statistic orders checkpoints by how much operand precision they need. Envelope (oracle rounding model + GPU goldens
+# full/cfg2_sharp{8,12,16}): bf16 <= ~4, f16 <= ~32 (wq / wk x 12: 28), beyond: fp32.
+F16_SHARPNESS_MAX = 32.0
+BF16_SHARPNESS_MAX = 4.0
+
+
+def attention_sharpness(sd, n_heads_obj: int, n_heads_mul: int) -> float:
+    """max over the encoder layers of obj_txf / mult_txf of ||Wq_h^T Wk_h||_F / sqrt(d) * r2(layer input). sd: numpy / torch
+    state dict under the reference's key names."""
+    def arr(k):
+        v = sd[k]
+        return (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)).astype(np.float64)
+
+    keys = {(k[7:] if k.startswith("module.") else k): k for k in sd}
+
+    def ln_r2(stack, layer):
+        for g, b in (("weight", "bias"), ("gamma", "beta")):
+            kg = f"{stack}.encoder.layers.{layer}.feedforward.layernorm.{g}"
+            if kg in keys:
+                return float((arr(keys[kg]) ** 2).mean() + (arr(keys[kg.replace(g, b)]) ** 2).mean())
+        return 1.0
+
+    n_obj = 1 + max([int(k.split(".")[3]) for k in keys if k.startswith("obj_txf.encoder.layers.")], default=-1)
+    worst = 0.0
+    for k in keys:
+        if not k.endswith("selfattn.layer.wq.weight"):
+            continue
+        stack, layer = k.split(".")[0], int(k.split(".")[3])
+        wq, wk = arr(keys[k]), arr(keys[k.replace("wq.weight", "wk.weight")])
+        d = wq.shape[0]
+        if layer > 0:
+            r2 = ln_r2(stack, layer - 1)
+        elif stack == "mult_txf" and n_obj > 0:
+            r2 = ln_r2("obj_txf", n_obj - 1)
+        else:
+            r2 = 0.25
+        H = n_heads_obj if stack == "obj_txf" else n_heads_mul
+        bounds = np.cumsum([0] + [len(c) for c in np.array_split(np.arange(d), H)])      # torch.chunk sizes (171/171/170)
+        for h in range(H):
+            a, b = wq[bounds[h]:bounds[h + 1]], wk[bounds[h]:bounds[h + 1]]
+            worst = max(worst, float(np.linalg.norm(a.T @ b)) / float(np.sqrt(d)) * r2)
+    return worst
 
 
 # ---- persistent BiLSTM: how many forwards may be in flight ---------------------------------------------
@@ -141,6 +191,10 @@ class VogEngine:
         self._graphs: Dict[tuple, C.c_void_p] = {}
         self._finalized = False
         self.use_graph = bool(cfg.hip.use_graph) if "hip" in cfg else True
+        hip = cfg.get("hip", {}) if hasattr(cfg, "get") else {}
+        self.tx_request = hip.get("tx_dtype", "auto") if hasattr(hip, "get") else "auto"
+        self.sharpness = 0.0            # attention_sharpness of the loaded checkpoint
+        self.precise = None             # precise.PreciseForward when this checkpoint runs the fp32 path
 
     # ---- weights -------------------------------------------------------------
     def expected_weights(self) -> Dict[str, int]:
@@ -163,6 +217,19 @@ class VogEngine:
             L.check(self.lib.vog_ctx_finalize(self.ctx), "vog_ctx_finalize")
         self._finalized = True
         self.weights_epoch += 1
+        # precision plan of THIS checkpoint (round 5): `auto` leaves the f16 kernels when the attention can get sharper than
+        # their envelope; an explicit bf16 / f16 request is honoured but the envelope is still reported
+        self.sharpness = attention_sharpness(sd, int(self.desc.obj_heads), int(self.desc.mul_heads)) \
+            if self.cfg.mdl.name in ("vgrnd", "vog") else 0.0
+        want_f32 = self.tx_request == "f32" or (self.tx_request == "auto" and self.sharpness > F16_SHARPNESS_MAX)
+        self.precise = None
+        if want_f32:
+            from .precise import PreciseForward
+            self.precise = PreciseForward(self, sd)
+        elif self.sharpness > (BF16_SHARPNESS_MAX if self.tx_request == "bf16" else F16_SHARPNESS_MAX):
+            import warnings
+            warnings.warn(f"attention sharpness {self.sharpness:.1f} of this checkpoint is outside the envelope in which "
+                          f"tx_dtype={self.tx_request} holds 1e-3 on pred_scores (DESIGN.md section 2); use tx_dtype=auto")
 
     # ---- workspace -----------------------------------------------------------
     def workspace(self, B: int, ncmp: int, T: int) -> torch.Tensor:
@@ -269,6 +336,8 @@ class VogEngine:
             ws = self.workspace(B, ncmp, T)
             L.check(self.lib.vog_forward(self.ctx, C.byref(b), ws.data_ptr(), ws.numel(),
                                          L.stream_ptr()), "vog_forward")
+            if self.precise is not None:                    # fp32 path overwrites the outputs (precise.py)
+                self.precise.run(inp, out)
         out["_keepalive"] = (inp, ws)
         return out
 
@@ -289,6 +358,9 @@ class VogEngine:
     def aql_submit(self, slots, queue: int = 0) -> None:
         """Enqueue the AQL programs of `slots` row-interleaved on one queue. NOT stream ordered:
         the slots' inputs must already be complete; collect results with slot.wait()."""
+        if self.precise is not None:
+            raise L.VogError("the AQL path submits pre-built packets only; this checkpoint runs the fp32 path "
+                             "(attention sharpness outside the f16 envelope): use slot.launch()")
         for sl in slots:
             for m in getattr(sl, "slots", [sl]):
                 m._check_epoch()
@@ -515,7 +587,21 @@ class Slot:
         else:
             L.check(self.eng.lib.vog_forward(self.eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
                                              self.ws.numel(), sp), "vog_forward")
+        self._precise(stream)
         return self.out
+
+    def _precise(self, stream):
+        """Checkpoints outside the f16 envelope: the fp32 forward runs behind whatever the slot's launch did (copies /
+        assembly of a fed slot included) on the same stream and overwrites the slot's outputs."""
+        pf = self.eng.precise
+        if pf is None:
+            return
+        with torch.cuda.device(self.eng.device):
+            if stream is None:
+                pf.run(self.inp, self.out)
+            else:
+                with torch.cuda.stream(stream):
+                    pf.run(self.inp, self.out)
 
     def __del__(self):
         try:
@@ -804,6 +890,8 @@ class Group:
             L.check(self.eng.lib.vog_group_forward(self.eng.ctx, C.byref(self.lb), self.lang_ws.data_ptr(),
                                                    self.lang_ws.numel(), self._members, self._wss, self._wsb,
                                                    len(self.slots), sp), "vog_group_forward")
+        for sl in self.slots:
+            sl._precise(stream)
         return self.out
 
     def build_aql(self) -> "Group":

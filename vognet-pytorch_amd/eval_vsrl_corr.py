@@ -267,7 +267,7 @@ class Evaluator(torch.nn.Module):
                 chunks.append(cols)
         merged = {k: np.concatenate([c[k] for c in chunks], axis=0) for k in chunks[0]} if chunks else {}
         if loss_log:
-            wts = torch.tensor([float(sz) for _, sz in loss_log], dtype=torch.float64, device=loss_log[0][0]["loss"].device)
+            wts = torch.tensor([float(sz) for _, sz in loss_log], dtype=torch.float64, device=next(iter(loss_log[0][0].values())).device)
             for k in loss_log[0][0]:
                 losses[k] = (torch.stack([d[k] for d, _ in loss_log]).double() * wts).sum()
         val_loss = {k: (v / max(1, nums)).float() for k, v in losses.items()}

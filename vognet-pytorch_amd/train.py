@@ -47,7 +47,12 @@ class FP32Trainer:
         self.v: Dict[str, torch.Tensor] = {}
         self.lr = float(cfg.train.lr if lr is None else lr)
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        # two counters (round 5): `num_it` = the Learner's iteration count (numbers the dropout masks; restored from a
+        # checkpoint on every resume, utils/trn_utils.py:588-590); `adam_step` = torch.optim.Adam's per-parameter `step`
+        # (bias correction), which the reference restores ONLY with the optimizer state (`load_opt`, :594-605) - a resume
+        # without it builds a fresh Adam at step 0 whose m / v are zero.
         self.num_it = 0
+        self.adam_step = 0
         self.pg = process_group
         # train-mode dropout (`mdl.train()` in Learner.train_epoch): LSTMEncoder's 0.1 / 0.1 (utils/mdl_srl_utils.py:77), the
         # transformers' cfg.mdl.{obj,mul}_tx.attn_drop on attention probabilities and sub-layer outputs; masks come from a
@@ -157,7 +162,7 @@ class FP32Trainer:
             out["vidf_outs"] = BW.linear_f32(h1, p["seg_verb_classf.2.weight"], p["seg_verb_classf.2.bias"], False)["y"].reshape(B, nc_v)
         # kept for the backward: the inputs and concatenated heads of every encoder layer, the language side's whole scratch
         acts = {"mul_x": mul_x, "obj_x": obj_x, "prop_feat": prop_feat, "seg_feat": seg_feat, "props": props, "inds_msk": msk, "T": T,
-                "mul_kept": mul_kept, "obj_kept": obj_kept, "lang_scratch": lf["_scratch"]}
+                "mul_kept": mul_kept, "obj_kept": obj_kept, "lang_scratch": lf["_scratch"], "hid": lf["_hid"]}
         return out, acts, g
 
     def gradients(self, batch, exchange: bool = False):
@@ -195,6 +200,7 @@ class FP32Trainer:
                                         and torch.distributed.get_world_size() > 1)
         ld, grads = self.gradients(batch, exchange=multi)
         self.num_it += 1
+        self.adam_step += 1
         st = L.stream_ptr()
         for k in sorted(grads):
             p = self.params[k]
@@ -202,7 +208,7 @@ class FP32Trainer:
                 self.m[k], self.v[k] = torch.zeros_like(p), torch.zeros_like(p)
             gk = grads[k].contiguous()
             L.check(self.lib.vog_adam_f32(L.ptr(p), L.ptr(gk), L.ptr(self.m[k]), L.ptr(self.v[k]), p.numel(), self.lr, self.betas[0],
-                                          self.betas[1], self.eps, self.num_it, st), "vog_adam_f32")
+                                          self.betas[1], self.eps, self.adam_step, st), "vog_adam_f32")
         return ld
 
     def broadcast_from_rank0(self, with_optimizer: bool = False) -> None:
@@ -220,9 +226,9 @@ class FP32Trainer:
                     self.m[k], self.v[k] = torch.zeros_like(self.params[k]), torch.zeros_like(self.params[k])
                 dist.broadcast(self.m[k], src=0, group=self.pg)
                 dist.broadcast(self.v[k], src=0, group=self.pg)
-            t = torch.tensor([self.num_it], dtype=torch.int64, device=self.dev)
+            t = torch.tensor([self.num_it, self.adam_step], dtype=torch.int64, device=self.dev)
             dist.broadcast(t, src=0, group=self.pg)
-            self.num_it = int(t.item())
+            self.num_it, self.adam_step = int(t[0].item()), int(t[1].item())
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """The parameters under the reference's key names (load into the inference model with `load_state_dict`)."""
@@ -232,7 +238,7 @@ class FP32Trainer:
     def optimizer_state_dict(self):
         """torch.optim.Adam.state_dict() layout (parameters numbered in state-dict key order)."""
         keys = list(self.params)
-        state = {i: {"step": torch.tensor(float(self.num_it)), "exp_avg": self.m[k].clone(), "exp_avg_sq": self.v[k].clone()}
+        state = {i: {"step": torch.tensor(float(self.adam_step)), "exp_avg": self.m[k].clone(), "exp_avg_sq": self.v[k].clone()}
                  for i, k in enumerate(keys) if k in self.m}
         return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0,
                                                   "amsgrad": False, "params": list(range(len(keys)))}]}
@@ -243,7 +249,7 @@ class FP32Trainer:
         checkpoint of another mdl.name / conc_type, or of a model with other sizes) is refused: vog_adam_f32 walks m / v with
         the parameter's element count."""
         keys = list(self.params)
-        new_m, new_v, num_it = {}, {}, self.num_it
+        new_m, new_v, adam_step = {}, {}, self.adam_step
         for i, stt in osd["state"].items():
             if not 0 <= int(i) < len(keys):
                 raise ValueError(f"optimizer state for parameter #{i}, the model has {len(keys)}")
@@ -254,10 +260,10 @@ class FP32Trainer:
                                      f"{tuple(self.params[k].shape)}: this checkpoint belongs to another model")
             new_m[k] = stt["exp_avg"].to(self.dev, torch.float32).contiguous().clone()
             new_v[k] = stt["exp_avg_sq"].to(self.dev, torch.float32).contiguous().clone()
-            num_it = int(stt["step"])
+            adam_step = int(stt["step"])
         self.m.update(new_m)
         self.v.update(new_v)
-        self.num_it = num_it
+        self.adam_step = adam_step
         g = osd["param_groups"][0]
         self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
 

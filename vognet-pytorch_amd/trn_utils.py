@@ -94,8 +94,11 @@ class Learner:
                                     if k in self.trainer.params})
         if load_opt and "optimizer_state_dict" in ck:
             self.trainer.load_optimizer_state_dict(ck["optimizer_state_dict"])
-        # the iteration counter is restored on every load (utils/trn_utils.py:588-590), with or without the optimizer state:
-        # it also numbers the dropout masks, which must not restart
+        # the Learner's iteration counter is restored on every load (utils/trn_utils.py:588-590), with or without the
+        # optimizer state: it also numbers the dropout masks, which must not restart. Adam's own step (bias correction) is
+        # NOT touched here: without `load_opt` the reference builds a fresh Adam at step 0 (m = v = 0), and a step count of N
+        # against zero moments would switch the bias correction off (first update ~3.2 x lr); `load_optimizer_state_dict`
+        # restores it together with m / v.
         if "num_it" in ck:
             self.trainer.num_it = self.num_it = int(ck["num_it"])
         self.num_epoch, self.best_met = int(ck.get("num_epoch", 0)), float(ck.get("best_met", 0.0))
@@ -117,7 +120,7 @@ class Learner:
         out = dict(sm.smooth)
         if D.get_world_size() > 1:
             # reduce_dict(average=True) over the ranks (utils/trn_utils.py:61-90, 527-530)
-            t = torch.tensor([out[k] for k in self.loss_keys], dtype=torch.float64, device=self.trainer.dev)
+            t = torch.tensor([float(out.get(k, 0.0)) for k in self.loss_keys], dtype=torch.float64, device=self.trainer.dev)
             torch.distributed.all_reduce(t)
             out = {k: float(v) / D.get_world_size() for k, v in zip(self.loss_keys, t.tolist())}
         return out
