@@ -405,6 +405,12 @@ typedef struct vog_lstm_layer_args {
    * A-fragment order of vog_gemm_args.a_frag (pad rows of the last 16-row tile readable); bias: [2][4R]
    * fp32 = b_ih + b_hh per direction. Needs Bn*T <= 64 and K % 256 == 0. */
   const void* wih; const void* xa; const float* bias; int K;
+  /* round 5: sticky fault counter (optional; device memory or device-visible pinned host memory): +1 per launch whose
+   * hand-off timed out. The library never clears it (sync[2] is re-zeroed by the next forward's prologue): the host reads
+   * it when it looks at the results - a stalled forward is an ERROR at the API, not NaN scores with rc 0 (the reference's
+   * LSTM, utils/mdl_srl_utils.py:114-169, cannot fail by scheduling). inject_stall != 0: test hook, the launch behaves as
+   * if its hand-off had timed out at once. */
+  uint32_t* fault; int inject_stall;
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);
 int64_t vog_bilstm_hx_bytes(int Bn, int T, int R);   /* size of vog_lstm_layer_args.hx */
@@ -725,6 +731,9 @@ typedef struct vog_batch {
    * shared_final_hidden: its rows [B*nvl, lang_enc] of the final hidden projection (sep only). */
   const float* shared_lang;
   const float* shared_final_hidden;
+  /* Optional (round 5): sticky stall counter of this batch's forwards, see vog_lstm_layer_args.fault. Pinned host memory
+   * lets the host poll it without synchronising the device. */
+  uint32_t* fault;
 } vog_batch;
 
 int64_t vog_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T);

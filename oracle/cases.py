@@ -127,7 +127,8 @@ CASES["small/edge_temp_cmpmsk"] = _case({**_SM, "ds.conc_type": "temp"}, B=2, vo
 # log-normal tail), mean ~0.5.
 _SPAT2 = {"mdl.name": "vog", "ds.conc_type": "spat", **REL}
 CASES["full/cfg2_sharp8"] = _case(_SPAT2, B=4, ragged=True, dseed=51, perturb_ln=True, sharp=(8.0, 4.0))
-CASES["full/cfg2_sharp12"] = _case(_SPAT2, B=4, ragged=True, dseed=58, perturb_ln=True, sharp=(12.0, 4.0))   # edge of the f16 envelope
+CASES["full/cfg2_sharp10"] = _case(_SPAT2, B=4, ragged=True, dseed=59, perturb_ln=True, sharp=(10.0, 4.0))   # edge of the f16 envelope
+CASES["full/cfg2_sharp12"] = _case(_SPAT2, B=4, ragged=True, dseed=58, perturb_ln=True, sharp=(12.0, 4.0))   # just outside (f16 measured 9.0e-4)
 CASES["full/cfg2_sharp16"] = _case(_SPAT2, B=4, ragged=True, dseed=52, perturb_ln=True, sharp=(16.0, 4.0))
 CASES["full/cfg2_relu_heavy"] = _case(_SPAT2, B=4, ragged=True, dseed=53, perturb_ln=True, sharp=(8.0, 4.0),
                                       feat="relu_heavy")

@@ -197,3 +197,112 @@ def test_gradient_allreduce_world2():
     for k in ref:
         assert torch.allclose(got[k], ref[k], atol=1e-6), k
     assert torch.equal(got["_d_x"], torch.zeros(3))                      # rank 0's own, not reduced
+
+
+# ---- world = 8 (round 5): exactly the exchange code `bench.py --gpus 8` and `Evaluator.forward` run, sized as they size it ----
+def _spawn(world, target, args, timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=timeout)
+    for p in ps:
+        p.join(timeout=timeout)
+        assert p.exitcode == 0
+    return got
+
+
+def _worker_ring8(rank, world, port, n_units, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py::measure with 4 lanes: per_half = max(nunits, (64 // nunits) * nunits) = 64 unit launches per half ring,
+    # unit_rows = G * B = 4 rows of 1700 words
+    nunits, rows, width = 4, 4, 1700
+    per_half = max(nunits, (64 // nunits) * nunits)
+    got = []
+    ring = D.RecordRing(rows, width, per_half, "cpu",
+                        on_half=lambda g, n: got.append(D.unpack_gathered(g, world, per_half, rows, n)[:, :2].clone()))
+    for step in range(n_units):
+        rec = torch.zeros(rows, width)
+        rec[:, 0] = float(step)
+        rec[:, 1] = float(rank) * 10 + torch.arange(rows)
+        ring.push(rec)
+    ring.flush()
+    assert ring.gathers == (n_units + per_half - 1) // per_half
+    if rank == 0:
+        q.put(torch.cat(got).tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_ring_world8_bench_geometry():
+    """Two full half rings + a partial one on 8 ranks, `per_half` as bench.py computes it for its 4 lanes: rank 0 sees every
+    unit's rows in (unit, rank, row) order - what a gather per unit would have produced."""
+    world, n_units = 8, 2 * 64 + 22
+    seen = _spawn(world, _worker_ring8, (n_units,))
+    expect = [[float(st), float(r * 10 + i)] for st in range(n_units) for r in range(world) for i in range(4)]
+    assert seen == expect
+
+
+class _FakeModel(torch.nn.Module):
+    """Stands in for the HIP model on CPU: records that carry the query's ann_idx, so that the merge order is visible."""
+    supports_T_hint = False
+
+    def __init__(self, rw, nsrl, NP):
+        super().__init__()
+        self.rw, self.nsrl, self.NP = rw, nsrl, NP
+
+    def forward(self, batch):
+        B = batch["ann_idx"].shape[0]
+        rec = torch.zeros(B, self.rw)
+        rec[:, 0] = batch["ann_idx"].float()
+        return {"mdl_outs_eval": torch.zeros(B, 1, self.nsrl, self.NP), "_pred_rec": rec}
+
+
+def _worker_eval8(rank, world, port, n_batches, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from oracle import cases
+    ev_mod = importlib.import_module("vognet-pytorch_amd.eval_vsrl_corr")
+    cfg, sd, batch, c = cases.build("small/vog_spat")
+    cfg.train.bsv = 2
+    comm = {"vocab_size": c["vocab"], "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1}, "num_prop_per_frm": c["nppf0"]}
+    evl = ev_mod.EvaluatorSPAT(cfg, comm, torch.device("cpu"))
+    ncmp, nsrl, nfrm0 = 4, 5, 10
+    rw = nsrl * ncmp * nfrm0 * 8 + nsrl * nfrm0 * 2
+    B = 2
+    dl = []
+    for i in D.shard_indices(n_batches, rank, world):
+        b = 1 if i == n_batches - 1 else B                       # the loader's LAST batch is short (drop_last = False)
+        ids = np.arange(i * B, i * B + b, dtype=np.int64)
+        dl.append({"ann_idx": torch.from_numpy(ids), "sent_idx": torch.from_numpy(ids.copy()),
+                   "new_srl_idxs": torch.zeros(b, ncmp, dtype=torch.int64), "num_cmp_msk": torch.ones(b, ncmp, dtype=torch.int64),
+                   "target_cmp": torch.zeros(b, dtype=torch.int64), "permute": torch.arange(ncmp).repeat(b, 1),
+                   "permute_inv": torch.arange(ncmp).repeat(b, 1)})
+    mdl = _FakeModel(rw, nsrl, 200)
+    evl(mdl, None, dl, "valid", rank=rank, pred_path=tmp)
+    if rank == 0:
+        q.put("done")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluator_forward_world8_rank_major_merge(tmp_path):
+    """`Evaluator.forward` itself on 8 gloo ranks (CPU, a stand-in model): 21 loader batches of 2 queries, the last one short;
+    `shard_indices` gives every rank 3 batches (the tail wraps: rank 7 owns [21 -> 0, 1, 2]); the short batch belongs to a
+    middle rank (6). Rank 0's pickle = all of rank 0's queries, then rank 1's, ... - the order in which the reference appends
+    its per-rank files (code/eval_vsrl_corr.py:131-137) - with the short batch's padding rows dropped."""
+    import pickle
+    world, n_batches = 8, 21
+    _spawn(world, _worker_eval8, (n_batches, str(tmp_path)))
+    recs = pickle.load(open(tmp_path / "valid_0.pkl", "rb"))
+    expect = []
+    for r in range(world):
+        for i in D.shard_indices(n_batches, r, world):
+            expect += [2 * i] if i == n_batches - 1 else [2 * i, 2 * i + 1]
+    assert D.shard_indices(n_batches, 6, world) == [18, 19, 20] and D.shard_indices(n_batches, 7, world) == [0, 1, 2]
+    assert [r["idx_vid"] for r in recs] == expect
+    assert [int(r["pred_boxes"][0][0][0][0]) for r in recs] == expect      # the records travelled with their metadata

@@ -1025,3 +1025,104 @@ def test_packed_staging_copy_stream_double_buffer():
     for o, r in zip(outs, refs):
         for k in dls.FWD_KEYS:
             assert torch.equal(o[k], r[k]), k
+
+
+# ---- round 5: a stalled BiLSTM hand-off is an error at the API, never NaN scores with rc 0 -----------------------------
+def test_stalled_handoff_raises_on_the_eager_path_and_degrades():
+    """`lstm_inject_stall`: every persistent layer launch behaves as if its hand-off had timed out (outputs poisoned with NaN,
+    the sticky counter in pinned host memory bumped). The NEXT host-visible point raises VogError; the engine has switched to
+    the step-launch BiLSTM, which cannot stall: the re-run of the batch is finite and matches the reference golden."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    eng = mdl.engine()
+    ok = mdl(dev)
+    torch.cuda.synchronize()
+    mdl.check_faults()                                        # nothing stalled
+    eng.set_option("lstm_inject_stall", 1)
+    bad = mdl(dev)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(bad["mdl_outs_eval"]).all()     # the poison reaches the scores ...
+    with pytest.raises(L.VogError, match="hand-off"):
+        mdl.check_faults()                                    # ... and the API says so
+    assert eng.stalls >= 1                                    # (counted per layer launch: 2 per forward)
+    again = mdl(dev)                                          # degraded: step launches (the hook only touches the layer kernel)
+    torch.cuda.synchronize()
+    mdl.check_faults()
+    assert torch.isfinite(again["mdl_outs_eval"]).all()
+    g = np.load(cases.golden_path(name))
+    pred = eng.unpack_pred(again["_pred_rec"], batch["new_srl_idxs"].shape[1])
+    _check_against(name, again, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+    # a forward() issued after an unnoticed stall raises before it enqueues anything
+    eng.set_option("lstm_persistent", 1)
+    mdl(dev)
+    torch.cuda.synchronize()
+    with pytest.raises(L.VogError, match="hand-off"):
+        mdl(dev)
+
+
+def test_stalled_handoff_raises_from_a_graph_slot():
+    name = "full/cfg2_ragged"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    eng = mdl.engine()
+    eng.set_option("lstm_inject_stall", 1)
+    slot = eng.make_slot({k: v for k, v in dev.items() if k in batch}, graph=True)
+    eng.set_option("lstm_inject_stall", 0)                    # (captured into the slot's graph)
+    slot.launch()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(slot.out["mdl_outs_eval"]).all()
+    with pytest.raises(L.VogError, match="hand-off"):
+        slot.launch()                                          # the next use of the slot
+    # a fresh slot captured now runs the step-launch BiLSTM
+    s2 = eng.make_slot({k: v for k, v in dev.items() if k in batch}, graph=True)
+    s2.launch()
+    torch.cuda.synchronize()
+    s2.check()
+    assert torch.isfinite(s2.out["mdl_outs_eval"]).all()
+
+
+def test_evaluator_refuses_to_write_a_pickle_with_poisoned_scores(tmp_path):
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    loss_fn = sel["loss"](cfg, comm_for(c))
+    tg = synth.make_targets(batch, cfg.ds.conc_type, c["nppf0"], seed=c["dseed"])
+    cpu = {k: v.cpu() for k, v in dev.items()}
+    cpu.update({k: torch.from_numpy(v) for k, v in tg.items()})
+    mdl.engine().set_option("lstm_inject_stall", 1)
+    with pytest.raises(L.VogError, match="hand-off"):
+        evl(mdl, loss_fn, _Loader([cpu, cpu, cpu]), "valid", rank=0, pred_path=tmp_path)
+    assert not (tmp_path / "valid_0.pkl").exists()
+    # the engine has degraded: the same call now completes with finite records
+    val_loss, _ = evl(mdl, loss_fn, _Loader([cpu, cpu, cpu]), "valid", rank=0, pred_path=tmp_path)
+    recs = pickle.load(open(tmp_path / "valid_0.pkl", "rb"))
+    assert len(recs) == 3 * batch["num_cmp_msk"].shape[0] and np.isfinite(float(val_loss["loss"]))
+    assert all(np.isfinite(np.array(r["pred_scores"])).all() for r in recs)
+
+
+def test_oversubscribed_persistent_layers_never_pass_nan_silently():
+    """Eight graph slots launched on eight streams AROUND the lane book (raw vog_graph_launch): up to 8 persistent layer kernels
+    compete for the CUs 4 of them fill. Whether hand-offs stall depends on how the hardware deals the workgroups; what must
+    hold is the contract: non-finite outputs <=> the slot's stall counter moved (and `check` raises)."""
+    import ctypes as C
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    eng = mdl.engine()
+    inp = {k: v for k, v in dev.items() if k in batch}
+    slots = [eng.make_slot(inp, graph=True) for _ in range(8)]
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    torch.cuda.synchronize()
+    for it in range(20):
+        for sl, st in zip(slots, streams):
+            L.check(eng.lib.vog_graph_launch(sl.graph, st.cuda_stream), "vog_graph_launch")
+    torch.cuda.synchronize()
+    stalled = 0
+    for sl in slots:
+        finite = bool(torch.isfinite(sl.out["mdl_outs_eval"]).all())
+        moved = int(sl._fault[0]) != sl._fault_seen
+        stalled += int(moved)
+        assert finite or moved, "NaN outputs without a recorded stall"
+        if moved:
+            with pytest.raises(L.VogError):
+                sl.check()
+        else:
+            sl.check()
+    print(f"oversubscription: {stalled} of 8 slots recorded a stall in 20 rounds")

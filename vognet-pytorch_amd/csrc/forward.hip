@@ -79,6 +79,7 @@ struct vog_ctx {
   std::map<std::string, std::vector<float>> host;
   std::vector<void*> allocs;
   bool finalized = false;
+  int lstm_inject_stall = 0;            // test hook: persistent layer launches behave as if their hand-off had timed out
   int lstm_persistent = 1;              // one launch per BiLSTM layer where supported (W_hh resident on chip; vog_hip.h)
   int fused_tail = 1;                   // Wo..LN2 (+ lin2 + score) of an encoder layer as one launch where supported
   // device weights
@@ -667,6 +668,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         pa.sync = ws.at<uint32_t>("lstm_sync_" + std::to_string(l));
         pa.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
         pa.lens = b->srl_arg_word_mask_len; pa.Bn = Bn; pa.T = T; pa.R = R; pa.dtype = et; pa.out_frag = ofrag ? 1 : 0;
+        pa.fault = b->fault; pa.inject_stall = c->lstm_inject_stall;
         if (ih_fused) {
           pa.wih = c->wih_p[l]; pa.bias = c->bsum[l]; pa.K = Kin;
           pa.xa = l == 0 ? ws.at<void>("emb_a0") : ws.at<void>("lstm_out16_" + std::to_string(l - 1));
@@ -1429,6 +1431,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
+  if (strcmp(name, "lstm_inject_stall") == 0) { c->lstm_inject_stall = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_argvec") == 0) { c->fused_argvec = value ? 1 : 0; return 0; }

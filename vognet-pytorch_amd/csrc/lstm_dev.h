@@ -137,6 +137,11 @@ struct LstmLayerParams {
   // rows is computed in the prologue. wih: [dir][unit/4][K/32][lane][8] (vog_lstm_pack_w), xa: the
   // layer input [Bn*T rows (b*T + t), K] in A-fragment order, bias: [2][4R] (b_ih + b_hh).
   const unsigned short* wih; const unsigned short* xa; const float* bias; int K;
+  // round 5: `fault` (optional; device or device-visible pinned host memory) is incremented once per launch whose hand-off
+  // timed out - unlike sync[2], which the next forward's prologue re-zeroes, it is never cleared by the library: the HOST
+  // owns it (engine.Slot reads it without a device synchronisation). inject_stall: test hook, every workgroup behaves as
+  // if its first wait had timed out.
+  unsigned int* fault; int inject_stall;
 };
 
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -345,7 +350,7 @@ struct LstmLayerBody {
     }
     __syncthreads();
     const bool same_xcd = flags[1] != 0;
-    dead = flags[0] != 0;
+    dead = flags[0] != 0 || p.inject_stall != 0;
 
     const unsigned hx_bytes = (unsigned)((size_t)p.T * 2 * p.Bn * R * 2);
     const int cps = RW / 8;                                // 16-byte chunks per sentence
@@ -490,6 +495,8 @@ struct LstmLayerBody {
     // holds, see vog_hip.h) must not pass for a result: the WHOLE output of the layer is poisoned
     // with NaN (every consumer - next layer, projection, argument vectors, both heads - propagates it
     // to mdl_outs) and sync[2] stays set for the host (vog_lstm_status).
+    if (dead && p.fault && tid == 0 && cx.bx == 0 && cx.by == 0)     // once per launch (every workgroup learns of a timeout)
+      __hip_atomic_fetch_add(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (valid_b) {
       const int unit = tile0 * 4 + ul;
       const unsigned short v = dead ? (unsigned short)0x7fff : to16<T16>(h_own);

@@ -140,11 +140,19 @@ class Evaluator(torch.nn.Module):
         ring = None
         layout = {}
 
+        def check_faults():
+            # (after a host synchronisation: every forward issued before it has completed) a stalled BiLSTM hand-off is an
+            # error here, never NaN scores in the prediction pickle
+            if hasattr(model, "check_faults"):
+                model.check_faults()
+
         def on_half(g, n_valid):
             if not D.is_main_process():
+                check_faults()
                 return
             # ONE device-to-host copy of the gathered rows; everything else is host-side slicing
             host = g.view(world, self.GATHER_EVERY, layout["B"], -1)[:, :n_valid].detach().cpu().numpy()
+            check_faults()
             for r in range(world):
                 rec_rows[r].append(host[r].reshape(n_valid * layout["B"], -1))
 
@@ -232,6 +240,9 @@ class Evaluator(torch.nn.Module):
             ring.push(row, torch.cuda.current_stream() if rec.is_cuda else None)
         if ring is not None:
             ring.flush()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        check_faults()
         # the metadata of every rank on rank 0: one exchange for the whole loop
         meta_all = None
         if meta_rows:

@@ -97,7 +97,7 @@ class LstmStepArgs(C.Structure):
 class LstmLayerArgs(C.Structure):
     _fields_ = [("gxs", c_vp), ("whh", c_vp), ("hx", c_vp), ("sync", c_vp), ("out16", c_vp),
                 ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32), ("out_frag", c_i32),
-                ("wih", c_vp), ("xa", c_vp), ("bias", c_vp), ("K", c_i32)]
+                ("wih", c_vp), ("xa", c_vp), ("bias", c_vp), ("K", c_i32), ("fault", c_vp), ("inject_stall", c_i32)]
 
 
 class VislangArgs(C.Structure):
@@ -243,7 +243,7 @@ class Batch(C.Structure):
                 ("pad_region_feature", c_vp), ("seg_feature_for_frms", c_vp), ("pad_proposals", c_vp),
                 ("mdl_outs", c_vp), ("mdl_outs_eval", c_vp), ("vidf_outs", c_vp),
                 ("fin_scores_loss", c_vp), ("fin_scores", c_vp), ("pred_rec", c_vp),
-                ("shared_lang", c_vp), ("shared_final_hidden", c_vp)]
+                ("shared_lang", c_vp), ("shared_final_hidden", c_vp), ("fault", c_vp)]
 
 
 # every symbol include/vog_hip.h declares: name -> (restype, argtypes)

@@ -161,6 +161,13 @@ class AnetBaseMdl(nn.Module):
 
     supports_T_hint = True
 
+    def check_faults(self) -> None:
+        """Raise VogError if a forward issued so far lost its BiLSTM hand-off (its outputs are NaN). Judges what has COMPLETED:
+        call it after synchronising (`torch.cuda.synchronize()`), before trusting results; `forward` itself checks the forwards
+        before it."""
+        if self._engine is not None:
+            self._engine.check()
+
     def forward(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """`forward(inp) -> {'mdl_outs', 'mdl_outs_eval'[, 'vidf_outs',
         'fin_scores_loss', 'fin_scores']}` as Conc{TEMP,SPAT,SEP}.forward
@@ -170,7 +177,7 @@ class AnetBaseMdl(nn.Module):
         `T`: the longest sentence of the batch if the caller already knows it (from the HOST copy of
         `srl_arg_word_mask_len`); without it the length is read back from the device as in the reference
         (mdl_vog.py:257 `.max().item()`), which drains the stream once per batch."""
-        out = self.engine().forward(inp, T=T, with_pred=True)
+        out = self.engine().forward(inp, T=T, with_pred=True)     # (raises VogError if an EARLIER forward's hand-off stalled)
         res = {k: v for k, v in out.items() if not k.startswith("_") and k != "pred_rec"}
         res["_pred_rec"] = out["pred_rec"]
         return res
