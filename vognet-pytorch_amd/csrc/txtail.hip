@@ -44,7 +44,8 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
     attr_set = true;
   }
   if (lds > 160 * 1024) VOG_FAIL(-1, "fused encoder tail: %zu bytes of LDS needed", lds);
-  ::vog::launch(kern, dim3(ceil_div(p.M, 64)), dim3(512), lds, st, p);
+  const int nblk = ceil_div(p.M, 64);
+  ::vog::launch(kern, dim3(p.xcds > 0 ? ceil_div(nblk, p.xcds) * 8 : nblk), dim3(512), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -112,6 +113,10 @@ int tx_tail_run(const vog_tx_tail_args* a, hipStream_t st) {
     p.nt_rows = nt_env >= 0 ? nt_env : (a->M >= 4 * 256 * 64 ? 1 : 0);
   }
   const bool score = a->score != nullptr;
+  {
+    static const int xc_env = perf_env("VOG_TAIL_XCDS") ? atoi(perf_env("VOG_TAIL_XCDS")) : -1;
+    p.xcds = (xc_env >= 0 && !g_pair_capture) ? xc_env : 0;
+  }
   if (score) {
     VOG_CHECK_ARG(a->wl_p && a->bl && a->score->w2 && a->score->b2 && a->score->arg_msk && a->score->cmp_msk &&
                   a->score->outs && a->score->outs_eval && a->score->dh == 256 && a->head_dtype == VOG_F16);

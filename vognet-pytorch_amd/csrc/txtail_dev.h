@@ -7,6 +7,10 @@
 #define VOG_TAIL_PF1 4      // k-steps of weight prefetch in the FFN1 stage (one 32-column block per wave); 8 measured: 84 more bytes of scratch in the mul tail, 0.5-1 % slower at cfg 2 and cfg 4 (scratch/r4_pf.sh)
 #endif
 
+#ifndef VOG_TAIL_PRIME
+#define VOG_TAIL_PRIME 0    // 1 (round 5): the first PF k-steps of a stage's weights are requested BEFORE the LayerNorm / epilogue /
+#endif                      // barrier in front of it (a stage boundary no longer restarts the weight stream from an empty pipe)
+
 namespace vog {
 
 struct TailParams {
@@ -22,6 +26,10 @@ struct TailParams {
   vog_pred_args pred; int64_t pred_rec_bytes; unsigned int* pred_counter;
   int M;
   int nt_rows;   // non-temporal loads of the attention rows (large M)
+  int xcds;      // > 0 (round 5): the row blocks run on the first `xcds` XCDs only (grid = ceil(blocks / xcds) * 8; block b sits on
+                 // XCD b % 8): every XCD's L2 fetches the whole weight set from the fabric once, so 63 workgroups on 4 XCDs move
+                 // half the fabric bytes of 63 workgroups on 8
+
   int dbgf;      // perf experiments only, read by the DBG & 4 instantiation: 1 no residual, 2 no attention staging, 4 no LayerNorm, 8 no outputs
 };
 
@@ -37,10 +45,26 @@ struct TailParams {
 //    found in L2 by the other seven (in lock-step every workgroup took the ~2 us fabric miss on
 //    every line: kernel boundaries leave the XCD L2s cold). The fp32 summation order depends on the
 //    row block only, so results stay bit-reproducible.
-template <typename TT, int NBW, int PF, bool ZERO, int DBG = 0, int RB = 2>
+// the first PF k-steps of a stage's weight stream (what tail_gemm starts with), as a call of its own: issued ahead of the
+// LayerNorm / epilogue / barrier in front of the stage (TailParams::prime)
+template <int NBW, int PF, int DBG = 0>
+__device__ __forceinline__ void tail_prime(u16x8 (&wq)[PF][NBW], const unsigned short* __restrict__ wp,
+                                           int blk0, int blk_step, int KS, int rot, int lane) {
+  constexpr int KST = (DBG & 1) ? 0 : 64;
+  if constexpr (DBG & 4) return;
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    int k = j + rot; k = k >= KS ? k - KS : k;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+      wq[j][i] = (reinterpret_cast<const u16x8*>(wp + ((int64_t)(blk0 + i * blk_step) * KS) * 512) + lane)[k * KST];
+  }
+}
+
+template <typename TT, int NBW, int PF, bool ZERO, int DBG = 0, int RB = 2, bool PRIMED = false>
 __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][RB], const unsigned short* __restrict__ wp,
                                           int blk0, int blk_step, int KS, int rot,
-                                          const unsigned char* xl, int pitch, int lane) {
+                                          const unsigned char* xl, int pitch, int lane, u16x8 (*wq_in)[NBW] = nullptr) {
   constexpr int KST = (DBG & 1) ? 0 : 64;     // DBG 1 (perf experiments): every weight load hits the block's first KiB
   const int ml = lane & 31, hi = lane >> 5;
   const u16x8* wb[NBW];
@@ -61,7 +85,10 @@ __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][RB], const unsigned
   for (int j = 0; j < PF; ++j) {
     const int k = kk(j);
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) wq[j][i] = wb[i][k * KST];
+    for (int i = 0; i < NBW; ++i) {
+      if constexpr (PRIMED) wq[j][i] = wq_in[j][i];
+      else wq[j][i] = wb[i][k * KST];
+    }
   }
   const unsigned char* x0 = xl + ml * pitch + hi * 16;
   u16x8 xf[RB];
@@ -210,7 +237,14 @@ struct TxTailBody {
   constexpr int NB1 = NB == 3 ? 2 : 1;              // FFN1 n-blocks per wave (DH/32 = 8 or 12 over 8 waves)
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = cx.bx * ROWS;
+  int rblk = cx.bx;
+  if (p.xcds > 0) {                                   // row blocks on the first `xcds` XCDs only (block b sits on XCD b % 8)
+    const int x = cx.bx & 7;
+    if (x >= p.xcds) return;
+    rblk = (cx.bx >> 3) * p.xcds + x;
+    if (rblk * ROWS >= p.M) return;
+  }
+  const int m0 = rblk * ROWS;
   const int xcols = p.KWO > D ? p.KWO : D;
   unsigned char* X = smem;
   unsigned char* Y = X + ROWS * (xcols + 8) * 2;
@@ -228,6 +262,13 @@ struct TxTailBody {
   // position of this workgroup among the ones that share its XCD's L2 (block b runs on XCD b % 8;
   // speed only): staggers the k order of the weight streams
   const int xpos = (cx.bx >> 3) & 7;
+  constexpr bool PRIME = VOG_TAIL_PRIME != 0;
+  constexpr int PF_WO = NB == 3 ? 4 : 6, PF_W2 = NB == 3 ? 4 : 8;
+  u16x8 wq_a[PF_WO][NB];                              // primed weights of the NB-block stages (Wo, then W2)
+  u16x8 wq_b[PF_W2][NB];
+  u16x8 wq_1[VOG_TAIL_PF1][1];                        // ... of FFN1's pass(es)
+  u16x8 wq_s[8][1];                                   // ... of lin2
+  if constexpr (PRIME) tail_prime<NB, PF_WO, DBG>(wq_a, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, lane);
 
   // ---- stage 0: attention rows + the epilogue vectors -> LDS; residual rows -> accumulators.
   // Everything the chain will need from memory besides the weight streams is requested here, in one
@@ -299,7 +340,8 @@ struct TxTailBody {
   __syncthreads();
 
   // ---- stage 1: x + attn Wo^T, LayerNorm
-  tail_gemm<T16, NB, NB == 3 ? 4 : 6, false, DBG, RB>(acc, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, p1, lane);
+  tail_gemm<T16, NB, PF_WO, false, DBG, RB, PRIME>(acc, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, p1, lane, wq_a);
+  if constexpr (PRIME) tail_prime<1, VOG_TAIL_PF1, DBG>(wq_1, p.w1_p, w, 8, D >> 4, (xpos * (D >> 4)) >> 3, lane);
   if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB, RB>(acc, g1p, b1np, red, w, lane, w * NB);
   // x1 stays in the accumulator registers through FFN1 (which accumulates elsewhere) and becomes,
   // with b2 added, the initial accumulator of FFN2: the fp32 residual stream never leaves registers.
@@ -345,17 +387,23 @@ struct TxTailBody {
     // (two blocks = two passes over K with one accumulator pair: 64 fewer live registers than one
     // pass with two pairs, which spilled x1; the extra LDS operand reads are free here)
     f32x16 hacc[1][RB];
-    tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane);
-    ffn1_epi(hacc[0], w);
+    tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB, PRIME>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane, wq_1);
     if (NB1 == 2 && w < 4) {
-      tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane);
+      if constexpr (PRIME) tail_prime<1, VOG_TAIL_PF1, DBG>(wq_1, p.w1_p, w + 8, 8, D >> 4, rot, lane);
+      ffn1_epi(hacc[0], w);
+      tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB, PRIME>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane, wq_1);
+      if constexpr (PRIME) tail_prime<NB, PF_W2, DBG>(wq_b, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, lane);
       ffn1_epi(hacc[0], w + 8);
+    } else {
+      if constexpr (PRIME) tail_prime<NB, PF_W2, DBG>(wq_b, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, lane);
+      ffn1_epi(hacc[0], w);
     }
   }
   __syncthreads();
 
   // ---- stage 3: (x1 + b2) + W2 hidden, LayerNorm
-  tail_gemm<T16, NB, NB == 3 ? 4 : 8, false, DBG, RB>(acc, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, pH, lane);
+  tail_gemm<T16, NB, PF_W2, false, DBG, RB, PRIME>(acc, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, pH, lane, wq_b);
+  if constexpr (PRIME && SCORE) tail_prime<1, 8, DBG>(wq_s, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, lane);
   if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB, RB>(acc, g2p, b2np, red, w, lane, w * NB);
   const int mlo = fresh(ml), hio = fresh(hi);
 #pragma unroll
@@ -412,7 +460,7 @@ struct TxTailBody {
     __syncthreads();
     // ---- stage 4: lin2.0 + ReLU, lin2.2 as a row dot product, inverse regroup + masks
     f32x16 sacc[1][RB];
-    tail_gemm<TH, 1, 8, true, DBG, RB>(sacc, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, X, pD, lane);
+    tail_gemm<TH, 1, 8, true, DBG, RB, PRIME>(sacc, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, X, pD, lane, wq_s);
     float part[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) part[rb] = 0.f;
@@ -449,7 +497,7 @@ struct TxTailBody {
       if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // wave 0 wrote this workgroup's 64 scores
         const unsigned int old = __hip_atomic_fetch_add(p.pred_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = old == cx.gx * cx.gy - 1 ? 1u : 0u;
+        flag[0] = old == (unsigned)((p.M + ROWS - 1) / ROWS) - 1 ? 1u : 0u;
       }
       __syncthreads();
       if (flag[0]) {
