@@ -208,6 +208,10 @@ typedef struct vog_attn_struct_args {
    * kernel forms q(a, p) = Qv[p] + Ql[a] itself (Ql = pl columns [0, H*dp)): nothing is fanned out
    * in HBM (plain vog_qkv_proj over the visual rows, pl = NULL). npad_q is ignored. */
   int q_visual;
+  /* round 5, optional: one int, zero at launch. With it, q_visual launches over several key blocks (p100) use the E x F
+   * factorisation (141 instead of 330 us at cfg 4): the kernel sets it when a row may leave the safe range of its 16-bit
+   * fragments and the same call then re-runs the per-row kernel (an empty launch otherwise). NULL: per-row kernels only. */
+  int* guard_flag;
 } vog_attn_struct_args;
 int vog_rel_attention_struct_fwd(const vog_attn_struct_args* a, void* stream);
 

@@ -11,6 +11,9 @@ nppf0 = B.ec.num_prop_per_frm(cfg)
 comm = {"vocab_size": B.VOCAB, "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1}, "num_prop_per_frm": nppf0}
 eng = B.eng_mod.VogEngine(cfg, comm)
 eng.load_state_dict(B.synth.init_state_dict(cfg, B.VOCAB, seed=1))
+for kv in os.environ.get("OPTS", "").split():          # engine switches, e.g. OPTS="qkv_lean=0 pair_launches=0"
+    k, v = kv.split("=")
+    eng.set_option(k, int(v))
 b = B.synth.make_batch(w["conc"], w["B"], nppf0, vocab_size=B.VOCAB, seed=7)
 slot = eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()}, graph=False)
 slot.launch(); torch.cuda.synchronize()

@@ -579,6 +579,21 @@ def test_pred_head_exact(conc, np0):
 def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, qvis):
     """Separable mul_tx layer-0 attention: token (a, p) has k = Kv[p] + Kl[a], v = Vv[p] + Vl[a]; the
     softmax over all nsrl*nppf keys must equal softmax_p'(.)Vv + softmax_a'(.)Vl."""
+    _struct_attention_case(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, qvis, 1.0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("spread", [3.0, 5.0])
+@pytest.mark.parametrize("S,nfrm,nsrl,nppf,H,dh,dp,use_rel,lpv", [(3, 3, 5, 400, 3, 256, 256, 1, 0), (4, 2, 5, 100, 3, 256, 256, 1, 1)])
+def test_rel_attention_struct_ef_large_logit_spread(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, spread):
+    """the E x F factorisation shifts by mA[p] + mB[a], which can sit far above a row's true maximum (a key weak in
+    A = Qv.Kv + bias but dominant through B = Ql.Kv). Queries / keys scaled so that the logits spread over 5 (x 3) to 15 (x 5)
+    nats of standard deviation - rows whose winner lies > 17 nats under the shift exist - must still match the full softmax:
+    E carries a factor 2^12 that cancels in the quotient (attn_struct_ef_dev.h, EF_ESHIFT)."""
+    _struct_attention_case(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, 1, spread)
+
+
+def _struct_attention_case(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv, dtype, qvis, spread):
     lib = _lib()
     torch.manual_seed(S * 100 + nppf)
     td = t16(dtype)
@@ -594,6 +609,15 @@ def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, 
     vvv[..., :dh] = torch.randn(S, H, nppf, dh, device="cuda")
     pl = torch.zeros(n_lang * nsrl, 3, H, dp, device="cuda")
     pl[..., :dh] = torch.randn(n_lang * nsrl, 3, H, dh, device="cuda")
+    if spread != 1.0:
+        # sharp attention: query and key parts scaled (values untouched) and put on a grid of 1/4 below 32, so that every
+        # operand AND the sum Qv + Ql are exact in bf16 / f16: kernel and reference then see the same logits (up to fp32
+        # summation order) and what is compared is the softmax arithmetic alone - the kernel rounds Qv and Ql separately,
+        # which at 10 nats of logit spread would otherwise dominate the comparison (6 % on competing probabilities)
+        grid = lambda t: (t * spread * 4).round().clamp(-60, 60) / 4
+        qv, kvv = grid(qv) / 2, grid(kvv)
+        pl[:, :2] = grid(pl[:, :2])
+        pl[:, 0] /= 2
     lrow = torch.tensor([(s // nfrm) if lpv else (s // nfrm) // nc_v for s in range(S)], device="cuda")
     pls = pl.view(n_lang, nsrl, 3, H, dp)[lrow]                     # [S, nsrl, 3, H, dp]
     ql, kl, vl = (pls[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # [S, H, nsrl, dp]
@@ -616,8 +640,11 @@ def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, 
     a.S, a.H, a.dp, a.nsrl, a.nppf, a.npad_q, a.npad_kv = S, H, dp, nsrl, nppf, npad_q, npad_kv
     a.nfrm, a.lang_per_vid, a.nc_v = nfrm, lpv, nc_v
     a.use_rel, a.seq_per_vid, a.NP, a.inv_scale, a.dtype = use_rel, nfrm, nfrm * nppf, inv_scale, DT[dtype]
+    guard = torch.zeros(4, dtype=torch.int32, device="cuda")      # (E x F form + its gated per-row fallback)
+    a.guard_flag = L.ptr(guard)
     L.check(lib.vog_rel_attention_struct_fwd(C.byref(a), _sp()), "struct attention")
     torch.cuda.synchronize()
+    raised = int(guard[0].item())
     # full reference over all (a', p') keys with the operands the kernel sees (16-bit rounded parts)
     klr, vlr = kl.to(td).float(), vl.to(td).float()
     k_tok = (kv16.float().unsqueeze(2) + klr.unsqueeze(3)).reshape(S, H, Nq, dp)
@@ -630,6 +657,14 @@ def test_rel_attention_struct_equals_full_attention(S, nfrm, nsrl, nppf, H, dh, 
         logits = logits + torch.relu(ut.unsqueeze(-1) - ut.unsqueeze(-2) + peb.view(1, -1, 1, 1))
     ref = torch.softmax(logits * inv_scale, dim=-1) @ v_tok
     got = out.float().view(S, Nq, H, dp).permute(0, 2, 1, 3)
+    if spread != 1.0:
+        xs = logits * inv_scale
+        print(f"spread x{spread}: logit std {xs.std(-1).mean().item():.1f} nats, max - median "
+              f"{(xs.max(-1).values - xs.median(-1).values).mean().item():.1f}; guard raised: {raised}")
+        if spread >= 5.0:
+            assert raised == 1, "rows 25+ nats under the shift must send the launch to the per-row kernel"
+    else:
+        assert raised == 0, "near-uniform attention must stay on the E x F kernel"
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item()
     tol = (3e-2 if dtype == "bf16" else 5e-3) * max(1.0, ref.abs().max().item())

@@ -54,7 +54,9 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
   static int ef_form = -2;            // VOG_ATTN_STRUCT_EF=0 (perf experiments): the per-(a, p) kernels below
   if (ef_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_EF"); ef_form = e ? atoi(e) : 1; }
   if constexpr (NDB % 4 == 0) {
-    if (ef_form && p.q_visual && p.npad_kv > 32 && p.npad_kv <= 512 && p.nsrl == EF_MAXA && !(p.dbg)) {
+    // (needs the guard word and its fallback, the LDS-ring kernel below: without them the per-row kernels run)
+    if (ef_form && p.q_visual && p.npad_kv > 32 && p.npad_kv <= 512 && p.nsrl == EF_MAXA && !(p.dbg) &&
+        (p.guard != nullptr || ef_form == 2) && lds_form && lds_res <= 150 * 1024) {
       const size_t lds_ef = attn_struct_ef_lds<NDB>(p.npad_kv);
       if (lds_ef <= 150 * 1024) {
         const dim3 grid_ef(p.S * p.H * ((p.nppf + 31) / 32));
@@ -76,6 +78,18 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
           ::vog::launch(kern, grid_ef, dim3(256), lds_ef, st, p);
         }
         VOG_LAUNCH_CHECK();
+        if (p.guard) {                // fallback pass: runs only if a row left the factorisation's safe range
+          AttnStructParams pf = p;
+          pf.guard_gate = 1;
+          auto kern = attn_struct_lds_kernel<T16, NDB>;
+          static bool attr_slf = false;
+          if (!attr_slf) {
+            VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_slf = true;
+          }
+          ::vog::launch(kern, grid, dim3(256), lds_res, st, pf);
+          VOG_LAUNCH_CHECK();
+        }
         return 0;
       }
     }
@@ -123,7 +137,7 @@ int attn_struct_run(const vog_attn_struct_args* a, hipStream_t st) {
   AttnStructParams p{(const unsigned short*)a->q, (const unsigned short*)a->kv, (const unsigned short*)a->vv, a->pl,
                      (unsigned short*)a->out16, a->u, a->pe_b, a->S, a->H, a->dp, a->nsrl, a->nppf, a->npad_q,
                      a->npad_kv, a->nfrm, a->lang_per_vid, a->nc_v, a->use_rel, a->seq_per_vid, a->NP, a->inv_scale,
-                     a->q_visual ? 1 : 0, 0};
+                     a->q_visual ? 1 : 0, 0, a->guard_flag, 0};
   { static const int dbg = perf_env("VOG_ATTN_STRUCT_DEBUG") ? atoi(perf_env("VOG_ATTN_STRUCT_DEBUG")) : 0; p.dbg = dbg; }
   VOG_DISPATCH_DTYPE(a->dtype, return (attn_struct_dispatch<T16>(p, st)));
   return 0;

@@ -677,6 +677,9 @@ struct AttnStructParams {
   float inv_scale; int q_visual;
   int dbg;          // perf experiments only (VOG_ATTN_STRUCT_DEBUG; wrong results): 1 no output stores, 2 no language block,
                     // 4 no visual key blocks
+  // round 5: attn_struct_ef_kernel sets *guard = 1 when a row of its shift mA[p] + mB[a] may sit too far above the row's true
+  // maximum for the 16-bit E / P fragments (attn_struct_ef_dev.h); attn_struct_lds_kernel with guard_gate = 1 runs only then
+  int* guard; int guard_gate;
 };
 
 #ifdef VOG_TS_ATTN   // scratch/ts_attn.hip: wall-clock stamps (100 MHz) per wave

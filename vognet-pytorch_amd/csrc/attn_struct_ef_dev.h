@@ -33,6 +33,18 @@ namespace vog {
 constexpr int EF_MAXA = 5;          // arguments per query set (cfg.misc.srl_arg_length)
 
 
+// E is parked as f16 and P = E * F is rounded to the MFMA operand type, both relative to the shift mA[p] + mB[a], which can sit far
+// above a row's true maximum max_p'(A + B) (a key that is weak in A but dominant through B: sharp trained attention, the -13.8 of
+// use_rel's log(clamp(., 1e-6))). Unscaled, E flushed to zero 24 binary orders (16.6 nats) under mA and P lost precision from 14
+// under the shift (f16 subnormals) - silently, there is no fallback on this path. E is therefore stored as
+// exp2(A - mA + EF_ESHIFT): every P, every row sum and every output accumulator carries the same factor 2^12, which cancels in
+// out = (P V) / sum P. Largest value 4096 (exact in f16 / bf16); full precision now reaches 26 binary orders (18 nats) under the
+// shift, flush-to-zero 36 (25 nats). Rows that may lie further down raise the guard flag (behind phase 2) and the launch is
+// redone by the per-row kernel.
+constexpr float EF_ESHIFT = 12.0f;
+constexpr float EF_GUARD_F = 5.9604644775390625e-08f;   // 2^-24: see the guard behind phase 2
+constexpr float EF_GUARD_E = 0.000244140625f;           // 2^-12 = 2^(EF_ESHIFT - 24)
+
 constexpr int EF_PLS_PAD = 16;      // floats between the language rows of two arguments (the 5 rows a lane group reads at once
                                     // sat 3 * DP floats apart = on the same banks)
 
@@ -45,6 +57,7 @@ static inline size_t attn_struct_ef_lds(int npad_kv) {
          + (size_t)nkb * 32 * 4                   // block maxima
          + (size_t)16 * 64 * 4                    // C tile (accumulator layout)
          + (size_t)EF_MAXA * 8 * 4                // D
+         + (size_t)(32 + 8) * 4                   // kA / kB: a key at which row p of A / row a of B takes its maximum (guard)
          + (size_t)(nkb < 3 ? 3 : nkb) * 2 * 64 * 16   // E fragments (f16); later the row-sum partials [a][wave][lane]
          + (size_t)2 * 2 * EF_MAXA * 64 * 16;     // P^T fragments of one round: [2 blocks][2][a][64 lanes] x 16 B; later the output staging
 }
@@ -66,7 +79,9 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
   float* mblk = Bl + NA * p.npad_kv;                                 // [nkb][32]
   float* Cl = mblk + nkb * 32;                                       // [16][64]
   float* Dl = Cl + 16 * 64;                                          // [NA][8]
-  u16x8* El = reinterpret_cast<u16x8*>(Dl + NA * 8);                 // [nkb * 2][64] f16 fragments of E
+  int* kAl = reinterpret_cast<int*>(Dl + NA * 8);                    // [32]
+  int* kBl = kAl + 32;                                               // [8]
+  u16x8* El = reinterpret_cast<u16x8*>(kBl + 8);                     // [nkb * 2][64] f16 fragments of E
   float* Ls = reinterpret_cast<float*>(El);                          // [NA][4 waves][64] row-sum partials (after the rounds)
   u16x8* Pl = El + (nkb < 3 ? 3 : nkb) * 2 * 64;                     // [2 blocks][2][NA][64] P^T fragments of one round
   const int tid = threadIdx.x, lane = tid & 63;
@@ -222,11 +237,16 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
     for (int i = 0; i < 4; ++i) {
       const int kb = wid + 4 * i;
       if (kb < nkb) {
+        // guard: remember a key at which this proposal's row of A takes its maximum (exact equality: m IS one of these values;
+        // several lanes may write - any of them is a witness)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (keep[i][r] == m) kAl[ql] = kb * 32 + c32_row(r, lane);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u16x8 ef;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ef[j] = to16<F16>(__builtin_amdgcn_exp2f(keep[i][ks * 8 + j] - m));
+          for (int j = 0; j < 8; ++j) ef[j] = to16<F16>(__builtin_amdgcn_exp2f(keep[i][ks * 8 + j] - m + EF_ESHIFT));
           El[(kb * 2 + ks) * 64 + lane] = ef;
         }
       }
@@ -235,14 +255,38 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
       const int a = tid >> 5, sub = tid & 31;
       float* brow = Bl + a * p.npad_kv;
       float mB = -1e30f;
-      for (int key = sub; key < p.npad_kv; key += 32) mB = fmaxf(mB, brow[key]);
+      int kB = 0;
+      for (int key = sub; key < p.npad_kv; key += 32)
+        if (brow[key] > mB) { mB = brow[key]; kB = key; }
 #pragma unroll
-      for (int o_ = 16; o_ >= 1; o_ >>= 1) mB = fmaxf(mB, __shfl_xor(mB, o_));
+      for (int o_ = 16; o_ >= 1; o_ >>= 1) {
+        const float om = __shfl_xor(mB, o_);
+        const int ok = __shfl_xor(kB, o_);
+        if (om > mB || (om == mB && ok < kB)) { mB = om; kB = ok; }
+      }
+      if (sub == 0) kBl[a] = kB;
       for (int key = sub; key < p.npad_kv; key += 32) brow[key] = __builtin_amdgcn_exp2f(brow[key] - mB);
     }
   }
   __syncthreads();
   VOG_ATS(4);
+  // ---- guard. x((a, p), kA[p]) = mA[p] + B[a, kA[p]] is a logit of the row, so its true maximum is at least that and the shift
+  // mA[p] + mB[a] sits at most mB[a] - B[a, kA[p]] = -log2 F[a, kA[p]] above it. With E scaled by 2^EF_ESHIFT the fragments keep
+  // full precision to 26 binary orders; past EF_GUARD (2 orders of margin) the launch is redone by the per-row kernel
+  // (attn_struct_lds_kernel, gated on this flag: normally an empty launch). A sufficient bound, not the exact gap: it can send
+  // a launch to the slow kernel needlessly, never the other way round.
+  // The same with the roles swapped - x((a, p), kB[a]) = A[p, kB[a]] + mB[a], read back from the parked E = 2^12 exp2(A - mA) -
+  // gives a second bound; the row is safe when EITHER witness lies within reach.
+  if (p.guard && tid < NA * 32) {
+    const int a = tid >> 5, pp = tid & 31;
+    if (pb * 32 + pp < p.nppf) {
+      const int kb_ = kBl[a], r16 = kb_ & 15;
+      const int jj = ((r16 >> 3) << 2) + (r16 & 3), hh = (r16 >> 2) & 1;
+      const unsigned short eh = reinterpret_cast<const unsigned short*>(El + ((kb_ >> 5) * 2 + ((kb_ & 31) >> 4)) * 64 + hh * 32 + pp)[jj];
+      if (Bl[a * p.npad_kv + kAl[pp]] < EF_GUARD_F && from16<F16>(eh) < EF_GUARD_E)
+        __hip_atomic_store(p.guard, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // ---- phase 3: rounds of 2 key blocks
   f32x16 o[NA][DPW];
   float lsum[NA];

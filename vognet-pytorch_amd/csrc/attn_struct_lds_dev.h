@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256, 1) void attn_struct_lds_kernel(AttnStructParam
   constexpr int PF = 3;                              // LDS fragments requested ahead of their MFMA
   static_assert(NF % 4 == 0, "fragments per key block must divide over the 4 waves");
   extern __shared__ __attribute__((aligned(1024))) unsigned char slsm[];
+  if (p.guard_gate && *reinterpret_cast<volatile const int*>(p.guard) == 0) return;   // fallback pass of attn_struct_ef_kernel: not needed
   constexpr int NBUF = 4, DIST = 2;                  // ring depth; blocks requested ahead
   const int nkb = p.npad_kv >> 5;
   unsigned char* kv = slsm;                          // [NBUF][NF][1024]

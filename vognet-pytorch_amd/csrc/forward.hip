@@ -346,6 +346,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   p.add("chain_flags", 1024);                         // done flags of the lean encoder workgroups (chain_obj_qkv)
   p.add("obj_guard", 256);                            // vog_attn_args.guard_flag of the two stacks (long-sequence attention): zeroed
   p.add("mul_guard", 256);                            // with the rest of this region, so the attention needs no clearing launch
+  p.add("mul_ef_guard", 256);                         // vog_attn_struct_args.guard_flag (E x F attention of mul_tx layer 0, p100)
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -463,6 +464,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       sa.npad_q = npad; sa.npad_kv = npad_kv; sa.nfrm = sv.nfrm; sa.lang_per_vid = sv.lang_per_vid;
       sa.nc_v = sv.nc_v; sa.use_rel = tw.use_rel; sa.seq_per_vid = spv; sa.NP = g.NP;
       sa.inv_scale = 1.0f / sqrtf((float)tw.d); sa.dtype = dt;
+      sa.guard_flag = (n == "mul") ? ws.at<int>("mul_ef_guard") : nullptr;
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_struct_fwd(&sa, st); }});
     } else {
       steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
@@ -472,8 +474,10 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.u = u; aa.pe_b = tw.pe_b; aa.S = S; aa.N = N; aa.H = tw.H; aa.dp = tw.dp; aa.npad = npad;
     aa.use_rel = tw.use_rel; aa.n_box = n_box; aa.seq_per_vid = spv; aa.NP = g.NP;
     aa.inv_scale = 1.0f / sqrtf((float)tw.d); aa.dtype = dt;
-    aa.guard_flag = ws.at<int>(n + "_guard");
-    aa.guard_precleared = 1;
+    // one guard word PER LAYER inside the stack's zero-filled 256 bytes (with one word per stack a flag raised by
+    // layer 0 stayed up - the prologue clears once per forward - and every later layer re-ran the running-maximum fallback)
+    aa.guard_flag = ws.at<int>(n + "_guard") + (l < 63 ? l : 63);
+    aa.guard_precleared = l < 63 ? 1 : 0;
     if (!fact)
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
     const bool last = l == tw.n_layers - 1;

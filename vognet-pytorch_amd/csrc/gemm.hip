@@ -255,6 +255,24 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
     static const int narrow_env = perf_env("VOG_QKV_NARROW") ? atoi(perf_env("VOG_QKV_NARROW")) : -1;
     const int narrow = narrow_env >= 0 ? narrow_env : (p.M >= 8192 && !a->dep_flags ? 1 : 0);
     const int nrb = ceil_div(p.M, 64);
+    // many rows (p100): one workgroup per row block walks ALL output columns (QkvRowAllBody, qkvrb_dev.h)
+    static const int all_env = perf_env("VOG_QKV_ROWALL") ? atoi(perf_env("VOG_QKV_ROWALL")) : -1;
+    const bool rowall = (all_env >= 0 ? all_env != 0 : p.M >= 8192) && !a->dep_flags && (p.N % 32) == 0 &&
+                        QkvRowAllBody<F16>::lds_bytes(p.K) <= 160 * 1024;
+    if (rowall) {
+      const size_t lds_a = QkvRowAllBody<F16>::lds_bytes(p.K);
+      VOG_DISPATCH_DTYPE(a->dtype, {
+        auto kern = qkv_rowall_kernel<T16>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr_set = true;
+        }
+        ::vog::launch(kern, dim3(nrb), dim3(512), lds_a, st, p);
+      });
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
     const size_t lds = QkvRowBlockBody<F16, 2>::lds_bytes(p.K);
 #define VOG_QKVRB(NBWV)                                                                                        \
     VOG_DISPATCH_DTYPE(a->dtype, {                                                                              \

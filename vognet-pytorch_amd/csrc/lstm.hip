@@ -82,7 +82,8 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
   vog::LstmLayerParams p{a->gxs, (const unsigned short*)a->whh, (unsigned short*)a->hx, a->sync,
                          (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R, a->out_frag,
                          (const unsigned short*)a->wih, (const unsigned short*)a->xa, a->bias, a->K,
-                         a->fault, a->inject_stall};
+                         a->fault, a->inject_stall, 0};
+  if (const char* e = vog::perf_env("VOG_LSTM_HALF_PROJ")) p.half_proj = atoi(e);
   const bool fused = a->wih != nullptr;
   if (fused) VOG_CHECK_ARG(a->xa && a->bias && a->K > 0 && (a->K % 256) == 0 && a->Bn * a->T <= 64);
   dim3 grid(a->R / 32, 2);

@@ -142,6 +142,8 @@ struct LstmLayerParams {
   // owns it (engine.Slot reads it without a device synchronisation). inject_stall: test hook, every workgroup behaves as
   // if its first wait had timed out.
   unsigned int* fault; int inject_stall;
+  int half_proj;   // perf experiments only (WRONG results): layers with K >= 2048 run half of their input projection - bounds what
+                   // moving half of it to helper workgroups could give (profiles/round5_lstm_proj_bound.md)
 };
 
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -244,7 +246,8 @@ struct LstmLayerBody {
     if (fused) {
       unsigned char* xch = uni;
       const int nct = (ncols + 15) >> 4;                                // <= 4 column tiles
-      const int ksteps = p.K >> 5, nchunk = ksteps >> 3;               // K % 256 == 0
+      const int ksteps = p.K >> 5;                                     // K % 256 == 0
+      const int nchunk = (p.half_proj && p.K >= 2048) ? (ksteps >> 4) : (ksteps >> 3);
       f32x4 ga[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) ga[ct] = f32x4{0.f, 0.f, 0.f, 0.f};

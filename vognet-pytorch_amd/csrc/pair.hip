@@ -34,6 +34,10 @@
 #include <tuple>
 #include "pair_ids.h"
 
+#ifndef VOG_VS_PAIR_DEPTH
+#define VOG_VS_PAIR_DEPTH 2      // measured (scratch/r5_ve2.sh): 2: 32.4 us for the cfg-2 pair launch, 4: 33.2, 6: 33.9; lean form 36.0
+#endif
+
 namespace vog {
 
 thread_local std::vector<LaunchRecord>* g_pair_capture = nullptr;
@@ -41,7 +45,7 @@ thread_local std::vector<LaunchRecord>* g_pair_capture = nullptr;
 template <typename A, typename B>
 __global__ __launch_bounds__((A::THREADS > B::THREADS ? A::THREADS : B::THREADS))
 void pair_kernel(typename A::Params a, typename B::Params b, unsigned nA, unsigned gax, unsigned gay,
-                 unsigned gbx, unsigned gby) {
+                 unsigned gbx, unsigned gby, unsigned delay_b) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char pair_smem[];
   constexpr int MAXT = A::THREADS > B::THREADS ? A::THREADS : B::THREADS;
   if (blockIdx.x < nA) {
@@ -50,6 +54,8 @@ void pair_kernel(typename A::Params a, typename B::Params b, unsigned nA, unsign
   } else {
     const unsigned id = blockIdx.x - nA;
     if (B::THREADS < MAXT && (int)threadIdx.x >= B::THREADS) return;
+    // perf experiments (VOG_PAIR_DELAY, units of ~0.5 us): the partner starts late, so that A's prologue has the fabric to itself
+    for (unsigned i = 0; i < delay_b; ++i) __builtin_amdgcn_s_sleep(16);
     B::run(b, BlockCtx{id % gbx, id / gbx, gbx, gby}, pair_smem);
   }
 }
@@ -138,7 +144,8 @@ static int launch_pair(const LaunchRecord& ra, const LaunchRecord& rb, hipStream
                                 156 * 1024));
     attr_set = true;
   }
-  ::vog::launch(kern, dim3(nA + nB), dim3(MAXT), lds, st, pa, pb, nA, ra.grid[0], ra.grid[1], rb.grid[0], rb.grid[1]);
+  static const unsigned delay_b = perf_env("VOG_PAIR_DELAY") ? (unsigned)atoi(perf_env("VOG_PAIR_DELAY")) : 0u;
+  ::vog::launch(kern, dim3(nA + nB), dim3(MAXT), lds, st, pa, pb, nA, ra.grid[0], ra.grid[1], rb.grid[0], rb.grid[1], delay_b);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -166,6 +173,7 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     using Lstm = LstmLayerBody<F16, 32>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_f16()}] = &launch_pair<Lstm, VisEncBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16()}] = &launch_pair<Lstm, VisEncLeanBody<F16>>;
+    r[{kid_lstm_layer_f16(), kid_vis_enc_stream_f16()}] = &launch_pair<Lstm, VisEncStreamBody<F16, VOG_VS_PAIR_DEPTH>>;   // (one workgroup per CU inside the pair: depth instead of occupancy)
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<Lstm, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;

@@ -11,4 +11,5 @@ const void* kid_lstm_layer_f16();           // lstm_layer_kernel<F16, 32>
 const void* kid_tx_tail_512(int dtype);     // tx_tail_kernel<T16, F16, 2, false, 0>
 const void* kid_vis_enc_f16();              // vis_enc_kernel<F16>
 const void* kid_vis_enc_lean_f16();         // vis_enc_lean_kernel<F16>
+const void* kid_vis_enc_stream_f16();       // vis_enc_stream_kernel<F16>
 }  // namespace vog

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void seg_replicate_kernel(float* c32, unsigned
 
 const void* kid_vis_enc_f16() { return reinterpret_cast<const void*>(vis_enc_kernel<F16>); }
 const void* kid_vis_enc_lean_f16() { return reinterpret_cast<const void*>(vis_enc_lean_kernel<F16>); }
+const void* kid_vis_enc_stream_f16() { return reinterpret_cast<const void*>(vis_enc_stream_kernel<F16>); }
 
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
   return (prop_dim % 256) == 0 && (seg_dim % 256) == 0 && (prop_enc % 32) == 0 && (seg_enc % 32) == 0 &&
@@ -71,8 +72,18 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
     if (a->defer_replicas && !can_copy) VOG_FAIL(-1, "vog_vis_encode: defer_replicas needs encode sizes and ldc %% 4 == 0");
     const bool split_rep = !a->defer_replicas && p.p[1].rep > 16 && can_copy;
     p.rep_first_only = (split_rep || a->defer_replicas) ? 1 : 0;
-    VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
-                                               VisEncLeanBody<T16>::LDS, st, p));
+    // the stream form (round 5; visenc_dev.h): same tiling, K chunks of 128, DEPTH chunks of fp32 rows in flight per workgroup.
+    // cfg 2 pair launch with BiLSTM layer 0: 36.0 -> 32.4 us; p100: 57.6 -> 45 us alone, 78 -> 69 us in the pair
+    // (VOG_VE_STREAM=0: round 4's lean form, perf experiments; the chained form - done_flags - stays on the lean body)
+    static const int stream_env = perf_env("VOG_VE_STREAM") ? atoi(perf_env("VOG_VE_STREAM")) : -1;
+    const bool stream = (stream_env >= 0 ? stream_env != 0 : true) && p.done_flags == nullptr;
+    if (stream) {
+      VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_stream_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
+                                                 VisEncStreamBody<T16>::LDS, st, p));
+    } else {
+      VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
+                                                 VisEncLeanBody<T16>::LDS, st, p));
+    }
     VOG_LAUNCH_CHECK();
     if (split_rep) {
       const int64_t total = (int64_t)p.p[1].M * (p.p[1].rep - 1) * (p.p[1].N / 4);

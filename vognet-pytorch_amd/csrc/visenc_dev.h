@@ -335,4 +335,157 @@ __global__ __launch_bounds__(512) void vis_enc_lean_kernel(VisEncParams a) {
   VisEncLeanBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vl_smem);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Stream" form (round 5) for many rows (p100: 16 000 proposal rows x 2048 fp32 = 131 MB per forward): the lean form's
+// chunk loop keeps ONE chunk of fp32 rows in flight per workgroup (64 KB per CU) and waits out the HBM latency once per
+// chunk - 66.7 us for 133.7 MB = 2.0 TB/s (profiles/round4_pmc_cfg4.md). Same tiling (64 rows x 128 columns per
+// workgroup, 8 waves x 16 columns, A converted to the MFMA operand type on the way into LDS), but K chunks of 128 and
+// DEPTH of them requested ahead through DEPTH register sets (fp32 rows and weight fragments alike): the wait for chunk
+// c + DEPTH - 1 overlaps DEPTH - 1 chunks of conversion + MFMA. Measured: what pays is OCCUPANCY, not depth - DEPTH = 2
+// fits two workgroups on a CU (45 us = 2.9 TB/s), 3 / 4 sets of registers leave room for one (52 / 55 us). No load is
+// conditional (chunk indices past the end are clamped: hipcc answers a conditional prefetch with s_waitcnt vmcnt(0)).
+// Same k order per output column as the lean form within a chunk; chunks are 128 instead of 256 deep, so the fp32
+// summation order is that of the lean form with VOG_VE_KC = 128.
+// ---------------------------------------------------------------------------------------------------
+#ifndef VOG_VS_DEPTH
+#define VOG_VS_DEPTH 2      // measured at p100 (scratch/r5_ve.sh): 2: 45.0 us (~110 registers: two workgroups per CU), 3: 52.2, 4: 54.6; lean form 57.6
+#endif
+template <typename T16, int DEPTH = VOG_VS_DEPTH>
+struct VisEncStreamBody {
+  using Params = VisEncParams;
+  static constexpr int THREADS = 512;
+  static constexpr int RB = 64, KC = 128, KSC = KC / 32;    // 4 k-steps per chunk
+  static constexpr int PIECES = KC / 8, RPP = THREADS / PIECES, NPASS = RB / RPP;   // 16 pieces per row, 32 rows per pass, 2 passes
+  static constexpr int IMG = (RB / 16) * KSC * 1024;        // one A-chunk image (fragment order): 16 KB
+  static constexpr size_t LDS = (size_t)2 * IMG;
+
+  static __device__ __forceinline__ void run(const VisEncParams& a, const BlockCtx& cx, unsigned char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb0 = (a.tiles0 + 3) >> 2, nb_all = nb0 + ((a.tiles_all - a.tiles0 + 3) >> 2);
+    // the two column halves of a row block sit 8 block ids apart = on the same XCD (second read of the rows: that L2)
+    const int grp = cx.bx >> 4, pos = cx.bx & 15;
+    const int blk = grp * 8 + (pos & 7), half0 = pos >> 3;
+    if (blk >= nb_all) return;
+    const bool second = blk >= nb0;
+    const float* qx = second ? a.p[1].x : a.p[0].x;
+    const unsigned short* qw = second ? a.p[1].w : a.p[0].w;
+    const float* qb = second ? a.p[1].bias : a.p[0].bias;
+    const int qM = second ? a.p[1].M : a.p[0].M, qN = second ? a.p[1].N : a.p[0].N;
+    const int qK = second ? a.p[1].K : a.p[0].K, qrep = second ? a.p[1].rep : a.p[0].rep;
+    const int qcol0 = second ? a.p[1].col0 : a.p[0].col0;
+    const int m0 = (second ? blk - nb0 : blk) * RB;
+    if (half0 * 128 >= qN) return;
+    const int ksteps = qK >> 5, nchunk = qK / KC;            // K % 256 == 0
+    const int n0 = half0 * 128 + w * 16;
+    const bool n_ok = n0 < qN;
+    const u16x8* wf = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok ? n0 : 0) >> 4) * ksteps) * 64 + lane;
+    const int pr = tid / PIECES, pc = tid % PIECES;
+    const float* xrow[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      int m = m0 + ps * RPP + pr;
+      m = m < qM ? m : qM - 1;
+      xrow[ps] = qx + (int64_t)m * qK + pc * 8;
+    }
+    f32x4 acc[RB / 16];
+#pragma unroll
+    for (int mt = 0; mt < RB / 16; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 xa[DEPTH][NPASS][2];
+    u16x8 wq[DEPTH][KSC];
+    auto request = [&](int set, int c) {                     // fp32 row pieces + weight fragments of chunk c (clamped)
+      const int cc = c < nchunk ? c : nchunk - 1;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const float4* src = reinterpret_cast<const float4*>(xrow[ps] + cc * KC);
+        xa[set][ps][0] = src[0];                             // (plain loads: the other column half of the row block, on the same
+        xa[set][ps][1] = src[1];                             // XCD, reads the same rows from that L2)
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) wq[set][ks] = wf[(cc * KSC + ks) * 64];
+    };
+    auto store_a = [&](int set, int c) {
+      unsigned char* img = smem + (size_t)(c & 1) * IMG;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const u16x8 h = {to16<T16>(xa[set][ps][0].x), to16<T16>(xa[set][ps][0].y), to16<T16>(xa[set][ps][0].z), to16<T16>(xa[set][ps][0].w),
+                         to16<T16>(xa[set][ps][1].x), to16<T16>(xa[set][ps][1].y), to16<T16>(xa[set][ps][1].z), to16<T16>(xa[set][ps][1].w)};
+        const int ks = pc >> 2, kgp = pc & 3;
+        const int rl = ps * RPP + pr;
+        *reinterpret_cast<u16x8*>(img + (((rl >> 4) * KSC + ks) * 64 + kgp * 16 + (rl & 15)) * 16) = h;
+      }
+    };
+    auto mfmas = [&](int set, int c) {
+      const unsigned char* img = smem + (size_t)(c & 1) * IMG;
+      u16x8 fa[KSC], fb[KSC];
+      auto rd = [&](u16x8 (&f)[KSC], int mt) {
+#pragma unroll
+        for (int j = 0; j < KSC; ++j) f[j] = *reinterpret_cast<const u16x8*>(img + ((mt * KSC + j) * 64 + lane) * 16);
+      };
+      rd(fa, 0);
+#pragma unroll
+      for (int mt = 0; mt < RB / 16; mt += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fb, mt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KSC; ++j) acc[mt] = mfma16<T16>(fa[j], wq[set][j], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt + 2 < RB / 16) rd(fa, mt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KSC; ++j) acc[mt + 1] = mfma16<T16>(fb[j], wq[set][j], acc[mt + 1]);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) request(d, d);
+    int c0 = 0;
+    for (; c0 + DEPTH <= nchunk; c0 += DEPTH) {              // (no condition around a load in the steady state)
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const int c = c0 + j;
+        store_a(j, c);                                       // image (c & 1) was last read two chunks ago (a barrier since)
+        request((j + DEPTH - 1) % DEPTH, c + DEPTH - 1);     // the set chunk c - 1 has just released
+        lds_barrier();
+        mfmas(j, c);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j) {                    // nchunk % DEPTH left-over chunks (their requests are out already)
+      const int c = c0 + j;
+      if (c < nchunk) {
+        store_a(j, c);
+        lds_barrier();
+        mfmas(j, c);
+      }
+    }
+    // D[row = 4*(lane>>4) + reg][col = lane & 15]
+    const int col = n0 + (lane & 15);
+    if (n_ok && col < qN) {
+      const float b = qb[col];
+      const int nrep = a.rep_first_only ? 1 : qrep;
+#pragma unroll
+      for (int mt = 0; mt < RB / 16; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + mt * 16 + (lane >> 4) * 4 + r;
+          if (row >= qM) continue;
+          const float o = fmaxf(acc[mt][r] + b, 0.f);
+          const unsigned short hv = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+          for (int j = 0; j < nrep; ++j) {
+            const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
+            if (a.c32) a.c32[off] = o;
+            if (a.c16) a.c16[off] = hv;
+          }
+        }
+    }
+  }
+};
+
+template <typename T16>
+__global__ __launch_bounds__(512) void vis_enc_stream_kernel(VisEncParams a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
+  VisEncStreamBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vs_smem);
+}
+
 }  // namespace vog

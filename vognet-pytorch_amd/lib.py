@@ -71,7 +71,7 @@ class AttnStructArgs(C.Structure):
                 ("S", c_i32), ("H", c_i32), ("dp", c_i32), ("nsrl", c_i32), ("nppf", c_i32), ("npad_q", c_i32),
                 ("npad_kv", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32), ("nc_v", c_i32),
                 ("use_rel", c_i32), ("seq_per_vid", c_i32), ("NP", c_i32), ("inv_scale", c_f32), ("dtype", c_i32),
-                ("q_visual", c_i32)]
+                ("q_visual", c_i32), ("guard_flag", c_vp)]
 
 
 class QkvCombArgs(C.Structure):
