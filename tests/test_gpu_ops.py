@@ -248,13 +248,14 @@ def test_rel_attention(S, N, H, dh, dp, nsrl, use_rel, dtype):
     (1, 2011, 3, 171, 192, 1, 1), (2, 1100, 3, 128, 128, 5, 1), (1, 4000, 1, 171, 192, 1, 1),
     (3, 1024, 2, 64, 64, 1, 0), (2, 1057, 1, 32, 32, 1, 1)])
 @pytest.mark.parametrize("hostile", [0, 1])
-def test_rel_attention_long_fixed_reference(S, N, H, dh, dp, nsrl, use_rel, hostile):
-    """Long bf16 sequences with a guard flag -> attn_tile2_kernel (csrc/attn_tile2_dev.h): softmax against
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_rel_attention_long_fixed_reference(S, N, H, dh, dp, nsrl, use_rel, hostile, dtype):
+    """Long sequences with a guard flag -> attn_tile2_kernel (csrc/attn_tile2_dev.h): softmax against
     the row maximum of key block 0. hostile = 1 plants keys far above anything in block 0 (logits +60
     and more): the kernel must raise the flag and the running-maximum pass must produce the result."""
     lib = _lib()
     torch.manual_seed(S * 1000 + N + hostile)
-    td = torch.bfloat16
+    td = t16(dtype)
     npad = (N + 31) // 32 * 32
     q = torch.zeros(S, H, N, dp, device="cuda")
     k = torch.zeros(S, H, N, dp, device="cuda")
@@ -285,7 +286,7 @@ def test_rel_attention_long_fixed_reference(S, N, H, dh, dp, nsrl, use_rel, host
         a.u, a.pe_b = L.ptr(u_box.contiguous()), L.ptr(peb)
         a.S, a.N, a.H, a.dp, a.npad = S, N, H, dp, npad
         a.use_rel, a.n_box, a.seq_per_vid, a.NP = use_rel, n_box, 1, n_box
-        a.inv_scale, a.dtype = inv_scale, DT["bf16"]
+        a.inv_scale, a.dtype = inv_scale, DT[dtype]
         a.guard_flag = L.ptr(guard) if guard is not None else None
         L.check(lib.vog_rel_attention_fwd(C.byref(a), _sp()), "attn")
         torch.cuda.synchronize()
@@ -296,7 +297,10 @@ def test_rel_attention_long_fixed_reference(S, N, H, dh, dp, nsrl, use_rel, host
         assert err <= tol, (guard is not None, err, tol)
         assert (got[..., dh:] == 0).all()
         outs.append(got)
-    assert int(flag[0].item()) == (1 if hostile else 0)          # raised exactly when the reference moved too far
+    if dtype == "bf16" or hostile:
+        assert int(flag[0].item()) == (1 if hostile else 0)      # raised exactly when the reference moved too far
+    # (f16 trips 13 nats above block 0's maximum instead of 28: the 3-4 nats of logit spread of the small-head cases here
+    #  may or may not get there - either way the result above was checked)
     assert (flag[1:] == 7).all()
     if hostile:
         assert torch.equal(outs[0], outs[1])                     # the fallback pass is the running-maximum kernel
@@ -414,7 +418,7 @@ def _pack32_cols(lib, w32, K, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("case", ["obj", "mul", "vis"])
+@pytest.mark.parametrize("case", ["obj", "mul", "vis", "obj_p100", "obj_big_ragged"])
 def test_qkv_rowblock_equals_tiled(dtype, case):
     """vog_qkv_proj with wqkv_p32 (row-block kernel, csrc/qkvrb_dev.h) writes the same Q/K/V^T fragment
     images as the tiled LDS-DMA GEMM (to the rounding of a different fp32 summation order) and touches
@@ -423,8 +427,11 @@ def test_qkv_rowblock_equals_tiled(dtype, case):
     lib = _lib()
     torch.manual_seed(23)
     td = t16(dtype)
+    # (>= 8192 rows: the all-columns form, QkvRowAllBody - obj_p100 takes its register / 16-byte fragment stores (4000 tokens
+    # per sequence: 16-token groups never straddle one), obj_big_ragged the shared V^T writer (203 tokens, ragged last block))
     S, N, H, dp, K, ld = {"obj": (3, 203, 3, 192, 512, 512), "mul": (7, 100, 3, 256, 768, 768),
-                          "vis": (13, 20, 3, 256, 512, 768)}[case]
+                          "vis": (13, 20, 3, 256, 512, 768), "obj_p100": (4, 4000, 3, 192, 512, 512),
+                          "obj_big_ragged": (41, 203, 3, 192, 512, 512)}[case]
     npad = (N + 31) // 32 * 32
     ncol = 3 * H * dp
     assert lib.vog_qkv_rowblock_supported(ncol, K) == 1

@@ -167,11 +167,11 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
   // long sequences: enough 128-query groups to fill the chip -> shared K/V tiles through LDS
   static int tile_min = -2;           // VOG_ATTN_TILE_MIN (perf experiments): N threshold, 0 = never
   if (tile_min == -2) { const char* e = perf_env("VOG_ATTN_TILE_MIN"); tile_min = e ? atoi(e) : 512; }
-  // very long bf16 sequences: two waves per SIMD, fixed-reference softmax (attn_tile2_dev.h)
+  // very long sequences: two waves per SIMD, fixed-reference softmax (attn_tile2_dev.h)
   static int tile2_min = -2;          // VOG_ATTN_TILE2_MIN (perf experiments): N threshold, 0 = never
   if (tile2_min == -2) { const char* e = perf_env("VOG_ATTN_TILE2_MIN"); tile2_min = e ? atoi(e) : 1024; }
   bool fallback_pass = false;         // tile2 ran: attn_tile_kernel below runs only if the guard was raised
-  if constexpr (NDB <= 6 && std::is_same<T16, BF16>::value) {   // (head dim 256 would spill at 2 waves per SIMD)
+  if constexpr (NDB <= 6) {           // (head dim 256 would spill at 2 waves per SIMD)
     constexpr int NF2 = (NDB * 32) / 16 + 2 * NDB;
     const size_t lds2 = (size_t)4 * NF2 * 1024 + (size_t)p.npad * sizeof(float);
     if (tile2_min > 0 && p.N >= tile2_min && p.guard && !force_general && lds2 <= 160 * 1024) {

@@ -22,7 +22,7 @@
 //     the O *= alpha pass. P may exceed 1 when a later block holds a larger logit; a row whose block
 //     sum passes 2^40 (a logit 28 nats above everything in block 0 - or anything non-finite) raises
 //     p.guard and the host-side sequence (attention.hip) re-runs the call with attn_tile_kernel,
-//     whose running maximum is safe for any input. bf16 only (P keeps fp32's exponent range).
+//     whose running maximum is safe for any input. f16 (round 5): the same with the trip point at a block sum of 2^15.
 //   * K / V^T of NBUF key blocks live in an LDS ring filled by LDS-DMA two blocks ahead; one barrier
 //     per key block, counted vmcnt; every LDS read in the loop goes through lds_read128 / lds_wait
 //     (common.h) so the DMA really stays in flight, with three fragments requested ahead.
@@ -157,6 +157,10 @@ __global__ __launch_bounds__(512) void attn_tile2_kernel(AttnParams p) {
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // f16: the reference sits 4 binary orders ABOVE block 0's maximum - every P, row sum and accumulator carries 2^-4, which
+    // cancels in O / l - so that the headroom to f16's 65504 is 19 binary orders (13 nats above block 0) instead of 15; block
+    // 0's own maximum becomes 2^-4 and P stays a normal f16 number down to 2^-10 of it (below: absolute error 2^-25 per key)
+    if constexpr (!std::is_same<T16, BF16>::value) mx += 4.0f;
     nm = -mx;
     uqm = uq - mx;
   }
@@ -199,7 +203,12 @@ __global__ __launch_bounds__(512) void attn_tile2_kernel(AttnParams p) {
       }
     }
     lsum += __shfl_xor(lsum, 32);
-    trip = trip || !(lsum < 1.0995e12f);             // 2^40; also catches inf / NaN
+    // bf16 P keeps fp32's exponent range: 2^40. f16 (round 5: the package default) holds 65504: a block sum under 2^15
+    // bounds every P of the block (a logit 10.4 nats above everything in block 0 sends the call to the fallback); values
+    // far UNDER the reference lose nothing that matters - the row's true maximum is >= the reference (block 0 is part of
+    // the row), so a P below f16's normal range (2^-14) weighs < 2^-14 of the row. Also catches inf / NaN.
+    constexpr float TRIP = std::is_same<T16, BF16>::value ? 1.0995e12f : 32768.0f;
+    trip = trip || !(lsum < TRIP);
     l_run += lsum;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(2);
