@@ -71,6 +71,10 @@ static int launch_pipe(const GemmParams& p, hipStream_t st) {
   if (ntiles(128, 64) >= 512) return launch_pipe_cfg<T16, 128, 64, 2, EPI>(p, st);
   if (ntiles(64, 64) * (p.splitk > 1 ? p.splitk : 1) < 256)
     return launch_pipe_cfg<T16, 64, 64, 4, EPI>(p, st);                            // <1 tile per CU: go deep
+  // long K, 1-3 tiles per CU (the BiLSTM input projections of cfg 3 / cfg 5: M = 96 / 192, N = 8192, K = 2048): a workgroup
+  // walks 32 k-tiles and there are too few of them per CU to hide each other's round trips - one more stage in flight:
+  // 21.5 -> 17.6 us (cfg 3), 23.1 -> 22.3 (cfg 5); scratch/r5_ih.sh
+  if (p.K >= 2048 && p.splitk <= 1 && ntiles(64, 64) <= 768) return launch_pipe_cfg<T16, 64, 64, 3, EPI>(p, st);
   return launch_pipe_cfg<T16, 64, 64, 2, EPI>(p, st);
 }
 
