@@ -136,6 +136,8 @@ CASES["full/cfg3_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "temp", **
                                   perturb_ln=True, sharp=(8.0, 4.0), feat="relu_heavy")
 CASES["full/cfg5_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "svsq", **REL}, B=16, ragged=True, dseed=55,
                                   perturb_ln=True, sharp=(8.0, 4.0))
+CASES["full/cfg4_p100_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "spat", "ds.exp_setting": "p100", **REL}, B=4, nppf0=100,
+                                  ragged=True, dseed=60, perturb_ln=True, sharp=(8.0, 4.0), feat="relu_heavy")
 for _c in ("spat", "temp", "sep", "svsq"):
     CASES[f"small/sharp8_vog_{_c}"] = _case(
         {"mdl.name": "vog", "ds.conc_type": _c, **REL, **SMALL_DIMS},

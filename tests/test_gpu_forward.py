@@ -350,6 +350,15 @@ def test_forward_graph_replay_matches_eager():
     assert torch.equal(out_e["pred_rec"], out_g["pred_rec"])
 
 
+def test_forward_p100_sharp_vs_reference_golden():
+    """p100 with sharpened attention and heavy-tailed features (wq / wk x 8: obj logit std ~2, mul ~7 nats): the f16 fixed-reference
+    attention (attn_tile2) and the guarded E x F attention - whichever of their fallbacks the data sends them to - against the
+    reference golden."""
+    name = "full/cfg4_p100_sharp8"
+    out, pred, g, _ = _run(name)
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
 def test_forward_p100_vs_reference_golden():
     name = "full/cfg4_vog_spat_p100_bs4"
     out, pred, g, _ = _run(name)
