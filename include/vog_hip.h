@@ -186,6 +186,10 @@ typedef struct vog_attn_args {
    * region its prologue zero-fills), so the clearing launch is skipped. */
   int* guard_flag;
   int guard_precleared;
+  /* round 5: 0 = the whole call; 1 = only the fixed-reference kernel, 2 = only its gated fallback (both need guard_flag and a shape
+   * that takes that kernel: -1 otherwise). vog_forward issues the two halves as separate steps so that the first one can share a
+   * launch with a BiLSTM layer (csrc/pair.hip). */
+  int phase;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
 

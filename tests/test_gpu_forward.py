@@ -230,7 +230,7 @@ def test_forward_unfused_tail_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
-@pytest.mark.parametrize("name", FULL)
+@pytest.mark.parametrize("name", FULL + ["full/cfg4_vog_spat_p100_bs4"])
 def test_paired_launches_equal_separate_launches(name):
     """pair_launches: two independent steps in one grid (csrc/pair.hip) run the same kernel bodies as
     the stand-alone launches -> bit-identical outputs."""
@@ -363,6 +363,19 @@ def test_forward_p100_vs_reference_golden():
     name = "full/cfg4_vog_spat_p100_bs4"
     out, pred, g, _ = _run(name)
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+def test_p100_lstm_layer_inside_long_attention_launch():
+    """`pair_attn` (latency option, off by default): BiLSTM layer 1 rides in obj_tx's long-sequence attention launch (192 + 64
+    workgroups = the chip) and the obj tail runs alone - same kernel bodies, bit-identical outputs."""
+    name = "full/cfg4_vog_spat_p100_bs4"
+    eng, cfg, sd, batch, c, dev = build_engine(name)
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("pair_attn", 1)
+    b = eng.forward(dev)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("fused", [1, 0])

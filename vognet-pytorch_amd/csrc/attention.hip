@@ -182,14 +182,19 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_t2 = true;
       }
-      if (!p.guard_precleared)
-        ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: recorded by the AQL path too)
-      dim3 grid(ceil_div(p.N, 256) * p.H * p.S);
-      ::vog::launch(kern, grid, dim3(512), lds2, st, p);
-      VOG_LAUNCH_CHECK();
+      if (p.phase != 2) {
+        if (!p.guard_precleared)
+          ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: recorded by the AQL path too)
+        dim3 grid(ceil_div(p.N, 256) * p.H * p.S);
+        ::vog::launch(kern, grid, dim3(512), lds2, st, p);
+        VOG_LAUNCH_CHECK();
+        if (p.phase == 1) return 0;
+      }
       fallback_pass = true;
     }
   }
+  if (p.phase != 0 && !fallback_pass)
+    VOG_FAIL(-1, "rel_attention: phase %d needs the fixed-reference kernel (guard_flag, >= %d tokens, head dim <= 192)", p.phase, tile2_min);
   AttnParams pt = p;
   if (!fallback_pass) pt.guard = nullptr;
   // (after attn_tile2 the running-maximum tile kernel is ALWAYS the second pass, whatever the experiment
@@ -250,6 +255,19 @@ static int attn_dispatch(const AttnParams& p, hipStream_t st) {
   }
 }
 
+// pair.hip: the fixed-reference kernel at head dim 192 (obj_tx) can take a BiLSTM layer into its launch
+const void* kid_attn_tile2_192(int dtype) {
+  return dtype == VOG_BF16 ? reinterpret_cast<const void*>(attn_tile2_kernel<BF16, 6>)
+                           : reinterpret_cast<const void*>(attn_tile2_kernel<F16, 6>);
+}
+// does vog_rel_attention_fwd take the fixed-reference kernel for this shape (given a guard flag)?
+int attn_uses_tile2(int N, int dp, int npad) {
+  if (perf_env("VOG_ATTN_TILE2_MIN") || perf_env("VOG_ATTN_GENERAL")) return 0;   // (experiments: keep the plan simple)
+  const int ndb = dp / 32;
+  const size_t lds2 = (size_t)4 * ((ndb * 32) / 16 + 2 * ndb) * 1024 + (size_t)npad * sizeof(float);
+  return N >= 1024 && ndb <= 6 && lds2 <= 160 * 1024;
+}
+
 int attn_head_pad(int dh) {
   const int opts[5] = {32, 64, 128, 192, 256};
   for (int i = 0; i < 5; ++i) if (dh <= opts[i]) return opts[i];
@@ -266,7 +284,7 @@ int attn_run(const vog_attn_args* a, hipStream_t st) {
   p.u = a->u; p.pe_b = a->pe_b;
   p.S = a->S; p.N = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad; p.use_rel = a->use_rel;
   p.n_box = a->n_box; p.seq_per_vid = a->seq_per_vid; p.NP = a->NP; p.inv_scale = a->inv_scale;
-  p.guard = a->guard_flag; p.guard_precleared = a->guard_precleared;
+  p.guard = a->guard_flag; p.guard_precleared = a->guard_precleared; p.phase = a->phase;
   VOG_DISPATCH_DTYPE(a->dtype, return attn_dispatch<T16>(p, st));
   return 0;
 }

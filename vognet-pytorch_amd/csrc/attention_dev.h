@@ -14,6 +14,7 @@ struct AttnParams {
   int* guard;       // attn_tile2_kernel: set to 1 when its fixed-reference softmax left its safe range;
                     // attn_tile_kernel: when non-null, run only if *guard != 0 (fallback pass)
   int guard_precleared;   // host side only: *guard is already 0 (no clearing launch)
+  int phase;              // host side only: 0 whole call, 1 fixed-reference kernel only, 2 its gated fallback only
 };
 
 template <typename T16, int NDB>

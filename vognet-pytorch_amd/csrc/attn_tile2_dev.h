@@ -37,14 +37,18 @@
 
 namespace vog {
 
+// Body form (common.h): at p100 its 192 workgroups (4 sequences x 3 heads x 16 query groups) and the 64 of a persistent
+// BiLSTM layer fill the chip exactly - the layer rides inside this launch (pair.hip, round 5).
 template <typename T16, int NDB>
-__global__ __launch_bounds__(512) void attn_tile2_kernel(AttnParams p) {
+struct AttnTile2Body {
+  using Params = AttnParams;
+  static constexpr int THREADS = 512;
+  static __device__ __forceinline__ void run(const AttnParams& p, const BlockCtx& cx, unsigned char* t2sm) {
   constexpr int DP = NDB * 32, KS = DP / 16;
   constexpr int NF = KS + 2 * NDB;                   // KiB fragments per key block (K then V^T)
   constexpr int NBUF = 4, DIST = 2;                  // ring depth; blocks requested ahead
   constexpr int FPW = (NF + 7) / 8;                  // DMA instructions per wave per block (tail waves repeat the last fragment)
   constexpr int PF = 3;                              // LDS fragments requested ahead of their MFMA
-  extern __shared__ __attribute__((aligned(1024))) unsigned char t2sm[];
   unsigned char* kv = t2sm;                          // [NBUF][NF][1024]
   float* us = reinterpret_cast<float*>(t2sm + NBUF * NF * 1024);   // [npad] key bias precursors * c2
   const int tid = threadIdx.x, lane = tid & 63;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(512) void attn_tile2_kernel(AttnParams p) {
   const int npair = p.S * p.H;
   int pair, qg;
   {   // XCD-aware: the query groups of one (sequence, head) stay on one XCD (its K/V in one L2)
-    const int b = blockIdx.x;
+    const int b = cx.bx;
     const int full = (npair / 8) * 8;
     const int grp = b / (8 * nqg);
     if (grp * 8 < full) { pair = grp * 8 + (b & 7); qg = (b >> 3) % nqg; }
@@ -240,6 +244,13 @@ __global__ __launch_bounds__(512) void attn_tile2_kernel(AttnParams p) {
         *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
       }
   }
+}
+};
+
+template <typename T16, int NDB>
+__global__ __launch_bounds__(512) void attn_tile2_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char t2sm_k[];
+  AttnTile2Body<T16, NDB>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, t2sm_k);
 }
 
 }  // namespace vog

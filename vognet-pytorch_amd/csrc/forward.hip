@@ -29,6 +29,7 @@ int attn_head_pad(int dh);
 int tx_tail_supported(int d, int dh, int kwo);
 int64_t tx_tail_scratch_bytes(int M, int d);
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
+int attn_uses_tile2(int N, int dp, int npad);
 int pair_launch3(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
                  const std::function<int(hipStream_t)>& fc, hipStream_t st, bool* fused);
 int pair_launch(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
@@ -79,6 +80,10 @@ struct vog_ctx {
   std::map<std::string, std::vector<float>> host;
   std::vector<void*> allocs;
   bool finalized = false;
+  int pair_attn = 0;                    // p100: 1 = BiLSTM layer 1 inside obj_tx's long attention launch instead of next to the obj tail.
+                                        // Measured (scratch/r5_pairattn*.sh): one forward 944 -> 888 us (-6 %), 4 in flight 5358 -> 5280
+                                        // queries/s (-1.5 %: the launch fills the chip exactly and leaves the other forwards' kernels
+                                        // no CU). Off: `value` is the throughput regime; on for latency-bound serving.
   int lstm_inject_stall = 0;            // test hook: persistent layer launches behave as if their hand-off had timed out
   int lstm_persistent = 1;              // one launch per BiLSTM layer where supported (W_hh resident on chip; vog_hip.h)
   int fused_tail = 1;                   // Wo..LN2 (+ lin2 + score) of an encoder layer as one launch where supported
@@ -478,8 +483,18 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     // layer 0 stayed up - the prologue clears once per forward - and every later layer re-ran the running-maximum fallback)
     aa.guard_flag = ws.at<int>(n + "_guard") + (l < 63 ? l : 63);
     aa.guard_precleared = l < 63 ? 1 : 0;
-    if (!fact)
-      steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
+    if (!fact) {
+      if (n == "obj" && l == 0 && aa.guard_precleared && attn_uses_tile2(N, tw.dp, npad)) {
+        // long sequences (p100): the fixed-reference kernel and its gated fallback as two steps - the first can share a launch
+        // with BiLSTM layer 1 (pair plan below)
+        vog_attn_args a1 = aa, a2 = aa;
+        a1.phase = 1; a2.phase = 2;
+        steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&a1, st); }});
+        steps.push_back({n + "_attnfb", [=](hipStream_t st) { return vog_rel_attention_fwd(&a2, st); }});
+      } else {
+        steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
+      }
+    }
     const bool last = l == tw.n_layers - 1;
     // 16-bit copy of the LAST layer's output: typed for its consumer (none for obj_tx,
     // the f16 score head for mul_tx)
@@ -909,10 +924,19 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     // input projection they measured SLOWER than apart: 22.5 vs 9.5 + 7.4 us).
     struct Want { const char* lang; int occ; const char* vis; const char* then[3]; };
     const bool has_rep = find("seg_rep", 0) >= 0;
-    const Want want[] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
-                                 : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}},
-                         {"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}},
-                         {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
+    // p100 (an "obj_attnfb" step exists): layer 1 rides inside obj_tx's long attention instead of next to its tail - 192 + 64
+    // workgroups fill the chip exactly, the tail then runs alone on all of it (next to the layer it took 71 us instead of 39:
+    // 250 workgroups on the 192 CUs the layer left)
+    const bool long_attn = find("obj_attnfb", 0) >= 0 && c->pair_attn;
+    const Want want_gt5[] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
+                                     : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}},
+                             {"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}},
+                             {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
+    const Want want_long[] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", nullptr}}
+                                      : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", nullptr, nullptr}},
+                              {"lstm_layer", 1, "obj_attn", {"obj_attnfb", "obj_tail", nullptr}},
+                              {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
+    const Want (&want)[3] = long_attn ? want_long : want_gt5;
     struct Plan2 { int ia, ib; int it[3]; };
     std::vector<Plan2> plans;
     bool ok = true;
@@ -1436,6 +1460,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "lstm_inject_stall") == 0) { c->lstm_inject_stall = value ? 1 : 0; return 0; }
+  if (strcmp(name, "pair_attn") == 0) { c->pair_attn = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_argvec") == 0) { c->fused_argvec = value ? 1 : 0; return 0; }

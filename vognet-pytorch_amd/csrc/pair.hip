@@ -31,6 +31,7 @@
 #include "txtail_dev.h"
 #include "visenc_dev.h"
 #include "qkvrb_dev.h"
+#include "attn_tile2_dev.h"
 #include <tuple>
 #include "pair_ids.h"
 
@@ -178,6 +179,10 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_F16)}] = &launch_pair<Lstm, TxTailBody<F16, F16, 2, false, 0>>;
+    // p100 (round 5): obj_tx's long-sequence attention is 192 workgroups x 171 us - with the 64 of BiLSTM layer 1 the chip is
+    // exactly full and the layer's 40 us disappear inside the attention
+    r[{kid_lstm_layer_f16(), kid_attn_tile2_192(VOG_BF16)}] = &launch_pair<Lstm, AttnTile2Body<BF16, 6>>;
+    r[{kid_lstm_layer_f16(), kid_attn_tile2_192(VOG_F16)}] = &launch_pair<Lstm, AttnTile2Body<F16, 6>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
   });

@@ -85,7 +85,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("vt", c_vp), ("out16", c_vp), ("u", c_vp), ("pe_b", c_vp),
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
                 ("use_rel", c_i32), ("n_box", c_i32), ("seq_per_vid", c_i32), ("NP", c_i32),
-                ("inv_scale", c_f32), ("dtype", c_i32), ("guard_flag", c_vp), ("guard_precleared", c_i32)]
+                ("inv_scale", c_f32), ("dtype", c_i32), ("guard_flag", c_vp), ("guard_precleared", c_i32), ("phase", c_i32)]
 
 
 class LstmStepArgs(C.Structure):
