@@ -484,7 +484,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.guard_flag = ws.at<int>(n + "_guard") + (l < 63 ? l : 63);
     aa.guard_precleared = l < 63 ? 1 : 0;
     if (!fact) {
-      if (n == "obj" && l == 0 && aa.guard_precleared && attn_uses_tile2(N, tw.dp, npad)) {
+      if (c->pair_attn && n == "obj" && l == 0 && aa.guard_precleared && attn_uses_tile2(N, tw.dp, npad)) {
         // long sequences (p100): the fixed-reference kernel and its gated fallback as two steps - the first can share a launch
         // with BiLSTM layer 1 (pair plan below)
         vog_attn_args a1 = aa, a2 = aa;
