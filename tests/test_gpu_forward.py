@@ -923,3 +923,63 @@ def test_slots_sharing_a_workspace_on_one_stream():
         for i in range(3):
             for k in ("mdl_outs", "mdl_outs_eval", "pred_rec"):
                 assert torch.equal(sh[i].out[k], own[i].out[k]), (order, i, k)
+
+
+# ---- round 5: the fp32 path (checkpoints outside the f16 envelope) behind EVERY engine surface --------------------------------
+def test_fp32_path_behind_batched_group_and_fed_surfaces():
+    """`auto` on a checkpoint whose attention sharpness is outside the f16 envelope (full/cfg2_sharp16: 50.6 > 20): batched
+    requests, a shared-language group and host-fed slots all hand out the fp32 path's results (the reference golden / the eager
+    precise forward to 1e-5), not the 16-bit kernels' (1.5e-3 there)."""
+    import importlib
+    dls = importlib.import_module("vognet-pytorch_amd.dat_loader_simple")
+    synth = importlib.import_module("vognet-pytorch_amd.synth")
+    from tests.gpu_util import comm_for
+    from oracle import vog_oracle as vo
+    name = "full/cfg2_sharp16"
+    members = _group_members(name, 2)
+    cfg, sd, batch0, c = members[0]
+    eng = engine_mod.VogEngine(cfg, comm_for(c))
+    eng.load_state_dict(sd)
+    assert eng.precise is not None and eng.sharpness > engine_mod.F16_SHARPNESS_MAX
+    devs = [{k: torch.from_numpy(v).cuda() for k, v in m[2].items()} for m in members]
+    refs = [{k: v.clone() for k, v in eng.forward(dv).items() if isinstance(v, torch.Tensor)} for dv in devs]
+    torch.cuda.synchronize()
+    g = np.load(cases.golden_path(name))
+    ncmp = batch0["new_srl_idxs"].shape[1]
+    _check_against(name, refs[0], eng.unpack_pred(refs[0]["pred_rec"], ncmp), g, None, tol_rel=5e-5, tol_logit=1e-4)
+    for kind, unit in (("batched", eng.make_batched(devs, graph=True)), ("group", eng.make_group(devs, graph=True))):
+        for rep in range(2):
+            outs = unit.launch()
+            torch.cuda.synchronize()
+            for m, (ref, out) in enumerate(zip(refs, outs)):
+                e = (ref["mdl_outs"] - out["mdl_outs"]).abs().max().item()
+                assert e <= 1e-5, (kind, m, e)
+                assert torch.equal(ref["pred_rec"], out["pred_rec"].contiguous()) or \
+                    (ref["pred_rec"] - out["pred_rec"]).abs().max().item() <= 1e-5, (kind, m)
+    # host-fed slots: the graph's copies / assembly land in the slot's input buffers, the fp32 forward reads them behind it
+    B = batch0["num_cmp_msk"].shape[0]
+    asm = dls.DeviceBatchAssembler(cfg, {"num_prop_per_frm": c["nppf0"]})
+    lang_keys = ("srl_arg_words_ind", "srl_arg_word_mask", "srl_arg_word_mask_len", "srl_arg_words_capture",
+                 "srl_arg_inds_msk", "num_cmp_msk")
+    it0 = synth.make_items(B, 4, c["nppf0"], seed=1)
+    spec = {**{k: np.zeros_like(it0[k]) for k in dls.FWD_KEYS}, **{k: np.zeros_like(batch0[k]) for k in lang_keys}}
+    T = int(batch0["srl_arg_word_mask_len"].max())
+    pipe = engine_mod.FedPipeline(eng, devs[0], spec, asm, streams=2, slots_per_stream=1, T=T)
+    got, fulls = [], []
+    for i in range(3):
+        it = synth.make_items(B, 4, c["nppf0"], seed=300 + i)
+        st = pipe.next_staging()
+        st.fill({k: it[k] for k in dls.FWD_KEYS})
+        st.fill({k: batch0[k] for k in lang_keys})
+        sl = pipe.submit()
+        with torch.cuda.stream(pipe.stream_of(sl)):
+            got.append(sl.out["mdl_outs"].clone())
+        full = dict(batch0)
+        full.update({k: vo.assemble_batch(it, cfg.ds.conc_type, 10, c["nppf0"])[k] for k in dls.FWD_KEYS})
+        fulls.append(full)
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    for i, (gm, full) in enumerate(zip(got, fulls)):
+        ref = eng.forward({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in full.items()}, T=T)
+        torch.cuda.synchronize()
+        assert (gm - ref["mdl_outs"]).abs().max().item() <= 1e-5, i
