@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 import bench as B
 w = B.WORKLOADS[os.environ.get("WL", "cfg2")]
+w = dict(w, tx=os.environ.get("TX", w["tx"]))
 cfg = B.make_cfg(w)
 nppf0 = B.ec.num_prop_per_frm(cfg)
 comm = {"vocab_size": B.VOCAB, "detect_size": 431, "itod": {}, "wtoi": {"UNK": 1}, "num_prop_per_frm": nppf0}
