@@ -136,6 +136,17 @@ CASES["full/cfg3_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "temp", **
                                   perturb_ln=True, sharp=(8.0, 4.0), feat="relu_heavy")
 CASES["full/cfg5_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "svsq", **REL}, B=16, ragged=True, dseed=55,
                                   perturb_ln=True, sharp=(8.0, 4.0))
+# other model kinds / deeper stacks with sharpened attention (the envelope must hold there too: errors compound over layers)
+CASES["full/vog_spat_3layers_sharp8"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, "mdl.obj_tx.n_layers": 3, "mdl.mul_tx.n_layers": 3},
+    B=4, ragged=True, dseed=61, perturb_ln=True, sharp=(8.0, 4.0))
+CASES["full/vog_spat_3layers_sharp4"] = _case(
+    {"mdl.name": "vog", "ds.conc_type": "spat", **REL, "mdl.obj_tx.n_layers": 3, "mdl.mul_tx.n_layers": 3},
+    B=4, ragged=True, dseed=62, perturb_ln=True, sharp=(4.0, 4.0), feat="relu_heavy")
+CASES["full/vgrnd_spat_sharp8"] = _case({"mdl.name": "vgrnd", "ds.conc_type": "spat", **REL}, B=4, ragged=True, dseed=63,
+                                        perturb_ln=True, sharp=(8.0, 4.0), feat="relu_heavy")
+CASES["full/vog_sep_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "sep", **REL}, B=4, ragged=True, dseed=64,
+                                     perturb_ln=True, sharp=(8.0, 4.0))
 CASES["full/cfg4_p100_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "spat", "ds.exp_setting": "p100", **REL}, B=4, nppf0=100,
                                   ragged=True, dseed=60, perturb_ln=True, sharp=(8.0, 4.0), feat="relu_heavy")
 for _c in ("spat", "temp", "sep", "svsq"):

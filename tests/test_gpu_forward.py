@@ -157,6 +157,18 @@ def test_forward_fp32_path_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=5e-5, tol_logit=1e-4)
 
 
+def test_precision_plan_for_deep_stacks():
+    """3-layer stacks: the f16 envelope ends at sharpness 5 (errors compound over sharp layers): x 4 stays on the f16 kernels,
+    x 8 - inside the single-layer envelope - runs the fp32 path; both hold the reference golden (run by the FULL list too)."""
+    E = engine_mod
+    eng, *_ = build_engine("full/vog_spat_3layers_sharp4")
+    assert eng.precise is None and eng.sharpness < E.F16_SHARPNESS_MAX_DEEP
+    eng, *_ = build_engine("full/vog_spat_3layers_sharp8")
+    assert eng.precise is not None and E.F16_SHARPNESS_MAX_DEEP < eng.sharpness < E.F16_SHARPNESS_MAX
+    eng, *_ = build_engine("full/cfg2_sharp8")
+    assert eng.precise is None
+
+
 def test_f16_just_outside_its_envelope_still_inside_the_bound():
     """wq / wk x 12 (sharpness 28.5; `auto` already runs fp32 there): f16 forced. Measured 9.0e-4 - the envelope's margin."""
     name = "full/cfg2_sharp12"
