@@ -786,7 +786,7 @@ def test_tx_tail_matches_torch_chain(M, d, kwo, mode, dtype):
 
 @pytest.mark.parametrize("lean", [0, 1])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("rows,nppf0", [(800, 5), (75, 5), (1600, 100)])
+@pytest.mark.parametrize("rows,nppf0", [(800, 5), (75, 5), (1600, 100), (8300, 100)])
 def test_vis_encode_fused(rows, nppf0, dtype, lean):
     """Both feature encoders + the prop||seg concat in one launch, from the fp32 features, against
     relu(Linear) on the same 16-bit-rounded operands (mdl_vog.py:291-314, mdl_conc_single.py:51-66)."""

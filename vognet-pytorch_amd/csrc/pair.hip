@@ -175,6 +175,7 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     r[{kid_lstm_layer_f16(), kid_vis_enc_f16()}] = &launch_pair<Lstm, VisEncBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16()}] = &launch_pair<Lstm, VisEncLeanBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_stream_f16()}] = &launch_pair<Lstm, VisEncStreamBody<F16, VOG_VS_PAIR_DEPTH>>;   // (one workgroup per CU inside the pair: depth instead of occupancy)
+    r[{kid_lstm_layer_f16(), kid_vis_enc_wide_f16()}] = &launch_pair<Lstm, VisEncWideBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<Lstm, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;

@@ -12,5 +12,6 @@ const void* kid_tx_tail_512(int dtype);     // tx_tail_kernel<T16, F16, 2, false
 const void* kid_vis_enc_f16();              // vis_enc_kernel<F16>
 const void* kid_vis_enc_lean_f16();         // vis_enc_lean_kernel<F16>
 const void* kid_vis_enc_stream_f16();       // vis_enc_stream_kernel<F16>
+const void* kid_vis_enc_wide_f16();         // vis_enc_wide_kernel<F16>
 const void* kid_attn_tile2_192(int dtype);  // attn_tile2_kernel<T16, 6>
 }  // namespace vog

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void seg_replicate_kernel(float* c32, unsigned
 const void* kid_vis_enc_f16() { return reinterpret_cast<const void*>(vis_enc_kernel<F16>); }
 const void* kid_vis_enc_lean_f16() { return reinterpret_cast<const void*>(vis_enc_lean_kernel<F16>); }
 const void* kid_vis_enc_stream_f16() { return reinterpret_cast<const void*>(vis_enc_stream_kernel<F16>); }
+const void* kid_vis_enc_wide_f16() { return reinterpret_cast<const void*>(vis_enc_wide_kernel<F16>); }
 
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
   return (prop_dim % 256) == 0 && (seg_dim % 256) == 0 && (prop_enc % 32) == 0 && (seg_enc % 32) == 0 &&
@@ -77,7 +78,15 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
     // (VOG_VE_STREAM=0: round 4's lean form, perf experiments; the chained form - done_flags - stays on the lean body)
     static const int stream_env = perf_env("VOG_VE_STREAM") ? atoi(perf_env("VOG_VE_STREAM")) : -1;
     const bool stream = (stream_env >= 0 ? stream_env != 0 : true) && p.done_flags == nullptr;
-    if (stream) {
+    // VOG_VE_WIDE=1 (perf experiments; measured, off): 128 rows x all 256 columns per workgroup - a row read once, a quarter of
+    // the weight bytes, but 127 workgroups of 224 registers with one chunk of look-ahead: 112 us alone at p100 against 41.5
+    // (the pair launch 113 against 68), cfg 4 5.52 vs 5.47 k queries/s (profiles/round5_vis_enc_stream.md)
+    static const int wide_env = perf_env("VOG_VE_WIDE") ? atoi(perf_env("VOG_VE_WIDE")) : -1;
+    const bool wide = stream && wide_env > 0 && p.p[0].N <= 256 && p.p[1].N <= 256;
+    if (wide) {
+      const int nbw = ceil_div(p.p[0].M, 128) + ceil_div(p.p[1].M, 128);
+      VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_wide_kernel<T16>), dim3(nbw), dim3(512), VisEncWideBody<T16>::LDS, st, p));
+    } else if (stream) {
       VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_stream_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
                                                  VisEncStreamBody<T16>::LDS, st, p));
     } else {

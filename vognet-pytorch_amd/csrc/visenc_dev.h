@@ -488,4 +488,152 @@ __global__ __launch_bounds__(512) void vis_enc_stream_kernel(VisEncParams a) {
   VisEncStreamBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vs_smem);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Wide" stream form (round 5) for p100-sized launches (>= 8192 proposal rows): 128 rows x ALL 256 columns per workgroup.
+// The stream form above moves every fp32 row through the CUs twice (once per column half) and every weight fragment once per
+// 64 rows: 500 workgroups x 1 MB = 0.5 GB of L2 -> CU traffic for 134 MB of features (11 TB/s at 45 us). Here a row is read
+// ONCE and a weight fragment once per 128 rows: a quarter of the weight bytes, half of the row bytes. 8 waves x 32 columns
+// (two 16-column tiles) x 8 row tiles: 64 accumulator registers, two register sets of (32 row-piece + 32 weight) registers,
+// ~240 in all - one workgroup per CU, which is what the launch gets anyway when it rides with the BiLSTM layer (the pair
+// kernel allocates the layer's 190 registers for every block). Same k order per output as the other stream form.
+// ---------------------------------------------------------------------------------------------------
+template <typename T16>
+struct VisEncWideBody {
+  using Params = VisEncParams;
+  static constexpr int THREADS = 512;
+  static constexpr int RB = 128, KC = 128, KSC = KC / 32;   // 4 k-steps per chunk
+  static constexpr int PIECES = KC / 8, RPP = THREADS / PIECES, NPASS = RB / RPP;   // 16 pieces per row, 32 rows per pass, 4 passes
+  static constexpr int IMG = (RB / 16) * KSC * 1024;        // one A-chunk image: 32 KB
+  static constexpr size_t LDS = (size_t)2 * IMG;
+  static constexpr int DEPTH = 2;
+
+  static __device__ __forceinline__ void run(const VisEncParams& a, const BlockCtx& cx, unsigned char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb0 = (a.p[0].M + RB - 1) / RB, nb_all = nb0 + (a.p[1].M + RB - 1) / RB;
+    // the FEW long segment blocks (K = 3072: 24 chunks) first, so that they do not start behind a round of proposal blocks
+    const int nb1 = nb_all - nb0;
+    if ((int)cx.bx >= nb_all) return;
+    const bool second = (int)cx.bx < nb1;
+    const int blk = second ? (int)cx.bx : (int)cx.bx - nb1;
+    const float* qx = second ? a.p[1].x : a.p[0].x;
+    const unsigned short* qw = second ? a.p[1].w : a.p[0].w;
+    const float* qb = second ? a.p[1].bias : a.p[0].bias;
+    const int qM = second ? a.p[1].M : a.p[0].M, qN = second ? a.p[1].N : a.p[0].N;
+    const int qK = second ? a.p[1].K : a.p[0].K, qrep = second ? a.p[1].rep : a.p[0].rep;
+    const int qcol0 = second ? a.p[1].col0 : a.p[0].col0;
+    const int m0 = blk * RB;
+    const int ksteps = qK >> 5, nchunk = qK / KC;
+    const int n0 = w * 32;                                   // this wave's 32 columns (two 16-column tiles)
+    const bool n_ok0 = n0 < qN, n_ok1 = n0 + 16 < qN;
+    const u16x8* wf0 = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok0 ? n0 : 0) >> 4) * ksteps) * 64 + lane;
+    const u16x8* wf1 = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok1 ? n0 + 16 : 0) >> 4) * ksteps) * 64 + lane;
+    const int pr = tid / PIECES, pc = tid % PIECES;
+    const float* xrow[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      int m = m0 + ps * RPP + pr;
+      m = m < qM ? m : qM - 1;
+      xrow[ps] = qx + (int64_t)m * qK + pc * 8;
+    }
+    f32x4 acc[RB / 16][2];
+#pragma unroll
+    for (int mt = 0; mt < RB / 16; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float4 xa[DEPTH][NPASS][2];
+    u16x8 wq[DEPTH][2][KSC];
+    auto request = [&](int set, int c) {
+      const int cc = c < nchunk ? c : nchunk - 1;            // (clamped: no conditional load)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(xrow[ps] + cc * KC);
+        const f32x4 v0 = __builtin_nontemporal_load(src);    // read exactly once in this launch
+        const f32x4 v1 = __builtin_nontemporal_load(src + 1);
+        xa[set][ps][0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+        xa[set][ps][1] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) { wq[set][0][ks] = wf0[(cc * KSC + ks) * 64]; wq[set][1][ks] = wf1[(cc * KSC + ks) * 64]; }
+    };
+    auto store_a = [&](int set, int c) {
+      unsigned char* img = smem + (size_t)(c & 1) * IMG;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const u16x8 h = {to16<T16>(xa[set][ps][0].x), to16<T16>(xa[set][ps][0].y), to16<T16>(xa[set][ps][0].z), to16<T16>(xa[set][ps][0].w),
+                         to16<T16>(xa[set][ps][1].x), to16<T16>(xa[set][ps][1].y), to16<T16>(xa[set][ps][1].z), to16<T16>(xa[set][ps][1].w)};
+        const int ks = pc >> 2, kgp = pc & 3;
+        const int rl = ps * RPP + pr;
+        *reinterpret_cast<u16x8*>(img + (((rl >> 4) * KSC + ks) * 64 + kgp * 16 + (rl & 15)) * 16) = h;
+      }
+    };
+    auto mfmas = [&](int set, int c) {
+      const unsigned char* img = smem + (size_t)(c & 1) * IMG;
+      u16x8 fa[KSC], fb[KSC];
+      auto rd = [&](u16x8 (&f)[KSC], int mt) {
+#pragma unroll
+        for (int j = 0; j < KSC; ++j) f[j] = *reinterpret_cast<const u16x8*>(img + ((mt * KSC + j) * 64 + lane) * 16);
+      };
+      rd(fa, 0);
+#pragma unroll
+      for (int mt = 0; mt < RB / 16; mt += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fb, mt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KSC; ++j) {
+          acc[mt][0] = mfma16<T16>(fa[j], wq[set][0][j], acc[mt][0]);
+          acc[mt][1] = mfma16<T16>(fa[j], wq[set][1][j], acc[mt][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt + 2 < RB / 16) rd(fa, mt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KSC; ++j) {
+          acc[mt + 1][0] = mfma16<T16>(fb[j], wq[set][0][j], acc[mt + 1][0]);
+          acc[mt + 1][1] = mfma16<T16>(fb[j], wq[set][1][j], acc[mt + 1][1]);
+        }
+      }
+    };
+    request(0, 0);
+    int c0 = 0;
+    for (; c0 + DEPTH <= nchunk; c0 += DEPTH) {              // nchunk is even (K % 256 == 0)
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const int c = c0 + j;
+        store_a(j, c);
+        request((j + DEPTH - 1) % DEPTH, c + DEPTH - 1);
+        lds_barrier();
+        mfmas(j, c);
+      }
+    }
+    // D[row = 4*(lane>>4) + reg][col = lane & 15]
+    const int nrep = a.rep_first_only ? 1 : qrep;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int col = n0 + ct * 16 + (lane & 15);
+      if (col >= qN) continue;
+      const float b = qb[col];
+#pragma unroll
+      for (int mt = 0; mt < RB / 16; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + mt * 16 + (lane >> 4) * 4 + r;
+          if (row >= qM) continue;
+          const float o = fmaxf(acc[mt][ct][r] + b, 0.f);
+          const unsigned short hv = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+          for (int j = 0; j < nrep; ++j) {
+            const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
+            if (a.c32) a.c32[off] = o;
+            if (a.c16) a.c16[off] = hv;
+          }
+        }
+    }
+  }
+};
+
+template <typename T16>
+__global__ __launch_bounds__(512) void vis_enc_wide_kernel(VisEncParams a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vw_smem[];
+  VisEncWideBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vw_smem);
+}
+
 }  // namespace vog
