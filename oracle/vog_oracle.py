@@ -188,8 +188,8 @@ def lang_encode(tokens, lens, sd, num_layers, quant=None, drop=None):
     lstm_out_feat_proj on every step and on final_hidden[-1]."""
     T = int(lens.max().item())
     x, fin = lstm_encoder(tokens[:, :T].contiguous(), lens, sd, num_layers, quant, drop=drop)
-    full = linear(x, sd, "lstm_out_feat_proj.0", relu=True, quant=quant)
-    hid = linear(fin, sd, "lstm_out_feat_proj.0", relu=True, quant=quant)
+    full = linear(x, sd, "lstm_out_feat_proj.0", relu=True, quant=quant, scope="enc.lang")
+    hid = linear(fin, sd, "lstm_out_feat_proj.0", relu=True, quant=quant, scope="enc.lang")
     return full, hid
 
 

@@ -380,10 +380,11 @@ class VogEngine:
             b, out, (B, ncmp, T) = self.make_batch(inp, T, with_pred)
             _lane_enter(self.device, None)
             ws = self.workspace(B, ncmp, T)
-            L.check(self.lib.vog_forward(self.ctx, C.byref(b), ws.data_ptr(), ws.numel(),
-                                         L.stream_ptr()), "vog_forward")
-            if self.precise is not None:                    # fp32 path overwrites the outputs (precise.py)
+            if self.precise is not None:                    # checkpoints outside the f16 envelope: the fp32 path alone (precise.py)
                 self.precise.run(inp, out)
+            else:
+                L.check(self.lib.vog_forward(self.ctx, C.byref(b), ws.data_ptr(), ws.numel(),
+                                             L.stream_ptr()), "vog_forward")
         out["_keepalive"] = (inp, ws)
         return out
 
@@ -640,11 +641,13 @@ class Slot:
         self.check()                          # the launches before this one
         _lane_enter(self.eng.device, stream)
         sp = L.stream_ptr(stream)
-        if self.graph is not None:
-            L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
-        else:
-            L.check(self.eng.lib.vog_forward(self.eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
-                                             self.ws.numel(), sp), "vog_forward")
+        # (fp32 path: a fed slot's graph still has to run - it moves / assembles the batch - anything else is skipped)
+        if self.eng.precise is None or getattr(self, "feed", None) is not None:
+            if self.graph is not None:
+                L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
+            else:
+                L.check(self.eng.lib.vog_forward(self.eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
+                                                 self.ws.numel(), sp), "vog_forward")
         self._precise(stream)
         return self.out
 
