@@ -416,8 +416,9 @@ typedef struct vog_lstm_layer_args {
   /* round 5: sticky fault counter (optional; device memory or device-visible pinned host memory): +1 per launch whose
    * hand-off timed out. The library never clears it (sync[2] is re-zeroed by the next forward's prologue): the host reads
    * it when it looks at the results - a stalled forward is an ERROR at the API, not NaN scores with rc 0 (the reference's
-   * LSTM, utils/mdl_srl_utils.py:114-169, cannot fail by scheduling). inject_stall != 0: test hook, the launch behaves as
-   * if its hand-off had timed out at once. */
+   * LSTM, utils/mdl_srl_utils.py:114-169, cannot fail by scheduling). inject_stall: test hook, 1 = the launch behaves as
+   * if its hand-off had timed out at once, 2 = only the workgroups of direction 1 do. Whichever workgroup ends dead first
+   * reports (sync[3], re-armed by the prologue): exactly +1 per stalled launch. */
   uint32_t* fault; int inject_stall;
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);

@@ -1080,6 +1080,30 @@ def test_stalled_handoff_raises_from_a_graph_slot():
     assert torch.isfinite(s2.out["mdl_outs_eval"]).all()
 
 
+def test_stall_confined_to_one_direction_is_still_an_error():
+    """the hand-off slots and the residency wait are per direction. `lstm_inject_stall = 2` makes only the workgroups
+    of direction 1 end dead - direction 0, workgroup (0, 0) included, finishes clean, as it does when a late workgroup of
+    direction 1 is the only one left without a CU. The sticky counter still has to move (whichever workgroup ends dead first
+    reports), once per layer launch, and the scores are poisoned through direction 1's half of the layer output."""
+    name = "full/cfg2_vog_spat_gt5_bs4"
+    cfg, sel, mdl, evl, dev, batch, c = _build(name)
+    eng = mdl.engine()
+    eng.set_option("lstm_inject_stall", 2)
+    slot = eng.make_slot({k: v for k, v in dev.items() if k in batch}, graph=True)
+    eng.set_option("lstm_inject_stall", 0)
+    slot.launch()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(slot.out["mdl_outs_eval"]).all()
+    assert int(slot._fault[0]) == 2                            # one report per layer launch, not one per dead workgroup
+    with pytest.raises(L.VogError, match="hand-off"):
+        slot.check()
+    eng.set_option("lstm_persistent", 1)                       # (the engine degraded; back for the second launch's count)
+    slot._fault_seen = int(slot._fault[0])
+    slot.launch()
+    torch.cuda.synchronize()
+    assert int(slot._fault[0]) == 4                            # sync[3] is re-armed by every forward's prologue
+
+
 def test_evaluator_refuses_to_write_a_pickle_with_poisoned_scores(tmp_path):
     name = "full/cfg2_vog_spat_gt5_bs4"
     cfg, sel, mdl, evl, dev, batch, c = _build(name)

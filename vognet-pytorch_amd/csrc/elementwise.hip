@@ -156,12 +156,18 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
                                                      const int64_t* __restrict__ msk,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias,
-                                                     float* __restrict__ lang, int T, int nsrl, int L) {
-  // grid (sentence*arg, L/16): each wave owns 4 outputs with 4 independent
-  // accumulators, so all of its weight-row loads are in flight together (argvec_dev.h)
-  const int ba[1] = {(int)blockIdx.x};                 // b*nsrl + a
+                                                     float* __restrict__ lang, int T, int nsrl, int L, int nrows) {
+  // grid (ceil(rows / 20), L/16): a workgroup owns 16 output columns (each wave 4 of them, 4 independent accumulators,
+  // all of its weight-row loads in flight together: argvec_dev.h) for up to 20 (sentence, argument) rows, 4 rows per pass -
+  // the 8 KB of weight rows a wave needs come from memory once and from its L1 afterwards. Round 6: 16 workgroups at cfg 2
+  // instead of 320 (one per row and column block: 1137 CU-us for 5 MFLOP, every one of them re-fetching its 32 KB weight
+  // slice; profiles/round5_busy_cu_cfg2.md). Same per-lane summation order as before: bit-identical.
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  argvec_rows<1>(full, capture, msk, w, bias, lang, T, nsrl, L, blockIdx.y * 16 + wid * 4, ba, lane, false);
+  const int r_end = min(nrows, ((int)blockIdx.x + 1) * 20);
+  for (int r0 = (int)blockIdx.x * 20; r0 < r_end; r0 += 4) {
+    const int ba[4] = {r0, r0 + 1 < r_end ? r0 + 1 : -1, r0 + 2 < r_end ? r0 + 2 : -1, r0 + 3 < r_end ? r0 + 3 : -1};
+    argvec_rows<4>(full, capture, msk, w, bias, lang, T, nsrl, L, blockIdx.y * 16 + wid * 4, ba, lane, false);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -540,7 +546,9 @@ static int lang_prep_setup(void* zero, int64_t zero_bytes, int64_t ones_bytes, c
   VOG_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && (zero_bytes == 0 || zero));
   VOG_CHECK_ARG(ones_bytes >= 0 && (ones_bytes % 16) == 0 && (ones_bytes == 0 || zero));
   const int64_t z16 = zero_bytes / 16, o16 = ones_bytes / 16;
-  int64_t blocks = (z16 + o16 + 255) / 256;
+  // 16 stores of 16 bytes per thread (round 6; one per thread before: 405 workgroups = 502 CU-us at cfg 2 for 1.6 MB of fill)
+  static const int fill_per_thread = perf_env("VOG_PREP_FILL") ? atoi(perf_env("VOG_PREP_FILL")) : 16;
+  int64_t blocks = (z16 + o16 + 256 * fill_per_thread - 1) / (256 * fill_per_thread);
   if (blocks > 1024) blocks = 1024;
   int64_t need = ((int64_t)Bn * T + 255) / 256;
   if (a0_frag) { const int64_t n2 = ((int64_t)Bn * T * (emb_dim / 8) + 255) / 256; need = n2 > need ? n2 : need; }
@@ -686,8 +694,8 @@ extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const i
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
   VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512 && (L % 4) == 0);
-  ::vog::launch(argvec_kernel, dim3(Bn * nsrl, ceil_div(L, 16)), dim3(256), 0,
-                     (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L);
+  ::vog::launch(argvec_kernel, dim3(ceil_div(Bn * nsrl, 20), ceil_div(L, 16)), dim3(256), 0,
+                     (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L, Bn * nsrl);
   VOG_LAUNCH_CHECK();
   return 0;
 }

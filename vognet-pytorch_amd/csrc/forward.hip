@@ -1459,7 +1459,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
-  if (strcmp(name, "lstm_inject_stall") == 0) { c->lstm_inject_stall = value ? 1 : 0; return 0; }
+  if (strcmp(name, "lstm_inject_stall") == 0) { c->lstm_inject_stall = value == 2 ? 2 : (value ? 1 : 0); return 0; }   // 2: direction 1 only
   if (strcmp(name, "pair_attn") == 0) { c->pair_attn = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }

@@ -180,7 +180,25 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
       // - 84 instead of 192 registers (the 8-deep form loads six zero fragments per operand), i.e. 4 instead of 2
       // workgroups per CU for the 144 workgroups of that launch. Same k order per wave: bit-identical.
       const bool shortk = p.K / 32 <= 8 && !p.av_counter;
-      if (shortk) {
+      // short K and many column tiles (mul_pl: 144 of them, M = 20): 4 column tiles per workgroup - the launch is 36
+      // workgroups instead of 144 (706 CU-us for 24 MFLOP at cfg 2, profiles/round5_busy_cu_cfg2.md); same k order per wave
+      // and the same partial-sum order in the finish: bit-identical
+      static const int nt4_off = perf_env("VOG_SKINNY_NT4_OFF") ? 1 : 0;
+      if (shortk && !nt4_off && ncol >= 64 && (ncol % 4) == 0 && grid.y == 1) {
+        const size_t lds4 = (size_t)4 * 4 * 4 * 64 * 4 * sizeof(float);          // 64 KiB
+        dim3 grid4(ncol / 4, 1);
+        if (g->a_is_f32) {
+          auto kern = gemm_skinny<T16, true, 2, 4, 4, false>;
+          static bool attr = false;
+          if (!attr) { VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); attr = true; }
+          ::vog::launch(kern, grid4, dim3(256), lds4, st, p);
+        } else {
+          auto kern = gemm_skinny<T16, false, 2, 4, 4, false>;
+          static bool attr = false;
+          if (!attr) { VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); attr = true; }
+          ::vog::launch(kern, grid4, dim3(256), lds4, st, p);
+        }
+      } else if (shortk) {
         if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
         else ::vog::launch((gemm_skinny<T16, false, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
       } else if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), lds1, st, p);

@@ -353,7 +353,9 @@ struct LstmLayerBody {
     }
     __syncthreads();
     const bool same_xcd = flags[1] != 0;
-    dead = flags[0] != 0 || p.inject_stall != 0;
+    // inject_stall (test hook): 1 = every workgroup behaves as if its first wait had timed out; 2 = only the workgroups of
+    // direction 1 do (the case a late / non-resident workgroup of ONE direction produces: direction 0 ends clean)
+    dead = flags[0] != 0 || p.inject_stall == 1 || (p.inject_stall == 2 && dir == 1);
 
     const unsigned hx_bytes = (unsigned)((size_t)p.T * 2 * p.Bn * R * 2);
     const int cps = RW / 8;                                // 16-byte chunks per sentence
@@ -498,7 +500,12 @@ struct LstmLayerBody {
     // holds, see vog_hip.h) must not pass for a result: the WHOLE output of the layer is poisoned
     // with NaN (every consumer - next layer, projection, argument vectors, both heads - propagates it
     // to mdl_outs) and sync[2] stays set for the host (vog_lstm_status).
-    if (dead && p.fault && tid == 0 && cx.bx == 0 && cx.by == 0)     // once per launch (every workgroup learns of a timeout)
+    // once per launch, reported by WHICHEVER workgroup ends dead first (the hand-off slots and the residency wait
+    // are per direction and sync[2] is only polled while spinning, so a stall confined to one direction - or one whose only
+    // late workgroup is (0, 0) itself - never reaches workgroup (0, 0)): sync[3] is zeroed by the forward's prologue with the
+    // rest of the sync block, the first dead workgroup to swap it to 1 bumps the host's sticky counter.
+    if (dead && p.fault && tid == 0 &&
+        __hip_atomic_exchange(p.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
       __hip_atomic_fetch_add(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (valid_b) {
       const int unit = tile0 * 4 + ul;
