@@ -289,8 +289,15 @@ def check_parity(w, cfg, sd, batch, slot, eng):
     sc, rsc = pred["scores"].float().cpu(), rp["scores"]
     snz = rsc != 0
     srel = float(((sc - rsc).abs() / rsc.abs().clamp(min=1e-6))[snz].max()) if bool(snz.any()) else 0.0
-    ok = bool(np.isfinite(rel) and np.isfinite(srel) and rel <= 1e-3 and srel <= 1e-3 and logit <= 6e-3 and masked_zero)
+    # pred_boxes: an arg-max gather - equal to the oracle's except where its top proposals of a frame are a near tie; the number of
+    # such flips is part of the record (bound: 0.5 % of the boxes, each flipped box's score within 2e-3 of the oracle's maximum)
+    bx, rbx = pred["boxes"].float().cpu(), rp["boxes"]
+    flip = (bx != rbx).any(-1)
+    nflip, nbox = int(flip.sum()), int(flip.numel())
+    flip_ok = nflip <= 0.005 * nbox and bool((((sc - rsc).abs() / rsc.abs().clamp(min=1e-6))[flip] <= 2e-3).all())
+    ok = bool(np.isfinite(rel) and np.isfinite(srel) and rel <= 1e-3 and srel <= 1e-3 and logit <= 6e-3 and masked_zero and flip_ok)
     return {"ok": ok, "rel_err_mdl_outs_eval": rel, "rel_err_pred_scores": srel, "abs_err_logits": logit,
+            "box_flips": nflip, "boxes": nbox, "box_flips_bound": int(0.005 * nbox),
             "masked_entries_exactly_zero": masked_zero, "bound_rel": 1e-3, "bound_logit_abs": 6e-3,
             "against": "CPU oracle (oracle/vog_oracle.py) on slot 0's batch, outputs of its last timed launch"}
 
@@ -597,6 +604,29 @@ def main():
                   "what": "the same strict per-batch path, 400 timed steps, f16 operands in obj_tx / mul_tx (the package default; "
                           "`value` is bf16 as BASELINE.json's config names it)"}
         del sl_h16, eng_h
+    # the same strict path for a checkpoint whose attention is too sharp for plain 16-bit logits (wq / wk x 16: logit std ~6 / ~30
+    # nats in obj_tx / mul_tx): `auto` plans hi + lo f16 operands for it (three MFMAs for everything that feeds attention logits;
+    # engine.py) - round 5 ran such checkpoints on the fp32 path at 1.7 k queries/s
+    hi_lo = None
+    if G == 1 and world == 1 and cfg_id in (2, 3, 5) and not args.throughput_only and not aql and not args.no_graph:
+        try:
+            sd_s = synth.sharpen_state_dict({k: np.array(v, copy=True) for k, v in sd.items()}, 16.0, 4.0)
+            cfg_s = make_cfg(dict(w, tx="auto"))
+            eng_s = eng_mod.VogEngine(cfg_s, comm)
+            eng_s.load_state_dict(sd_s)
+            eng_s.set_option("lstm_persistent", int(persistent))
+            dts_, sl_s2, b_s2, n_s2 = measure(G, 400, 40, eng=eng_s)
+            par_s = check_parity(w, cfg_s, sd_s, b_s2[0], sl_s2[0], eng_s)
+            lo_, lm_ = eng_s.observed_logit_max()
+            hi_lo = {"value": 400 * w["B"] / dts_ if (par_s["ok"] and eng_s.plan == "split") else None, "unit": "queries/s",
+                     "ms_per_step": dts_ / 400 * 1e3, "steps": 400, "warmup": 40, "batches_in_flight": n_s2, "plan": eng_s.plan,
+                     "attention_sharpness": eng_s.sharpness, "observed_logit_max_nats": {"obj_tx": lo_, "mul_tx": lm_},
+                     "parity": {k_: par_s[k_] for k_ in ("ok", "rel_err_mdl_outs_eval", "rel_err_pred_scores", "abs_err_logits", "box_flips")},
+                     "what": "the same strict per-batch path with wq / wk of both transformers x 16 (pe x 4): outside the f16 envelope, "
+                             "`auto` runs the hi + lo operand kernels; parity against the CPU oracle with the same weights"}
+            del sl_s2, eng_s
+        except Exception as e:          # never fail the bench line on the side measurement
+            hi_lo = {"value": None, "error": str(e)}
     # the same strict path with the inputs coming from HBM: N distinct input sets cycle through the streams' workspaces
     hbm_inputs = None
     if G == 1 and world == 1 and rot_sets > 1 and not aql and not args.no_graph and not args.throughput_only and not args.rotate_main:
@@ -695,6 +725,8 @@ def main():
         res["steady_state_400_steps"] = steady
     if f16_tx is not None:
         res["f16_transformers"] = f16_tx
+    if hi_lo is not None:
+        res["hi_lo_plan_sharp16"] = hi_lo
     if hbm_inputs is not None:
         res["value_hbm_inputs"] = hbm_inputs["value"]
         res["hbm_inputs"] = hbm_inputs
@@ -763,7 +795,7 @@ def main():
             nbytes = nbytes + (sum(wih) + sum(xin)) // 2
             us_launch = 0.5 * (ktimes["lstm_layer#0"] + ktimes["lstm_layer#1"])
         ach_b = nbytes / (us_launch * 1e-6) / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "lstm_layer", "achieved": ach_b, "peak": PEAK_HBM_GBS,
+        res["roofline"] = {"bound": "latency (cache stream)", "governing_peak": "hbm", "kernel": "lstm_layer", "achieved": ach_b, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
                            "traffic": (pmc.get("kernels", {}).get("lstm_layer") or {}).get("bytes_per_launch"),
                            "usec_per_launch": us_launch, "bytes_per_launch": nbytes, "launches_per_forward": 2,
@@ -799,11 +831,24 @@ def main():
                            "launches_per_forward": 2 * T}
         res["roofline_mfma"] = roof_mfma
     pmc = pmc_traffic(args.workload + ("" if persistent else "_lstm_steps")) or {}
+    # whole-forward fractions INSIDE `roofline` (the block the driver keeps): dense / executed MFMA work and the algorithmic bytes
+    # (16-bit weights read once + the fp32 inputs + outputs) against the measured step time
+    step_s = dt / args.steps
+    alg_bytes = 88.4e6 + sum(v.numel() * v.element_size() for k, v in slots[0].inp.items()) + \
+        sum(v.numel() * v.element_size() for k, v in slots[0].out.items() if torch.is_tensor(v))
+    res["roofline"].update({
+        "forward_frac_mfma_dense": total_flops / step_s / 1e12 / PEAK_MFMA_TFLOPS,
+        "forward_frac_mfma_executed": executed_total / step_s / 1e12 / PEAK_MFMA_TFLOPS,
+        "forward_frac_hbm_algorithmic": alg_bytes / step_s / 1e9 / PEAK_HBM_GBS,
+        "forward_algorithmic_bytes": alg_bytes,
+        "wasted_traffic_ratio": (pmc["bytes_per_forward"] / alg_bytes) if pmc.get("bytes_per_forward") else None})
     if pmc.get("bytes_per_forward"):
-        # whole-forward view: every kernel's measured HBM-side bytes / the measured step time
-        gbs = pmc["bytes_per_forward"] / (dt / args.steps) / 1e9
-        res["forward_hbm"] = {"bytes_per_forward_pmc": pmc["bytes_per_forward"], "achieved": gbs, "unit": "GB/s",
-                              "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS, "source": pmc.get("source")}
+        # memory-side traffic by counters / the measured step time: a traffic RATE (it counts Infinity-Cache hits and the per-XCD
+        # re-fetches of the weights: `wasted_traffic_ratio` above), not a roofline fraction
+        gbs = pmc["bytes_per_forward"] / step_s / 1e9
+        res["forward_traffic"] = {"bytes_per_forward_pmc": pmc["bytes_per_forward"], "rate_gbs": gbs, "source": pmc.get("source"),
+                                  "note": "counter bytes / step time; the roofline fraction of the forward is "
+                                          "roofline.forward_frac_hbm_algorithmic"}
     res["kernels_usec"] = {k: (round(v, 2) if v else None) for k, v in ktimes.items()}
     res["forward_roofline"] = {"algorithmic_gflop_per_batch": total_flops / 1e9,
                                "achieved_tflops": total_flops / (dt / args.steps) / 1e12,

@@ -97,6 +97,9 @@ typedef struct vog_gemm_args {
    * (out_frag) so that the LSTM -> projection hand-off needs no strided fragment loads. */
   int a_frag;
   const vog_argvec_tail* argvec_tail;   /* NULL, or see above (M <= 64, c32 set, N == ldc == tail->L) */
+  /* round 6, optional (M <= 64 kernel, a_is_f32, w_frag): w_lo = the fragment-ordered 16-bit remainder t16(w - t16(w)) of the fp32
+   * weights; the fp32 rows of `a` are split the same way in the kernel and the product is a.w + a_lo.w + a.w_lo (three MFMAs). */
+  const void* w_lo;
 } vog_gemm_args;
 /* host: fp32 [N, ld] (first K columns) -> 16-bit fragment order, N*K halfwords. */
 int vog_pack_w_frag(const float* w, int64_t ld, int N, int K, void* dst_host, vog_dtype dtype);
@@ -145,6 +148,10 @@ typedef struct vog_qkv_args {
    * (dep_nb0 = ceil(n_prop_rows / 64), dep_rep = nppf0, dep_nh0 / dep_nh1 = ceil(prop_enc / 128), ceil(seg_enc / 128)).
    * NULL: no waiting. Set outside such a launch it is harmless (the flags are already up). */
   const unsigned int* dep_flags; int dep_nb0, dep_rep, dep_nh0, dep_nh1;
+  /* round 6, hi + lo operands (optional; all four or none; plain form, pl == NULL): x16_lo = t16(x - t16(x)) of the fp32
+   * activations ([rows, ldx] like x16), wqkv_lo the same of the fp32 weights ([3*H*dp, ldw] like wqkv); the projection is
+   * x.w + x_lo.w + x.w_lo (three MFMAs) and Q / K are written as q + q_lo, k + k_lo (V^T as one 16-bit image). */
+  const void* x16_lo; const void* wqkv_lo; void* q_lo; void* k_lo;
 } vog_qkv_args;
 int vog_qkv_proj(const vog_qkv_args* a, void* stream);
 int vog_qkv_rowblock_supported(int n_out, int K);
@@ -190,6 +197,13 @@ typedef struct vog_attn_args {
    * that takes that kernel: -1 otherwise). vog_forward issues the two halves as separate steps so that the first one can share a
    * launch with a BiLSTM layer (csrc/pair.hip). */
   int phase;
+  /* round 6, hi + lo operands (optional; both or neither): q_lo / k_lo = the 16-bit remainders t16(x - t16(x)) of the fp32 Q / K
+   * projections, same fragment order as q / k (vog_qkv_args.q_lo / k_lo). With them Q.K^T = q.k + q_lo.k + q.k_lo (three MFMAs,
+   * fp32 accumulate): the logits carry ~2^-21 relative operand error instead of 2^-11 (f16) - what a checkpoint with sharp
+   * attention needs. Sequences of <= 256 tokens. out16_lo (optional): remainder of out16, same layout (read
+   * by a hi + lo vog_tx_tail_fwd). logit_max (optional): 4 device bytes, zero on entry; the launch leaves the largest |logit|
+   * (after bias and scale, in nats) it saw there as the bits of a non-negative float (atomic max). */
+  const void* q_lo; const void* k_lo; void* out16_lo; unsigned int* logit_max;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
 
@@ -216,6 +230,10 @@ typedef struct vog_attn_struct_args {
    * factorisation (141 instead of 330 us at cfg 4): the kernel sets it when a row may leave the safe range of its 16-bit
    * fragments and the same call then re-runs the per-row kernel (an empty launch otherwise). NULL: per-row kernels only. */
   int* guard_flag;
+  /* round 6, hi + lo operands (optional; both or neither; q_visual form with nppf <= 32): the 16-bit remainders of Qv / Kv, same
+   * fragment order; the language parts are split in the kernel from the fp32 `pl`. out16_lo / logit_max: as in vog_attn_args
+   * (the logit bound is max|x| + max|y| of the separable parts). */
+  const void* q_lo; const void* kv_lo; void* out16_lo; unsigned int* logit_max;
 } vog_attn_struct_args;
 int vog_rel_attention_struct_fwd(const vog_attn_struct_args* a, void* stream);
 
@@ -262,6 +280,11 @@ typedef struct vog_tx_tail_args {
    * the head for the whole batch, reading mdl_outs_eval past L1 / L2 - nobody waits. pred->outs_eval must be
    * score->outs_eval; not for sep / svsq (the head reads pred_cmp's fin_scores). Bit-identical to vog_pred_head. */
   const struct vog_pred_args* pred; unsigned int* pred_counter;
+  /* round 6, hi + lo operands (optional; the first four together, not with `score`): attn16_lo = out16_lo of the attention,
+   * w*_p_lo = the 32x16 fragment-ordered 16-bit remainders t16(w - t16(w)) of the fp32 weights. Every GEMM stage is then
+   * W.X + W_lo.X + W.X_lo (three MFMAs, 32 rows per workgroup) and y16_lo (optional) receives the remainder of y16: the tail of a
+   * layer whose OUTPUT feeds another attention layer of a checkpoint with sharp logits. */
+  const void* attn16_lo; const void* wo_p_lo; const void* w1_p_lo; const void* w2_p_lo; void* y16_lo;
 } vog_tx_tail_args;
 int vog_tx_tail_supported(int d, int dh, int kwo);
 int64_t vog_tx_tail_scratch_bytes(int M, int d);
@@ -312,6 +335,11 @@ typedef struct vog_visenc_args {
    * set to 1 when that workgroup's rows are in memory, and the 16-bit copy is written through: lets consumers of the rows run
    * in the same launch (vog_qkv_args.dep_flags). Blocks: ceil(n_prop_rows / 64) proposal blocks, then the segment blocks. */
   unsigned int* done_flags;
+  /* round 6, hi + lo operands (optional; all three or none; lean = 1, nppf0 <= 16): w_*_f_lo = the fragment-ordered 16-bit
+   * remainders t16(w - t16(w)) of the fp32 weights; the fp32 feature rows are split the same way in the kernel and a k-step is
+   * x.w + x_lo.w + x.w_lo (three MFMAs). c16_lo: the remainder of the output rows, laid out like c16 (read by a hi + lo
+   * vog_qkv_proj). */
+  const void* w_prop_f_lo; const void* w_seg_f_lo; void* c16_lo;
 } vog_visenc_args;
 int vog_vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
 int vog_vis_encode(const vog_visenc_args* a, void* stream);
@@ -481,6 +509,10 @@ int vog_pred_cmp_head(const vog_predcmp_args* a, void* stream);
 typedef struct vog_pred_args {
   const float* outs_eval; const float* props; const float* fin_scores; void* rec;
   int B, ncmp, nsrl, nfrm0, nppf0; int conc_type;
+  /* round 6, optional: logit_max = the forward's [2 stacks][32 layers] words of vog_attn_args.logit_max; the head (the last
+   * kernel of a forward) folds them into stats[0] (obj_tx) / stats[1] (mul_tx) with a system-scope atomic max - pinned host
+   * memory, read by the host without a device synchronisation (vog_batch.stats). */
+  const unsigned int* logit_max; unsigned int* stats;
 } vog_pred_args;
 int64_t vog_pred_record_bytes(int ncmp, int nsrl, int nfrm0);
 int vog_pred_head(const vog_pred_args* a, void* stream);
@@ -743,6 +775,11 @@ typedef struct vog_batch {
   /* Optional (round 5): sticky stall counter of this batch's forwards, see vog_lstm_layer_args.fault. Pinned host memory
    * lets the host poll it without synchronising the device. */
   uint32_t* fault;
+  /* Optional (round 6): two words of pinned host memory, the largest |attention logit| (nats; bits of a non-negative float)
+   * the forwards of this batch have seen in obj_tx / mul_tx. Sticky maximum, owned by the host (it may reset it): the
+   * run-time check behind the per-checkpoint precision plan (engine.py: a logit scale outside the envelope of the operand
+   * precision in use is reported and the plan is raised). Needs pred_rec (the prediction head publishes it). */
+  uint32_t* stats;
 } vog_batch;
 
 int64_t vog_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T);
@@ -794,6 +831,10 @@ int vog_graph_capture_fed(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_by
  * by the layer's 64 CUs (+7 / +17 us per layer against 6.4 / 9.7 us for the whole-chip GEMMs):
  * 43.1 k vs 40.9 k queries/s with 4 batches in flight, 10 us more single-batch latency. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);
+/* round 6: 1 if the option "tx_split" (hi + lo 16-bit operands: three MFMAs per product for everything that feeds attention
+ * logits - encoders, QKV projections, Q.K^T, the tails whose output is another layer's input) has kernels for this model at
+ * `ncmp` videos per query (gt5-sized sequences). Set the option BEFORE vog_ctx_finalize (the remainder weights are made there). */
+int vog_ctx_split_supported(const vog_ctx* c, int ncmp);
 int vog_graph_destroy(vog_graph* g);
 
 /* ---- language encoder over a group of batches ------------------------------------------------

@@ -130,6 +130,19 @@ CASES["full/cfg2_sharp8"] = _case(_SPAT2, B=4, ragged=True, dseed=51, perturb_ln
 CASES["full/cfg2_sharp10"] = _case(_SPAT2, B=4, ragged=True, dseed=59, perturb_ln=True, sharp=(10.0, 4.0))   # edge of the f16 envelope
 CASES["full/cfg2_sharp12"] = _case(_SPAT2, B=4, ragged=True, dseed=58, perturb_ln=True, sharp=(12.0, 4.0))   # just outside (f16 measured 9.0e-4)
 CASES["full/cfg2_sharp16"] = _case(_SPAT2, B=4, ragged=True, dseed=52, perturb_ln=True, sharp=(16.0, 4.0))
+# round 6: past the f16 envelope, where `auto` runs hi + lo f16 operands (engine.py: tx_split; x 24 / x 32 = sharpness 114 / 202) and,
+# past that plan's envelope too (x 48 = 455), the fp32 path; cfg 3 / cfg 5 / VidGrnd / sep at x 16 for the other kernel shapes
+CASES["full/cfg2_sharp24"] = _case(_SPAT2, B=4, ragged=True, dseed=65, perturb_ln=True, sharp=(24.0, 4.0))
+CASES["full/cfg2_sharp32"] = _case(_SPAT2, B=4, ragged=True, dseed=66, perturb_ln=True, sharp=(32.0, 4.0), feat="relu_heavy")
+CASES["full/cfg2_sharp48"] = _case(_SPAT2, B=4, ragged=True, dseed=67, perturb_ln=True, sharp=(48.0, 4.0))
+CASES["full/cfg3_sharp16"] = _case({"mdl.name": "vog", "ds.conc_type": "temp", **REL}, B=8, ragged=True, dseed=68,
+                                   perturb_ln=True, sharp=(16.0, 4.0))
+CASES["full/cfg5_sharp16"] = _case({"mdl.name": "vog", "ds.conc_type": "svsq", **REL}, B=16, ragged=True, dseed=69,
+                                   perturb_ln=True, sharp=(16.0, 4.0), feat="relu_heavy")
+CASES["full/vgrnd_spat_sharp16"] = _case({"mdl.name": "vgrnd", "ds.conc_type": "spat", **REL}, B=4, ragged=True, dseed=70,
+                                         perturb_ln=True, sharp=(16.0, 4.0))
+CASES["full/vog_sep_sharp16"] = _case({"mdl.name": "vog", "ds.conc_type": "sep", **REL}, B=4, ragged=True, dseed=71,
+                                      perturb_ln=True, sharp=(16.0, 4.0))
 CASES["full/cfg2_relu_heavy"] = _case(_SPAT2, B=4, ragged=True, dseed=53, perturb_ln=True, sharp=(8.0, 4.0),
                                       feat="relu_heavy")
 CASES["full/cfg3_sharp8"] = _case({"mdl.name": "vog", "ds.conc_type": "temp", **REL}, B=8, ragged=True, dseed=54,
@@ -159,12 +172,7 @@ CASES["small/sharp16_vgrnd_spat"] = _case(
 
 
 def sharpen_state_dict(sd, qk: float, pe: float):
-    for k in list(sd):
-        if k.endswith("selfattn.layer.wq.weight") or k.endswith("selfattn.layer.wk.weight"):
-            sd[k] = (sd[k] * np.float32(qk)).astype(np.float32)
-        elif k.startswith("pe_obj_sub_enc.") or k.startswith("pe_mul_sub_enc."):
-            sd[k] = (sd[k] * np.float32(pe)).astype(np.float32)
-    return sd
+    return _synth.sharpen_state_dict(sd, qk, pe)
 
 
 def relu_heavy(x: np.ndarray, seed: int) -> np.ndarray:

@@ -34,6 +34,13 @@ SMALL = [n for n in cases.CASES if n.startswith("small/")]
 SHARP = [n for n in cases.CASES if cases.CASES[n].get("sharp")]
 # random-init scale, single-layer stacks: the cases bf16 transformers are specified for (3-layer stacks: 1.0-1.1e-3 measured)
 BF16_OK = [n for n in FULL if n not in SHARP and "3layers" not in n]
+# round 6: the cases `auto` runs with hi + lo operands / the fp32 path; the launch-structure variants below (step-launch BiLSTM,
+# unfused tail, pairing) keep to the others (same kernels, one plan: the suite's time goes into new coverage instead)
+R6 = ["full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg2_sharp48", "full/cfg3_sharp16", "full/cfg5_sharp16",
+      "full/vgrnd_spat_sharp16", "full/vog_sep_sharp16"]
+FULL_VARIANTS = [n for n in FULL if n not in R6 and n not in ("full/cfg2_sharp12", "full/cfg2_sharp16", "full/vog_spat_3layers_sharp8")]
+SPLIT_CASES = ["full/cfg2_sharp12", "full/cfg2_sharp16", "full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg3_sharp16",
+               "full/cfg5_sharp16", "full/vgrnd_spat_sharp16", "full/vog_sep_sharp16", "full/vog_spat_3layers_sharp8"]
 
 
 def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
@@ -61,6 +68,10 @@ def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
     bx = pred["boxes"].cpu().numpy()
     diff = np.any(bx != g["boxes"], axis=-1)
     nflip = int(diff.sum())
+    print(f"  box flips {nflip} of {diff.size}")
+    # (round 6) the NUMBER of flips is bounded too: 0.5 % of the boxes of a case (and at least the 2 a handful-of-boxes case may
+    # legitimately have); north_star asks pred_boxes within 1e-3 - a flip is only ever a near tie, but not any number of them
+    assert nflip <= max(2, int(0.005 * diff.size)), f"{name}: {nflip} of {diff.size} boxes differ from the reference"
     if nflip:
         # the score of the box we picked must be within tolerance of the reference max
         bad = rel_err(sc[diff], g["scores"][diff]) > 2e-3
@@ -127,16 +138,21 @@ def test_precision_plan_follows_attention_sharpness():
     import warnings
     E = engine_mod
     seen = {}
-    for name in ("full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp10", "full/cfg2_sharp12", "full/cfg2_sharp16"):
+    for name in ("full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp10", "full/cfg2_sharp12", "full/cfg2_sharp16",
+                 "full/cfg2_sharp32", "full/cfg2_sharp48"):
         eng, *_ = build_engine(name)
-        seen[name] = (eng.sharpness, eng.precise is not None)
-        assert eng.desc.tx_dtype == L.VOG_F16
+        seen[name] = (eng.sharpness, eng.plan)
+        assert eng.desc.tx_dtype == L.VOG_F16 and (eng.precise is not None) == (eng.plan == "f32")
     print(seen)
-    assert seen["full/cfg2_vog_spat_gt5_bs4"][0] < 1 and not seen["full/cfg2_vog_spat_gt5_bs4"][1]
-    assert E.BF16_SHARPNESS_MAX < seen["full/cfg2_sharp8"][0] < E.F16_SHARPNESS_MAX and not seen["full/cfg2_sharp8"][1]
-    assert seen["full/cfg2_sharp10"][0] < E.F16_SHARPNESS_MAX and not seen["full/cfg2_sharp10"][1]
-    assert seen["full/cfg2_sharp12"][0] > E.F16_SHARPNESS_MAX and seen["full/cfg2_sharp12"][1]
-    assert seen["full/cfg2_sharp16"][0] > E.F16_SHARPNESS_MAX and seen["full/cfg2_sharp16"][1]
+    assert seen["full/cfg2_vog_spat_gt5_bs4"][0] < 1 and seen["full/cfg2_vog_spat_gt5_bs4"][1] == "f16"
+    assert E.BF16_SHARPNESS_MAX < seen["full/cfg2_sharp8"][0] < E.F16_SHARPNESS_MAX and seen["full/cfg2_sharp8"][1] == "f16"
+    assert seen["full/cfg2_sharp10"][0] < E.F16_SHARPNESS_MAX and seen["full/cfg2_sharp10"][1] == "f16"
+    # round 6: past the f16 envelope `auto` runs hi + lo f16 operands (three MFMAs for what feeds the logits), the fp32 path only
+    # past THAT plan's envelope
+    assert E.F16_SHARPNESS_MAX < seen["full/cfg2_sharp12"][0] and seen["full/cfg2_sharp12"][1] == "split"
+    assert seen["full/cfg2_sharp16"][1] == "split"
+    assert seen["full/cfg2_sharp32"][0] < E.SPLIT_SHARPNESS_MAX and seen["full/cfg2_sharp32"][1] == "split"
+    assert seen["full/cfg2_sharp48"][0] > E.SPLIT_SHARPNESS_MAX and seen["full/cfg2_sharp48"][1] == "f32"
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         eng, *_ = build_engine("full/cfg2_sharp8", "bf16")
@@ -162,11 +178,88 @@ def test_precision_plan_for_deep_stacks():
     x 8 - inside the single-layer envelope - runs the fp32 path; both hold the reference golden (run by the FULL list too)."""
     E = engine_mod
     eng, *_ = build_engine("full/vog_spat_3layers_sharp4")
-    assert eng.precise is None and eng.sharpness < E.F16_SHARPNESS_MAX_DEEP
-    eng, *_ = build_engine("full/vog_spat_3layers_sharp8")
-    assert eng.precise is not None and E.F16_SHARPNESS_MAX_DEEP < eng.sharpness < E.F16_SHARPNESS_MAX
+    assert eng.plan == "f16" and eng.sharpness < E.F16_SHARPNESS_MAX_DEEP
+    eng, *_ = build_engine("full/vog_spat_3layers_sharp8")      # round 6: hi + lo operands (fp32 path in round 5)
+    assert eng.plan == "split" and E.F16_SHARPNESS_MAX_DEEP < eng.sharpness < E.SPLIT_SHARPNESS_MAX_DEEP
     eng, *_ = build_engine("full/cfg2_sharp8")
-    assert eng.precise is None
+    assert eng.plan == "f16"
+
+
+@pytest.mark.parametrize("name", SPLIT_CASES)
+def test_forward_hi_lo_plan_vs_reference_golden(name):
+    """Round 6: checkpoints past the f16 envelope (wq / wk x 12 ... x 32; 3-layer stacks x 8; temp / svsq / sep / VidGrnd x 16) on
+    the hi + lo plan `auto` picks for them - the fast kernels with three MFMAs for everything that feeds attention logits - against
+    the reference goldens, eager and from a graph slot. (Round 5 ran these on the fp32 path, 34 x slower.)"""
+    eng, *_ = build_engine(name)
+    assert eng.plan == "split", (eng.plan, eng.sharpness)
+    out, pred, g, _ = _run(name)
+    nf = _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+    out2, pred2, g, _ = _run(name, graph=True)
+    _check_against(name, out2, pred2, g, None, tol_rel=1e-3, tol_logit=6e-3)
+    assert torch.equal(out["mdl_outs"], out2["mdl_outs"])
+
+
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_ragged", "small/vog_spat", "small/vog_temp",
+                                  "small/vog_sep", "small/vgrnd_spat", "small/sharp8_vog_spat"])
+def test_forward_hi_lo_forced_vs_reference_golden(name):
+    """tx_dtype = split on checkpoints that do not need it: same goldens, errors at or below the f16 plan's."""
+    eng, *_ = build_engine(name, "split")
+    assert eng.plan == "split"
+    out, pred, g, _ = _run(name, tx_dtype="split")
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+def test_logit_scale_guard_raises_the_plan():
+    """The run-time side of the precision plan: the attention kernels report the largest |logit| they saw (vog_batch.stats, folded
+    into pinned host memory by the prediction head). A checkpoint whose weight statistic UNDER-reports its logit scale (here:
+    the statistic is patched to 0, so `auto` plans plain f16 for wq / wk x 16) is caught on its first batch: a warning, the plan
+    raised to hi + lo operands, and the next forward is inside the bound."""
+    import warnings
+    E = engine_mod
+    name = "full/cfg2_sharp16"
+    real = E.attention_sharpness
+    E.attention_sharpness = lambda *a, **k: 0.0
+    try:
+        eng, cfg, sd, batch, c, dev = build_engine(name)
+    finally:
+        E.attention_sharpness = real
+    assert eng.plan == "f16"
+    g = np.load(cases.golden_path(name))
+    nz = g["mdl_outs_eval"] != 0
+    out = eng.forward(dev)
+    torch.cuda.synchronize()
+    e0 = float(rel_err(out["mdl_outs_eval"].cpu().numpy()[nz], g["mdl_outs_eval"][nz]).max())
+    lo, lm = eng.observed_logit_max()
+    print(f"{name} planned f16: eval rel {e0:.2e}; observed |logit| max obj {lo:.1f} mul {lm:.1f} nats")
+    assert max(lo, lm) > E.F16_LOGIT_MAX
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert eng.check_logit_scale() is False
+        assert any("nats observed" in str(x.message) for x in w)
+    assert eng.plan == "split"
+    out = eng.forward(dev)
+    torch.cuda.synchronize()
+    e1 = float(rel_err(out["mdl_outs_eval"].cpu().numpy()[nz], g["mdl_outs_eval"][nz]).max())
+    print(f"   re-planned {eng.plan}: eval rel {e1:.2e}")
+    assert e1 < 1e-3 < e0
+    assert eng.check_logit_scale() is True
+
+
+def test_observed_logit_scale_of_the_goldens():
+    """What the kernels report on the sharpened goldens (the numbers behind engine.F16_LOGIT_MAX / SPLIT_LOGIT_MAX): every case
+    inside a plan's envelope stays under that plan's logit limit, so `check_logit_scale` never fires on them."""
+    E = engine_mod
+    rows = []
+    for name in ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp10", "full/cfg2_sharp12", "full/cfg2_sharp16",
+                 "full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg3_sharp8", "full/cfg5_sharp8", "full/vog_spat_3layers_sharp8"]:
+        eng, cfg, sd, batch, c, dev = build_engine(name)
+        eng.forward(dev)
+        torch.cuda.synchronize()
+        lo, lm = eng.observed_logit_max()
+        rows.append((name, eng.plan, eng.sharpness, lo, lm))
+        print(f"{name:36s} plan {eng.plan:5s} sharpness {eng.sharpness:7.1f}  |logit| max obj {lo:8.1f} mul {lm:8.1f}")
+        assert eng.check_logit_scale(escalate=False), (name, eng.plan, lo, lm)
+        assert lm > 0 and (lo > 0 or cfg.mdl.name == "igrnd")
 
 
 def test_f16_just_outside_its_envelope_still_inside_the_bound():
@@ -213,7 +306,7 @@ def test_forward_persistent_lstm_layer(name):
     assert ds < 4e-4, ds
 
 
-@pytest.mark.parametrize("name", FULL + ["small/vog_spat", "small/vgrnd_sep", "small/edge_temp_len1",
+@pytest.mark.parametrize("name", FULL_VARIANTS + ["small/vog_spat", "small/vgrnd_sep", "small/edge_temp_len1",
                                          "small/edge_sep_maxlen"])
 def test_forward_step_launch_lstm_vs_reference_golden(name):
     """The step-launch BiLSTM (lstm_persistent = 0: lowest latency fallback, any number in flight)
@@ -229,7 +322,7 @@ def test_forward_step_launch_lstm_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=tol[0], tol_logit=tol[1])
 
 
-@pytest.mark.parametrize("name", FULL + ["small/vog_spat"])
+@pytest.mark.parametrize("name", FULL_VARIANTS + ["small/vog_spat"])
 def test_forward_unfused_tail_vs_reference_golden(name):
     """fused_tail = 0: the separate Wo / LayerNorm / FFN / lin2 / score launches (the path of every
     shape the fused kernel does not cover) against the same goldens."""
@@ -242,7 +335,7 @@ def test_forward_unfused_tail_vs_reference_golden(name):
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
-@pytest.mark.parametrize("name", FULL + ["full/cfg4_vog_spat_p100_bs4"])
+@pytest.mark.parametrize("name", FULL_VARIANTS + ["full/cfg2_sharp16", "full/cfg4_vog_spat_p100_bs4"])
 def test_paired_launches_equal_separate_launches(name):
     """pair_launches: two independent steps in one grid (csrc/pair.hip) run the same kernel bodies as
     the stand-alone launches -> bit-identical outputs."""
@@ -374,6 +467,14 @@ def test_forward_p100_sharp_vs_reference_golden():
 def test_forward_p100_vs_reference_golden():
     name = "full/cfg4_vog_spat_p100_bs4"
     out, pred, g, _ = _run(name)
+    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+
+
+def test_forward_p100_bf16_vs_reference_golden():
+    """cfg 4 in the operand type bench.py times it in (`--workload cfg4`: tx = bf16, 7.6e-4 in bench_r5_cfg4.json's parity block):
+    the p100 golden with bf16 transformers."""
+    name = "full/cfg4_vog_spat_p100_bs4"
+    out, pred, g, _ = _run(name, tx_dtype="bf16")
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 

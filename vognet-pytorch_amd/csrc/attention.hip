@@ -45,6 +45,8 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
                                      : (size_t)p.npad_kv * sizeof(float);
   if (lds > 64 * 1024) VOG_FAIL(-1, "struct attention: %d visual keys exceed the LDS budget", p.nppf);
   dim3 grid(p.S * p.H * ((nqb + 3) / 4));
+  if (p.q_lo && !(p.npad_kv == 32 && p.q_visual && p.kv_lo))
+    VOG_FAIL(-1, "struct attention with hi + lo operands: needs q_visual and one visual key block (nppf <= 32)");
   // several visual key blocks: K / V^T through an LDS ring shared by the workgroup (attn_struct_lds_dev.h)
   static int lds_form = -2;           // VOG_ATTN_STRUCT_LDS=0 (perf experiments): per-wave L2 loads instead
   if (lds_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_LDS"); lds_form = e ? atoi(e) : 1; }
@@ -105,6 +107,17 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
     VOG_LAUNCH_CHECK();
     return 0;
   }
+  // hi + lo operands (round 6): one visual key block, queries formed in the kernel - the gt5 shapes
+  if (p.q_lo) {
+    if constexpr (((NDB * 32) / 16) % 2 == 0) {
+      if (p.npad_kv == 32 && p.q_visual && p.kv_lo) {
+        ::vog::launch((attn_struct1_lean_kernel<T16, NDB, true>), grid, dim3(256), lds, st, p);
+        VOG_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    VOG_FAIL(-1, "struct attention with hi + lo operands: needs q_visual, one visual key block (nppf <= 32) and a head dim of 64 / 128 / 192 / 256");
+  }
   // lean form (<= 128 registers, four workgroups per CU) unless VOG_ATTN_STRUCT1_LEAN=0 (perf experiments): bit-identical
   static int lean1 = -2;
   if (lean1 == -2) { const char* e = perf_env("VOG_ATTN_STRUCT1_LEAN"); lean1 = e ? atoi(e) : 1; }
@@ -137,7 +150,9 @@ int attn_struct_run(const vog_attn_struct_args* a, hipStream_t st) {
   AttnStructParams p{(const unsigned short*)a->q, (const unsigned short*)a->kv, (const unsigned short*)a->vv, a->pl,
                      (unsigned short*)a->out16, a->u, a->pe_b, a->S, a->H, a->dp, a->nsrl, a->nppf, a->npad_q,
                      a->npad_kv, a->nfrm, a->lang_per_vid, a->nc_v, a->use_rel, a->seq_per_vid, a->NP, a->inv_scale,
-                     a->q_visual ? 1 : 0, 0, a->guard_flag, 0};
+                     a->q_visual ? 1 : 0, 0, a->guard_flag, 0,
+                     (const unsigned short*)a->q_lo, (const unsigned short*)a->kv_lo, (unsigned short*)a->out16_lo, a->logit_max};
+  VOG_CHECK_ARG((a->q_lo == nullptr) == (a->kv_lo == nullptr));
   { static const int dbg = perf_env("VOG_ATTN_STRUCT_DEBUG") ? atoi(perf_env("VOG_ATTN_STRUCT_DEBUG")) : 0; p.dbg = dbg; }
   VOG_DISPATCH_DTYPE(a->dtype, return (attn_struct_dispatch<T16>(p, st)));
   return 0;
@@ -149,6 +164,31 @@ template <typename T16, int NDB>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   static int force_general = -2;      // VOG_ATTN_GENERAL=1: perf experiments only
   if (force_general == -2) { const char* e = perf_env("VOG_ATTN_GENERAL"); force_general = e ? atoi(e) : 0; }
+  if (p.q_lo) {
+    // hi + lo Q / K (round 6): the two kernels of the gt5 shapes carry the three-MFMA contraction
+    if (p.N <= 128) {
+      constexpr int HB = (NDB + 1) / 2;
+      const size_t lds = ((size_t)4 * HB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);
+      auto kern = attn_sb_kernel<T16, NDB, true>;
+      static bool attr_sbs = false;
+      if (!attr_sbs && lds > 48 * 1024) {
+        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_sbs = true;
+      }
+      ::vog::launch(kern, dim3(ceil_div(p.N, 32) * p.H * p.S), dim3(256), lds, st, p);
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
+    if constexpr (((NDB * 32) / 16) % 2 == 0) {
+      if (p.npad <= 256) {
+        const size_t ldsl = (size_t)8 * 2 * 64 * 16 + (size_t)2 * 8 * 32 * sizeof(float) + (size_t)p.npad * sizeof(float);
+        ::vog::launch((attn_frag_lean_kernel<T16, NDB, true>), dim3(ceil_div(p.N, 32) * p.H * p.S), dim3(256), ldsl, st, p);
+        VOG_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    VOG_FAIL(-1, "rel_attention with hi + lo operands: sequences of more than 256 tokens are not supported (N = %d)", p.N);
+  }
   if (p.N <= 128 && !force_general) {
     constexpr int HB = (NDB + 1) / 2;
     const size_t lds = ((size_t)4 * HB * 16 * 64 + 4 * 2 * 64 + p.npad) * sizeof(float);
@@ -285,6 +325,9 @@ int attn_run(const vog_attn_args* a, hipStream_t st) {
   p.S = a->S; p.N = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad; p.use_rel = a->use_rel;
   p.n_box = a->n_box; p.seq_per_vid = a->seq_per_vid; p.NP = a->NP; p.inv_scale = a->inv_scale;
   p.guard = a->guard_flag; p.guard_precleared = a->guard_precleared; p.phase = a->phase;
+  VOG_CHECK_ARG((a->q_lo == nullptr) == (a->k_lo == nullptr));
+  p.q_lo = (const unsigned short*)a->q_lo; p.k_lo = (const unsigned short*)a->k_lo; p.out_lo = (unsigned short*)a->out16_lo;
+  p.logit_max = a->logit_max;
   VOG_DISPATCH_DTYPE(a->dtype, return attn_dispatch<T16>(p, st));
   return 0;
 }

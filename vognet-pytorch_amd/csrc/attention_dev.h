@@ -15,7 +15,48 @@ struct AttnParams {
                     // attn_tile_kernel: when non-null, run only if *guard != 0 (fallback pass)
   int guard_precleared;   // host side only: *guard is already 0 (no clearing launch)
   int phase;              // host side only: 0 whole call, 1 fixed-reference kernel only, 2 its gated fallback only
+  // round 6, hi + lo operands (SPLIT kernels): q / k = q + q_lo, k + k_lo with q_lo = t16(x - t16(x)) in the same fragment
+  // order; Q.K^T = q.k + q_lo.k + q.k_lo (three MFMAs, the lo x lo term is below fp32 resolution). out_lo (optional): the
+  // 16-bit remainder of the output rows (the Wo GEMM of a split tail reads both).
+  const unsigned short* q_lo; const unsigned short* k_lo; unsigned short* out_lo;
+  // optional: max |scaled logit| seen by this launch, as the bits of a non-negative float (atomicMax; zeroed by the caller)
+  unsigned int* logit_max;
 };
+
+// S^T += K_blk . Q^T for one k-step; SPLIT adds the two cross terms of the hi + lo operands
+template <typename T16, bool SPLIT>
+__device__ __forceinline__ f32x16 qk_mfma(u16x8 kh, u16x8 qh, u16x8 kl, u16x8 ql, f32x16 s) {
+  s = mfma32<T16>(kh, qh, s);
+  if constexpr (SPLIT) {
+    s = mfma32<T16>(kl, qh, s);
+    s = mfma32<T16>(kh, ql, s);
+  }
+  return s;
+}
+// hi + lo of an fp32 vector piece
+template <typename T16>
+__device__ __forceinline__ void split16(float v, unsigned short& hi, unsigned short& lo) {
+  hi = to16<T16>(v);
+  lo = to16<T16>(v - from16<T16>(hi));
+}
+// one wave's contribution to the launch's max |logit| (amax >= 0 in every lane)
+__device__ __forceinline__ void publish_logit_max(unsigned int* dst, float amax, int lane) {
+  if (!dst) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if (lane == 0 && amax > 0.f) atomicMax(dst, __float_as_uint(amax));
+}
+// output rows: 4 consecutive head columns as 16-bit (+ their 16-bit remainder when the consumer is a split tail)
+template <typename T16>
+__device__ __forceinline__ void store_out4(unsigned short* orow, unsigned short* orow_lo, float a, float b, float c, float d) {
+  u16x4 v = {to16<T16>(a), to16<T16>(b), to16<T16>(c), to16<T16>(d)};
+  *reinterpret_cast<u16x4*>(orow) = v;
+  if (orow_lo) {
+    u16x4 l = {to16<T16>(a - from16<T16>(v[0])), to16<T16>(b - from16<T16>(v[1])), to16<T16>(c - from16<T16>(v[2])),
+               to16<T16>(d - from16<T16>(v[3]))};
+    *reinterpret_cast<u16x4*>(orow_lo) = l;
+  }
+}
 
 template <typename T16, int NDB>
 struct AttnFragBody {
@@ -198,8 +239,8 @@ struct AttnFragBody {
 // merge of partial outputs): P^T fragments (16 bit, MFMA B-operand order) and block sums to LDS; (3) the waves split the
 // OUTPUT d-blocks: one accumulator per d-block, V^T fragments streamed from L2, P^T fragments from LDS. <= 128 registers:
 // four workgroups per CU.
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256, 4) void attn_frag_lean_kernel(AttnParams p) {
+template <typename T16, int NDB, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_frag_lean_kernel(AttnParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
   constexpr int MAXKB = 8;
   static_assert(KS % 2 == 0, "two k-steps per round");
@@ -229,6 +270,9 @@ __global__ __launch_bounds__(256, 4) void attn_frag_lean_kernel(AttnParams p) {
   const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
   const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + lane;
   const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + lane;
+  // (SPLIT: the 16-bit remainders of Q and K, same fragment order)
+  const u16x8* Qlf = SPLIT ? reinterpret_cast<const u16x8*>(p.q_lo + base) + (int64_t)qb * KS * 64 + lane : Qf;
+  const u16x8* Klf = SPLIT ? reinterpret_cast<const u16x8*>(p.k_lo + base) + lane : Kf;
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
@@ -243,21 +287,29 @@ __global__ __launch_bounds__(256, 4) void attn_frag_lean_kernel(AttnParams p) {
 
   // ---- phase 1: S^T tiles of this wave's key blocks (kb = wid, wid + 4), scaled logits kept in registers
   f32x16 sacc[2];
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int kb = wid + 4 * i;
     if (kb < nkb) {
       const u16x8* Kb = Kf + (int64_t)kb * KS * 64;
+      const u16x8* Klb = Klf + (int64_t)kb * KS * 64;
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
       u16x8 nq0 = Qf[0], nq1 = Qf[64], nk0 = Kb[0], nk1 = Kb[64];
+      u16x8 nql0 = nq0, nql1 = nq1, nkl0 = nk0, nkl1 = nk1;
+      if constexpr (SPLIT) { nql0 = Qlf[0]; nql1 = Qlf[64]; nkl0 = Klb[0]; nkl1 = Klb[64]; }
 #pragma unroll 1
       for (int ks = 0; ks < KS; ks += 2) {
         const u16x8 q0 = nq0, q1 = nq1, k0 = nk0, k1 = nk1;
-        if (ks + 2 < KS) { nq0 = Qf[(ks + 2) * 64]; nq1 = Qf[(ks + 3) * 64]; nk0 = Kb[(ks + 2) * 64]; nk1 = Kb[(ks + 3) * 64]; }
-        s0 = mfma32<T16>(k0, q0, s0);
-        s1 = mfma32<T16>(k1, q1, s1);
+        const u16x8 ql0 = nql0, ql1 = nql1, kl0 = nkl0, kl1 = nkl1;
+        if (ks + 2 < KS) {
+          nq0 = Qf[(ks + 2) * 64]; nq1 = Qf[(ks + 3) * 64]; nk0 = Kb[(ks + 2) * 64]; nk1 = Kb[(ks + 3) * 64];
+          if constexpr (SPLIT) { nql0 = Qlf[(ks + 2) * 64]; nql1 = Qlf[(ks + 3) * 64]; nkl0 = Klb[(ks + 2) * 64]; nkl1 = Klb[(ks + 3) * 64]; }
+        }
+        s0 = qk_mfma<T16, SPLIT>(k0, q0, kl0, ql0, s0);
+        s1 = qk_mfma<T16, SPLIT>(k1, q1, kl1, ql1, s1);
       }
       float mblk = -1e30f;
 #pragma unroll
@@ -268,11 +320,13 @@ __global__ __launch_bounds__(256, 4) void attn_frag_lean_kernel(AttnParams p) {
         x = key < p.N ? x * c2 : -1e30f;
         sacc[i][r] = x;
         mblk = fmaxf(mblk, x);
+        amax = fmaxf(amax, key < p.N ? fabsf(x) : 0.f);
       }
       mblk = fmaxf(mblk, __shfl_xor(mblk, 32));
       if (hi == 0) mloc[kb * 32 + ql] = mblk;
     }
   }
+  publish_logit_max(p.logit_max, q_ok ? amax * 0.69314718056f : 0.f, lane);      // (log2 units -> nats)
   __syncthreads();
   // ---- phase 2: probabilities against the row maximum over all key blocks; P^T fragments straight from the registers
   float m = -1e30f;
@@ -315,14 +369,11 @@ __global__ __launch_bounds__(256, 4) void attn_frag_lean_kernel(AttnParams p) {
       o = mfma32<T16>(a1, Pl[(kb * 2 + 1) * 64 + lane], o);
     }
     if (q_ok) {
-      unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP;
+      const int64_t oo = ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP + db * 32 + hi * 4;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[g * 4 + e] * inv_l);
-        *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
-      }
+      for (int g = 0; g < 4; ++g)
+        store_out4<T16>(p.out + oo + g * 8, p.out_lo ? p.out_lo + oo + g * 8 : nullptr, o[g * 4] * inv_l, o[g * 4 + 1] * inv_l,
+                        o[g * 4 + 2] * inv_l, o[g * 4 + 3] * inv_l);
     }
   }
 }
@@ -345,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
 // 4 waves reduce the halves in parallel (wave w sums and stores d-block w). <= 256
 // registers => two workgroups per CU overlap each other's load round trip.
 // ----------------------------------------------------------------------------
-template <typename T16, int NDB>
+template <typename T16, int NDB, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
   constexpr int HB = (NDB + 1) / 2;                  // d-blocks per half
@@ -375,6 +426,9 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
   const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
   const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + (int64_t)wid * KS * 64 + lane;
   const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + (int64_t)wid * NDB * 2 * 64 + lane;
+  // (SPLIT: the 16-bit remainders of Q and K; streamed through the contraction loop, two k-steps at a time)
+  const u16x8* Qlf = SPLIT ? reinterpret_cast<const u16x8*>(p.q_lo + base) + (int64_t)qb * KS * 64 + lane : Qf;
+  const u16x8* Klf = SPLIT ? reinterpret_cast<const u16x8*>(p.k_lo + base) + (int64_t)wid * KS * 64 + lane : Kf;
 
   // requests first: K and Q (needed at once), then the first V half
   u16x8 kf[KS], qf[KS], vf[HB * 2];
@@ -404,19 +458,31 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) s1[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ks += 2) {
-      sacc = mfma32<T16>(kf[ks], qf[ks], sacc);
-      if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+      if constexpr (SPLIT) {
+        const u16x8 kl0 = Klf[ks * 64], ql0 = Qlf[ks * 64];
+        sacc = qk_mfma<T16, true>(kf[ks], qf[ks], kl0, ql0, sacc);
+        if (ks + 1 < KS) {
+          const u16x8 kl1 = Klf[(ks + 1) * 64], ql1 = Qlf[(ks + 1) * 64];
+          s1 = qk_mfma<T16, true>(kf[ks + 1], qf[ks + 1], kl1, ql1, s1);
+        }
+      } else {
+        sacc = mfma32<T16>(kf[ks], qf[ks], sacc);
+        if (ks + 1 < KS) s1 = mfma32<T16>(kf[ks + 1], qf[ks + 1], s1);
+      }
     }
+    float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = wid * 32 + c32_row(r, lane);
       float x = sacc[r] + s1[r];
       if (p.use_rel) x += fmaxf(uq - us[key] + peb, 0.f);
       x *= p.inv_scale;
+      amax = fmaxf(amax, (key < p.N && q_ok) ? fabsf(x) : 0.f);
       x = key < p.N ? x : -1e30f;
       sacc[r] = x;
       m_w = fmaxf(m_w, x);
     }
+    publish_logit_max(p.logit_max, amax, lane);
     m_w = fmaxf(m_w, __shfl_xor(m_w, 32));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -481,15 +547,11 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += slots[w * SLOT + (db * 16 + r) * 64 + lane];
       if (q_ok) {
-        unsigned short* orow = p.out + ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP +
-                               (half * HB + db) * 32;
+        const int64_t oo = ((int64_t)s * p.N + qi) * ((int64_t)p.H * DP) + (int64_t)h * DP + (half * HB + db) * 32 + hi * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = to16<T16>(acc[g * 4 + e] * inv_l);
-          *reinterpret_cast<u16x4*>(orow + g * 8 + hi * 4) = v;
-        }
+        for (int g = 0; g < 4; ++g)
+          store_out4<T16>(p.out + oo + g * 8, p.out_lo ? p.out_lo + oo + g * 8 : nullptr, acc[g * 4] * inv_l,
+                          acc[g * 4 + 1] * inv_l, acc[g * 4 + 2] * inv_l, acc[g * 4 + 3] * inv_l);
       }
     }
   }
@@ -681,6 +743,9 @@ struct AttnStructParams {
   // round 5: attn_struct_ef_kernel sets *guard = 1 when a row of its shift mA[p] + mB[a] may sit too far above the row's true
   // maximum for the 16-bit E / P fragments (attn_struct_ef_dev.h); attn_struct_lds_kernel with guard_gate = 1 runs only then
   int* guard; int guard_gate;
+  // round 6 (SPLIT kernel; q_visual form): 16-bit remainders of the visual query / key parts, same fragment order as q / kv;
+  // the language parts come from the fp32 `pl` and are split in the kernel. out_lo / logit_max: as in AttnParams.
+  const unsigned short* q_lo; const unsigned short* kv_lo; unsigned short* out_lo; unsigned int* logit_max;
 };
 
 #ifdef VOG_TS_ATTN   // scratch/ts_attn.hip: wall-clock stamps (100 MHz) per wave
@@ -759,14 +824,11 @@ __device__ __forceinline__ u16x8 struct_load_vl(const AttnStructParams& p, int d
 template <typename T16>
 __device__ __forceinline__ void struct_store(const AttnStructParams& p, const f32x16& o, int db, int64_t row,
                                              int h, int DP, int hi) {
-  unsigned short* orow = p.out + row * ((int64_t)p.H * DP) + (int64_t)h * DP;
+  const int64_t oo = row * ((int64_t)p.H * DP) + (int64_t)h * DP + db * 32 + hi * 4;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    u16x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = to16<T16>(o[g * 4 + e]);
-    *reinterpret_cast<u16x4*>(orow + db * 32 + g * 8 + hi * 4) = v;
-  }
+  for (int g = 0; g < 4; ++g)
+    store_out4<T16>(p.out + oo + g * 8, p.out_lo ? p.out_lo + oo + g * 8 : nullptr, o[g * 4], o[g * 4 + 1], o[g * 4 + 2],
+                    o[g * 4 + 3]);
 }
 
 // ---- ONE visual key block (nppf <= 32: every gt5 shape). Both softmaxes are complete before any
@@ -953,8 +1015,8 @@ __global__ __launch_bounds__(256) void attn_struct1_kernel(AttnStructParams p) {
 // kernel's 120 workgroups held 120 CUs for 13 us at 6 % MFMA utilisation. Here the contraction over the head dimension is
 // walked two k-steps at a time (the next pair's global fragments in flight), <= 128 registers: four workgroups share a CU and
 // their load latencies hide each other. Same MFMA order as attn_struct1_kernel (even / odd k-step chains): bit-identical.
-template <typename T16, int NDB>
-__global__ __launch_bounds__(256, 4) void attn_struct1_lean_kernel(AttnStructParams p) {
+template <typename T16, int NDB, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_struct1_lean_kernel(AttnStructParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
   static_assert(KS % 2 == 0, "two k-steps per round");
   extern __shared__ __attribute__((aligned(16))) float ssm[];
@@ -1000,7 +1062,13 @@ __global__ __launch_bounds__(256, 4) void attn_struct1_lean_kernel(AttnStructPar
   auto load_q = [&](int ks) -> u16x8 {
     return p.q_visual ? *reinterpret_cast<const u16x8*>(qv + frag_qk(qp, ks * 16 + hi * 8, DP)) : Qf[ks * 64];
   };
+  // (SPLIT, q_visual form only: 16-bit remainders of Qv and Kv)
+  const unsigned short* qvl = SPLIT ? p.q_lo + kvbase : qv;
+  const u16x8* Klof = SPLIT ? reinterpret_cast<const u16x8*>(p.kv_lo + kvbase) + lane : Kf;
+  auto load_ql = [&](int ks) -> u16x8 { return *reinterpret_cast<const u16x8*>(qvl + frag_qk(qp, ks * 16 + hi * 8, DP)); };
   u16x8 nq0 = load_q(0), nq1 = load_q(1), nk0 = Kf[0], nk1 = Kf[64];
+  u16x8 nql0 = nq0, nql1 = nq1, nkl0 = nk0, nkl1 = nk1;
+  if constexpr (SPLIT) { nql0 = load_ql(0); nql1 = load_ql(1); nkl0 = Klof[0]; nkl1 = Klof[64]; }
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
@@ -1035,18 +1103,49 @@ __global__ __launch_bounds__(256, 4) void attn_struct1_lean_kernel(AttnStructPar
       return u16x8{to16<T16>(x0.x), to16<T16>(x0.y), to16<T16>(x0.z), to16<T16>(x0.w),
                    to16<T16>(x1.x), to16<T16>(x1.y), to16<T16>(x1.z), to16<T16>(x1.w)};
     };
+    // SPLIT: q(a, p) = (Qv + Qv_lo)[p] + Ql[a] formed in fp32 and split again; the language keys split from their fp32 rows
+    auto make_q = [&](u16x8 v, u16x8 vl, int ks, u16x8& qh, u16x8& qlo) {
+      const float4 l0 = *reinterpret_cast<const float4*>(qlr + ks * 16);
+      const float4 l1_ = *reinterpret_cast<const float4*>(qlr + ks * 16 + 4);
+      const float lq[8] = {l0.x, l0.y, l0.z, l0.w, l1_.x, l1_.y, l1_.z, l1_.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsigned short h_, l_;
+        split16<T16>(from16<T16>(v[j]) + from16<T16>(vl[j]) + lq[j], h_, l_);
+        qh[j] = h_; qlo[j] = l_;
+      }
+    };
+    auto make_kl = [&](int ks, u16x8& kh, u16x8& klo) {
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (a_ok) { x0 = *reinterpret_cast<const float4*>(kr + ks * 16); x1 = *reinterpret_cast<const float4*>(kr + ks * 16 + 4); }
+      const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsigned short h_, l_;
+        split16<T16>(xs[j], h_, l_);
+        kh[j] = h_; klo[j] = l_;
+      }
+    };
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
-      const u16x8 q0 = add_ql(nq0, ks), q1 = add_ql(nq1, ks + 1), k0 = nk0, k1 = nk1;
+      u16x8 q0, q1, ql0, ql1, kl0, kl1, kll0, kll1;
+      const u16x8 k0 = nk0, k1 = nk1, kv0 = nkl0, kv1 = nkl1;
+      if constexpr (SPLIT) {
+        make_q(nq0, nql0, ks, q0, ql0); make_q(nq1, nql1, ks + 1, q1, ql1);
+      } else {
+        q0 = add_ql(nq0, ks); q1 = add_ql(nq1, ks + 1); ql0 = q0; ql1 = q1;
+      }
       if (ks + 2 < KS) {                                  // the next round's global fragments
         nq0 = load_q(ks + 2); nq1 = load_q(ks + 3);
         nk0 = Kf[(ks + 2) * 64]; nk1 = Kf[(ks + 3) * 64];
+        if constexpr (SPLIT) { nql0 = load_ql(ks + 2); nql1 = load_ql(ks + 3); nkl0 = Klof[(ks + 2) * 64]; nkl1 = Klof[(ks + 3) * 64]; }
       }
-      const u16x8 kl0 = load_kl(ks), kl1 = load_kl(ks + 1);
-      sv = mfma32<T16>(k0, q0, sv);
-      sl = mfma32<T16>(kl0, q0, sl);
-      s1 = mfma32<T16>(k1, q1, s1);
-      l1 = mfma32<T16>(kl1, q1, l1);
+      if constexpr (SPLIT) { make_kl(ks, kl0, kll0); make_kl(ks + 1, kl1, kll1); }
+      else { kl0 = load_kl(ks); kl1 = load_kl(ks + 1); kll0 = kl0; kll1 = kl1; }
+      sv = qk_mfma<T16, SPLIT>(k0, q0, kv0, ql0, sv);
+      sl = qk_mfma<T16, SPLIT>(kl0, q0, kll0, ql0, sl);
+      s1 = qk_mfma<T16, SPLIT>(k1, q1, kv1, ql1, s1);
+      l1 = qk_mfma<T16, SPLIT>(kl1, q1, kll1, ql1, l1);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sv[r] += s1[r]; sl[r] += l1[r]; }
@@ -1054,7 +1153,7 @@ __global__ __launch_bounds__(256, 4) void attn_struct1_lean_kernel(AttnStructPar
   // ---- two independent softmaxes, probabilities normalised before P.V (as attn_struct1_kernel)
   u16x8 pv_[2], pl_[2];
   {
-    float mv = -1e30f, ml = -1e30f;
+    float mv = -1e30f, ml = -1e30f, av = 0.f, al = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = c32_row(r, lane);
@@ -1064,7 +1163,10 @@ __global__ __launch_bounds__(256, 4) void attn_struct1_lean_kernel(AttnStructPar
       const float y = key < p.nsrl ? sl[r] * c2 : -1e30f;
       sv[r] = x; sl[r] = y;
       mv = fmaxf(mv, x); ml = fmaxf(ml, y);
+      av = fmaxf(av, key < p.nppf ? fabsf(x) : 0.f); al = fmaxf(al, key < p.nsrl ? fabsf(y) : 0.f);
     }
+    // (the logit of key (a', p') is x[p'] + y[a']: the largest magnitude of the pair bounds it; log2 units -> nats)
+    publish_logit_max(p.logit_max, q_ok ? (av + al) * 0.69314718056f : 0.f, lane);
     mv = fmaxf(mv, __shfl_xor(mv, 32));
     ml = fmaxf(ml, __shfl_xor(ml, 32));
     float lv_ = 0.f, ll = 0.f;

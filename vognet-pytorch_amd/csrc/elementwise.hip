@@ -151,22 +151,64 @@ __global__ void srl_gather_kernel(const int64_t* __restrict__ words, const int64
 // argument vectors (retrieve_srl_arg_from_lang_encode mdl_vog.py:97-140)
 // one workgroup per (sentence, arg); wave-per-output dot products, fp32 exact
 // ---------------------------------------------------------------------------
+constexpr int AV_ROWS = 20;      // (sentence, argument) rows per workgroup
 __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ full,
                                                      const int64_t* __restrict__ capture,
                                                      const int64_t* __restrict__ msk,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias,
                                                      float* __restrict__ lang, int T, int nsrl, int L, int nrows) {
-  // grid (ceil(rows / 20), L/16): a workgroup owns 16 output columns (each wave 4 of them, 4 independent accumulators,
-  // all of its weight-row loads in flight together: argvec_dev.h) for up to 20 (sentence, argument) rows, 4 rows per pass -
-  // the 8 KB of weight rows a wave needs come from memory once and from its L1 afterwards. Round 6: 16 workgroups at cfg 2
-  // instead of 320 (one per row and column block: 1137 CU-us for 5 MFLOP, every one of them re-fetching its 32 KB weight
-  // slice; profiles/round5_busy_cu_cfg2.md). Same per-lane summation order as before: bit-identical.
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int r_end = min(nrows, ((int)blockIdx.x + 1) * 20);
-  for (int r0 = (int)blockIdx.x * 20; r0 < r_end; r0 += 4) {
-    const int ba[4] = {r0, r0 + 1 < r_end ? r0 + 1 : -1, r0 + 2 < r_end ? r0 + 2 : -1, r0 + 3 < r_end ? r0 + 3 : -1};
-    argvec_rows<4>(full, capture, msk, w, bias, lang, T, nsrl, L, blockIdx.y * 16 + wid * 4, ba, lane, false);
+  // grid (ceil(rows / 20), L/16): a workgroup owns 16 output columns for up to 20 (sentence, argument) rows. Round 6: 16
+  // workgroups at cfg 2 instead of 320 (one per row and column block: 1137 CU-us for 5 MFLOP, each re-fetching its 32 KB
+  // weight slice; profiles/round5_busy_cu_cfg2.md). The rows' [full[cap0] || full[cap1]] vectors are staged in LDS with ONE
+  // round of loads (every row of the block requested before anything is waited for; a first form that walked the rows in
+  // passes of dependent loads took 33 us), each wave keeps the weight rows of its 4 outputs in registers (requested in the
+  // same round) and forms 4 dot products per row: per-lane partial sums over the same elements in the same order as
+  // argvec_rows (argvec_dev.h), then the same wave reduction.
+  extern __shared__ __attribute__((aligned(16))) float av_x[];          // [AV_ROWS][2L]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r0 = (int)blockIdx.x * AV_ROWS;
+  const int nr = min(AV_ROWS, nrows - r0);
+  const int nq = (2 * L) >> 2, lq = L >> 2;
+  for (int idx = tid; idx < nr * nq; idx += 256) {
+    const int r = idx / nq, i = idx - r * nq;
+    const int row = r0 + r, b = row / nsrl;
+    int64_t c = capture[(int64_t)row * 2 + (i < lq ? 0 : 1)];
+    c = c < 0 ? 0 : (c >= T ? T - 1 : c);
+    reinterpret_cast<float4*>(av_x)[idx] =
+        reinterpret_cast<const float4*>(full + ((int64_t)b * T + c) * L)[i < lq ? i : i - lq];
+  }
+  constexpr int MAXQ = 4;
+  const int o0 = (int)blockIdx.y * 16 + wid * 4;
+  float4 wv[4][MAXQ];
+#pragma unroll
+  for (int it = 0; it < MAXQ; ++it) {
+    const int i = lane + it * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      wv[k][it] = (i < nq && o0 + k < L) ? reinterpret_cast<const float4*>(w + (int64_t)(o0 + k) * 2 * L)[i]
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float bs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bs[k] = o0 + k < L ? bias[o0 + k] : 0.f;
+  __syncthreads();
+  for (int r = 0; r < nr; ++r) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < MAXQ; ++it) {
+      const int i = lane + it * 64;
+      const float4 x = i < nq ? reinterpret_cast<const float4*>(av_x)[r * nq + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        acc[k] += (wv[k][it].x * x.x + wv[k][it].y * x.y) + (wv[k][it].z * x.z + wv[k][it].w * x.w);
+    }
+    const float mk = (float)msk[r0 + r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0 && o0 + k < L) lang[(int64_t)(r0 + r) * L + o0 + k] = relu_nan(v + bs[k]) * mk;
+    }
   }
 }
 
@@ -375,7 +417,16 @@ __device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
   }
 }
 
+// the forward's largest |attention logit| per stack -> the host's sticky maximum (vog_batch.stats): threads 0 / 1 of block 0
+__device__ __forceinline__ void publish_stats(const vog_pred_args& a) {
+  if (!a.stats || !a.logit_max || blockIdx.x != 0 || threadIdx.x >= 2) return;
+  unsigned int m = 0;
+  for (int l = 0; l < 32; ++l) { const unsigned int v = a.logit_max[threadIdx.x * 32 + l]; m = v > m ? v : m; }
+  if (m) __hip_atomic_fetch_max(a.stats + threadIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t rec_bytes) {
+  publish_stats(a);
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int per_q = a.nsrl * a.nfrm0 * a.ncmp;
@@ -439,6 +490,7 @@ __global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t
 }
 
 __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
+  publish_stats(a);
   pred_item<false>(a, rec_bytes, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
@@ -694,7 +746,7 @@ extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const i
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
   VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512 && (L % 4) == 0);
-  ::vog::launch(argvec_kernel, dim3(ceil_div(Bn * nsrl, 20), ceil_div(L, 16)), dim3(256), 0,
+  ::vog::launch(argvec_kernel, dim3(ceil_div(Bn * nsrl, AV_ROWS), ceil_div(L, 16)), dim3(256), (size_t)AV_ROWS * 2 * L * sizeof(float),
                      (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L, Bn * nsrl);
   VOG_LAUNCH_CHECK();
   return 0;

@@ -61,6 +61,8 @@ struct TxLayer {
   unsigned short *wo_p, *w1_p, *w2_p;      // 32x16 fragment order (fused encoder tail, txtail.hip), or null
   unsigned short *wqkv_p, *wqkv_pv;        // padded Wqkv in the same order (row-block QKV, qkvrb_dev.h): all d columns / the first d_vis
   float *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
+  // hi + lo operands (tx_split): 16-bit remainders t16(w - t16(w)) in the layouts of wqkv, wqkv_lang_f, wo_p, w1_p, w2_p
+  unsigned short *wqkv_lo, *wqkv_lang_f_lo, *wo_p_lo, *w1_p_lo, *w2_p_lo;
 };
 struct TxWeights {
   int d = 0, H = 0, dp = 0, dh = 0, n_layers = 0, use_rel = 0;
@@ -84,6 +86,11 @@ struct vog_ctx {
                                         // Measured (scratch/r5_pairattn*.sh): one forward 944 -> 888 us (-6 %), 4 in flight 5358 -> 5280
                                         // queries/s (-1.5 %: the launch fills the chip exactly and leaves the other forwards' kernels
                                         // no CU). Off: `value` is the throughput regime; on for latency-bound serving.
+  int tx_split = 0;                     // round 6: hi + lo 16-bit operands (three MFMAs per product) for everything that feeds attention
+                                        // logits - encoders, QKV projections, Q.K^T, and the tails whose output is another layer's
+                                        // input: the plan for checkpoints whose attention is too sharp for 16-bit logits but does
+                                        // not need the fp32 path (engine.py picks it from the weights; set before vog_ctx_finalize)
+  unsigned short *w_prop_f_lo = nullptr, *w_seg_f_lo = nullptr;
   int lstm_inject_stall = 0;            // test hook: persistent layer launches behave as if their hand-off had timed out
   int lstm_persistent = 1;              // one launch per BiLSTM layer where supported (W_hh resident on chip; vog_hip.h)
   int fused_tail = 1;                   // Wo..LN2 (+ lin2 + score) of an encoder layer as one launch where supported
@@ -164,6 +171,19 @@ static int upload(vog_ctx* c, const std::vector<T>& h, T** out) {
 
 static const std::vector<float>& W(vog_ctx* c, const std::string& n) { return c->host.at(n); }
 
+// w - t16(w): what the second operand of a hi + lo product carries (exact in fp32)
+static std::vector<float> remainder16(const float* w, size_t n, int dt) {
+  std::vector<float> r(n);
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned short h = h_to16(w[i], dt);
+    float back;
+    if (dt == VOG_BF16) { unsigned int u = (unsigned int)h << 16; memcpy(&back, &u, 4); }
+    else { _Float16 f; memcpy(&f, &h, 2); back = (float)f; }
+    r[i] = w[i] - back;
+  }
+  return r;
+}
+
 static int up32(vog_ctx* c, const std::string& n, float** out) { return upload<float>(c, W(c, n), out); }
 
 static int up16(vog_ctx* c, const std::string& n, int dt, unsigned short** out) {
@@ -214,6 +234,7 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
     VOG_TRY(upload<unsigned short>(c, wqkv, &L.wqkv));
     L.wqkv_lang_f = nullptr;
     L.wqkv_p = L.wqkv_pv = nullptr;
+    L.wqkv_lo = L.wqkv_lang_f_lo = L.wo_p_lo = L.w1_p_lo = L.w2_p_lo = nullptr;
     {
       std::vector<float> wqf((size_t)3 * H * dp * d, 0.f);
       for (int which = 0; which < 3; ++which) {
@@ -221,6 +242,12 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
         for (int h = 0; h < H; ++h)
           for (int dd = 0; dd < tw->head_dim[h]; ++dd)
             memcpy(&wqf[((size_t)(which * H + h) * dp + dd) * d], &w[(size_t)(tw->head_off[h] + dd) * d], d * sizeof(float));
+      }
+      if (c->tx_split) {     // remainder of the padded [3*H*dp, d] weights, same plain layout
+        const std::vector<float> r = remainder16(wqf.data(), wqf.size(), dt);
+        std::vector<unsigned short> lo(r.size());
+        for (size_t i = 0; i < r.size(); ++i) lo[i] = h_to16(r[i], dt);
+        VOG_TRY(upload<unsigned short>(c, lo, &L.wqkv_lo));
       }
       if (vog_qkv_rowblock_supported(3 * H * dp, d)) VOG_TRY(up_frag32(c, wqf.data(), d, 3 * H * dp, d, dt, &L.wqkv_p));
       const int dv = d - c->d.lang_enc;
@@ -242,6 +269,11 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
         std::vector<unsigned short> wf(wl.size());
         VOG_TRY(vog_pack_w_frag(wl.data(), dl, 3 * H * dp, dl, wf.data(), (vog_dtype)dt));
         VOG_TRY(upload<unsigned short>(c, wf, &L.wqkv_lang_f));
+        if (c->tx_split) {
+          const std::vector<float> r = remainder16(wl.data(), wl.size(), dt);
+          VOG_TRY(vog_pack_w_frag(r.data(), dl, 3 * H * dp, dl, wf.data(), (vog_dtype)dt));
+          VOG_TRY(upload<unsigned short>(c, wf, &L.wqkv_lang_f_lo));
+        }
       }
     }
     std::vector<unsigned short> wo((size_t)d * H * dp, 0);
@@ -265,6 +297,13 @@ static int finalize_tx(vog_ctx* c, const char* prefix, const char* pe_name, int 
       VOG_TRY(up_frag32(c, wof.data(), (int64_t)H * dp, d, H * dp, dt, &L.wo_p));
       VOG_TRY(up_frag32(c, W(c, p + ".feedforward.layer.linear1.weight").data(), d, dh, d, dt, &L.w1_p));
       VOG_TRY(up_frag32(c, W(c, p + ".feedforward.layer.linear2.weight").data(), dh, d, dh, dt, &L.w2_p));
+      if (c->tx_split) {
+        const auto& w1 = W(c, p + ".feedforward.layer.linear1.weight");
+        const auto& w2 = W(c, p + ".feedforward.layer.linear2.weight");
+        VOG_TRY(up_frag32(c, remainder16(wof.data(), wof.size(), dt).data(), (int64_t)H * dp, d, H * dp, dt, &L.wo_p_lo));
+        VOG_TRY(up_frag32(c, remainder16(w1.data(), w1.size(), dt).data(), d, dh, d, dt, &L.w1_p_lo));
+        VOG_TRY(up_frag32(c, remainder16(w2.data(), w2.size(), dt).data(), dh, d, dh, dt, &L.w2_p_lo));
+      }
     }
     VOG_TRY(up16(c, p + ".feedforward.layer.linear1.weight", dt, &L.w1));
     VOG_TRY(up16(c, p + ".feedforward.layer.linear2.weight", dt, &L.w2));
@@ -352,6 +391,7 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   p.add("obj_guard", 256);                            // vog_attn_args.guard_flag of the two stacks (long-sequence attention): zeroed
   p.add("mul_guard", 256);                            // with the rest of this region, so the attention needs no clearing launch
   p.add("mul_ef_guard", 256);                         // vog_attn_struct_args.guard_flag (E x F attention of mul_tx layer 0, p100)
+  p.add("logit_max", 256);                            // [2 stacks][32 layers] largest |attention logit| of this forward (float bits)
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -371,8 +411,16 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   p.add("enc_slabs", (int64_t)16 * (g.rows_obj * d.prop_enc + (int64_t)g.n_vid * g.Fv * d.seg_enc) * 4);
   p.add("prop_seg", g.rows_obj * g.d_obj * 4);
   p.add("prop_seg16", g.rows_obj * g.d_obj * 2);
+  if (c->tx_split) p.add("prop_seg16_lo", g.rows_obj * g.d_obj * 2);
   auto tx = [&](const char* nm, const TxWeights& tw, int64_t rows, int S, int npad) {
     const std::string n(nm);
+    if (c->tx_split) {     // 16-bit remainders of Q / K, of the attention rows and of the layer outputs (hi + lo operands)
+      p.add(n + "_q_lo", (int64_t)S * tw.H * tw.dp * npad * 2);
+      p.add(n + "_k_lo", (int64_t)S * tw.H * tw.dp * npad * 2);
+      p.add(n + "_attn16_lo", rows * tw.H * tw.dp * 2);
+      p.add(n + "_outA16_lo", rows * tw.d * 2);
+      if (tw.n_layers > 1) p.add(n + "_outB16_lo", rows * tw.d * 2);
+    }
     p.add(n + "_u", g.rows_obj * tw.H * 4);
     p.add(n + "_q", (int64_t)S * tw.H * tw.dp * npad * 2);      // fragment order, npad = N up to 32
     p.add(n + "_k", (int64_t)S * tw.H * tw.dp * npad * 2);
@@ -424,7 +472,12 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
                      const vog_vislang_args* structured = nullptr, const void* vis16 = nullptr,
                      bool last_needs_f32 = true, const vog_score_args* score = nullptr,
                      const vog_pred_args* pred = nullptr, unsigned int* pred_counter = nullptr, bool* pred_done = nullptr,
-                     const vog_qkv_args* dep = nullptr) {
+                     const vog_qkv_args* dep = nullptr,
+                     // hi + lo operands (c->tx_split): remainders of the stack's input rows / of the visual rows (structured
+                     // layer 0); out_feeds_attn: the LAST layer's output is another attention layer's input (obj_tx under mul_tx);
+                     // *out16_lo: remainder of the 16-bit output copy
+                     const void* x_in16_lo = nullptr, const void* vis16_lo = nullptr, bool out_feeds_attn = false,
+                     const void** out16_lo = nullptr, int* err = nullptr) {
   const std::string n(nm);
   const vog_model_desc& d = c->d;
   const vog_dtype dt = (vog_dtype)d.tx_dtype;
@@ -433,6 +486,9 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
   (void)fdiv;   // the bias precursors u are produced by the fused visual prologue (vis_prep)
   const float* cur32 = x_in32;
   const void* cur16 = x_in16;
+  const bool split = c->tx_split != 0;
+  const void* cur16_lo = x_in16_lo;
+  unsigned int* lmax = ws.at<unsigned int>("logit_max") + (n == "mul" ? 32 : 0);
   for (int l = 0; l < tw.n_layers; ++l) {
     const TxLayer& L = tw.layers[l];
     const bool toA = (l % 2) == 0;
@@ -450,6 +506,16 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       qa.dep_nh1 = dep->dep_nh1;
     }
     const bool fact = structured && l == 0;
+    const bool last_l = l == tw.n_layers - 1;
+    // hi + lo tail: this layer's output is read by another attention layer (a later layer of the stack, or mul_tx behind obj_tx)
+    const bool tail_split = split && (!last_l || out_feeds_attn);
+    void* attn16_lo = split ? ws.at<void>(n + "_attn16_lo") : nullptr;
+    void* o16_lo = split ? ws.at<void>(n + (toA ? "_outA16_lo" : "_outB16_lo")) : nullptr;
+    if (split) {
+      qa.x16_lo = cur16_lo; qa.wqkv_lo = L.wqkv_lo; qa.q_lo = ws.at<void>(n + "_q_lo"); qa.k_lo = ws.at<void>(n + "_k_lo");
+      qa.wqkv_p32 = nullptr;
+      if (!qa.x16_lo || !qa.wqkv_lo) { if (err) *err = -1; set_error("hi + lo operands: layer %d of %s has no remainder rows", l, nm); return; }
+    }
     if (fact) {
       // layer 0 of mul_tx: tokens are [vis[p] || lang[a]] -> project the two parts once each
       const vog_vislang_args sv = *structured;
@@ -460,7 +526,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       const float* plang = ws.at<float>(n + "_pl");
       const int npad_kv = (int)round_up64(sv.nppf, 32);
       qs.N = sv.nppf; qs.npad = npad_kv;
-      qs.wqkv_p32 = qkv_rb ? L.wqkv_pv : nullptr;
+      qs.wqkv_p32 = (qkv_rb && !split) ? L.wqkv_pv : nullptr;
+      if (split) qs.x16_lo = vis16_lo;
       steps.push_back({n + "_pv", [=](hipStream_t st) { return vog_qkv_proj(&qs, st); }});
       vog_attn_struct_args sa{};
       sa.q_visual = 1;
@@ -470,6 +537,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       sa.nc_v = sv.nc_v; sa.use_rel = tw.use_rel; sa.seq_per_vid = spv; sa.NP = g.NP;
       sa.inv_scale = 1.0f / sqrtf((float)tw.d); sa.dtype = dt;
       sa.guard_flag = (n == "mul") ? ws.at<int>("mul_ef_guard") : nullptr;
+      sa.logit_max = lmax + (l < 31 ? l : 31);
+      if (split) { sa.q_lo = qa.q_lo; sa.kv_lo = qa.k_lo; sa.out16_lo = tail_split ? attn16_lo : nullptr; }
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_struct_fwd(&sa, st); }});
     } else {
       steps.push_back({n + "_qkv", [=](hipStream_t st) { return vog_qkv_proj(&qa, st); }});
@@ -483,6 +552,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     // layer 0 stayed up - the prologue clears once per forward - and every later layer re-ran the running-maximum fallback)
     aa.guard_flag = ws.at<int>(n + "_guard") + (l < 63 ? l : 63);
     aa.guard_precleared = l < 63 ? 1 : 0;
+    aa.logit_max = lmax + (l < 31 ? l : 31);
+    if (split) { aa.q_lo = qa.q_lo; aa.k_lo = qa.k_lo; aa.out16_lo = tail_split ? attn16_lo : nullptr; }
     if (!fact) {
       if (c->pair_attn && n == "obj" && l == 0 && aa.guard_precleared && attn_uses_tile2(N, tw.dp, npad)) {
         // long sequences (p100): the fixed-reference kernel and its gated fallback as two steps - the first can share a launch
@@ -513,6 +584,10 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       ta.y32 = o32w; ta.y16 = o16w; ta.y16_dtype = (int)odt;
       ta.x1_scratch = ws.at<float>(n + "_x1s");
       ta.M = (int)rows; ta.d = tw.d; ta.dh = tw.dh; ta.dtype = dt; ta.head_dtype = d.enc_dtype;
+      if (tail_split) {
+        ta.attn16_lo = attn16_lo; ta.wo_p_lo = L.wo_p_lo; ta.w1_p_lo = L.w1_p_lo; ta.w2_p_lo = L.w2_p_lo;
+        ta.y16_lo = o16w ? o16_lo : nullptr;
+      }
       const bool with_score = last && score && c->w_lin2_p;
       vog_score_args sc{};
       if (with_score) { sc = *score; ta.wl_p = c->w_lin2_p; ta.bl = c->b_lin2; ta.y32 = nullptr; ta.y16 = nullptr; }
@@ -531,9 +606,11 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       if (with_score) *out16 = nullptr;            // tells the caller that lin2 + score already ran
       cur32 = o32;
       cur16 = o16;
-      if (last) { *out32 = cur32; if (!with_score) *out16 = cur16; return; }
+      cur16_lo = tail_split ? o16_lo : nullptr;
+      if (last) { *out32 = cur32; if (!with_score) *out16 = cur16; if (out16_lo) *out16_lo = cur16_lo; return; }
       continue;
     }
+    if (split) { if (err) *err = -1; set_error("hi + lo operands need the fused encoder-layer tail (d = 512 / 768; stack %s)", nm); return; }
     vog_gemm_args wo{}; wo.c16_dtype = -1;
     wo.a = aa.out16; wo.a_is_f32 = 0; wo.lda = (int64_t)tw.H * tw.dp; wo.w = L.wo; wo.ldw = (int64_t)tw.H * tw.dp;
     wo.residual = cur32; wo.ldr = tw.d; wo.c32 = ws.at<float>(n + "_tmp"); wo.ldc = tw.d;
@@ -756,6 +833,20 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       gl.c32 = ws.at<float>("mul_pl"); gl.ldc = ncol; gl.M = g.Bn * d.nsrl; gl.N = ncol; gl.K = g.L;
       gl.rep = 1; gl.dtype = (vog_dtype)d.tx_dtype;
       if (gl.M <= 64 && L0.wqkv_lang_f) { gl.w = L0.wqkv_lang_f; gl.ldw = g.L; gl.w_frag = 1; }
+      if (c->tx_split) {
+        // hi + lo operands: the M <= 64 kernel carries them; more than 64 (sentence, argument) rows go through it 64 at a time
+        if (!L0.wqkv_lang_f || !L0.wqkv_lang_f_lo) VOG_FAIL(-5, "tx_split: lang_enc %% 32 != 0");
+        gl.w = L0.wqkv_lang_f; gl.ldw = g.L; gl.w_frag = 1; gl.w_lo = L0.wqkv_lang_f_lo;
+        const int Mall = gl.M;
+        steps.push_back({"mul_pl", [=](hipStream_t st) {
+          for (int m0 = 0; m0 < Mall; m0 += 64) {
+            vog_gemm_args g2 = gl;
+            g2.a = (const float*)gl.a + (int64_t)m0 * gl.lda; g2.c32 = gl.c32 + (int64_t)m0 * gl.ldc;
+            g2.M = Mall - m0 < 64 ? Mall - m0 : 64;
+            VOG_TRY(vog_gemm_bias_act(&g2, st));
+          }
+          return 0; }});
+      } else
       steps.push_back({"mul_pl", [=](hipStream_t st) { return vog_gemm_bias_act(&gl, st); }});
     }
   }
@@ -795,9 +886,14 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       // encoders share the launch of a BiLSTM layer (busy-CU time matters, latency is hidden), and for
       // the p100 shapes where the wide form's 8 column slices per row tile re-stream the features
       ve.lean = c->enc_lean < 0 ? ((will_pair || Mp >= 4096) ? 1 : 0) : c->enc_lean;
+      if (c->tx_split) {     // hi + lo operands: the stream form carries them (visenc_dev.h)
+        ve.lean = 1;
+        ve.w_prop_f_lo = c->w_prop_f_lo; ve.w_seg_f_lo = c->w_seg_f_lo; ve.c16_lo = ws.at<void>("prop_seg16_lo");
+      }
       // many proposals per frame: the replication of the segment rows is its own (chip-wide) copy launch,
       // so the encoder kernel stays one launch and can still share the BiLSTM layer's
       const bool rep_step = ve.lean && d.nppf0 > 16 && (d.seg_enc % 4) == 0 && (d.prop_enc % 4) == 0 && (g.d_obj % 4) == 0;
+      if (c->tx_split && rep_step) VOG_FAIL(-5, "tx_split: more than 16 proposals per frame are not supported (use the fp32 path)");
       ve.defer_replicas = rep_step ? 1 : 0;
       // chain_obj_qkv: obj_tx's layer-0 QKV (row-block form) in the same launch, its workgroups waiting for the encoder
       // workgroups that write their rows (flags zeroed by the prologue)
@@ -845,10 +941,17 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // ---- object transformer (a7, a8)
   const float* vis32 = ps32;
   const void* vis16 = ps16;
-  if (has_obj(d))
+  const void* vis16_lo = c->tx_split ? ws.at<void>("prop_seg16_lo") : nullptr;
+  int tx_err = 0;
+  if (c->tx_split && !(c->fused_enc && c->w_prop_f_lo))
+    VOG_FAIL(-5, "tx_split needs the fused feature encoders (feature dims %% 256, encode sizes %% 32 and <= 256)");
+  if (has_obj(d)) {
+    const void* in_lo = vis16_lo;
     tx_steps(c, c->obj, "obj", g, ws, b, ps32, ps16, g.S_obj, g.N_obj, g.npad_obj, g.spv_obj, g.N_obj,
              g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16, nullptr, nullptr, true, nullptr, nullptr, nullptr,
-             nullptr, obj_dep.dep_flags ? &obj_dep : nullptr);
+             nullptr, obj_dep.dep_flags ? &obj_dep : nullptr, in_lo, nullptr, /*out_feeds_attn=*/has_mul(d), &vis16_lo, &tx_err);
+    if (tx_err) return tx_err;
+  }
   // ---- vis || lang tokens in mul_tx order (a10, a11)
   vog_vislang_args va{};
   va.vis = vis32; va.lang = lang_vec; va.x32 = ws.at<float>("xmul"); va.x16 = ws.at<void>("xmul16");
@@ -872,6 +975,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   pr.outs_eval = b->mdl_outs_eval; pr.props = b->pad_proposals; pr.fin_scores = b->fin_scores;
   pr.rec = b->pred_rec; pr.B = g.B; pr.ncmp = g.ncmp; pr.nsrl = d.nsrl; pr.nfrm0 = d.nfrm0;
   pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
+  pr.logit_max = ws.at<unsigned int>("logit_max"); pr.stats = b->stats;
   bool pred_done = false;
   // (sep / svsq: the head reads fin_scores of pred_cmp, which runs after the tail; p100: the wave-per-item head)
   const bool pred_in_tail = c->fused_pred && b->pred_rec && !g.sep && d.nppf0 < 32;
@@ -879,7 +983,12 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
              (float)g.nfrm, d.enc_dtype, steps, &x32, &x16, structured ? &va : nullptr, vis16,
              /*last_needs_f32=*/false, d.enc_dtype == VOG_F16 ? &sa : nullptr,
-             pred_in_tail ? &pr : nullptr, pred_in_tail ? ws.at<unsigned int>("pred_sync") : nullptr, &pred_done);
+             pred_in_tail ? &pr : nullptr, pred_in_tail ? ws.at<unsigned int>("pred_sync") : nullptr, &pred_done, nullptr,
+             // (not structured: mul_tx would read the materialised token matrix, which has no remainder copy)
+             structured ? vis16_lo : nullptr, structured ? vis16_lo : nullptr, false, nullptr, &tx_err);
+  if (tx_err) return tx_err;
+  if (c->tx_split && has_mul(d) && !structured)
+    VOG_FAIL(-5, "tx_split needs the structured mul_tx layer 0 (d_obj %% 64 == 0, lang_enc %% 32 == 0, more than 64 visual rows)");
   // ---- score head (a9 tail / a20 / a17); x16 == NULL: the fused mul_tx tail already ran it
   if (x16 != nullptr) {
     vog_gemm_args l2{}; l2.c16_dtype = -1;
@@ -1208,6 +1317,15 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
     VOG_TRY(vog_pack_w_frag(W(c, "seg_encoder.0.weight").data(), d.seg_dim, d.seg_enc, d.seg_dim, ws.data(), (vog_dtype)et));
     VOG_TRY(upload<unsigned short>(c, wf, &c->w_prop_f));
     VOG_TRY(upload<unsigned short>(c, ws, &c->w_seg_f));
+    c->w_prop_f_lo = c->w_seg_f_lo = nullptr;
+    if (c->tx_split) {
+      const auto& wp = W(c, "prop_encoder.0.weight");
+      const auto& wsg = W(c, "seg_encoder.0.weight");
+      VOG_TRY(vog_pack_w_frag(remainder16(wp.data(), wp.size(), et).data(), d.prop_dim, d.prop_enc, d.prop_dim, wf.data(), (vog_dtype)et));
+      VOG_TRY(vog_pack_w_frag(remainder16(wsg.data(), wsg.size(), et).data(), d.seg_dim, d.seg_enc, d.seg_dim, ws.data(), (vog_dtype)et));
+      VOG_TRY(upload<unsigned short>(c, wf, &c->w_prop_f_lo));
+      VOG_TRY(upload<unsigned short>(c, ws, &c->w_seg_f_lo));
+    }
   }
   VOG_TRY(up32(c, "seg_encoder.0.bias", &c->b_seg));
   VOG_TRY(up16(c, "lin2.0.weight", et, &c->w_lin2));
@@ -1246,6 +1364,29 @@ extern "C" int vog_ctx_destroy(vog_ctx* c) {
 extern "C" int64_t vog_workspace_bytes(const vog_ctx* c, int B, int ncmp, int T) {
   if (!c || !c->finalized || B <= 0 || ncmp <= 0 || T <= 0) return -1;
   return make_plan(c, make_geo(c->d, B, ncmp, T)).total;
+}
+
+// Can this model run with hi + lo operands (option tx_split) at `ncmp` videos per query? The kernels that carry the three-MFMA
+// products cover the gt5-sized shapes: fused feature encoders (stream form, <= 16 proposals per frame), the LDS-DMA QKV GEMM,
+// attention over <= 256 tokens (plain) / one visual key block (structured mul_tx layer 0), the fused encoder-layer tails.
+extern "C" int vog_ctx_split_supported(const vog_ctx* c, int ncmp) {
+  if (!c || ncmp <= 0) return 0;
+  const vog_model_desc& d = c->d;
+  if (!has_obj_weights(d)) return 0;                                   // ImgGrnd: no attention at all
+  if (!vis_encode_supported(d.prop_dim, d.seg_dim, d.prop_enc, d.seg_enc) || d.nppf0 > 16) return 0;
+  const Geo g = make_geo(d, 4, ncmp, 1);
+  const int d_obj = d.prop_enc + d.seg_enc, d_mul = d_obj + d.lang_enc;
+  auto tx_ok = [&](int dm, int H, int N) {
+    const int chunk = (dm + H - 1) / H, dp = attn_head_pad(chunk);
+    return dp > 0 && tx_tail_supported(dm, dm / 2, H * dp) && (dm % 64) == 0 && N <= 256;
+  };
+  if (has_obj(d) && !tx_ok(d_obj, d.obj_heads, g.N_obj)) return 0;
+  if (has_mul(d)) {
+    if ((d_obj % 64) != 0 || (d.lang_enc % 32) != 0 || g.nppf > 32) return 0;     // structured layer 0, one visual key block
+    if (!tx_ok(d_mul, d.mul_heads, d.mul_layers > 1 ? g.N_mul : 1)) return 0;
+    if (d.mul_layers > 1 && g.N_mul > 256) return 0;
+  }
+  return 1;
 }
 
 extern "C" int vog_workspace_init(const vog_ctx* c, int B, int ncmp, int T, void* ws, size_t ws_bytes,
@@ -1456,6 +1597,11 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   VOG_CHECK_ARG(c && name);
   if (strcmp(name, "graph_dag") == 0) {
     if (value) VOG_FAIL(-4, "graph_dag was removed (parallel graph branches: slower with batches in flight, unstable in the runtime)");
+    return 0;
+  }
+  if (strcmp(name, "tx_split") == 0) {        // takes effect at the next vog_ctx_finalize (the remainder weights are made there)
+    if ((value != 0) != (c->tx_split != 0)) c->finalized = false;
+    c->tx_split = value ? 1 : 0;
     return 0;
   }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }

@@ -28,12 +28,12 @@ namespace vog {
 // ----------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------
-template <typename T16, int BM, int BN, int STAGES, int EPI>
+template <typename T16, int BM, int BN, int STAGES, int EPI, bool SPLIT = false>
 static int launch_pipe_cfg(const GemmParams& p, hipStream_t st) {
-  constexpr size_t ring = (size_t)STAGES * (BM + BN) * 128;
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * 128 * (SPLIT ? 2 : 1);
   constexpr size_t epi = (size_t)4 * (BM / 2) * (BN / 2 + 4) * 4;   // LDS-staged epilogue tile
   constexpr size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_pipe<T16, BM, BN, STAGES, EPI>;
+  auto kern = gemm_pipe<T16, BM, BN, STAGES, EPI, SPLIT>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -134,6 +134,8 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
     return launch_pipe<T16, EPI_PLAIN>(p, st);
   }
   p.w_frag = g->w_frag; p.a_frag = g->a_frag;
+  if (g->w_lo && !(p.M <= 64 && (p.K % 32) == 0 && p.w_frag))
+    VOG_FAIL(-1, "vog_gemm_args.w_lo: only the M <= 64 kernel with fragment-ordered weights takes hi + lo operands");
   if (g->argvec_tail) {
     const vog_argvec_tail* t = g->argvec_tail;
     VOG_CHECK_ARG(t->counter && t->capture && t->inds_msk && t->w && t->bias && t->lang && t->Bn > 0 && t->nsrl > 0);
@@ -180,24 +182,12 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
       // - 84 instead of 192 registers (the 8-deep form loads six zero fragments per operand), i.e. 4 instead of 2
       // workgroups per CU for the 144 workgroups of that launch. Same k order per wave: bit-identical.
       const bool shortk = p.K / 32 <= 8 && !p.av_counter;
-      // short K and many column tiles (mul_pl: 144 of them, M = 20): 4 column tiles per workgroup - the launch is 36
-      // workgroups instead of 144 (706 CU-us for 24 MFLOP at cfg 2, profiles/round5_busy_cu_cfg2.md); same k order per wave
-      // and the same partial-sum order in the finish: bit-identical
-      static const int nt4_off = perf_env("VOG_SKINNY_NT4_OFF") ? 1 : 0;
-      if (shortk && !nt4_off && ncol >= 64 && (ncol % 4) == 0 && grid.y == 1) {
-        const size_t lds4 = (size_t)4 * 4 * 4 * 64 * 4 * sizeof(float);          // 64 KiB
-        dim3 grid4(ncol / 4, 1);
-        if (g->a_is_f32) {
-          auto kern = gemm_skinny<T16, true, 2, 4, 4, false>;
-          static bool attr = false;
-          if (!attr) { VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); attr = true; }
-          ::vog::launch(kern, grid4, dim3(256), lds4, st, p);
-        } else {
-          auto kern = gemm_skinny<T16, false, 2, 4, 4, false>;
-          static bool attr = false;
-          if (!attr) { VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); attr = true; }
-          ::vog::launch(kern, grid4, dim3(256), lds4, st, p);
-        }
+      if (g->w_lo) {
+        // hi + lo operands (round 6): fp32 rows split in the kernel, fragment-ordered W and W_lo
+        if (!(g->a_is_f32 && p.w_frag && !p.av_counter))
+          VOG_FAIL(-1, "hi + lo M <= 64 GEMM: needs an fp32 A operand and fragment-ordered weights (w_frag) with their remainder (w_lo)");
+        p.w_lo = (const unsigned short*)g->w_lo;
+        ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, false, true>), grid, dim3(256), lds1, st, p);
       } else if (shortk) {
         if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
         else ::vog::launch((gemm_skinny<T16, false, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
@@ -213,6 +203,7 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
 
 const void* kid_gemm_skinny_f16() { return reinterpret_cast<const void*>(gemm_skinny<F16, false, 8, 1, 4>); }
 const void* kid_gemm_skinny_wide_f16() { return reinterpret_cast<const void*>(gemm_skinny<F16, false, 8, 2, 8>); }
+const void* kid_gemm_pipe_qkv_split_f16() { return reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 2, EPI_QKV, true>); }
 const void* kid_gemm_pipe_qkv(int dtype) {
   return dtype == VOG_BF16 ? reinterpret_cast<const void*>(gemm_pipe<BF16, 64, 64, 2, EPI_QKV>)
                            : reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 2, EPI_QKV>);
@@ -265,6 +256,14 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
     p.fdT_mul = d <= 1 ? 0u : (unsigned)((((1ull << 32) * ((1ull << sh) - (unsigned long long)d)) / (unsigned long long)d) + 1ull);
   }
   p.debug = gemm_debug_flags();
+  if (a->x16_lo || a->wqkv_lo || a->q_lo || a->k_lo) {
+    // hi + lo operands (round 6): the LDS-DMA GEMM with two images per stage, Q / K written as hi + lo fragments
+    VOG_CHECK_ARG(a->x16_lo && a->wqkv_lo && a->q_lo && a->k_lo && !a->pl);
+    p.a_lo = a->x16_lo; p.w_lo = (const unsigned short*)a->wqkv_lo; p.q_lo = (unsigned short*)a->q_lo; p.k_lo = (unsigned short*)a->k_lo;
+    if (!pipe_ok(p, false) || ((uintptr_t)p.a_lo % 16) != 0 || ((uintptr_t)p.w_lo % 16) != 0)
+      VOG_FAIL(-1, "hi + lo QKV projection needs the LDS-DMA GEMM (K %% 64 == 0, more than 64 rows, 16-byte aligned operands)");
+    VOG_DISPATCH_DTYPE(a->dtype, return (launch_pipe_cfg<T16, 64, 64, 2, EPI_QKV, true>(p, st)));
+  }
   if (a->wqkv_p32) {
     if (!qkv_rowblock_supported(p.N, p.K))
       VOG_FAIL(-1, "row-block QKV: unsupported shape (K %% 128 == 0, 256 <= K <= 1024, (3*H*dp / 32) even)");

@@ -45,6 +45,10 @@ struct GemmParams {
   // workgroups (visenc_dev.h: done_flags[block * 2 + half]); dep_nb0 = proposal row blocks, dep_rep = proposals per segment
   // row, dep_nh0 / dep_nh1 = column halves of the proposal / segment encoder
   const unsigned int* dep_flags; int dep_nb0, dep_rep, dep_nh0, dep_nh1;
+  // round 6, hi + lo operands: a_lo / w_lo = t16(x - t16(x)) of the fp32 activations / weights in the layout of a / w (w_lo in
+  // fragment order for the M <= 64 kernel); product = a.w + a_lo.w + a.w_lo (three MFMAs, fp32 accumulate). QKV epilogue:
+  // q_lo / k_lo = the remainders of the Q / K fragments (the attention kernels' hi + lo contraction reads them).
+  const void* a_lo; const unsigned short* w_lo; unsigned short* q_lo; unsigned short* k_lo;
 };
 
 template <typename T16, bool A_F32>
@@ -336,6 +340,7 @@ __device__ __forceinline__ void qkv_epilogue_tile(const GemmParams& p, const flo
       }
     } else if (which < 2) {
       unsigned short* base = which == 0 ? p.q : p.k;
+      unsigned short* base_lo = which == 0 ? p.q_lo : p.k_lo;   // (hi + lo operands: the remainder fragments, or null)
       const int c = lane & 7, rsub = lane >> 3;     // 8 chunks of 4 columns per row, 8 rows per pass
 #pragma unroll 4
       for (int ps = 0; ps < WTM / 8; ++ps) {
@@ -345,8 +350,13 @@ __device__ __forceinline__ void qkv_epilogue_tile(const GemmParams& p, const flo
         const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
         const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
         const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
-        *reinterpret_cast<u16x4*>(base + ((int64_t)sq * p.H + h) * npad_w * p.dp +
-                                  frag_qk(tok, dd0 + 4 * c, p.dp)) = o;
+        const int64_t off = ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_qk(tok, dd0 + 4 * c, p.dp);
+        *reinterpret_cast<u16x4*>(base + off) = o;
+        if (base_lo) {
+          const u16x4 l = {to16<T16>(v.x - from16<T16>(o[0])), to16<T16>(v.y - from16<T16>(o[1])),
+                           to16<T16>(v.z - from16<T16>(o[2])), to16<T16>(v.w - from16<T16>(o[3]))};
+          *reinterpret_cast<u16x4*>(base_lo + off) = l;
+        }
       }
     } else {
       // V fragments: lane = token; 2-byte stores inside this token's fragment block
@@ -381,14 +391,19 @@ __device__ __forceinline__ void qkv_epilogue_tile(const GemmParams& p, const flo
 // applied to the per-lane SOURCE chunk and, identically, to the read address
 // (same involution on both sides).
 // ----------------------------------------------------------------------------
-template <typename T16, int BM, int BN, int STAGES, int EPI>
+// SPLIT (round 6): hi + lo operands. A stage holds two images, [A | W] and [A_lo | W_lo] (same rows, same swizzle); a k-step is
+// three MFMAs (a.w + a.w_lo + a_lo.w). Twice the DMA instructions and LDS bytes per tile, fp32-grade products at 1/3 of the 16-bit
+// MFMA rate - the QKV projections of a checkpoint whose attention is too sharp for 16-bit logits.
+template <typename T16, int BM, int BN, int STAGES, int EPI, bool SPLIT = false>
 struct GemmPipeBody {
   using Params = GemmParams;
   static constexpr int THREADS = 256;
   static __device__ __forceinline__ void run(GemmParams p, const BlockCtx& cx, unsigned char* smem) {
   constexpr int ROWS = BM + BN;
-  constexpr int STAGE_BYTES = ROWS * 128;
-  constexpr int LPT = ROWS / 32;                   // DMA instructions per wave per tile
+  constexpr int HALF_BYTES = ROWS * 128;
+  constexpr int STAGE_BYTES = HALF_BYTES * (SPLIT ? 2 : 1);
+  constexpr int LPH = ROWS / 32;                   // DMA instructions per wave per tile and image
+  constexpr int LPT = LPH * (SPLIT ? 2 : 1);       // ... per tile
   constexpr int FM = BM / 64, FN = BN / 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,17 +422,19 @@ struct GemmPipeBody {
   const unsigned short* gsrc[LPT];
 #pragma unroll
   for (int i = 0; i < LPT; ++i) {
-    const int rr = (wid * LPT + i) * 8 + (lane >> 3);        // row in the combined [A | W] tile
+    const int ih = i % LPH;                                  // (SPLIT: i >= LPH addresses the remainder images)
+    const bool lo = i >= LPH;
+    const int rr = (wid * LPH + ih) * 8 + (lane >> 3);       // row in the combined [A | W] tile
     const int c = (lane & 7) ^ ((rr >> 1) & 7);              // source chunk for LDS chunk lane&7
     if (rr < BM) {
       int m = m0 + rr;
       m = m < p.M ? m : p.M - 1;                             // clamp: rows >= M are discarded later
       const int64_t src = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
-      gsrc[i] = reinterpret_cast<const unsigned short*>(p.a) + src * p.lda + c * 8;
+      gsrc[i] = reinterpret_cast<const unsigned short*>(lo ? p.a_lo : p.a) + src * p.lda + c * 8;
     } else {
       int n = n0 + rr - BM;
       n = n < p.N ? n : p.N - 1;
-      gsrc[i] = p.w + (int64_t)n * p.ldw + c * 8;
+      gsrc[i] = (lo ? p.w_lo : p.w) + (int64_t)n * p.ldw + c * 8;
     }
   }
   auto issue = [&](int kt, int stage) {
@@ -426,7 +443,8 @@ struct GemmPipeBody {
     for (int i = 0; i < LPT; ++i) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(gsrc[i] + (int64_t)kt * 64),
-          (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (wid * LPT + i) * 1024),
+          (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (i >= LPH ? HALF_BYTES : 0) +
+                                                    (wid * LPH + (i % LPH)) * 1024),
           16, 0, 0);
     }
   };
@@ -485,12 +503,35 @@ struct GemmPipeBody {
       for (int j = 0; j < FN; ++j)
         fb[ks][j] = *reinterpret_cast<const u16x8*>(st + b_row[j] * 128 + ((g ^ ((b_row[j] >> 1) & 7)) << 4));
     }
+    if constexpr (SPLIT) {
+      // the remainder images one k-step at a time (8 more fragment registers instead of 32): a.w + a.w_lo + a_lo.w
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int g = ks * 2 + hi;
+        u16x8 la[FM], lb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          la[i] = *reinterpret_cast<const u16x8*>(st + HALF_BYTES + a_row[i] * 128 + ((g ^ ((a_row[i] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          lb[j] = *reinterpret_cast<const u16x8*>(st + HALF_BYTES + b_row[j] * 128 + ((g ^ ((b_row[j] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            acc[i][j] = mfma32<T16>(fb[ks][j], fa[ks][i], acc[i][j]);
+            acc[i][j] = mfma32<T16>(lb[j], fa[ks][i], acc[i][j]);
+            acc[i][j] = mfma32<T16>(fb[ks][j], la[i], acc[i][j]);
+          }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mfma32<T16>(fb[ks][j], fa[ks][i], acc[i][j]);   // C^T: D[n][m]
+    }
   }
   if (p.debug & 4) { if (acc[0][0][0] != 123.456f) return; }
   // ---- epilogue through LDS -------------------------------------------------------
@@ -567,10 +608,10 @@ struct GemmPipeBody {
 }
 };
 
-template <typename T16, int BM, int BN, int STAGES, int EPI>
+template <typename T16, int BM, int BN, int STAGES, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  GemmPipeBody<T16, BM, BN, STAGES, EPI>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, smem);
+  GemmPipeBody<T16, BM, BN, STAGES, EPI, SPLIT>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, smem);
 }
 
 // ----------------------------------------------------------------------------
@@ -582,7 +623,9 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
 // TAIL = false: the body without the argument-vector tail (vog_argvec_tail) - what shares a launch with the QKV GEMM
 // (pair.hip): the tail's row gather costs ~50 registers, and a pair kernel allocates the maximum of its halves for EVERY
 // workgroup (200 registers halved the occupancy of the 516 QKV workgroups riding with the 64 of the out-projection).
-template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true>
+// SPLIT (round 6; fp32 A, fragment-ordered W and W_lo): hi + lo operands, three MFMAs per k-step - the language half of
+// mul_tx's layer-0 QKV for checkpoints whose attention is too sharp for 16-bit logits.
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true, bool SPLIT = false>
 struct GemmSkinnyBody {
   using Params = GemmParams;
   static constexpr int THREADS = KW * 64;
@@ -627,6 +670,7 @@ struct GemmSkinnyBody {
   // wave `wid` owns k-steps wid, wid+4, ... ; processed SK_CH at a time
   for (int base = wid; base < ksteps; base += KW * SK_CH) {
     u16x8 fw[NT][SK_CH];
+    u16x8 fwl[SPLIT ? NT : 1][SPLIT ? SK_CH : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -636,6 +680,9 @@ struct GemmSkinnyBody {
           u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
           fw[t][c] = (ks < ksteps && n_ok[t]) ? *reinterpret_cast<const u16x8*>(
                                     p.w + (((int64_t)(ct0 + t) * ksteps + ks) * 64 + lane) * 8) : z;
+          if constexpr (SPLIT)
+            fwl[t][c] = (ks < ksteps && n_ok[t]) ? *reinterpret_cast<const u16x8*>(
+                                       p.w_lo + (((int64_t)(ct0 + t) * ksteps + ks) * 64 + lane) * 8) : z;
         } else {
           fw[t][c] = load_a_chunk<T16, false>(p.w, w_off[t], ks * 32 + kg, n_ok[t] && ks < ksteps);
         }
@@ -655,10 +702,36 @@ struct GemmSkinnyBody {
             fa[c] = load_a_chunk<T16, A_F32>(p.a, a_off[mt], ks * 32 + kg, a_ok[mt] && ks < ksteps);
           }
         }
+        if constexpr (SPLIT) {
+          // fp32 rows again for the remainder: lo = t16(x - t16(x)) (A_F32 only)
+          u16x8 fal[SK_CH];
+#pragma unroll
+          for (int c = 0; c < SK_CH; ++c) {
+            const int ks = base + c * KW;
+            u16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (a_ok[mt] && ks < ksteps) {
+              const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.a) + a_off[mt] + ks * 32 + kg);
+              const float4 x = src[0], y = src[1];
+              const float xs[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) r[j] = to16<T16>(xs[j] - from16<T16>(fa[c][j]));
+            }
+            fal[c] = r;
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < SK_CH; ++c) {
+              acc[t][mt] = mfma16<T16>(fa[c], fw[t][c], acc[t][mt]);
+              acc[t][mt] = mfma16<T16>(fal[c], fw[t][c], acc[t][mt]);
+              acc[t][mt] = mfma16<T16>(fa[c], fwl[t][c], acc[t][mt]);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int c = 0; c < SK_CH; ++c) acc[t][mt] = mfma16<T16>(fa[c], fw[t][c], acc[t][mt]);
+        }
       }
     }
   }
@@ -722,10 +795,10 @@ struct GemmSkinnyBody {
 }
 };
 
-template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true>
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true, bool SPLIT = false>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-  GemmSkinnyBody<T16, A_F32, SK_CH, NT, KW, TAIL>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, sk_smem);
+  GemmSkinnyBody<T16, A_F32, SK_CH, NT, KW, TAIL, SPLIT>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, sk_smem);
 }
 
 }  // namespace vog

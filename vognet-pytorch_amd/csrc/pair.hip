@@ -184,6 +184,10 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     // exactly full and the layer's 40 us disappear inside the attention
     r[{kid_lstm_layer_f16(), kid_attn_tile2_192(VOG_BF16)}] = &launch_pair<Lstm, AttnTile2Body<BF16, 6>>;
     r[{kid_lstm_layer_f16(), kid_attn_tile2_192(VOG_F16)}] = &launch_pair<Lstm, AttnTile2Body<F16, 6>>;
+    // hi + lo operand forms (round 6): the same three pairs for a checkpoint on the tx_split plan
+    r[{kid_lstm_layer_f16(), kid_vis_enc_stream_split_f16()}] = &launch_pair<Lstm, VisEncStreamBody<F16, VOG_VS_DEPTH, true>>;
+    r[{kid_lstm_layer_f16(), kid_tx_tail_split_512_f16()}] = &launch_pair<Lstm, TxTailBody<F16, F16, 2, false, 0, 1, true>>;
+    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv_split_f16()}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV, true>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
   });

@@ -14,4 +14,8 @@ const void* kid_vis_enc_lean_f16();         // vis_enc_lean_kernel<F16>
 const void* kid_vis_enc_stream_f16();       // vis_enc_stream_kernel<F16>
 const void* kid_vis_enc_wide_f16();         // vis_enc_wide_kernel<F16>
 const void* kid_attn_tile2_192(int dtype);  // attn_tile2_kernel<T16, 6>
+// hi + lo operand forms (round 6, f16)
+const void* kid_gemm_pipe_qkv_split_f16();  // gemm_pipe<F16, 64, 64, 2, EPI_QKV, true>
+const void* kid_tx_tail_split_512_f16();    // tx_tail_split_kernel<F16, F16, 2>
+const void* kid_vis_enc_stream_split_f16(); // vis_enc_stream_kernel<F16, true>
 }  // namespace vog

@@ -67,6 +67,24 @@ static int launch_tail32(const TailParams& p, hipStream_t st) {
   return 0;
 }
 
+// hi + lo operands (round 6): TxTailBody<..., RB = 1, SPLIT>
+template <typename T16, int NB>
+static int launch_tail_split(const TailParams& p, hipStream_t st) {
+  using Body = TxTailBody<T16, F16, NB, false, 0, 1, true>;
+  const size_t lds = Body::lds_bytes(p.KWO);
+  auto kern = tx_tail_split_kernel<T16, F16, NB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (lds > 160 * 1024) VOG_FAIL(-1, "fused encoder tail (hi + lo operands): %zu bytes of LDS needed", lds);
+  ::vog::launch(kern, dim3(ceil_div(p.M, 32)), dim3(512), lds, st, p);
+  VOG_LAUNCH_CHECK();
+  return 0;
+}
+const void* kid_tx_tail_split_512_f16() { return reinterpret_cast<const void*>(tx_tail_split_kernel<F16, F16, 2>); }
+
 const void* kid_tx_tail_512(int dtype) {
   return dtype == VOG_BF16 ? reinterpret_cast<const void*>(tx_tail_kernel<BF16, F16, 2, false, 0>)
                            : reinterpret_cast<const void*>(tx_tail_kernel<F16, F16, 2, false, 0>);
@@ -129,6 +147,15 @@ int tx_tail_run(const vog_tx_tail_args* a, hipStream_t st) {
       p.pred = *a->pred; p.pred_counter = a->pred_counter;
       p.pred_rec_bytes = vog_pred_record_bytes(a->pred->ncmp, a->pred->nsrl, a->pred->nfrm0);
     }
+  }
+  if (a->attn16_lo || a->wo_p_lo || a->w1_p_lo || a->w2_p_lo || a->y16_lo) {
+    // hi + lo operands (round 6): every operand of the three GEMM stages with its 16-bit remainder
+    VOG_CHECK_ARG(a->attn16_lo && a->wo_p_lo && a->w1_p_lo && a->w2_p_lo && !score);
+    p.attn16_lo = (const unsigned short*)a->attn16_lo; p.wo_p_lo = (const unsigned short*)a->wo_p_lo;
+    p.w1_p_lo = (const unsigned short*)a->w1_p_lo; p.w2_p_lo = (const unsigned short*)a->w2_p_lo;
+    p.y16_lo = (unsigned short*)a->y16_lo; p.nt_rows = 0; p.xcds = 0;
+    if (a->d == 512) { VOG_DISPATCH_DTYPE(a->dtype, return (launch_tail_split<T16, 2>(p, st))); }
+    else { VOG_DISPATCH_DTYPE(a->dtype, return (launch_tail_split<T16, 3>(p, st))); }
   }
 #define VOG_TAIL(NBV)                                                                        \
   do {                                                                                       \

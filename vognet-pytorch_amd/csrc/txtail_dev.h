@@ -31,6 +31,9 @@ struct TailParams {
                  // half the fabric bytes of 63 workgroups on 8
 
   int dbgf;      // perf experiments only, read by the DBG & 4 instantiation: 1 no residual, 2 no attention staging, 4 no LayerNorm, 8 no outputs
+  // round 6, hi + lo operands (SPLIT bodies): 16-bit remainders of the attention rows and of the three weight matrices (same
+  // layouts), and of the output rows (y16_lo, optional)
+  const unsigned short *attn16_lo, *wo_p_lo, *w1_p_lo, *w2_p_lo; unsigned short* y16_lo;
 };
 
 // One GEMM stage of the chain: acc[i][rb] (32 columns n x 32 rows m, swapped) += W_blk(i) . X^T over
@@ -130,6 +133,70 @@ __device__ __forceinline__ void tail_gemm(f32x16 (&acc)[NBW][RB], const unsigned
   for (int j = 0; j < PF; ++j) step(j, t + j, false);
 }
 
+// The same stage with hi + lo operands (round 6): weights W + W_lo (two fragment streams), activations X + X_lo (two LDS images,
+// same pitch): acc += W.X + W_lo.X + W.X_lo per k-step - fp32-grade operand precision at three MFMAs per product. For the tails
+// whose OUTPUT feeds another attention layer of a checkpoint with sharp logits; same rotated k order.
+template <typename TT, int NBW, int PF, bool ZERO, int RB>
+__device__ __forceinline__ void tail_gemm_split(f32x16 (&acc)[NBW][RB], const unsigned short* __restrict__ wp,
+                                                const unsigned short* __restrict__ wpl, int blk0, int blk_step, int KS, int rot,
+                                                const unsigned char* xl, const unsigned char* xll, int pitch, int lane) {
+  const int ml = lane & 31, hi = lane >> 5;
+  const u16x8* wb[NBW]; const u16x8* wbl[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    wb[i] = reinterpret_cast<const u16x8*>(wp + ((int64_t)(blk0 + i * blk_step) * KS) * 512) + lane;
+    wbl[i] = reinterpret_cast<const u16x8*>(wpl + ((int64_t)(blk0 + i * blk_step) * KS) * 512) + lane;
+    if constexpr (ZERO) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][rb][r] = 0.f;
+    }
+  }
+  auto kk = [&](int t) { const int k = t + rot; return k >= KS ? k - KS : k; };   // t < 2*KS - rot
+  u16x8 wq[PF][NBW], wql[PF][NBW];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int k = kk(j);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) { wq[j][i] = wb[i][k * 64]; wql[j][i] = wbl[i][k * 64]; }
+  }
+  const unsigned char* x0 = xl + ml * pitch + hi * 16;
+  const unsigned char* x0l = xll + ml * pitch + hi * 16;
+  auto step = [&](int j, int t, bool refill) {
+    const int kc = kk(t);
+    u16x8 xf[RB], xfl[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      xf[rb] = *reinterpret_cast<const u16x8*>(x0 + rb * 32 * pitch + kc * 32);
+      xfl[rb] = *reinterpret_cast<const u16x8*>(x0l + rb * 32 * pitch + kc * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        acc[i][rb] = mfma32<TT>(wq[j][i], xf[rb], acc[i][rb]);
+        acc[i][rb] = mfma32<TT>(wql[j][i], xf[rb], acc[i][rb]);
+        acc[i][rb] = mfma32<TT>(wq[j][i], xfl[rb], acc[i][rb]);
+      }
+    }
+    if (refill) {
+      const int kl = kk(t + PF);
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) { wq[j][i] = wb[i][kl * 64]; wql[j][i] = wbl[i][kl * 64]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int t = 0;
+#pragma unroll 1
+  for (; t < KS - PF; t += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) step(j, t + j, true);
+  }
+#pragma unroll
+  for (int j = 0; j < PF; ++j) step(j, t + j, false);
+}
+
 // LayerNorm over n of the swapped accumulator tile of the whole workgroup (D columns spread over the
 // 8 waves): two-pass statistics as layernorm_kernel (mean, then sum of squared deviations); gamma / beta
 // come from LDS (prefetched at kernel start: no dependent global round trip in the epilogue).
@@ -222,15 +289,21 @@ __device__ __forceinline__ float tail_sigmoid(float x) { return 1.0f / (1.0f + _
 // "<= 80 KB / <= 128 VGPR" form round 3's verdict asked to be measured): 32 rows, the LayerNorm / bias vectors read from
 // memory instead of LDS (76 KB), so that two workgroups share a CU and overlap each other's stage boundaries - at twice the
 // weight bytes per row through the CU's vector memory path.
-template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0, int RB = 2>
+// SPLIT (round 6; RB = 1): hi + lo operands in the three GEMM stages (tail_gemm_split), second LDS images of the activations behind
+// the first ones, outputs as y16 + y16_lo.
+template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0, int RB = 2, bool SPLIT = false>
 struct TxTailBody {
   using Params = TailParams;
   static constexpr int THREADS = 512;
   static constexpr int ROWS = 32 * RB;
-  static constexpr size_t lds_bytes(int kwo) {
+  static constexpr size_t lds_base(int kwo) {
     const int D_ = NB * 256, DH_ = D_ / 2, xcols = kwo > D_ ? kwo : D_;
     return (size_t)ROWS * (xcols + 8) * 2 + (size_t)ROWS * (DH_ + 8) * 2 + (size_t)8 * ROWS * sizeof(float) +
            (RB == 2 ? (size_t)(3 * D_ + DH_) * sizeof(float) : 0);
+  }
+  static constexpr size_t lds_bytes(int kwo) {
+    const int D_ = NB * 256, DH_ = D_ / 2, xcols = kwo > D_ ? kwo : D_;
+    return lds_base(kwo) + (SPLIT ? (size_t)ROWS * (xcols + 8) * 2 + (size_t)ROWS * (DH_ + 8) * 2 : 0);
   }
   static __device__ __forceinline__ void run(const TailParams& p, const BlockCtx& cx, unsigned char* smem) {
   constexpr int D = NB * 256, DH = D / 2;
@@ -251,6 +324,8 @@ struct TxTailBody {
   float* red = reinterpret_cast<float*>(Y + ROWS * (DH + 8) * 2);    // [8 waves][ROWS rows]
   float* vec2 = red + 8 * ROWS;                     // ln2 gamma, ln2 beta, b2 [D each], b1 [DH]  (RB == 2 only)
   float* vec1 = reinterpret_cast<float*>(Y);        // ln1 gamma, ln1 beta [D each]: parked in Y until FFN1 writes it (RB == 2 only)
+  unsigned char* XL = smem + lds_base(p.KWO);        // SPLIT: the remainder images of X and Y
+  unsigned char* YL = XL + ROWS * (xcols + 8) * 2;
   // the epilogue vectors: staged in LDS (RB == 2) or read where they are (RB == 1: L1 / L2 hits, 10 KB less LDS)
   const float* g1p = RB == 2 ? vec1 : p.ln1g;
   const float* b1np = RB == 2 ? vec1 + D : p.ln1b;
@@ -284,6 +359,8 @@ struct TxTailBody {
       const u32x4* src = reinterpret_cast<const u32x4*>(p.attn16 + (int64_t)m * p.KWO + c * 8);
       const u32x4 v = p.nt_rows ? __builtin_nontemporal_load(src) : *src;
       *reinterpret_cast<u32x4*>(X + r * p1 + c * 16) = v;
+      if constexpr (SPLIT)
+        *reinterpret_cast<u32x4*>(XL + r * p1 + c * 16) = *reinterpret_cast<const u32x4*>(p.attn16_lo + (int64_t)m * p.KWO + c * 8);
     }
     if constexpr (RB == 2) {
       for (int i = tid; i < D / 4; i += 512) {
@@ -340,6 +417,8 @@ struct TxTailBody {
   __syncthreads();
 
   // ---- stage 1: x + attn Wo^T, LayerNorm
+  if constexpr (SPLIT) tail_gemm_split<T16, NB, 4, false, RB>(acc, p.wo_p, p.wo_p_lo, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, XL, p1, lane);
+  else
   tail_gemm<T16, NB, PF_WO, false, DBG, RB, PRIME>(acc, p.wo_p, w * NB, 1, p.KWO >> 4, (xpos * (p.KWO >> 4)) >> 3, X, p1, lane, wq_a);
   if constexpr (PRIME) tail_prime<1, VOG_TAIL_PF1, DBG>(wq_1, p.w1_p, w, 8, D >> 4, (xpos * (D >> 4)) >> 3, lane);
   if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB, RB>(acc, g1p, b1np, red, w, lane, w * NB);
@@ -356,8 +435,12 @@ struct TxTailBody {
       const float4 b = *reinterpret_cast<const float4*>(fb2p + n);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        *reinterpret_cast<u16x4*>(X + (rb * 32 + mlx) * pD + n * 2) =
-            cvt4<T16>(acc[i][rb][4 * g], acc[i][rb][4 * g + 1], acc[i][rb][4 * g + 2], acc[i][rb][4 * g + 3]);
+        const u16x4 xh = cvt4<T16>(acc[i][rb][4 * g], acc[i][rb][4 * g + 1], acc[i][rb][4 * g + 2], acc[i][rb][4 * g + 3]);
+        *reinterpret_cast<u16x4*>(X + (rb * 32 + mlx) * pD + n * 2) = xh;
+        if constexpr (SPLIT)
+          *reinterpret_cast<u16x4*>(XL + (rb * 32 + mlx) * pD + n * 2) =
+              cvt4<T16>(acc[i][rb][4 * g] - from16<T16>(xh[0]), acc[i][rb][4 * g + 1] - from16<T16>(xh[1]),
+                        acc[i][rb][4 * g + 2] - from16<T16>(xh[2]), acc[i][rb][4 * g + 3] - from16<T16>(xh[3]));
         acc[i][rb][4 * g + 0] += b.x; acc[i][rb][4 * g + 1] += b.y;
         acc[i][rb][4 * g + 2] += b.z; acc[i][rb][4 * g + 3] += b.w;
       }
@@ -377,20 +460,29 @@ struct TxTailBody {
         const int n = blk * 32 + 8 * g + 4 * hix;
         const float4 b = *reinterpret_cast<const float4*>(b1l + n);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-          *reinterpret_cast<u16x4*>(Y + (rb * 32 + mlx) * pH + n * 2) =
-              cvt4<T16>(relu_nan(h[rb][4 * g] + b.x), relu_nan(h[rb][4 * g + 1] + b.y),
-                        relu_nan(h[rb][4 * g + 2] + b.z), relu_nan(h[rb][4 * g + 3] + b.w));
+        for (int rb = 0; rb < RB; ++rb) {
+          const float h0 = relu_nan(h[rb][4 * g] + b.x), h1 = relu_nan(h[rb][4 * g + 1] + b.y),
+                      h2 = relu_nan(h[rb][4 * g + 2] + b.z), h3 = relu_nan(h[rb][4 * g + 3] + b.w);
+          const u16x4 yh = cvt4<T16>(h0, h1, h2, h3);
+          *reinterpret_cast<u16x4*>(Y + (rb * 32 + mlx) * pH + n * 2) = yh;
+          if constexpr (SPLIT)
+            *reinterpret_cast<u16x4*>(YL + (rb * 32 + mlx) * pH + n * 2) =
+                cvt4<T16>(h0 - from16<T16>(yh[0]), h1 - from16<T16>(yh[1]), h2 - from16<T16>(yh[2]), h3 - from16<T16>(yh[3]));
+        }
       }
     };
     const int rot = (xpos * (D >> 4)) >> 3;
     // (two blocks = two passes over K with one accumulator pair: 64 fewer live registers than one
     // pass with two pairs, which spilled x1; the extra LDS operand reads are free here)
     f32x16 hacc[1][RB];
+    if constexpr (SPLIT) tail_gemm_split<T16, 1, 4, true, RB>(hacc, p.w1_p, p.w1_p_lo, w, 8, D >> 4, rot, X, XL, pD, lane);
+    else
     tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB, PRIME>(hacc, p.w1_p, w, 8, D >> 4, rot, X, pD, lane, wq_1);
     if (NB1 == 2 && w < 4) {
       if constexpr (PRIME) tail_prime<1, VOG_TAIL_PF1, DBG>(wq_1, p.w1_p, w + 8, 8, D >> 4, rot, lane);
       ffn1_epi(hacc[0], w);
+      if constexpr (SPLIT) tail_gemm_split<T16, 1, 4, true, RB>(hacc, p.w1_p, p.w1_p_lo, w + 8, 8, D >> 4, rot, X, XL, pD, lane);
+      else
       tail_gemm<T16, 1, VOG_TAIL_PF1, true, DBG, RB, PRIME>(hacc, p.w1_p, w + 8, 8, D >> 4, rot, X, pD, lane, wq_1);
       if constexpr (PRIME) tail_prime<NB, PF_W2, DBG>(wq_b, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, lane);
       ffn1_epi(hacc[0], w + 8);
@@ -402,6 +494,8 @@ struct TxTailBody {
   __syncthreads();
 
   // ---- stage 3: (x1 + b2) + W2 hidden, LayerNorm
+  if constexpr (SPLIT) tail_gemm_split<T16, NB, 4, false, RB>(acc, p.w2_p, p.w2_p_lo, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, YL, pH, lane);
+  else
   tail_gemm<T16, NB, PF_W2, false, DBG, RB, PRIME>(acc, p.w2_p, w * NB, 1, DH >> 4, (xpos * (DH >> 4)) >> 3, Y, pH, lane, wq_b);
   if constexpr (PRIME && SCORE) tail_prime<1, 8, DBG>(wq_s, p.wl_p, w, 1, D >> 4, (xpos * (D >> 4)) >> 3, lane);
   if (!((DBG & 4) && (p.dbgf & 4))) tail_ln<NB, RB>(acc, g2p, b2np, red, w, lane, w * NB);
@@ -417,9 +511,16 @@ struct TxTailBody {
                     a3 = acc[i][rb][4 * g + 3];
         if (mrow[rb] < p.M && !((DBG & 4) && (p.dbgf & 8))) {
           if (p.y32) *reinterpret_cast<float4*>(p.y32 + (int64_t)mrow[rb] * D + n) = make_float4(a0, a1, a2, a3);
-          if (p.y16)
-            *reinterpret_cast<u16x4*>(p.y16 + (int64_t)mrow[rb] * D + n) =
-                p.y16_bf16 ? cvt4<BF16>(a0, a1, a2, a3) : cvt4<F16>(a0, a1, a2, a3);
+          if (p.y16) {
+            const u16x4 yh = p.y16_bf16 ? cvt4<BF16>(a0, a1, a2, a3) : cvt4<F16>(a0, a1, a2, a3);
+            *reinterpret_cast<u16x4*>(p.y16 + (int64_t)mrow[rb] * D + n) = yh;
+            if constexpr (SPLIT) {
+              if (p.y16_lo)
+                *reinterpret_cast<u16x4*>(p.y16_lo + (int64_t)mrow[rb] * D + n) =
+                    p.y16_bf16 ? cvt4<BF16>(a0 - from16<BF16>(yh[0]), a1 - from16<BF16>(yh[1]), a2 - from16<BF16>(yh[2]), a3 - from16<BF16>(yh[3]))
+                               : cvt4<F16>(a0 - from16<F16>(yh[0]), a1 - from16<F16>(yh[1]), a2 - from16<F16>(yh[2]), a3 - from16<F16>(yh[3]));
+            }
+          }
         }
         if constexpr (SCORE)       // lin2 operand, in the head's own 16-bit type (X was last read in stage 2)
           *reinterpret_cast<u16x4*>(X + (rb * 32 + mlo) * pD + n * 2) = cvt4<TH>(a0, a1, a2, a3);
@@ -513,6 +614,13 @@ template <typename T16, typename TH, int NB, bool SCORE, int DBG = 0>
 __global__ __launch_bounds__(512) void tx_tail_kernel(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tt_smem[];
   TxTailBody<T16, TH, NB, SCORE, DBG>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, tt_smem);
+}
+
+// hi + lo operands (round 6): 32 rows per workgroup (the second LDS images take the room of the other 32)
+template <typename T16, typename TH, int NB>
+__global__ __launch_bounds__(512) void tx_tail_split_kernel(TailParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tts_smem[];
+  TxTailBody<T16, TH, NB, false, 0, 1, true>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, tts_smem);
 }
 
 // the 32-row form: <= 128 registers (4 waves per SIMD), two workgroups per CU

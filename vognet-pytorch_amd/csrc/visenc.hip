@@ -45,6 +45,7 @@ const void* kid_vis_enc_f16() { return reinterpret_cast<const void*>(vis_enc_ker
 const void* kid_vis_enc_lean_f16() { return reinterpret_cast<const void*>(vis_enc_lean_kernel<F16>); }
 const void* kid_vis_enc_stream_f16() { return reinterpret_cast<const void*>(vis_enc_stream_kernel<F16>); }
 const void* kid_vis_enc_wide_f16() { return reinterpret_cast<const void*>(vis_enc_wide_kernel<F16>); }
+const void* kid_vis_enc_stream_split_f16() { return reinterpret_cast<const void*>(vis_enc_stream_kernel<F16, true>); }
 
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
   return (prop_dim % 256) == 0 && (seg_dim % 256) == 0 && (prop_enc % 32) == 0 && (seg_enc % 32) == 0 &&
@@ -58,9 +59,12 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
     VOG_FAIL(-1, "fused encoders: unsupported dims (feature dims %% 256, encode sizes %% 32 and <= 256)");
   VisEncParams p{};
   p.p[0] = VisEncProb{a->prop, (const unsigned short*)a->w_prop_f, a->b_prop, a->n_prop_rows, a->prop_enc,
-                      a->prop_dim, 1, 0};
+                      a->prop_dim, 1, 0, (const unsigned short*)a->w_prop_f_lo};
   p.p[1] = VisEncProb{a->seg, (const unsigned short*)a->w_seg_f, a->b_seg, a->n_prop_rows / a->nppf0, a->seg_enc,
-                      a->seg_dim, a->nppf0, a->prop_enc};
+                      a->seg_dim, a->nppf0, a->prop_enc, (const unsigned short*)a->w_seg_f_lo};
+  const bool split = a->w_prop_f_lo || a->w_seg_f_lo || a->c16_lo;     // hi + lo operands (round 6): the stream form only
+  if (split) VOG_CHECK_ARG(a->w_prop_f_lo && a->w_seg_f_lo && a->c16_lo && a->c16 && a->lean && !a->defer_replicas && !a->done_flags);
+  p.c16_lo = (unsigned short*)a->c16_lo;
   p.tiles0 = ceil_div(p.p[0].M, 16);
   p.tiles_all = p.tiles0 + ceil_div(p.p[1].M, 16);
   p.c32 = a->c32; p.c16 = (unsigned short*)a->c16; p.ldc = a->ldc;
@@ -77,7 +81,24 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
     // cfg 2 pair launch with BiLSTM layer 0: 36.0 -> 32.4 us; p100: 57.6 -> 45 us alone, 78 -> 69 us in the pair
     // (VOG_VE_STREAM=0: round 4's lean form, perf experiments; the chained form - done_flags - stays on the lean body)
     static const int stream_env = perf_env("VOG_VE_STREAM") ? atoi(perf_env("VOG_VE_STREAM")) : -1;
-    const bool stream = (stream_env >= 0 ? stream_env != 0 : true) && p.done_flags == nullptr;
+    const bool stream = ((stream_env >= 0 ? stream_env != 0 : true) && p.done_flags == nullptr) || split;
+    if (split) {
+      if (split_rep) VOG_FAIL(-1, "vog_vis_encode with hi + lo operands: more than 16 replicas per segment row are not supported");
+      auto launch_split = [&](auto tag) {
+        using T16 = decltype(tag);
+        auto kern = vis_enc_stream_kernel<T16, true>;
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)VisEncStreamBody<T16, VOG_VS_DEPTH, true>::LDS);
+          attr = true;
+        }
+        ::vog::launch(kern, dim3(ceil_div(nb, 8) * 16), dim3(512), VisEncStreamBody<T16, VOG_VS_DEPTH, true>::LDS, st, p);
+      };
+      if (a->dtype == VOG_BF16) launch_split(BF16{}); else launch_split(F16{});
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
     // VOG_VE_WIDE=1 (perf experiments; measured, off): 128 rows x all 256 columns per workgroup - a row read once, a quarter of
     // the weight bytes, but 127 workgroups of 224 registers with one chunk of look-ahead: 112 us alone at p100 against 41.5
     // (the pair launch 113 against 68), cfg 4 5.52 vs 5.47 k queries/s (profiles/round5_vis_enc_stream.md)

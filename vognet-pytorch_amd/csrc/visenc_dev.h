@@ -7,6 +7,7 @@ namespace vog {
 struct VisEncProb {
   const float* x; const unsigned short* w; const float* bias;
   int M, N, K, rep, col0;        // output rows m*rep + j, columns [col0, col0 + N)
+  const unsigned short* w_lo;    // round 6 (stream form, SPLIT): 16-bit remainder of the fp32 weights, same fragment order
 };
 struct VisEncParams {
   VisEncProb p[2];
@@ -16,6 +17,7 @@ struct VisEncParams {
   // lean form, optional: done_flags[block * 2 + column half] = 1 once that workgroup's rows are in memory (16-bit copy
   // written through): consumers in the SAME launch (pair3_kernel: obj_tx's row-block QKV) wait on the flags of their rows
   unsigned int* done_flags;
+  unsigned short* c16_lo;        // round 6 (SPLIT): 16-bit remainder of the output rows (c16 + c16_lo = the fp32 value to ~2^-22)
 };
 
 template <typename T16>
@@ -350,14 +352,18 @@ __global__ __launch_bounds__(512) void vis_enc_lean_kernel(VisEncParams a) {
 #ifndef VOG_VS_DEPTH
 #define VOG_VS_DEPTH 2      // measured at p100 (scratch/r5_ve.sh): 2: 45.0 us (~110 registers: two workgroups per CU), 3: 52.2, 4: 54.6; lean form 57.6
 #endif
-template <typename T16, int DEPTH = VOG_VS_DEPTH>
+// SPLIT (round 6): hi + lo operands - the fp32 rows are split into t16(x) and t16(x - t16(x)) on the way into LDS (two images per
+// chunk), the weights arrive as two fragment streams, a k-step is three MFMAs (x.w + x_lo.w + x.w_lo): encoder outputs with
+// fp32-grade operand precision for checkpoints whose attention logits amplify a 2^-11 input error past the 1e-3 bound. The kernel
+// stays bound by the fp32 feature stream; the outputs carry a 16-bit remainder copy (c16_lo) for the hi + lo QKV projection.
+template <typename T16, int DEPTH = VOG_VS_DEPTH, bool SPLIT = false>
 struct VisEncStreamBody {
   using Params = VisEncParams;
   static constexpr int THREADS = 512;
   static constexpr int RB = 64, KC = 128, KSC = KC / 32;    // 4 k-steps per chunk
   static constexpr int PIECES = KC / 8, RPP = THREADS / PIECES, NPASS = RB / RPP;   // 16 pieces per row, 32 rows per pass, 2 passes
   static constexpr int IMG = (RB / 16) * KSC * 1024;        // one A-chunk image (fragment order): 16 KB
-  static constexpr size_t LDS = (size_t)2 * IMG;
+  static constexpr size_t LDS = (size_t)2 * IMG * (SPLIT ? 2 : 1);   // (SPLIT: the remainder images behind the two hi images)
 
   static __device__ __forceinline__ void run(const VisEncParams& a, const BlockCtx& cx, unsigned char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -380,6 +386,8 @@ struct VisEncStreamBody {
     const int n0 = half0 * 128 + w * 16;
     const bool n_ok = n0 < qN;
     const u16x8* wf = reinterpret_cast<const u16x8*>(qw) + ((int64_t)((n_ok ? n0 : 0) >> 4) * ksteps) * 64 + lane;
+    const unsigned short* qwl = second ? a.p[1].w_lo : a.p[0].w_lo;
+    const u16x8* wfl = SPLIT ? reinterpret_cast<const u16x8*>(qwl) + ((int64_t)((n_ok ? n0 : 0) >> 4) * ksteps) * 64 + lane : wf;
     const int pr = tid / PIECES, pc = tid % PIECES;
     const float* xrow[NPASS];
 #pragma unroll
@@ -393,6 +401,7 @@ struct VisEncStreamBody {
     for (int mt = 0; mt < RB / 16; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 xa[DEPTH][NPASS][2];
     u16x8 wq[DEPTH][KSC];
+    u16x8 wql[SPLIT ? DEPTH : 1][SPLIT ? KSC : 1];
     auto request = [&](int set, int c) {                     // fp32 row pieces + weight fragments of chunk c (clamped)
       const int cc = c < nchunk ? c : nchunk - 1;
 #pragma unroll
@@ -402,7 +411,10 @@ struct VisEncStreamBody {
         xa[set][ps][1] = src[1];                             // XCD, reads the same rows from that L2)
       }
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) wq[set][ks] = wf[(cc * KSC + ks) * 64];
+      for (int ks = 0; ks < KSC; ++ks) {
+        wq[set][ks] = wf[(cc * KSC + ks) * 64];
+        if constexpr (SPLIT) wql[set][ks] = wfl[(cc * KSC + ks) * 64];
+      }
     };
     auto store_a = [&](int set, int c) {
       unsigned char* img = smem + (size_t)(c & 1) * IMG;
@@ -413,10 +425,37 @@ struct VisEncStreamBody {
         const int ks = pc >> 2, kgp = pc & 3;
         const int rl = ps * RPP + pr;
         *reinterpret_cast<u16x8*>(img + (((rl >> 4) * KSC + ks) * 64 + kgp * 16 + (rl & 15)) * 16) = h;
+        if constexpr (SPLIT) {
+          const float xs[8] = {xa[set][ps][0].x, xa[set][ps][0].y, xa[set][ps][0].z, xa[set][ps][0].w,
+                               xa[set][ps][1].x, xa[set][ps][1].y, xa[set][ps][1].z, xa[set][ps][1].w};
+          u16x8 l;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) l[j] = to16<T16>(xs[j] - from16<T16>(h[j]));
+          *reinterpret_cast<u16x8*>(img + 2 * IMG + (((rl >> 4) * KSC + ks) * 64 + kgp * 16 + (rl & 15)) * 16) = l;
+        }
       }
     };
     auto mfmas = [&](int set, int c) {
       const unsigned char* img = smem + (size_t)(c & 1) * IMG;
+      if constexpr (SPLIT) {
+        // x.w + x_lo.w + x.w_lo per k-step (the stream of fp32 rows, not the matrix pipe, bounds this kernel)
+#pragma unroll
+        for (int mt = 0; mt < RB / 16; ++mt) {
+          u16x8 fh[KSC], fl[KSC];
+#pragma unroll
+          for (int j = 0; j < KSC; ++j) {
+            fh[j] = *reinterpret_cast<const u16x8*>(img + ((mt * KSC + j) * 64 + lane) * 16);
+            fl[j] = *reinterpret_cast<const u16x8*>(img + 2 * IMG + ((mt * KSC + j) * 64 + lane) * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < KSC; ++j) {
+            acc[mt] = mfma16<T16>(fh[j], wq[set][j], acc[mt]);
+            acc[mt] = mfma16<T16>(fl[j], wq[set][j], acc[mt]);
+            acc[mt] = mfma16<T16>(fh[j], wql[set][j], acc[mt]);
+          }
+        }
+        return;
+      }
       u16x8 fa[KSC], fb[KSC];
       auto rd = [&](u16x8 (&f)[KSC], int mt) {
 #pragma unroll
@@ -472,20 +511,22 @@ struct VisEncStreamBody {
           if (row >= qM) continue;
           const float o = fmaxf(acc[mt][r] + b, 0.f);
           const unsigned short hv = a.c16_bf16 ? to16<BF16>(o) : to16<F16>(o);
+          const unsigned short lv = a.c16_bf16 ? to16<BF16>(o - from16<BF16>(hv)) : to16<F16>(o - from16<F16>(hv));
           for (int j = 0; j < nrep; ++j) {
             const int64_t off = ((int64_t)row * qrep + j) * a.ldc + qcol0 + col;
             if (a.c32) a.c32[off] = o;
             if (a.c16) a.c16[off] = hv;
+            if (SPLIT && a.c16_lo) a.c16_lo[off] = lv;
           }
         }
     }
   }
 };
 
-template <typename T16>
+template <typename T16, bool SPLIT = false>
 __global__ __launch_bounds__(512) void vis_enc_stream_kernel(VisEncParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
-  VisEncStreamBody<T16>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vs_smem);
+  VisEncStreamBody<T16, VOG_VS_DEPTH, SPLIT>::run(a, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, vs_smem);
 }
 
 // ---------------------------------------------------------------------------------------------------

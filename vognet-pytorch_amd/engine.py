@@ -27,7 +27,7 @@ def model_desc_from_cfg(cfg, comm) -> L.ModelDesc:
     m = cfg.mdl
     hip = cfg.get("hip", {}) if hasattr(cfg, "get") else {}
     tx = hip.get("tx_dtype", "auto") if hasattr(hip, "get") else "auto"
-    if tx in ("auto", "f32"):
+    if tx in ("auto", "f32", "split"):
         # f16 transformers by default (round 5): same MFMA rate as bf16 on gfx950, three more mantissa bits. bf16 holds the
         # 1e-3 bound only while attention is near-uniform (random-init weights; fails at wq / wk x 8, logit std ~ 1); f16 holds
         # to x 12 ("envelope"). Past that `auto` routes forwards through the fp32 kernels
@@ -75,10 +75,30 @@ BF16_SHARPNESS_MAX = 4.0
 # seeds: 2 layers x 5 / 6 / 7 -> 3.9e-4 / 7.9e-4 / 1.1e-3; 3 layers x 5 / 6 / 7 / 8 -> 5.1e-4 / 1.0e-3 / 1.7e-3 / 3.8e-3
 # (sharpness 4.9 / 7.1 / 9.6 / 12.6). GPU goldens: full/vog_spat_3layers_sharp4 (3.1: f16), full/vog_spat_3layers_sharp8 (fp32 path).
 F16_SHARPNESS_MAX_DEEP = 5.0
+# Round 6: hi + lo f16 operands (`tx_split`): everything that feeds attention logits - the encoders, the QKV projections,
+# Q.K^T, and the tails whose output is another layer's input - carries a second 16-bit operand t16(x - t16(x)) and runs three
+# MFMAs per product (~2^-21 relative operand error); P.V, the last tail, the BiLSTM and the heads stay f16. Rounding model
+# (scratch/r6_quant_split*.py) at wq / wk x 16 / 24 / 32 / 48 (sharpness 51 / 114 / 202 / 455): 2.6e-4 / 3.4e-4 / 4.4e-4 /
+# 1.1e-3; GPU goldens full/cfg2_sharp{12,16,24,32}. Beyond: the fp32 path.
+# Stacks of 2-3 layers (scratch/r6_quant_split3.py): an inner layer's P.V (f16 probabilities and values) feeds the next layer's
+# sharp logits - 3 layers x 8 (sharpness 12.6): 3.0e-4 with the plan above, x 12 (28.5): 2.1e-3 (2.2e-4 only with hi + lo P / V as
+# well, which the kernels do not carry): the deep envelope ends at 16.
+SPLIT_SHARPNESS_MAX = 250.0
+SPLIT_SHARPNESS_MAX_DEEP = 16.0
+# Run-time check behind the plan (vog_batch.stats: the largest |attention logit| the forwards have seen, in nats): the statistic
+# above assumes isotropic inputs; what the kernels observe does not. Thresholds = the largest logits of the sharpest goldens each
+# operand precision still holds 1e-3 on (tests/test_gpu_forward.py::test_logit_scale_guard prints them).
+F16_LOGIT_MAX = 60.0
+BF16_LOGIT_MAX = 12.0
+SPLIT_LOGIT_MAX = 1500.0
 
 
 def f16_sharpness_max(obj_layers: int, mul_layers: int) -> float:
     return F16_SHARPNESS_MAX if max(int(obj_layers), int(mul_layers)) <= 1 else F16_SHARPNESS_MAX_DEEP
+
+
+def split_sharpness_max(obj_layers: int, mul_layers: int) -> float:
+    return SPLIT_SHARPNESS_MAX if max(int(obj_layers), int(mul_layers)) <= 1 else SPLIT_SHARPNESS_MAX_DEEP
 
 
 def attention_sharpness(sd, n_heads_obj: int, n_heads_mul: int) -> float:
@@ -212,6 +232,11 @@ class VogEngine:
         self.stalls = 0                 # stalled forwards seen so far (all slots)
         self.sharpness = 0.0            # attention_sharpness of the loaded checkpoint
         self.precise = None             # precise.PreciseForward when this checkpoint runs the fp32 path
+        self.plan = "f16"               # operand precision in use: bf16 / f16 / split (hi + lo f16) / f32
+        # largest |attention logit| (obj_tx, mul_tx) the forwards have seen: pinned host words the prediction head folds its
+        # forward's maxima into (vog_batch.stats) - `observed_logit_max`, `check_logit_scale`
+        self._stats = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self._scale_warned = False
 
     # ---- weights -------------------------------------------------------------
     def expected_weights(self) -> Dict[str, int]:
@@ -229,26 +254,75 @@ class VogEngine:
             L.check(self.lib.vog_ctx_set_weight(self.ctx, k.encode(), a.ctypes.data, a.size),
                     f"vog_ctx_set_weight({k})")
         self._drop_graphs()
+        self._sd_ref = sd                       # (kept for a plan raised at run time: `check_logit_scale`)
+        # precision plan of THIS checkpoint (round 5 / 6), decided from the weights before they are converted: `auto` = f16
+        # operands inside their envelope, hi + lo f16 operands (`tx_split`: three MFMAs for everything that feeds attention logits)
+        # up to ~12 x that sharpness, the fp32 path beyond; an explicit bf16 / f16 request is honoured but the envelope is reported
+        has_tx = self.cfg.mdl.name in ("vgrnd", "vog")
+        self.sharpness = attention_sharpness(sd, int(self.desc.obj_heads), int(self.desc.mul_heads)) if has_tx else 0.0
+        nl = (self.desc.obj_layers if has_tx else 0, self.desc.mul_layers if self.cfg.mdl.name == "vog" else 0)
+        f16_max, split_max = f16_sharpness_max(*nl), split_sharpness_max(*nl)
+        split_ok = bool(self.lib.vog_ctx_split_supported(self.ctx, 1 if self.conc_type == "svsq" else 4))
+        want_split = self.tx_request == "split" or (self.tx_request == "auto" and f16_max < self.sharpness <= split_max and split_ok)
+        if self.tx_request == "split" and not split_ok:
+            raise L.VogError("cfg.hip.tx_dtype = split: this model shape has no hi + lo kernels (gt5-sized sequences, fused encoders "
+                             "and tails: vog_ctx_split_supported); use auto / f32")
+        want_f32 = self.tx_request == "f32" or (self.tx_request == "auto" and self.sharpness > f16_max and not want_split)
+        self.set_option("tx_split", int(want_split))
         with torch.cuda.device(self.device):
             torch.cuda.synchronize()            # nothing in flight may still read the buffers finalize frees
             L.check(self.lib.vog_ctx_finalize(self.ctx), "vog_ctx_finalize")
         self._finalized = True
         self.weights_epoch += 1
-        # precision plan of THIS checkpoint (round 5): `auto` leaves the f16 kernels when the attention can get sharper than
-        # their envelope; an explicit bf16 / f16 request is honoured but the envelope is still reported
-        self.sharpness = attention_sharpness(sd, int(self.desc.obj_heads), int(self.desc.mul_heads)) \
-            if self.cfg.mdl.name in ("vgrnd", "vog") else 0.0
-        f16_max = f16_sharpness_max(self.desc.obj_layers if self.cfg.mdl.name in ("vgrnd", "vog") else 0,
-                                    self.desc.mul_layers if self.cfg.mdl.name == "vog" else 0)
-        want_f32 = self.tx_request == "f32" or (self.tx_request == "auto" and self.sharpness > f16_max)
         self.precise = None
+        self.plan = "split" if want_split else ("f32" if want_f32 else ("bf16" if self.desc.tx_dtype == L.VOG_BF16 else "f16"))
+        self._stats.zero_()
+        self._scale_warned = False
         if want_f32:
             from .precise import PreciseForward
             self.precise = PreciseForward(self, sd)
-        elif self.sharpness > (min(BF16_SHARPNESS_MAX, f16_max) if self.tx_request == "bf16" else f16_max):
+        elif not want_split and self.sharpness > (min(BF16_SHARPNESS_MAX, f16_max) if self.tx_request == "bf16" else f16_max):
             import warnings
             warnings.warn(f"attention sharpness {self.sharpness:.1f} of this checkpoint is outside the envelope in which "
                           f"tx_dtype={self.tx_request} holds 1e-3 on pred_scores (DESIGN.md section 2); use tx_dtype=auto")
+
+    # ---- observed logit scale (round 6) ----------------------------------------
+    def observed_logit_max(self):
+        """(obj_tx, mul_tx): the largest |attention logit| (nats, after bias and 1 / sqrt(d)) any forward of this engine has
+        computed since the weights were loaded - written by the kernels (vog_attn_args.logit_max), folded into pinned host memory
+        by the prediction head; a host read, no device synchronisation (forwards still in flight are not in it yet). 0.0 for a
+        stack whose kernels do not report (the long-sequence kernels of p100)."""
+        w = self._stats[:2].numpy().view(np.float32)
+        return float(w[0]), float(w[1])
+
+    def check_logit_scale(self, escalate: bool = True) -> bool:
+        """The run-time side of the precision plan: the per-checkpoint statistic (`attention_sharpness`) assumes isotropic inputs;
+        this compares what the attention kernels actually saw with the logit scale the operand precision in use holds 1e-3 on. Past
+        it: a warning (the batches already returned may be off by more than 1e-3 in pred_scores), and with `escalate` the plan is
+        raised for everything issued from now on (f16 -> hi + lo -> fp32; slots captured before refuse to launch, like after any
+        `load_state_dict`). Returns True while the plan holds. Called by `mdl_base.forward` and the evaluator after their
+        synchronisations; cheap (two host words)."""
+        if self.plan == "f32" or self.tx_request not in ("auto", "bf16", "f16", "split"):
+            return True
+        lim = {"bf16": BF16_LOGIT_MAX, "f16": F16_LOGIT_MAX, "split": SPLIT_LOGIT_MAX}[self.plan]
+        seen = max(self.observed_logit_max())
+        if seen <= lim:
+            return True
+        import warnings
+        nxt = "split" if (self.plan in ("bf16", "f16") and seen <= SPLIT_LOGIT_MAX and
+                          bool(self.lib.vog_ctx_split_supported(self.ctx, 1 if self.conc_type == "svsq" else 4))) else "f32"
+        if not self._scale_warned:
+            warnings.warn(f"attention logits of up to {seen:.0f} nats observed: outside the range in which {self.plan} operands hold "
+                          f"1e-3 on pred_scores ({lim:.0f}); results so far may exceed the bound" +
+                          (f" - re-planning to '{nxt}' for the forwards issued from now on" if escalate and self.tx_request == "auto" else ""))
+            self._scale_warned = True
+        if escalate and self.tx_request == "auto":
+            req, self.tx_request = self.tx_request, nxt
+            try:
+                self.load_state_dict(self._sd_ref)
+            finally:
+                self.tx_request = req
+        return False
 
     # ---- stalled hand-offs ---------------------------------------------------
     def _stalled(self, n: int, where: str):
@@ -369,6 +443,7 @@ class VogEngine:
         b.mdl_outs_eval = L.ptr(out["mdl_outs_eval"])
         b.pred_rec = L.ptr(rec)
         b.fault = self._fault.data_ptr()            # (slots replace it with their own word before they capture)
+        b.stats = self._stats.data_ptr() if with_pred else None
         return b, out, (B, ncmp, T)
 
     def forward(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None,
@@ -376,6 +451,7 @@ class VogEngine:
         """Eager launch sequence on the current stream (fresh output tensors)."""
         assert self._finalized, "load_state_dict first"
         self.check()
+        self.check_logit_scale()                # (two host words; raises the plan if the forwards so far saw sharper logits than planned)
         with torch.cuda.device(self.device):
             b, out, (B, ncmp, T) = self.make_batch(inp, T, with_pred)
             _lane_enter(self.device, None)
@@ -606,6 +682,7 @@ class Slot:
     def wait(self, timeout_us: int = 10_000_000):
         """Block until the slot's AQL program has completed; returns the output dict."""
         L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
+        self.check()                          # (ADVICE r5: a stalled hand-off is a VogError here too, never NaN outputs with rc 0)
         return self.out
 
     def update_inputs(self, inp, check_lengths: bool = True):
@@ -637,6 +714,9 @@ class Slot:
             self.eng._stalled(k, f"a slot (B = {self.B}, T = {self.T})")
 
     def launch(self, stream: Optional[torch.cuda.Stream] = None):
+        self._launches = getattr(self, "_launches", 0) + 1
+        if (self._launches & 15) == 1:        # every 16th launch: the observed logit scale against the plan (may re-plan: this slot
+            self.eng.check_logit_scale()      # then refuses to launch, like after any load_state_dict)
         self._check_epoch()
         self.check()                          # the launches before this one
         _lane_enter(self.eng.device, stream)
@@ -955,14 +1035,18 @@ class Group:
             self.eng._stalled(k, "a group's shared language encoder")
         _lane_enter(self.eng.device, stream)
         sp = L.stream_ptr(stream)
+        if self.eng.precise is not None:
+            # fp32 path: nothing of the 16-bit group forward is needed - its persistent BiLSTM layers could only
+            # stall, its outputs would be overwritten
+            for sl in self.slots:
+                sl._precise(stream)
+            return self.out
         if self.graph is not None:
             L.check(self.eng.lib.vog_graph_launch(self.graph, sp), "vog_graph_launch")
         else:
             L.check(self.eng.lib.vog_group_forward(self.eng.ctx, C.byref(self.lb), self.lang_ws.data_ptr(),
                                                    self.lang_ws.numel(), self._members, self._wss, self._wsb,
                                                    len(self.slots), sp), "vog_group_forward")
-        for sl in self.slots:
-            sl._precise(stream)
         return self.out
 
     def build_aql(self) -> "Group":
@@ -978,6 +1062,11 @@ class Group:
 
     def wait(self, timeout_us: int = 10_000_000):
         L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
+        for sl in self.slots:
+            sl.check()
+        if self._lb_fault_seen != int(self._lb_fault[0]):
+            k, self._lb_fault_seen = int(self._lb_fault[0]) - self._lb_fault_seen, int(self._lb_fault[0])
+            self.eng._stalled(k, "a group's shared language encoder")
         return self.out
 
     def __del__(self):

@@ -167,6 +167,7 @@ class AnetBaseMdl(nn.Module):
         before it."""
         if self._engine is not None:
             self._engine.check()
+            self._engine.check_logit_scale()      # (round 6: the observed attention-logit scale against the precision plan)
 
     def forward(self, inp: Dict[str, torch.Tensor], T: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """`forward(inp) -> {'mdl_outs', 'mdl_outs_eval'[, 'vidf_outs',

@@ -320,3 +320,16 @@ def make_items(B: int, ncmp: int, nppf0: int, *, prop_dim: int = 2048, seg_dim: 
         "srl_boxes": rng.integers(0, 12, size=(B, 1, nsrl, n_box)).astype(np.int64),
         "srl_boxes_lens": (rng.uniform(size=(B, 1, nsrl, n_box)) < 0.6).astype(np.int64),
     }
+
+
+def sharpen_state_dict(sd: Dict[str, np.ndarray], qk: float, pe: float = 4.0) -> Dict[str, np.ndarray]:
+    """Weights away from the random-init regime (in place): wq / wk of every obj_txf / mult_txf layer x qk (attention logits
+    x qk^2: x 8 -> std ~1 nat, x 16 -> ~4-30), the box-bias Linear(5, H) x pe. What a trained checkpoint (EXPTS.md:95-189) looks like
+    to the precision plan (engine.attention_sharpness); used by the sharpened parity cases (oracle/cases.py) and bench.py's
+    `hi_lo_plan` measurement."""
+    for k in list(sd):
+        if k.endswith("selfattn.layer.wq.weight") or k.endswith("selfattn.layer.wk.weight"):
+            sd[k] = (sd[k] * np.float32(qk)).astype(np.float32)
+        elif k.startswith("pe_obj_sub_enc.") or k.startswith("pe_mul_sub_enc."):
+            sd[k] = (sd[k] * np.float32(pe)).astype(np.float32)
+    return sd
