@@ -439,7 +439,8 @@ typedef struct vog_lstm_layer_args {
    * LDS) - no separate GEMM launch and no [2][T][Bn][4R] fp32 round trip. wih: vog_lstm_pack_w of
    * (weight_ih, weight_ih_reverse) [2][4R][K]; xa: layer input [Bn*T (row b*T + t), K] t16 in the
    * A-fragment order of vog_gemm_args.a_frag (pad rows of the last 16-row tile readable); bias: [2][4R]
-   * fp32 = b_ih + b_hh per direction. Needs Bn*T <= 64 and K % 256 == 0. */
+   * fp32 = b_ih + b_hh per direction. Needs Bn*T <= vog_bilstm_fused_cols() (80: a bs = 4 batch with 20-word sentences) and
+   * K % 256 == 0. */
   const void* wih; const void* xa; const float* bias; int K;
   /* round 5: sticky fault counter (optional; device memory or device-visible pinned host memory): +1 per launch whose
    * hand-off timed out. The library never clears it (sync[2] is re-zeroed by the next forward's prologue): the host reads
@@ -450,6 +451,7 @@ typedef struct vog_lstm_layer_args {
   uint32_t* fault; int inject_stall;
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);
+int vog_bilstm_fused_cols(void);                      /* largest Bn*T the in-kernel input projection (wih) takes: 80 */
 int64_t vog_bilstm_hx_bytes(int Bn, int T, int R);   /* size of vog_lstm_layer_args.hx */
 int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream);
 

@@ -40,7 +40,8 @@ R6 = ["full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg2_sharp48", "full/cfg3_
       "full/vgrnd_spat_sharp16", "full/vog_sep_sharp16"]
 FULL_VARIANTS = [n for n in FULL if n not in R6 and n not in ("full/cfg2_sharp12", "full/cfg2_sharp16", "full/vog_spat_3layers_sharp8")]
 SPLIT_CASES = ["full/cfg2_sharp12", "full/cfg2_sharp16", "full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg3_sharp16",
-               "full/cfg5_sharp16", "full/vgrnd_spat_sharp16", "full/vog_sep_sharp16", "full/vog_spat_3layers_sharp8"]
+               "full/cfg5_sharp16", "full/vog_sep_sharp16", "full/vog_spat_3layers_sharp8"]
+# (full/vgrnd_spat_sharp16: VidGrnd has obj_tx only - sharpness 12.3, inside the f16 envelope; it runs with the FULL list)
 
 
 def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
@@ -199,14 +200,19 @@ def test_forward_hi_lo_plan_vs_reference_golden(name):
     assert torch.equal(out["mdl_outs"], out2["mdl_outs"])
 
 
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_ragged", "small/vog_spat", "small/vog_temp",
-                                  "small/vog_sep", "small/vgrnd_spat", "small/sharp8_vog_spat"])
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8",
+                                  "full/cfg5_vog_svsq_gt5_bs16", "full/vog_sep_gt5_bs4_ragged", "full/vgrnd_spat_sharp16",
+                                  "full/vog_spat_gt5_bs4_3layers"])
 def test_forward_hi_lo_forced_vs_reference_golden(name):
-    """tx_dtype = split on checkpoints that do not need it: same goldens, errors at or below the f16 plan's."""
+    """tx_dtype = split on checkpoints that do not need it (every model kind / conc type at full size): same goldens, errors at or
+    below the f16 plan's. Small-dim models have no hi + lo kernels (vog_ctx_split_supported) and say so."""
     eng, *_ = build_engine(name, "split")
     assert eng.plan == "split"
     out, pred, g, _ = _run(name, tx_dtype="split")
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
+    if name == "full/cfg2_vog_spat_gt5_bs4":
+        with pytest.raises(L.VogError, match="hi \\+ lo kernels"):
+            build_engine("small/vog_spat", "split")
 
 
 def test_logit_scale_guard_raises_the_plan():

@@ -50,7 +50,8 @@ def test_rel_attention_hi_lo(S, N, H, dh, dp, nsrl, use_rel):
         out_lo = torch.full_like(out, float("nan"))
         lmax = torch.zeros(4, dtype=torch.int32, device="cuda")
         a = L.AttnArgs()
-        a.q, a.k, a.vt, a.out16 = L.ptr(to_frag(qh, "qk")), L.ptr(to_frag(kh, "qk")), L.ptr(to_frag(v16, "v")), L.ptr(out)
+        frs = [to_frag(qh, "qk"), to_frag(kh, "qk"), to_frag(v16, "v")]       # (kept alive: the kernel reads them)
+        a.q, a.k, a.vt, a.out16 = L.ptr(frs[0]), L.ptr(frs[1]), L.ptr(frs[2]), L.ptr(out)
         a.u, a.pe_b = L.ptr(u_box.contiguous()), L.ptr(peb)
         a.S, a.N, a.H, a.dp, a.npad = S, N, H, dp, npad
         a.use_rel, a.n_box, a.seq_per_vid, a.NP = use_rel, n_box, 1, n_box

@@ -708,7 +708,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     int32_t* lrows = ws.at<int32_t>("lstm_rows");
     {
       const int64_t* lens = b->srl_arg_word_mask_len;
-      const bool a0f = Bn * T <= 64 && c->emb16 && (g.E % 32) == 0;
+      const bool a0f = Bn * T <= vog_bilstm_fused_cols() && c->emb16 && (g.E % 32) == 0;
       const void* e16 = c->emb16;
       void* a0 = a0f ? ws.at<void>("emb_a0") : nullptr;
       const int E = g.E;
@@ -721,18 +721,27 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
           return vog_lang_prep(z, zb, ob, wi, wm, lens, tok, lrows, Bn, T, nsrl, sl, V, e16, a0, E, st); }});
       }
     }
+    // input projection inside the persistent layer kernel (no GEMM launch, no gx round trip): needs the layer input in fragment
+    // order (embedding rows from lang_prep / the previous layer's out16). Round 6: up to 80 (sentence, position) columns (64
+    // before: a bs = 4 batch whose longest sentence has 17-20 words fell back to the GEMM launches).
+    // fused_ih: 1 = every layer, 2 = layer 0 only, 3 = layers >= 1 only (experiments)
+    auto can_fuse_ih = [&](int l) {
+      const int Kin = l == 0 ? g.E : 2 * R;
+      return l < d.rnn_layers && (c->fused_ih == 1 || (c->fused_ih == 2 && l == 0) || (c->fused_ih == 3 && l > 0)) && c->lstm_persistent &&
+             vog_bilstm_layer_supported(Bn, R) && c->wih_p[l] && (Kin % 256) == 0 && Bn * T <= vog_bilstm_fused_cols() &&
+             (l > 0 || (c->emb16 && (g.E % 32) == 0));
+    };
+    // LSTM outputs that feed M <= 64 GEMMs (next layer's input projection, final projection) or the next layer's in-kernel
+    // projection are written in A-fragment order: those consumers load contiguous fragments
+    auto out_frag_of = [&](int l) {
+      const bool small = (Bn * T + Bn) <= 64;
+      return l == d.rnn_layers - 1 ? small : (small || can_fuse_ih(l + 1));
+    };
     for (int l = 0; l < d.rnn_layers; ++l) {
       vog_gemm_args ga{}; ga.c16_dtype = -1;
-      // LSTM outputs feed M <= 64 GEMMs (next layer's input projection, final projection): then the
-      // step kernel writes them in A-fragment order and those GEMMs load contiguous fragments
-      const bool ofrag = (Bn * T + Bn) <= 64;
-      // input projection inside the persistent layer kernel (no GEMM launch, no gx round trip): needs
-      // the layer input in fragment order (embedding rows from lang_prep / the previous layer's out16)
+      const bool ofrag = out_frag_of(l);
       const int Kin = l == 0 ? g.E : 2 * R;
-      // fused_ih: 1 = every layer, 2 = layer 0 only, 3 = layers >= 1 only (experiments)
-      const bool ih_fused = (c->fused_ih == 1 || (c->fused_ih == 2 && l == 0) || (c->fused_ih == 3 && l > 0)) && c->lstm_persistent && vog_bilstm_layer_supported(Bn, R) && ofrag &&
-                            c->wih_p[l] && (Kin % 256) == 0 && Bn * T <= 64 &&
-                            (l > 0 || (c->emb16 && (g.E % 32) == 0));
+      const bool ih_fused = can_fuse_ih(l) && (l == 0 || out_frag_of(l - 1));
       if (l == 0) {
         ga.a = c->emb; ga.a_is_f32 = 1; ga.lda = g.E; ga.a_rows = tok; ga.K = g.E;
         // M > 64 runs on the LDS-DMA kernel, which cannot convert in flight: same values, pre-rounded
@@ -744,7 +753,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       }
       else {
         ga.a = ws.at<void>("lstm_out16_" + std::to_string(l - 1)); ga.lda = 2 * R; ga.K = 2 * R;
-        ga.a_frag = ofrag ? 1 : 0;
+        ga.a_frag = out_frag_of(l - 1) ? 1 : 0;      // (only read when this layer's projection is NOT in its kernel: then M <= 64)
       }
       // output rows land in (direction, step) order: gxs[dir][step][b][4R]
       ga.w = c->wih[l]; ga.ldw = ga.K; ga.bias = c->bsum[l]; ga.c32 = gx; ga.ldc = 4 * R;

@@ -70,6 +70,9 @@ extern "C" int vog_bilstm_layer_supported(int Bn, int R) {
   return Bn >= 1 && Bn <= 16 && R % 32 == 0 && R / 32 <= 64 && (ks == 1 || ks == 2 || ks == 4 || ks == 32);
 }
 
+// (sentence, position) columns the layer kernel's own input projection takes (vog_lstm_layer_args.wih)
+extern "C" int vog_bilstm_fused_cols(void) { return 16 * vog::LstmLayerBody<vog::F16, 32>::NCT_MAX; }
+
 extern "C" int64_t vog_bilstm_hx_bytes(int Bn, int T, int R) {
   if (Bn <= 0 || T <= 0 || R <= 0) return -1;
   return (int64_t)T * 2 * Bn * R * 2;
@@ -85,7 +88,7 @@ extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
                          a->fault, a->inject_stall, 0};
   if (const char* e = vog::perf_env("VOG_LSTM_HALF_PROJ")) p.half_proj = atoi(e);
   const bool fused = a->wih != nullptr;
-  if (fused) VOG_CHECK_ARG(a->xa && a->bias && a->K > 0 && (a->K % 256) == 0 && a->Bn * a->T <= 64);
+  if (fused) VOG_CHECK_ARG(a->xa && a->bias && a->K > 0 && (a->K % 256) == 0 && a->Bn * a->T <= vog_bilstm_fused_cols());
   dim3 grid(a->R / 32, 2);
   hipStream_t st = (hipStream_t)stream;
   // perf experiments only: a larger LDS claim per workgroup (prices what the footprint costs the other streams' kernels)

@@ -198,9 +198,11 @@ struct LstmLayerBody {
   //      [union: layer-input chunks of the projection (2 x nct x 8 KiB) | h staging (2 x Bn x HS_LD x 2 B)] [16 B flags] [publish buffer]
   static constexpr int GX_PITCH = 20;                      // floats per column (16 + 4: spreads the banks)
   // gates of the fused projection: [8 waves][column tiles x 16 columns][GX_PITCH] fp32, sized by the columns the layer
-  // really has (Bn*T <= 64): 30 KB instead of 40 at cfg 2, which puts the whole workgroup under half a CU's LDS
+  // really has (Bn*T <= 80, round 6: 64 before - a bs = 4 batch with a sentence of 17-20 words used to fall back to the GEMM
+  // launches and the gx round trip): 30 KB instead of 40 at cfg 2, which puts the whole workgroup under half a CU's LDS
+  static constexpr int NCT_MAX = 5;                        // 16-column tiles of the fused projection
   static constexpr size_t gx_bytes(int ncols) { return (size_t)8 * ((ncols + 15) / 16 * 16) * GX_PITCH * 4; }
-  static constexpr size_t GX_BYTES = gx_bytes(64);
+  static constexpr size_t GX_BYTES = gx_bytes(16 * NCT_MAX);
   static constexpr size_t hs_bytes(int Bn) { return ((size_t)2 * Bn * HS_LD * 2 + 15) / 16 * 16; }
   static constexpr size_t xbuf_bytes(int ncols) { return (size_t)2 * ((ncols + 15) / 16) * 8 * 1024; }
   static constexpr size_t TAIL = 16 + 16 * 32 * 2;          // flags + the publish buffer [<= 16 sentences][32 units]
@@ -208,7 +210,7 @@ struct LstmLayerBody {
   static constexpr size_t lds_fused(int Bn, int ncols) {
     return gx_bytes(ncols) + (hs_bytes(Bn) > xbuf_bytes(ncols) ? hs_bytes(Bn) : xbuf_bytes(ncols)) + TAIL;
   }
-  static constexpr size_t LDS_MAX = GX_BYTES + ((size_t)2 * 16 * HS_LD * 2 > (size_t)2 * 4 * 8 * 1024 ? (size_t)2 * 16 * HS_LD * 2 : (size_t)2 * 4 * 8 * 1024) + TAIL;
+  static constexpr size_t LDS_MAX = GX_BYTES + ((size_t)2 * 16 * HS_LD * 2 > (size_t)2 * NCT_MAX * 8 * 1024 ? (size_t)2 * 16 * HS_LD * 2 : (size_t)2 * NCT_MAX * 8 * 1024) + TAIL;
 
   static __device__ __forceinline__ void run(const LstmLayerParams& p, const BlockCtx& cx, unsigned char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -245,12 +247,12 @@ struct LstmLayerBody {
     float* gxl = reinterpret_cast<float*>(smem) + (size_t)wid * gx_cols * GX_PITCH;
     if (fused) {
       unsigned char* xch = uni;
-      const int nct = (ncols + 15) >> 4;                                // <= 4 column tiles
+      const int nct = (ncols + 15) >> 4;                                // <= NCT_MAX column tiles
       const int ksteps = p.K >> 5;                                     // K % 256 == 0
       const int nchunk = (p.half_proj && p.K >= 2048) ? (ksteps >> 4) : (ksteps >> 3);
-      f32x4 ga[4];
+      f32x4 ga[NCT_MAX];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) ga[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < NCT_MAX; ++ct) ga[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
       const u16x8* wsrc = reinterpret_cast<const u16x8*>(p.wih) + (((int64_t)dir * (R / 4) + tile0) * ksteps) * 64 + lane;
       const uint4* xsrc = reinterpret_cast<const uint4*>(p.xa);
       // chunk c of column tile ct: k-steps [8c, 8c+8) = 8 KiB contiguous at ((ct*ksteps + 8c)*64) uint4.
@@ -266,7 +268,7 @@ struct LstmLayerBody {
       };
       auto dma_x = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NCT_MAX; ++j) {
           const int piece = j * 8 + wid;                                  // 1 KiB = 64 lanes x 16 B
           const int ct = piece >> 3, r = ((piece & 7) << 6) + lane;       // 8 pieces per (column tile, chunk)
           __builtin_amdgcn_global_load_lds(
@@ -278,7 +280,7 @@ struct LstmLayerBody {
       auto mfmas = [&](const u16x8 (&wq)[8], int c) {
         const unsigned char* xb = xbuf[c & 1];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT_MAX; ++ct)
           if (ct < nct) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -291,15 +293,15 @@ struct LstmLayerBody {
       dma_x(0); load_w(w0, 0);
       if (nchunk > 1) { dma_x(1); load_w(w1, 1); }
       for (int c = 0; c < nchunk; c += 2) {
-        // chunk c (even): everything issued before the 12 most recent VMEM ops has landed
-        if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // chunk c (even): everything issued before the NCT_MAX + 8 most recent VMEM ops (the next chunk's) has landed
+        if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCT_MAX + 8) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         mfmas(w0, c);
         __syncthreads();                                                  // xbuf[0] free again
         if (c + 2 < nchunk) { dma_x(c + 2); load_w(w0, c + 2); }
         if (c + 1 < nchunk) {
-          if (c + 2 < nchunk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          if (c + 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCT_MAX + 8) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           mfmas(w1, c + 1);
@@ -312,7 +314,7 @@ struct LstmLayerBody {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bs[r] = p.bias[(int64_t)dir * 4 * R + (int64_t)r * R + tile0 * 4 + ul];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < NCT_MAX; ++ct)
         if (ct < nct)
           *reinterpret_cast<float4*>(gxl + (ct * 16 + b) * GX_PITCH + ul * 4) =
               make_float4(ga[ct][0] + bs[0], ga[ct][1] + bs[1], ga[ct][2] + bs[2], ga[ct][3] + bs[3]);
@@ -382,22 +384,47 @@ struct LstmLayerBody {
         // h_{s-1} of ALL units: slot s-1. One 16-byte chunk (8 units of one sentence) per thread and round.
         unsigned short* hsb = hs + (s & 1) * hs_buf;
         const unsigned slot_off = (unsigned)(((size_t)(s - 1) * 2 + dir) * p.Bn * R * 2);
-        for (int base = tid; base < nchunks; base += THREADS) {
-          const int sb = base / cps, j = base - sb * cps;
-          const unsigned off = slot_off + (unsigned)(sb * R + j * 8) * 2;
-          u32x4 v = load16_l2(p.hx, off, hx_bytes);
-          unsigned int spins = 0;
-          while (has_unwritten(v) && !dead) {
-            asm volatile("" ::: "memory");
-            v = load16_l2(p.hx, off, hx_bytes);
-            if ((++spins & 255u) == 0 &&
-                (spins > (1u << 20) || __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0)) {   // ~1 s: give up
-              __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
-              dead = true;
+        // Round 6: ALL of a thread's chunks are requested before the first one is looked at (Bn = 16: four per thread; the loop
+        // used to wait out one L2 round trip per chunk - a step took 4.4 us at Bn = 16 against 2.5 at Bn = 4, with the same
+        // MFMA and gate work); chunks that still hold the pattern are re-fetched one by one as before.
+        constexpr int MAXR = 4;                            // Bn <= 16: <= 4 chunks per thread
+#ifndef VOG_LSTM_INFL
+#define VOG_LSTM_INFL 4      // measured on the GPU (scratch/r6_c.sh): see DESIGN.md
+#endif
+        constexpr int INFL = VOG_LSTM_INFL;                // chunks in flight per thread (registers: 4 each)
+        u32x4 vq[INFL];
+        // (cps = RW / 8 is a power of two at every supported width: chunk r of a thread is sentence sb0 + r * (THREADS / cps))
+        const int sb0 = tid / cps, j0 = tid - sb0 * cps;
+        const unsigned off0 = slot_off + (unsigned)(sb0 * R + j0 * 8) * 2;
+        const unsigned off_step = (unsigned)((THREADS / cps) * R) * 2;
+        const int lds0 = sb0 * HS_LD + j0 * 8, lds_step = (THREADS / cps) * HS_LD;
+        static_assert(THREADS % (RW / 8) == 0 || (RW / 8) % THREADS == 0, "hand-off fetch: chunk stride");
+#pragma unroll
+        for (int r0 = 0; r0 < MAXR; r0 += INFL) {
+#pragma unroll
+        for (int q = 0; q < INFL; ++q)
+          if (tid + (r0 + q) * THREADS < nchunks) vq[q] = load16_l2(p.hx, off0 + (r0 + q) * off_step, hx_bytes);
+#pragma unroll
+        for (int q = 0; q < INFL; ++q) {
+          const int r = r0 + q;
+          if (tid + r * THREADS < nchunks) {
+            u32x4 v = vq[q];
+            unsigned int spins = 0;
+            const unsigned offr = off0 + r * off_step;
+            while (has_unwritten(v) && !dead) {
+              asm volatile("" ::: "memory");
+              v = load16_l2(p.hx, offr, hx_bytes);
+              if ((++spins & 255u) == 0 &&
+                  (spins > (1u << 20) || __hip_atomic_load(p.sync + 2, VOG_RLX_AGENT) != 0)) {   // ~1 s: give up
+                __hip_atomic_store(p.sync + 2, 1u, VOG_RLX_AGENT);
+                dead = true;
+              }
             }
+            *reinterpret_cast<u32x4*>(&hsb[lds0 + r * lds_step]) = v;
           }
-          *reinterpret_cast<u32x4*>(&hsb[sb * HS_LD + j * 8]) = v;
         }
+        }
+        static_assert(16 * (RW / 8) <= MAXR * THREADS, "hand-off fetch: more chunks per thread than MAXR");
         if (dead) flags[0] = 1;
         VOG_TSL(s, 1);
         __syncthreads();

@@ -254,6 +254,7 @@ class Batch(C.Structure):
 SYMBOLS = {
     "vog_version": (c_i32, []),
     "vog_ctx_split_supported": (c_i32, [c_vp, c_i32]),
+    "vog_bilstm_fused_cols": (c_i32, []),
     "vog_last_error": (C.c_char_p, []),
     "vog_gemm_bias_act": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "vog_pack_w_frag": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32]),
