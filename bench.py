@@ -325,13 +325,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="graph", choices=["aql", "graph"],
-                    help="graph: one hipGraph per slot on --streams HIP streams (default, stream ordered); "
-                         "aql: pre-built AQL packets on the library's own queues (same throughput, "
-                         "~2 us instead of ~45 us of host time per forward)")
-    ap.add_argument("--queues", type=int, default=4, help="aql: hardware queues")
-    ap.add_argument("--interleave", type=int, default=1,
-                    help="aql: forwards submitted together, row-interleaved behind shared barrier packets")
     ap.add_argument("--cobatch", type=int, default=1,
                     help="G > 1: the language encoder (BiLSTM) of G in-flight batches runs as one pass "
                          "(W_hh streamed once per recurrent step for all of them); every batch keeps its own "
@@ -345,7 +338,6 @@ def main():
                          "beside the strict per-batch figure")
     ap.add_argument("--cobatch-extra", action="store_true",
                     help="also time round 2's shared language encoder (4 in-flight batches per BiLSTM pass): `lang_cobatch4`")
-    ap.add_argument("--no-split", action="store_true", help="aql: one kernel per row (no lang/vis row sharing)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--set", action="append", metavar="OPTION=INT", help="vog_ctx_set_int switch (A/B measurements)")
@@ -403,15 +395,12 @@ def main():
     eng.load_state_dict(sd)
     # the persistent layer kernel needs all its 64 workgroups co-resident: safe up to 4 of them in
     # flight (4 hardware queues x 64 workgroups = 256 CUs); a stalled hand-off poisons the output with NaN
-    # (AQL: a submission of K row-interleaved programs on Q queues runs Q*K instances at once)
-    persistent = not args.lstm_steps and (args.mode != "aql" or
-                                          max(1, args.queues) * max(1, args.interleave) <= 4)
+    persistent = not args.lstm_steps
     eng.set_option("lstm_persistent", int(persistent))
-    for kv in args.set or []:            # engine switches for A/B runs, e.g. --set fused_pred=0 (defaults are what `value` is for)
+    for kv in args.set or []:            # engine switches for A/B runs, e.g. --set pair_launches=0 (defaults are what `value` is for)
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     cfg_id = int(args.workload[3:4])
-    aql = args.mode == "aql"
 
     # ONE set of streams for every measurement of this process. Which hardware queue a HIP stream lands on depends on the
     # order in which ALL streams of the process were created and first used (scratch/dbg_streams2.py: the same 4-stream loop
@@ -440,11 +429,8 @@ def main():
         rotate = R > 0 (graph mode, G = 1): R distinct device-resident input sets per stream are cycled through the
         stream's workspace (slot j runs on stream j % streams and shares that stream's workspace), so that a forward's
         features come from HBM, not from the Infinity Cache a 4-slot replay loop leaves them in."""
-        Q, K, DEPTH = max(1, args.queues), max(1, args.interleave), 2
-        if G > 1:
-            K = 1
-        nunits = Q * K * DEPTH if aql else max(1, args.streams)      # units in flight (slot or group)
-        nsets = max(1, rotate) if (G == 1 and not aql) else 1
+        nunits = max(1, args.streams)                                 # units in flight (slot or group)
+        nsets = max(1, rotate) if G == 1 else 1
         nstreams = nunits * G * nsets                                 # batch buffers (in flight: nunits * G)
         slots, streams, batches, units = [], [], [], []
         for s in range(nstreams):
@@ -460,7 +446,7 @@ def main():
         if G == 1:
             for s_, b in enumerate(batches):
                 slots.append(eng.make_slot({k: torch.from_numpy(v) for k, v in b.items()},
-                                           graph=(not args.no_graph) and not aql,
+                                           graph=not args.no_graph,
                                            pred_rec=recbuf[s_ * w["B"]:(s_ + 1) * w["B"]],
                                            share_ws_with=slots[s_ % nunits] if (nsets > 1 and s_ >= nunits) else None))
             units = slots
@@ -469,14 +455,10 @@ def main():
             for u in range(nunits * nsets):
                 mk = eng.make_batched if batched else eng.make_group
                 grp = mk([{k: torch.from_numpy(v) for k, v in b.items()}
-                          for b in batches[u * G:(u + 1) * G]], graph=(not args.no_graph) and not aql,
+                          for b in batches[u * G:(u + 1) * G]], graph=not args.no_graph,
                          pred_rec=recbuf[u * G * w["B"]:(u + 1) * G * w["B"]])
                 units.append(grp)
                 slots.extend(grp.slots)
-        if aql:
-            eng.aql_open(Q)
-            for un in units:
-                un.build_aql(split_chains=not args.no_split) if G == 1 else un.build_aql()
         # ---- exchange step (N > 1): the packed prediction records of every batch are copied (27 KB,
         # on the batch's own stream) into a ring of RING batches; ONE RCCL all-gather moves half a ring
         # at a time. A collective per batch was measured to cost 12-20 us per step on one GPU already:
@@ -489,8 +471,6 @@ def main():
         forced_lanes = os.environ.get("VOG_FORCE_MULTI_RANK_LANES") == "1"
         ring = D.RecordRing(unit_rows, recbuf.shape[1], per_half, dev,
                             on_half=(lambda g_, n_: None) if forced_lanes else None) if use_dist else None
-        gathered_aql = torch.empty((world * recbuf.shape[0], recbuf.shape[1]), dtype=torch.float32, device=dev) \
-            if (aql and use_dist) else None
 
         def step(i):                       # graph mode: one unit (slot, or group of G batches) per call
             u = i % (nunits * nsets)       # (rotation: unit u lives on stream u % nunits, see above)
@@ -499,51 +479,22 @@ def main():
                 ring.push(recbuf[u * unit_rows:(u + 1) * unit_rows], streams[u])
 
         def fence():
-            if ring is not None and not aql:
+            if ring is not None:
                 ring.flush()
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # aql mode: groups of K units; group g lives on queue g % Q; a group is re-submitted only
-        # after its previous submission completed (DEPTH groups per queue keep the queue fed).
-        groups = [units[g * K:(g + 1) * K] for g in range(Q * DEPTH)] if aql else []
-        inflight = [0] * len(groups)
-
-        def wait_group(g):
-            for un in groups[g][:inflight[g]]:
-                un.wait()
-            inflight[g] = 0
-            if use_dist and g == len(groups) - 1:
-                # AQL completion is a host wait, so the records are final here; the exchange is made
-                # synchronous (this submission mode is not the N > 1 default)
-                dist.all_gather_into_tensor(gathered_aql, recbuf)
-                torch.cuda.current_stream().synchronize()
-
         def run(nsteps):
-            if not aql:
-                for i in range(nsteps // G):
-                    step(i)
-                return
-            done, g = 0, 0
-            while done < nsteps:
-                n = min(K, (nsteps - done) // G)
-                if inflight[g]:
-                    wait_group(g)
-                eng.aql_submit(groups[g][:n], g % Q)
-                inflight[g] = n
-                done += n * G
-                g = (g + 1) % len(groups)
-            for g in range(len(groups)):
-                if inflight[g]:
-                    wait_group(g)
+            for i in range(nsteps // G):
+                step(i)
 
         # device warm-up in front of the W warm-up steps (untimed, reported as `device_warmup_ms`): an idle MI355X needs some
         # milliseconds of work before its clocks are up - 5 warm-up steps are 0.4 ms. K = 20 from a cold device: 52.2 k queries/s,
         # after 20 ms of forwards: 55.3-56.4 k; K = 400 does not care (scratch/r4_burn.sh). VOG_BENCH_BURNIN_MS=0 turns it off.
         burn_ms = float(os.environ.get("VOG_BENCH_BURNIN_MS", "25"))
-        if burn_ms > 0 and not aql:
+        if burn_ms > 0:
             tb = time.perf_counter()
             while True:
                 run(4 * max(1, nunits) * G)
@@ -571,7 +522,6 @@ def main():
     rot_sets = (args.rotate_inputs + max(1, args.streams) - 1) // max(1, args.streams) if args.rotate_inputs > 0 else 0
     dt, slots, batches, nstreams = measure(G, args.steps, args.warmup, rotate=rot_sets if args.rotate_main else 0)
     T = slots[0].T
-    Q, K = max(1, args.queues), (1 if G > 1 else max(1, args.interleave))
     # a short timed region (the driver's K = 20) carries a fixed ~160 us of pipeline fill and drain (4 forwards in flight,
     # a forward takes ~280 us under load): the same strict path timed over 400 steps is reported BESIDE `value`
     steady = None
@@ -585,7 +535,7 @@ def main():
     # the same strict path with f16 transformers (`cfg.hip.tx_dtype = auto`, the package default since round 5: same MFMA rate,
     # three more mantissa bits - it holds the 1e-3 bound to wq / wk x 12 where bf16 leaves it at x 8)
     f16_tx = None
-    if G == 1 and world == 1 and w["tx"] == "bf16" and not args.throughput_only and not aql and not args.no_graph:
+    if G == 1 and world == 1 and w["tx"] == "bf16" and not args.throughput_only and not args.no_graph:
         cfg_h = make_cfg(dict(w, tx="auto"))
         eng_h = eng_mod.VogEngine(cfg_h, comm)
         eng_h.load_state_dict(sd)
@@ -608,7 +558,7 @@ def main():
     # nats in obj_tx / mul_tx): `auto` plans hi + lo f16 operands for it (three MFMAs for everything that feeds attention logits;
     # engine.py) - round 5 ran such checkpoints on the fp32 path at 1.7 k queries/s
     hi_lo = None
-    if G == 1 and world == 1 and cfg_id in (2, 3, 5) and not args.throughput_only and not aql and not args.no_graph:
+    if G == 1 and world == 1 and cfg_id in (2, 3, 5) and not args.throughput_only and not args.no_graph:
         try:
             sd_s = synth.sharpen_state_dict({k: np.array(v, copy=True) for k, v in sd.items()}, 16.0, 4.0)
             cfg_s = make_cfg(dict(w, tx="auto"))
@@ -629,7 +579,7 @@ def main():
             hi_lo = {"value": None, "error": str(e)}
     # the same strict path with the inputs coming from HBM: N distinct input sets cycle through the streams' workspaces
     hbm_inputs = None
-    if G == 1 and world == 1 and rot_sets > 1 and not aql and not args.no_graph and not args.throughput_only and not args.rotate_main:
+    if G == 1 and world == 1 and rot_sets > 1 and not args.no_graph and not args.throughput_only and not args.rotate_main:
         ksteps = max(400, args.steps)
         dth, sl_h, _, n_h = measure(G, ksteps, max(40, rot_sets * max(1, args.streams)), rotate=rot_sets)
         nfin_h = int(sum(int((~torch.isfinite(sl.out["mdl_outs_eval"])).sum().item()) for sl in sl_h))
@@ -645,7 +595,7 @@ def main():
     # four bs=4 requests served as ONE forward (dynamic batching; `make_batched`): reported beside `value`, never instead of
     # it - `value` is one bs=4 forward per launch sequence
     batched4 = None
-    if G == 1 and world == 1 and not args.throughput_only and not args.no_graph and not aql and not args.no_cobatch_extra:
+    if G == 1 and world == 1 and not args.throughput_only and not args.no_graph and not args.no_cobatch_extra:
         dtb, sl_b, _, n_b = measure(4, 400, 40, batched=True)
         nfin = int(sum(int((~torch.isfinite(sl.out["mdl_outs_eval"])).sum().item()) for sl in sl_b))
         batched4 = {"value": 400 * w["B"] / dtb if nfin == 0 else None, "unit": "queries/s", "ms_per_step": dtb / 400 * 1e3, "steps": 400,
@@ -711,9 +661,7 @@ def main():
         "config": {"workload": w["desc"], "global_batch": world * w["B"], "batch_per_gpu": w["B"],
                    "sentence_len": T, "batches_in_flight": nstreams, "lang_cobatch": G,
                    "lstm": "persistent layer kernel (1 launch per layer)" if persistent else "step launches (2T per forward)",
-                   "submission": (f"AQL packets, {Q} queues x {K} row-interleaved forwards"
-                                  + ("" if args.no_split else ", lang/vis chains share rows")) if aql
-                   else f"hipGraph on {nstreams} HIP streams",
+                   "submission": f"hipGraph on {nstreams} HIP streams",
                    "weights": "seeded default-init-like, vocab 5000",
                    "launches_per_forward": "see kernels_usec: steps joined by '+' share one launch (csrc/pair.hip)",
                    "parallelism": f"dp{world} (replicated weights; prediction records of every batch staged in a "
@@ -900,7 +848,7 @@ def main():
                                      "note": "raw per-video items cross PCIe once (8.7 MB per batch), the SPAT/TEMP layout is "
                                              "made on the device; with the copy overlapped the slower of (H2D, forward) bounds "
                                              "the rate - never reported as `value`"}
-            if G == 1 and not aql and not args.no_graph and len(slots) >= 2:
+            if G == 1 and not args.no_graph and len(slots) >= 2:
                 # the same K steps with the inputs STARTING IN HOST MEMORY: per step, on the slot's own stream, the
                 # raw items go pinned host -> device, vog_assemble_batch writes the slot's input buffers, the
                 # forward graph runs; copies of one slot overlap the forwards of the others

@@ -55,17 +55,6 @@ const char* vog_last_error(void);
  * (rep > 1 broadcasts a frame's segment feature onto its proposals,
  * mdl_conc_single.py:51-66). */
 struct vog_vislang_args;
-/* Optional tail of the M <= 64 GEMM kernel: the argument vectors of vog_srl_argvec computed in the SAME
- * launch from the GEMM's fp32 output (c32 = `full` [Bn*T + .., L], ldc = L = N): every workgroup publishes
- * its tile, waits for the others of the launch (`counter`, zero at launch) and computes its share of
- * lang[b,a,:] - bit-identical to vog_srl_argvec. One launch and one dependent boundary less on the
- * language chain (the out-projection's workgroups are few and co-resident; the wait is bounded). */
-typedef struct vog_argvec_tail {
-  unsigned int* counter;
-  const int64_t* capture; const int64_t* inds_msk; const float* w; const float* bias; float* lang;
-  int Bn, T, nsrl, L;
-} vog_argvec_tail;
-
 typedef struct vog_gemm_args {
   const void* a; int a_is_f32; int64_t lda; const int32_t* a_rows;
   const void* w; int64_t ldw;
@@ -96,7 +85,6 @@ typedef struct vog_gemm_args {
    * [m/16][K/32][lane = ((k%32)/8)*16 + m%16][k%8] — written that way by vog_bilstm_step
    * (out_frag) so that the LSTM -> projection hand-off needs no strided fragment loads. */
   int a_frag;
-  const vog_argvec_tail* argvec_tail;   /* NULL, or see above (M <= 64, c32 set, N == ldc == tail->L) */
   /* round 6, optional (M <= 64 kernel, a_is_f32, w_frag): w_lo = the fragment-ordered 16-bit remainder t16(w - t16(w)) of the fp32
    * weights; the fp32 rows of `a` are split the same way in the kernel and the product is a.w + a_lo.w + a.w_lo (three MFMAs). */
   const void* w_lo;
@@ -137,17 +125,10 @@ typedef struct vog_qkv_args {
    * VISUAL tokens of every sequence only ([S,H,npad_kv*dp], no language part): the operands of
    * vog_rel_attention_struct_fwd. */
   int kv_visual_only, npad_kv;
-  /* wqkv_p32 != NULL: row-block form (csrc/qkvrb_dev.h). The same [3*H*dp, K] weights in
-   * vog_pack_w_frag32 order; a workgroup owns 64 rows x 512 output columns, stages its rows in LDS
-   * once and streams each weight fragment once: ~1/3 of the busy-CU time of the tiled GEMM at
-   * M = 800, at twice its latency (the right trade with several forwards in flight). Needs
-   * vog_qkv_rowblock_supported(3*H*dp, K); wqkv / ldw are not read. */
+  /* wqkv_p32 != NULL: row-block form for MANY rows (csrc/qkvrb_dev.h; p100): the same [3*H*dp, K] weights in vog_pack_w_frag32
+   * order; one workgroup per 64 rows stages its rows in LDS once and walks all output columns, streaming each weight fragment
+   * once. Needs vog_qkv_rowblock_supported(3*H*dp, K); wqkv / ldw are not read. */
   const void* wqkv_p32;
-  /* row-block form as a consumer inside the encoders' launch (forward option chain_obj_qkv; csrc/pair.hip pair3_kernel):
-   * dep_flags = the done_flags of vog_visenc_args; a workgroup waits for the encoder workgroups that write its 64 rows
-   * (dep_nb0 = ceil(n_prop_rows / 64), dep_rep = nppf0, dep_nh0 / dep_nh1 = ceil(prop_enc / 128), ceil(seg_enc / 128)).
-   * NULL: no waiting. Set outside such a launch it is harmless (the flags are already up). */
-  const unsigned int* dep_flags; int dep_nb0, dep_rep, dep_nh0, dep_nh1;
   /* round 6, hi + lo operands (optional; all four or none; plain form, pl == NULL): x16_lo = t16(x - t16(x)) of the fp32
    * activations ([rows, ldx] like x16), wqkv_lo the same of the fp32 weights ([3*H*dp, ldw] like wqkv); the projection is
    * x.w + x_lo.w + x.w_lo (three MFMAs) and Q / K are written as q + q_lo, k + k_lo (V^T as one 16-bit image). */
@@ -193,10 +174,6 @@ typedef struct vog_attn_args {
    * region its prologue zero-fills), so the clearing launch is skipped. */
   int* guard_flag;
   int guard_precleared;
-  /* round 5: 0 = the whole call; 1 = only the fixed-reference kernel, 2 = only its gated fallback (both need guard_flag and a shape
-   * that takes that kernel: -1 otherwise). vog_forward issues the two halves as separate steps so that the first one can share a
-   * launch with a BiLSTM layer (csrc/pair.hip). */
-  int phase;
   /* round 6, hi + lo operands (optional; both or neither): q_lo / k_lo = the 16-bit remainders t16(x - t16(x)) of the fp32 Q / K
    * projections, same fragment order as q / k (vog_qkv_args.q_lo / k_lo). With them Q.K^T = q.k + q_lo.k + q.k_lo (three MFMAs,
    * fp32 accumulate): the logits carry ~2^-21 relative operand error instead of 2^-11 (f16) - what a checkpoint with sharp
@@ -262,7 +239,6 @@ int vog_residual_layernorm(const float* x, const float* gamma, const float* beta
  *   x1_scratch: vog_tx_tail_scratch_bytes(M, d) bytes (0 for d = 512), workgroup-private spill slab
  * Shapes: d in {512, 768}, dh = d/2 (vog_tx_tail_supported); other shapes use the unfused entries. */
 struct vog_score_args;
-struct vog_pred_args;
 typedef struct vog_tx_tail_args {
   const void* attn16; int kwo;
   const void* wo_p; const void* w1_p; const void* w2_p;
@@ -275,11 +251,6 @@ typedef struct vog_tx_tail_args {
   int head_dtype;                                /* vog_dtype of wl_p (VOG_F16) */
   float* x1_scratch;
   int M, d, dh; vog_dtype dtype;
-  /* round 3: with `score`, the prediction head (vog_pred_head) in the same launch: every workgroup writes its scores
-   * through and counts itself in at *pred_counter (one zeroed uint per launch); the workgroup that arrives last runs
-   * the head for the whole batch, reading mdl_outs_eval past L1 / L2 - nobody waits. pred->outs_eval must be
-   * score->outs_eval; not for sep / svsq (the head reads pred_cmp's fin_scores). Bit-identical to vog_pred_head. */
-  const struct vog_pred_args* pred; unsigned int* pred_counter;
   /* round 6, hi + lo operands (optional; the first four together, not with `score`): attn16_lo = out16_lo of the attention,
    * w*_p_lo = the 32x16 fragment-ordered 16-bit remainders t16(w - t16(w)) of the fp32 weights. Every GEMM stage is then
    * W.X + W_lo.X + W.X_lo (three MFMAs, 32 rows per workgroup) and y16_lo (optional) receives the remainder of y16: the tail of a
@@ -331,10 +302,6 @@ typedef struct vog_visenc_args {
    * runs vog_seg_replicate (the forward does, so that the encoder kernel stays ONE launch and can share
    * the launch of a BiLSTM layer). */
   int defer_replicas;
-  /* lean form, optional: done_flags[(64-row block) * 2 + (128-column half)] (uint, zeroed by the caller before the launch) is
-   * set to 1 when that workgroup's rows are in memory, and the 16-bit copy is written through: lets consumers of the rows run
-   * in the same launch (vog_qkv_args.dep_flags). Blocks: ceil(n_prop_rows / 64) proposal blocks, then the segment blocks. */
-  unsigned int* done_flags;
   /* round 6, hi + lo operands (optional; all three or none; lean = 1, nppf0 <= 16): w_*_f_lo = the fragment-ordered 16-bit
    * remainders t16(w - t16(w)) of the fp32 weights; the fp32 feature rows are split the same way in the kernel and a k-step is
    * x.w + x_lo.w + x.w_lo (three MFMAs). c16_lo: the remainder of the output rows, laid out like c16 (read by a hi + lo
@@ -849,7 +816,6 @@ int vog_graph_destroy(vog_graph* g);
  * the argument gather are row-wise), so each member's argument vectors are what its own forward
  * computes up to fp32 summation order. Members then run vog_forward / graphs / AQL programs with
  * vog_batch.shared_lang pointing at their rows of vog_lang_outputs(). */
-typedef struct vog_aql_program vog_aql_program;
 int64_t vog_lang_workspace_bytes(const vog_ctx* c, int B_total, int ncmp, int T);
 int vog_lang_workspace_init(const vog_ctx* c, int B_total, int ncmp, int T, void* lang_ws, size_t bytes, void* stream);
 /* lb: only B, ncmp, T and the five srl_* word-level pointers are read */
@@ -879,40 +845,7 @@ int vog_group_forward(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t lan
 int vog_group_graph_capture(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t lang_bytes,
                             const vog_batch* const* members, void* const* workspaces,
                             const size_t* ws_bytes, int n_members, void* stream, vog_graph** out);
-int vog_group_aql_program_create(vog_ctx* c, const vog_batch* lb, void* lang_ws, size_t lang_bytes,
-                                 const vog_batch* const* members, void* const* workspaces,
-                                 const size_t* ws_bytes, int n_members, vog_aql_program** out);
 
-/* ---- AQL programs: the forward as pre-built dispatch packets on user-mode queues ---------------
- * The steady-state path of the validation loop (replaces `for batch in dl: mdl(batch)` of
- * utils/trn_utils.py:497-501 for a fixed batch shape). One forward is ~50 short dependent
- * kernels; through a stream or a hipGraph every dependent kernel costs >= 4.2 us on MI355X.
- * A program is the launch sequence of vog_forward recorded once (same buffers as given here,
- * which must stay alive), stored as AQL kernel-dispatch packets with device-resident kernargs,
- * and submitted by copying them into an HSA queue owned by the library: agent-scope fences
- * between the kernels of a forward, the barrier bit only at the head of each ROW of mutually
- * independent kernels (csrc/aql.hip).
- *
- * vog_aql_open(n)           create n hardware queues on the current HIP device (idempotent, grows).
- * vog_aql_program_create    split_chains = 1: the language chain and the vision chain of the
- *                           forward share rows until they join (fewer barrier packets); 0: one
- *                           kernel per row, program order.
- * vog_aql_submit(progs,n,q) enqueue n distinct idle programs on queue q, row-interleaved: row r of
- *                           every program is dispatched behind ONE barrier packet. Inputs must be
- *                           complete (synchronise the stream that staged them). Not stream ordered.
- * vog_aql_wait(p, us)       block (spinning) until p's last kernel has completed and its outputs are
- *                           visible system-wide; error -2008 after `us` microseconds, -2006 if the
- *                           queue reported an error.
- * The HIP path (vog_forward / vog_graph_*) computes exactly the same thing from the same kernels;
- * tests/test_gpu_forward.py holds the bit-equality check. */
-typedef struct vog_aql_program vog_aql_program;
-int vog_aql_open(int n_queues);
-int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* workspace, size_t ws_bytes,
-                           int split_chains, vog_aql_program** out);
-int vog_aql_program_info(const vog_aql_program* p, int* packets, int* rows);
-int vog_aql_submit(vog_aql_program* const* progs, int n, int queue);
-int vog_aql_wait(vog_aql_program* p, uint64_t timeout_us);
-int vog_aql_program_destroy(vog_aql_program* p);
 
 /* HIP-event timing of `iters` back-to-back launches of ONE hot kernel of the
  * forward on `stream` (bench.py roofline leg). kernel: "mul_qkv", "mul_attn",

@@ -3,7 +3,15 @@ rocprofv3's vgpr column reports half of the allocated registers for wave64 kerne
 import re, subprocess, sys, glob, os
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vognet-pytorch_amd", "csrc")
 pat = sys.argv[1] if len(sys.argv) > 1 else "."
-cos = [a for a in sys.argv[2:]] or sorted(glob.glob(os.path.join(here, "libvog_hip.*.co")))
+cos = [a for a in sys.argv[2:]]
+if not cos:      # device-only code objects of every kernel translation unit, built on demand under /tmp (round 6: build.py no longer makes them)
+    for tu in ("gemm", "attention", "elementwise", "lstm", "txtail", "visenc", "pair", "loss", "assemble", "backward"):
+        src, co = os.path.join(here, tu + ".hip"), f"/tmp/kmeta_{tu}.co"
+        hdrs = glob.glob(os.path.join(here, "*.h"))
+        if not os.path.exists(co) or any(os.path.getmtime(f) > os.path.getmtime(co) for f in [src] + hdrs):
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only",
+                            "--no-gpu-bundle-output", src, "-o", co], capture_output=True)
+        cos.append(co)
 for co in cos:
     txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
     for blk in txt.split("  - .agpr_count:")[1:]:

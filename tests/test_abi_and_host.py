@@ -151,7 +151,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     import shutil
     import subprocess
     L = importlib.import_module("vognet-pytorch_amd.lib")
-    pairs = {"vog_gemm_args": L.GemmArgs, "vog_argvec_tail": L.ArgvecTail, "vog_splitk_prob": L.SplitkProb, "vog_qkv_args": L.QkvArgs,
+    pairs = {"vog_gemm_args": L.GemmArgs, "vog_splitk_prob": L.SplitkProb, "vog_qkv_args": L.QkvArgs,
              "vog_qkvcomb_args": L.QkvCombArgs, "vog_attn_args": L.AttnArgs,
              "vog_attn_struct_args": L.AttnStructArgs, "vog_visprep_args": L.VisprepArgs,
              "vog_lstm_step_args": L.LstmStepArgs, "vog_lstm_layer_args": L.LstmLayerArgs,

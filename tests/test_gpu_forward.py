@@ -357,60 +357,6 @@ def test_paired_launches_equal_separate_launches(name):
 
 
 @pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
-                                  "full/cfg1_igrnd_spat_gt5_bs2", "small/vog_spat", "small/vog_sep_r64"])
-@pytest.mark.parametrize("pair", [0, 1])
-def test_argvec_tail_equals_separate_launch(name, pair):
-    """fused_argvec: the argument vectors computed by the out-projection's own workgroups after an in-launch
-    arrival barrier (vog_argvec_tail, csrc/gemm_dev.h) vs the stand-alone vog_srl_argvec launch: the same
-    device function on the same fp32 rows -> bit-identical outputs, alone and inside the pair launch."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    eng.set_option("pair_launches", pair)
-    eng.set_option("fused_argvec", 0)
-    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    eng.set_option("fused_argvec", 1)
-    B, ncmp = batch["srl_arg_words_ind"].shape[0], batch["new_srl_idxs"].shape[1]
-    T = int(batch["srl_arg_word_mask_len"].max())
-    nb = eng.lib.vog_workspace_bytes(eng.ctx, B, ncmp, T)
-    for _ in range(3):                                   # (replays: the arrival counter is re-zeroed by the prologue)
-        # poison the argument vectors left by the previous run: `lang` lies outside the region the prologue re-zeroes, so a
-        # fused run that never wrote them (round 4: the paired out-projection body has no tail) would pass on stale values
-        off, sz = ctypes.c_int64(), ctypes.c_int64()
-        L.check(eng.lib.vog_workspace_stage(eng.ctx, B, ncmp, T, b"lang", ctypes.byref(off), ctypes.byref(sz)), "stage lang")
-        eng.workspace(B, ncmp, T)[off.value: off.value + sz.value].view(torch.float32).fill_(float("nan"))
-        b = eng.forward(dev)
-        torch.cuda.synchronize()
-        for k in a:
-            assert torch.equal(a[k], b[k]), (name, k)
-
-
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8", "small/vog_spat",
-                                  "small/vog_temp"])
-def test_pred_head_in_score_tail_equals_separate_launch(name):
-    """fused_pred (off by default: measured no faster): the prediction head runs in the last mul_tx tail's launch - every workgroup writes its
-    scores through and counts itself in, the last one to arrive runs `pred_item` for the whole batch - vs the
-    stand-alone vog_pred_head launch: same device function -> bit-identical records, over replays (the counter is
-    re-zeroed by the prologue) and under a captured graph on 4 streams."""
-    if not os.path.exists(cases.golden_path(name)):
-        pytest.skip("no golden for " + name)
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    eng.set_option("fused_pred", 0)
-    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    eng.set_option("fused_pred", 1)
-    for _ in range(5):
-        b = eng.forward(dev)
-        torch.cuda.synchronize()
-        for k in a:
-            assert torch.equal(a[k], b[k]), (name, k)
-    streams = [torch.cuda.Stream() for _ in range(4)]
-    slots = [eng.make_slot({k: v.cpu() for k, v in dev.items()}, graph=True) for _ in range(4)]
-    for it in range(200):
-        slots[it % 4].launch(streams[it % 4])
-    torch.cuda.synchronize()
-    for sl in slots:
-        assert torch.equal(sl.out["pred_rec"], a["pred_rec"]) and torch.equal(sl.out["mdl_outs_eval"], a["mdl_outs_eval"])
-
-
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
                                   "full/cfg1_igrnd_spat_gt5_bs2"])
 def test_fused_lstm_input_projection_matches_separate_gemm(name):
     """fused_ih: x W_ih^T + b computed in the persistent layer kernel's prologue vs the separate GEMM
@@ -428,22 +374,6 @@ def test_fused_lstm_input_projection_matches_separate_gemm(name):
     pa, pb = eng.unpack_pred(a["pred_rec"], ncmp), eng.unpack_pred(b["pred_rec"], ncmp)
     ds = (pa["scores"] - pb["scores"]).abs().max().item()
     assert ds < 4e-4, ds
-
-
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
-                                  "full/cfg4_vog_spat_p100_bs4", "small/vog_spat"])
-def test_forward_rowblock_qkv_vs_reference_golden(name):
-    """qkv_lean = 1: the row-block QKV projections (csrc/qkvrb_dev.h; off by default) against the same
-    goldens as the tiled GEMM they replace (shapes they do not cover keep the tiled kernel)."""
-    if not os.path.exists(cases.golden_path(name)):
-        pytest.skip("no golden for " + name)
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    eng.set_option("qkv_lean", 1)
-    out = eng.forward(dev)
-    torch.cuda.synchronize()
-    pred = eng.unpack_pred(out["pred_rec"], batch["new_srl_idxs"].shape[1])
-    g = np.load(cases.golden_path(name))
-    _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
 def test_forward_f16_transformers():
@@ -482,19 +412,6 @@ def test_forward_p100_bf16_vs_reference_golden():
     name = "full/cfg4_vog_spat_p100_bs4"
     out, pred, g, _ = _run(name, tx_dtype="bf16")
     _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
-
-
-def test_p100_lstm_layer_inside_long_attention_launch():
-    """`pair_attn` (latency option, off by default): BiLSTM layer 1 rides in obj_tx's long-sequence attention launch (192 + 64
-    workgroups = the chip) and the obj tail runs alone - same kernel bodies, bit-identical outputs."""
-    name = "full/cfg4_vog_spat_p100_bs4"
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    eng.set_option("pair_attn", 1)
-    b = eng.forward(dev)
-    torch.cuda.synchronize()
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("fused", [1, 0])
@@ -537,96 +454,6 @@ def test_stages_vs_oracle(fused):
     e = (mo - st["mul_out"]).abs().max().item()
     print("mul_out abs err", e)
     assert e < 3e-2
-
-
-# ---- AQL submission path (csrc/aql.hip): same kernels, own queue, pre-built packets --------------
-def _aql_outputs(eng, dev, split, n_slots=1, queue=0, reps=2):
-    slots = [eng.make_slot(dev, graph=False).build_aql(split_chains=split) for _ in range(n_slots)]
-    for _ in range(reps):                      # replays must be idempotent (state re-zeroed in-program)
-        for s in slots:
-            for k in ("mdl_outs", "mdl_outs_eval", "pred_rec"):
-                s.out[k].fill_(float("nan"))
-        torch.cuda.synchronize()
-        eng.aql_submit(slots, queue)
-        for s in slots:
-            s.wait(timeout_us=5_000_000)
-    return slots
-
-
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8",
-                                  "full/vog_sep_gt5_bs4_ragged", "full/cfg1_igrnd_spat_gt5_bs2",
-                                  "small/vgrnd_temp", "small/vog_spat_p7"])
-@pytest.mark.parametrize("split", [False, True])
-def test_aql_program_equals_stream_forward(name, split):
-    """Raw AQL dispatch of the recorded forward == the HIP-stream forward, bit for bit."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    eng.set_option("enc_lean", 1)            # (the encoder form otherwise follows the pairing decision)
-    ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    torch.cuda.synchronize()
-    eng.aql_open(1)
-    (slot,) = _aql_outputs(eng, dev, split)
-    assert slot.aql_packets >= slot.aql_rows >= 3
-    for k in ref:
-        assert torch.equal(ref[k], slot.out[k]), (name, k)
-    if split and cfg.mdl.name != "igrnd":
-        # language and vision chains share ROWS where they do not already share LAUNCHES (csrc/pair.hip
-        # moves the whole visual chain into the language chain's launches at the full-size shapes)
-        eng.set_option("pair_launches", 0)
-        (s2,) = _aql_outputs(eng, dev, split)
-        assert s2.aql_rows < s2.aql_packets
-        for k in ref:
-            assert torch.equal(ref[k], s2.out[k]), (name, k, "unpaired")
-
-
-def test_aql_program_p100_long_sequence_kernels():
-    """The p100 forward through AQL packets: the long-sequence attention (guard clear + attn_tile2 + the
-    conditional running-maximum pass) and the LDS-ring separable attention are recorded like any other
-    kernel; outputs equal the stream forward bit for bit."""
-    name = "full/cfg4_vog_spat_p100_bs4"
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    torch.cuda.synchronize()
-    eng.aql_open(1)
-    (slot,) = _aql_outputs(eng, dev, False)
-    for k in ref:
-        assert torch.equal(ref[k], slot.out[k]), k
-
-
-def test_aql_interleaved_programs_and_queues():
-    """Two forwards row-interleaved behind shared barrier packets on each of two queues at once."""
-    name = "full/cfg2_vog_spat_gt5_bs4"
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    ref = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    torch.cuda.synchronize()
-    eng.aql_open(2)
-    slots = [eng.make_slot(dev, graph=False).build_aql(split_chains=True) for _ in range(5)]
-    # co-residency guard: 2 queues open -> at most 2 persistent-BiLSTM programs per (concurrent) submission
-    with pytest.raises(Exception):
-        eng.aql_submit(slots[:3], 0)
-    slots = slots[:4]
-    for rep in range(3):
-        for s in slots:
-            s.out["pred_rec"].fill_(float("nan"))
-        torch.cuda.synchronize()
-        eng.aql_submit(slots[:2], 0)
-        eng.aql_submit(slots[2:], 1)
-        with pytest.raises(Exception):
-            eng.aql_submit(slots[:1], 1)         # still in flight: refused, not re-queued
-        for s in slots:
-            out = s.wait(timeout_us=5_000_000)
-            for k in ref:
-                assert torch.equal(ref[k], out[k]), (rep, k)
-
-
-def test_aql_golden_parity():
-    name = "full/cfg2_vog_spat_gt5_bs4"
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    eng.aql_open(1)
-    (slot,) = _aql_outputs(eng, dev, True)
-    ncmp = batch["new_srl_idxs"].shape[1]
-    pred = eng.unpack_pred(slot.out["pred_rec"], ncmp)
-    g = np.load(cases.golden_path(name))
-    _check_against(name, slot.out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
 # ---- language encoder shared by a group of in-flight batches ---------------------------------
@@ -699,7 +526,7 @@ def test_batched_requests_match_standalone_forwards(name, n):
                                     ("full/vog_sep_gt5_bs4_ragged", 2), ("full/cfg3_vog_temp_gt5_bs8", 2),
                                     ("full/cfg1_igrnd_spat_gt5_bs2", 3), ("small/vog_spat", 4),
                                     ("small/vgrnd_sep", 2)])
-@pytest.mark.parametrize("mode", ["eager", "graph", "aql"])
+@pytest.mark.parametrize("mode", ["eager", "graph"])
 def test_group_language_encoder_matches_standalone_forwards(name, n, mode):
     """Every member of a group (one shared BiLSTM pass for all members' sentences) must get the
     outputs of its own stand-alone forward: rows never interact, only the fp32 summation order of
@@ -720,14 +547,8 @@ def test_group_language_encoder_matches_standalone_forwards(name, n, mode):
         for s in grp.slots:
             s.out["mdl_outs"].fill_(float("nan"))
         torch.cuda.synchronize()
-        if mode == "aql":
-            eng.aql_open(1)
-            grp.build_aql()
-            eng.aql_submit([grp], 0)
-            outs = grp.wait(timeout_us=5_000_000)
-        else:
-            outs = grp.launch()
-            torch.cuda.synchronize()
+        outs = grp.launch()
+        torch.cuda.synchronize()
         ncmp = members[0][2]["new_srl_idxs"].shape[1]
         for m, (ref, out) in enumerate(zip(refs, outs)):
             # a 1-ulp fp32 difference in a gate can flip the 16-bit rounding of h; downstream that is
@@ -985,38 +806,6 @@ def test_persistent_lstm_handoff_is_deterministic_under_load():
                 for k in ref[w]:
                     assert torch.equal(sl.out[k], ref[w][k]), (i, k)
 
-
-
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8", "full/cfg5_vog_svsq_gt5_bs16",
-                                  "small/vog_spat", "small/vgrnd_sep"])
-def test_chained_obj_qkv_equals_separate_launches(name):
-    """chain_obj_qkv: obj_tx's layer-0 QKV projection (row-block form) runs INSIDE the BiLSTM layer 0 || encoders launch - its
-    workgroups wait on the done flags of the encoder workgroups that write their 64 rows (written through) - vs the same
-    kernels as separate launches: bit-identical, also over 400 graph replays on 4 streams (a consumer that read a row before
-    its producer had written it would show); and within the golden bounds."""
-    if not os.path.exists(cases.golden_path(name)):
-        pytest.skip("no golden for " + name)
-    eng, cfg, sd, batch, c, dev = build_engine(name)
-    eng.set_option("chain_obj_qkv", 1)
-    eng.set_option("enc_lean", 1)
-    eng.set_option("pair_launches", 0)                     # same kernels, every step its own launch
-    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
-    eng.set_option("pair_launches", 1)
-    for _ in range(3):
-        b = eng.forward(dev)
-        torch.cuda.synchronize()
-        for k in a:
-            assert torch.equal(a[k], b[k]), (name, k)
-    streams = [torch.cuda.Stream() for _ in range(4)]
-    slots = [eng.make_slot({k: v.cpu() for k, v in dev.items()}, graph=True) for _ in range(4)]
-    for it in range(400):
-        slots[it % 4].launch(streams[it % 4])
-    torch.cuda.synchronize()
-    for sl in slots:
-        assert torch.equal(sl.out["mdl_outs"], a["mdl_outs"]) and torch.equal(sl.out["pred_rec"], a["pred_rec"])
-    pred = eng.unpack_pred(b["pred_rec"], batch["new_srl_idxs"].shape[1])
-    g = np.load(cases.golden_path(name))
-    _check_against(name, b, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
 
 
 def test_slots_sharing_a_workspace_on_one_stream():

@@ -118,13 +118,15 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
     }
     VOG_FAIL(-1, "struct attention with hi + lo operands: needs q_visual, one visual key block (nppf <= 32) and a head dim of 64 / 128 / 192 / 256");
   }
-  // lean form (<= 128 registers, four workgroups per CU) unless VOG_ATTN_STRUCT1_LEAN=0 (perf experiments): bit-identical
-  static int lean1 = -2;
-  if (lean1 == -2) { const char* e = perf_env("VOG_ATTN_STRUCT1_LEAN"); lean1 = e ? atoi(e) : 1; }
-  if (p.npad_kv == 32 && lean1 && (NDB % 1) == 0 && ((NDB * 32) / 16) % 2 == 0)
-    ::vog::launch((attn_struct1_lean_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
-  else if (p.npad_kv == 32) ::vog::launch((attn_struct1_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
-  else ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+  // one visual key block: the lean form (<= 128 registers, four workgroups per CU)
+  if constexpr (((NDB * 32) / 16) % 2 == 0) {
+    if (p.npad_kv == 32) {
+      ::vog::launch((attn_struct1_lean_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  ::vog::launch((attn_struct_kernel<T16, NDB>), grid, dim3(256), lds, st, p);
   VOG_LAUNCH_CHECK();
   return 0;
 }
@@ -222,19 +224,14 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_t2 = true;
       }
-      if (p.phase != 2) {
-        if (!p.guard_precleared)
-          ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: recorded by the AQL path too)
-        dim3 grid(ceil_div(p.N, 256) * p.H * p.S);
-        ::vog::launch(kern, grid, dim3(512), lds2, st, p);
-        VOG_LAUNCH_CHECK();
-        if (p.phase == 1) return 0;
-      }
+      if (!p.guard_precleared)
+        ::vog::launch(attn_guard_clear_kernel, dim3(1), dim3(64), 0, st, p.guard);   // (a kernel, not a memset: graph-capturable on any stream)
+      dim3 grid(ceil_div(p.N, 256) * p.H * p.S);
+      ::vog::launch(kern, grid, dim3(512), lds2, st, p);
+      VOG_LAUNCH_CHECK();
       fallback_pass = true;
     }
   }
-  if (p.phase != 0 && !fallback_pass)
-    VOG_FAIL(-1, "rel_attention: phase %d needs the fixed-reference kernel (guard_flag, >= %d tokens, head dim <= 192)", p.phase, tile2_min);
   AttnParams pt = p;
   if (!fallback_pass) pt.guard = nullptr;
   // (after attn_tile2 the running-maximum tile kernel is ALWAYS the second pass, whatever the experiment
@@ -295,19 +292,6 @@ static int attn_dispatch(const AttnParams& p, hipStream_t st) {
   }
 }
 
-// pair.hip: the fixed-reference kernel at head dim 192 (obj_tx) can take a BiLSTM layer into its launch
-const void* kid_attn_tile2_192(int dtype) {
-  return dtype == VOG_BF16 ? reinterpret_cast<const void*>(attn_tile2_kernel<BF16, 6>)
-                           : reinterpret_cast<const void*>(attn_tile2_kernel<F16, 6>);
-}
-// does vog_rel_attention_fwd take the fixed-reference kernel for this shape (given a guard flag)?
-int attn_uses_tile2(int N, int dp, int npad) {
-  if (perf_env("VOG_ATTN_TILE2_MIN") || perf_env("VOG_ATTN_GENERAL")) return 0;   // (experiments: keep the plan simple)
-  const int ndb = dp / 32;
-  const size_t lds2 = (size_t)4 * ((ndb * 32) / 16 + 2 * ndb) * 1024 + (size_t)npad * sizeof(float);
-  return N >= 1024 && ndb <= 6 && lds2 <= 160 * 1024;
-}
-
 int attn_head_pad(int dh) {
   const int opts[5] = {32, 64, 128, 192, 256};
   for (int i = 0; i < 5; ++i) if (dh <= opts[i]) return opts[i];
@@ -324,7 +308,7 @@ int attn_run(const vog_attn_args* a, hipStream_t st) {
   p.u = a->u; p.pe_b = a->pe_b;
   p.S = a->S; p.N = a->N; p.H = a->H; p.dp = a->dp; p.npad = a->npad; p.use_rel = a->use_rel;
   p.n_box = a->n_box; p.seq_per_vid = a->seq_per_vid; p.NP = a->NP; p.inv_scale = a->inv_scale;
-  p.guard = a->guard_flag; p.guard_precleared = a->guard_precleared; p.phase = a->phase;
+  p.guard = a->guard_flag; p.guard_precleared = a->guard_precleared;
   VOG_CHECK_ARG((a->q_lo == nullptr) == (a->k_lo == nullptr));
   p.q_lo = (const unsigned short*)a->q_lo; p.k_lo = (const unsigned short*)a->k_lo; p.out_lo = (unsigned short*)a->out16_lo;
   p.logit_max = a->logit_max;

@@ -14,9 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRCS = ["forward.hip", "gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip", "backward.hip", "aql.hip"]
-# translation units that hold kernels: also built device-only into libvog_hip.<tu>.co for the AQL path
-KERNEL_SRCS = ["gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip", "backward.hip"]
+SRCS = ["forward.hip", "gemm.hip", "attention.hip", "elementwise.hip", "lstm.hip", "txtail.hip", "visenc.hip", "pair.hip", "loss.hip", "assemble.hip", "backward.hip"]
 HDRS = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join(ROOT, "include", "vog_hip.h")]
 OUT = os.path.join(HERE, "libvog_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -44,36 +42,16 @@ def _cc(src):
     return obj
 
 
-def _co(src):
-    """Device-only code object of one translation unit (same flags as the fat binary)."""
-    co = os.path.join(HERE, "libvog_hip." + src.replace(".hip", ".co"))
-    path = os.path.join(HERE, src)
-    if _stale(co, [path] + HDRS):
-        cmd = [HIPCC] + FLAGS + ["--cuda-device-only", "--no-gpu-bundle-output", path, "-o", co]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc (device only) failed for {src}:\n{r.stdout}\n{r.stderr}")
-    return co
-
-
 def build(force: bool = False) -> str:
     if force:
         for s in SRCS:
             o = os.path.join(HERE, s.replace(".hip", ".o"))
             if os.path.exists(o):
                 os.remove(o)
-        for s in KERNEL_SRCS:
-            o = os.path.join(HERE, "libvog_hip." + s.replace(".hip", ".co"))
-            if os.path.exists(o):
-                os.remove(o)
-    with ThreadPoolExecutor(max_workers=len(SRCS) + len(KERNEL_SRCS)) as ex:
-        cos = [ex.submit(_co, s) for s in KERNEL_SRCS]
+    with ThreadPoolExecutor(max_workers=len(SRCS)) as ex:
         objs = list(ex.map(_cc, SRCS))
-        for f in cos:
-            f.result()
     if _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + [
-            "-L/opt/rocm/lib", "-lhsa-runtime64"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -148,11 +148,12 @@ __host__ __device__ __forceinline__ int64_t frag_a(int m, int k, int K) {
 // with the hardware indices; pair_kernel (pair.hip) calls two different bodies from one grid.
 struct BlockCtx { unsigned bx, by, gx, gy; };
 
-// ---- kernel launch: HIP stream, or recorded into an AQL program (aql.hip) -----------------------
-// Every kernel of the library is launched through vog::launch. With an ordinary stream it is
-// hipLaunchKernelGGL. With the recorder pseudo-stream (vog_aql_program_create) nothing is
-// launched: the kernel's host stub, geometry and packed kernarg bytes are appended to the
-// active recording, from which aql.hip builds raw AQL dispatch packets.
+// ---- kernel launch ---------------------------------------------------------------------------
+// Every kernel of the library is launched through vog::launch: hipLaunchKernelGGL on the caller's stream, or - while pair.hip
+// has its capture open - a record of the kernel's host stub, geometry and packed kernarg bytes, from which two independent steps
+// of the forward are issued as ONE grid (horizontal fusion). (Round 2-5 also recorded whole forwards into raw AQL packets on the
+// library's own HSA queues; measured no faster than hipGraph replay - 54.9 vs 57.1 k queries/s - and removed in round 6:
+// scratch/negatives/r6_pruned/.)
 struct LaunchRecord {
   const void* host_fn;
   unsigned grid[3], block[3];      // grid in workgroups
@@ -160,15 +161,7 @@ struct LaunchRecord {
   unsigned arg_bytes;              // explicit kernarg bytes (natural alignment packing)
   unsigned char args[1024];
 };
-struct LaunchRecorder {
-  virtual void add(const LaunchRecord& r) = 0;
-  virtual ~LaunchRecorder() {}
-};
-extern thread_local LaunchRecorder* g_recorder;
-// Pair capture (pair.hip): while set, vog::launch appends here instead of launching, so that two
-// independent steps of the forward can be issued as ONE grid (horizontal fusion).
 extern thread_local std::vector<LaunchRecord>* g_pair_capture;
-static inline hipStream_t recorder_stream() { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(0x7e0c0de1)); }
 
 template <typename T>
 inline void pack_arg(LaunchRecord& r, const T& v) {
@@ -190,16 +183,6 @@ inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hi
     r.dyn_lds = (unsigned)lds; r.arg_bytes = 0;
     (pack_arg<KArgs>(r, static_cast<KArgs>(args)), ...);
     g_pair_capture->push_back(r);
-    return;
-  }
-  if (st == recorder_stream() && g_recorder) {
-    LaunchRecord r;
-    r.host_fn = reinterpret_cast<const void*>(kern);
-    r.grid[0] = grid.x; r.grid[1] = grid.y; r.grid[2] = grid.z;
-    r.block[0] = block.x; r.block[1] = block.y; r.block[2] = block.z;
-    r.dyn_lds = (unsigned)lds; r.arg_bytes = 0;
-    (pack_arg<KArgs>(r, static_cast<KArgs>(args)), ...);
-    g_recorder->add(r);
     return;
   }
   hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<KArgs>(args)...);

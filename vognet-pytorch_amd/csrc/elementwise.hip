@@ -3,12 +3,16 @@
 // pred_cmp head, prediction head. fp32 arithmetic throughout (these are exact
 // restatements; only the MFMA contractions run in 16 bit).
 #include "common.h"
-#include "argvec_dev.h"
 #include "pred_dev.h"
 
 namespace vog {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 
 // ---------------------------------------------------------------------------
 // K3 layernorm: one wave per row, row held in registers (d <= 1024)
@@ -163,8 +167,7 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
   // weight slice; profiles/round5_busy_cu_cfg2.md). The rows' [full[cap0] || full[cap1]] vectors are staged in LDS with ONE
   // round of loads (every row of the block requested before anything is waited for; a first form that walked the rows in
   // passes of dependent loads took 33 us), each wave keeps the weight rows of its 4 outputs in registers (requested in the
-  // same round) and forms 4 dot products per row: per-lane partial sums over the same elements in the same order as
-  // argvec_rows (argvec_dev.h), then the same wave reduction.
+  // same round) and forms 4 dot products per row: per-lane partial sums (16 bytes per lane and access), then a wave reduction.
   extern __shared__ __attribute__((aligned(16))) float av_x[];          // [AV_ROWS][2L]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r0 = (int)blockIdx.x * AV_ROWS;

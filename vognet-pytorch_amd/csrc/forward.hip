@@ -12,7 +12,6 @@
 #include <vector>
 #include <stdlib.h>
 #include "common.h"
-#include "aql.h"
 
 namespace vog {
 
@@ -29,9 +28,6 @@ int attn_head_pad(int dh);
 int tx_tail_supported(int d, int dh, int kwo);
 int64_t tx_tail_scratch_bytes(int M, int d);
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc);
-int attn_uses_tile2(int N, int dp, int npad);
-int pair_launch3(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
-                 const std::function<int(hipStream_t)>& fc, hipStream_t st, bool* fused);
 int pair_launch(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
                 hipStream_t st, bool* fused);
 
@@ -59,7 +55,7 @@ struct TxLayer {
   unsigned short *wqkv, *wo, *w1, *w2;     // 16-bit, padded
   unsigned short* wqkv_lang_f;             // Wqkv[:, d_vis:] in fragment order (structured layer 0)
   unsigned short *wo_p, *w1_p, *w2_p;      // 32x16 fragment order (fused encoder tail, txtail.hip), or null
-  unsigned short *wqkv_p, *wqkv_pv;        // padded Wqkv in the same order (row-block QKV, qkvrb_dev.h): all d columns / the first d_vis
+  unsigned short *wqkv_p, *wqkv_pv;        // padded Wqkv in the same order (all-columns QKV of p100, qkvrb_dev.h): all d columns / the first d_vis
   float *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
   // hi + lo operands (tx_split): 16-bit remainders t16(w - t16(w)) in the layouts of wqkv, wqkv_lang_f, wo_p, w1_p, w2_p
   unsigned short *wqkv_lo, *wqkv_lang_f_lo, *wo_p_lo, *w1_p_lo, *w2_p_lo;
@@ -82,10 +78,6 @@ struct vog_ctx {
   std::map<std::string, std::vector<float>> host;
   std::vector<void*> allocs;
   bool finalized = false;
-  int pair_attn = 0;                    // p100: 1 = BiLSTM layer 1 inside obj_tx's long attention launch instead of next to the obj tail.
-                                        // Measured (scratch/r5_pairattn*.sh): one forward 944 -> 888 us (-6 %), 4 in flight 5358 -> 5280
-                                        // queries/s (-1.5 %: the launch fills the chip exactly and leaves the other forwards' kernels
-                                        // no CU). Off: `value` is the throughput regime; on for latency-bound serving.
   int tx_split = 0;                     // round 6: hi + lo 16-bit operands (three MFMAs per product) for everything that feeds attention
                                         // logits - encoders, QKV projections, Q.K^T, and the tails whose output is another layer's
                                         // input: the plan for checkpoints whose attention is too sharp for 16-bit logits but does
@@ -110,17 +102,7 @@ struct vog_ctx {
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
-  int chain_obj_qkv = 0;                // 1: obj_tx's QKV projection (row-block form) rides in the BiLSTM layer 0 || encoders launch,
-                                        // its blocks waiting for the encoder blocks that produce their rows (pair3_kernel)
-  int fused_pred = 0;                   // 1: the prediction head runs in the score tail's launch (its last workgroup; txtail_dev.h).
-                                        // Bit-identical and one launch less, but no faster (55.4 vs 55.8 k queries/s): off
-  int fused_argvec = 0;                 // 1: argument vectors inside the language out-projection's launch (vog_argvec_tail): one
-                                        // launch less, but the in-launch arrival wait costs more than the boundary it removes
-                                        // (210.6 vs 205.2 us per forward, 72.6 vs 70.6 us per batch with 4 in flight): off
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
-  int qkv_lean = -1;                    // -1: auto (row-block form from 8192 visual rows: +1.5 % at cfg 4, neutral / negative at gt5); 1: row-block QKV projections (qkvrb_dev.h) where the shape allows: ~1/3 of the
-                                        // busy-CU time of the tiled GEMM at twice its latency; measured neutral at cfg 2
-                                        // (47.9 k vs 49.1 k queries/s with 4 forwards in flight), so off by default
   int enc_lean = -1;                    // -1: lean form exactly when the encoders share a BiLSTM layer's launch
   int pair_launches = 1;                // step i of the language chain shares a launch with step i of the visual chain (pair.hip)
   int pair_mask = 7;                    // which of the three pairs are formed: 1 BiLSTM layer 0 + encoders, 2 layer 1 + obj tail, 4 out-projection + mul QKV
@@ -385,9 +367,6 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
     p.add("lstm_c_" + std::to_string(l), (int64_t)g.Bn16 * 2 * g.R * 4);
     p.add("lstm_sync_" + std::to_string(l), 1024);   // [2] timeout, [16 + 16 dir + xcc] workgroups arrived per XCC id
   }
-  p.add("argvec_sync", 256);                          // arrival counter of the out-projection's argument-vector tail
-  p.add("pred_sync", 256);                            // arrival counter of the score tail's prediction head
-  p.add("chain_flags", 1024);                         // done flags of the lean encoder workgroups (chain_obj_qkv)
   p.add("obj_guard", 256);                            // vog_attn_args.guard_flag of the two stacks (long-sequence attention): zeroed
   p.add("mul_guard", 256);                            // with the rest of this region, so the attention needs no clearing launch
   p.add("mul_ef_guard", 256);                         // vog_attn_struct_args.guard_flag (E x F attention of mul_tx layer 0, p100)
@@ -471,8 +450,6 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
                      const float** out32, const void** out16,
                      const vog_vislang_args* structured = nullptr, const void* vis16 = nullptr,
                      bool last_needs_f32 = true, const vog_score_args* score = nullptr,
-                     const vog_pred_args* pred = nullptr, unsigned int* pred_counter = nullptr, bool* pred_done = nullptr,
-                     const vog_qkv_args* dep = nullptr,
                      // hi + lo operands (c->tx_split): remainders of the stack's input rows / of the visual rows (structured
                      // layer 0); out_feeds_attn: the LAST layer's output is another attention layer's input (obj_tx under mul_tx);
                      // *out16_lo: remainder of the 16-bit output copy
@@ -498,13 +475,10 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     qa.x16 = cur16; qa.ldx = tw.d; qa.wqkv = L.wqkv; qa.ldw = tw.d;
     qa.q = ws.at<void>(n + "_q"); qa.k = ws.at<void>(n + "_k"); qa.vt = ws.at<void>(n + "_vt");
     qa.S = S; qa.N = N; qa.H = tw.H; qa.dp = tw.dp; qa.npad = npad; qa.K = tw.d; qa.dtype = dt;
-    const bool qkv_rb = c->qkv_lean > 0 || (c->qkv_lean < 0 && g.rows_obj >= 8192);
+    // many rows (p100): one workgroup per 64 rows walks all output columns (qkvrb_dev.h: +1.5 % at cfg 4); the tiled LDS-DMA GEMM
+    // otherwise (a 64-row x 512-column row-block form measured -3 % at cfg 2 and was removed in round 6)
+    const bool qkv_rb = g.rows_obj >= 8192;
     qa.wqkv_p32 = qkv_rb ? L.wqkv_p : nullptr;
-    if (dep && l == 0 && L.wqkv_p) {      // layer 0 rides in the encoders' launch: row-block form, waits for its rows' producers
-      qa.wqkv_p32 = L.wqkv_p;
-      qa.dep_flags = dep->dep_flags; qa.dep_nb0 = dep->dep_nb0; qa.dep_rep = dep->dep_rep; qa.dep_nh0 = dep->dep_nh0;
-      qa.dep_nh1 = dep->dep_nh1;
-    }
     const bool fact = structured && l == 0;
     const bool last_l = l == tw.n_layers - 1;
     // hi + lo tail: this layer's output is read by another attention layer (a later layer of the stack, or mul_tx behind obj_tx)
@@ -554,18 +528,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     aa.guard_precleared = l < 63 ? 1 : 0;
     aa.logit_max = lmax + (l < 31 ? l : 31);
     if (split) { aa.q_lo = qa.q_lo; aa.k_lo = qa.k_lo; aa.out16_lo = tail_split ? attn16_lo : nullptr; }
-    if (!fact) {
-      if (c->pair_attn && n == "obj" && l == 0 && aa.guard_precleared && attn_uses_tile2(N, tw.dp, npad)) {
-        // long sequences (p100): the fixed-reference kernel and its gated fallback as two steps - the first can share a launch
-        // with BiLSTM layer 1 (pair plan below)
-        vog_attn_args a1 = aa, a2 = aa;
-        a1.phase = 1; a2.phase = 2;
-        steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&a1, st); }});
-        steps.push_back({n + "_attnfb", [=](hipStream_t st) { return vog_rel_attention_fwd(&a2, st); }});
-      } else {
-        steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
-      }
-    }
+    if (!fact) steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
     const bool last = l == tw.n_layers - 1;
     // 16-bit copy of the LAST layer's output: typed for its consumer (none for obj_tx,
     // the f16 score head for mul_tx)
@@ -593,15 +556,10 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       if (with_score) { sc = *score; ta.wl_p = c->w_lin2_p; ta.bl = c->b_lin2; ta.y32 = nullptr; ta.y16 = nullptr; }
       vog_vislang_args sv{};
       if (fact) sv = *structured;
-      // the prediction head rides in the score tail's launch (its last workgroup runs it): one launch less
-      const bool with_pred = with_score && pred && pred_counter;
-      vog_pred_args pr{};
-      if (with_pred) { pr = *pred; ta.pred_counter = pred_counter; if (pred_done) *pred_done = true; }
       steps.push_back({n + "_tail", [=](hipStream_t st) {
         vog_tx_tail_args t2 = ta;
         if (fact) t2.res_vislang = &sv;
         if (with_score) t2.score = &sc;
-        if (with_pred) t2.pred = &pr;
         return vog_tx_tail_fwd(&t2, st); }});
       if (with_score) *out16 = nullptr;            // tells the caller that lin2 + score already ran
       cur32 = o32;
@@ -681,7 +639,6 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   // different programs)
   const bool fuse_prep = !shared && !lang_only;
   // one launch for both encoders + the concat, straight from the fp32 features (visenc.hip)
-  vog_qkv_args obj_dep{};               // chain_obj_qkv: the flags obj_tx's layer-0 QKV waits on (set with the encoders below)
   const bool enc_fused = c->fused_enc && c->w_prop_f && c->w_seg_f && !lang_only;
   auto make_visprep = [&]() {
     vog_visprep_args vp{};
@@ -791,7 +748,6 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         steps.push_back({"lstm_step", [=](hipStream_t st) { return vog_bilstm_step(&la, st); }});
       }
     }
-    bool argvec_done = false;
     vog_gemm_args po{}; po.c16_dtype = -1;
     po.a = ws.at<void>("lstm_out16_" + std::to_string(d.rnn_layers - 1)); po.lda = 2 * R;
     po.w = c->w_outproj; po.ldw = 2 * R; po.bias = c->b_outproj; po.relu = 1;
@@ -809,15 +765,6 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       f0.slabs = ps.c32; f0.splits = 8; f0.M = po.M; f0.N = g.L; f0.bias = c->b_outproj; f0.relu = 1; f0.rep = 1;
       f0.c32 = full32; f0.ldc = g.L;
       steps.push_back({"lstm_outproj_finish", [=](hipStream_t st) { return vog_splitk_finish(&f0, nullptr, st); }});
-    } else if (c->fused_argvec && po.M <= 64 && (po.K % 32) == 0 && (g.L % 16) == 0 && g.L <= 512 && g.L / 16 < 128) {
-      // the argument vectors ride in the out-projection's launch (vog_argvec_tail): no argvec launch
-      vog_argvec_tail av{};
-      av.counter = ws.at<unsigned int>("argvec_sync"); av.capture = b->srl_arg_words_capture;
-      av.inds_msk = b->srl_arg_inds_msk; av.w = c->w_arg; av.bias = c->b_arg; av.lang = lang_vec;
-      av.Bn = Bn; av.T = T; av.nsrl = nsrl; av.L = g.L;
-      steps.push_back({"lstm_outproj", [=](hipStream_t st) {
-        vog_gemm_args p2 = po; p2.argvec_tail = &av; return vog_gemm_bias_act(&p2, st); }});
-      argvec_done = true;
     } else {
       steps.push_back({"lstm_outproj", [=](hipStream_t st) { return vog_gemm_bias_act(&po, st); }});
     }
@@ -826,9 +773,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     const int64_t *cap = b->srl_arg_words_capture, *im = b->srl_arg_inds_msk;
     const float *wa = c->w_arg, *ba = c->b_arg;
     const int L = g.L;
-    if (!argvec_done)
-      steps.push_back({"argvec", [=](hipStream_t st) {
-        return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
+    steps.push_back({"argvec", [=](hipStream_t st) {
+      return vog_srl_argvec(full, cap, im, wa, ba, lang, Bn, T, nsrl, L, st); }});
   }
   if (structured && !lang_only) {
     {
@@ -904,14 +850,6 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       const bool rep_step = ve.lean && d.nppf0 > 16 && (d.seg_enc % 4) == 0 && (d.prop_enc % 4) == 0 && (g.d_obj % 4) == 0;
       if (c->tx_split && rep_step) VOG_FAIL(-5, "tx_split: more than 16 proposals per frame are not supported (use the fp32 path)");
       ve.defer_replicas = rep_step ? 1 : 0;
-      // chain_obj_qkv: obj_tx's layer-0 QKV (row-block form) in the same launch, its workgroups waiting for the encoder
-      // workgroups that write their rows (flags zeroed by the prologue)
-      if (c->chain_obj_qkv && ve.lean && !rep_step && has_obj(d) && !c->obj.layers.empty() && c->obj.layers[0].wqkv_p &&
-          (ceil_div(Mp, 64) + ceil_div(Ms, 64)) * 2 <= 256) {
-        ve.done_flags = ws.at<unsigned int>("chain_flags");
-        obj_dep.dep_flags = ve.done_flags; obj_dep.dep_nb0 = ceil_div(Mp, 64); obj_dep.dep_rep = d.nppf0;
-        obj_dep.dep_nh0 = ceil_div(d.prop_enc, 128); obj_dep.dep_nh1 = ceil_div(d.seg_enc, 128);
-      }
       steps.push_back({"vis_enc", [=](hipStream_t st) { return vog_vis_encode(&ve, st); }});
       if (rep_step) steps.push_back({"seg_rep", [=](hipStream_t st) { return vog_seg_replicate(&ve, st); }});
     }
@@ -957,8 +895,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   if (has_obj(d)) {
     const void* in_lo = vis16_lo;
     tx_steps(c, c->obj, "obj", g, ws, b, ps32, ps16, g.S_obj, g.N_obj, g.npad_obj, g.spv_obj, g.N_obj,
-             g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16, nullptr, nullptr, true, nullptr, nullptr, nullptr,
-             nullptr, obj_dep.dep_flags ? &obj_dep : nullptr, in_lo, nullptr, /*out_feeds_attn=*/has_mul(d), &vis16_lo, &tx_err);
+             g.fdiv_obj, has_mul(d) ? d.tx_dtype : -1, steps, &vis32, &vis16, nullptr, nullptr, true, nullptr,
+             in_lo, nullptr, /*out_feeds_attn=*/has_mul(d), &vis16_lo, &tx_err);
     if (tx_err) return tx_err;
   }
   // ---- vis || lang tokens in mul_tx order (a10, a11)
@@ -985,14 +923,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
   pr.rec = b->pred_rec; pr.B = g.B; pr.ncmp = g.ncmp; pr.nsrl = d.nsrl; pr.nfrm0 = d.nfrm0;
   pr.nppf0 = d.nppf0; pr.conc_type = d.conc_type;
   pr.logit_max = ws.at<unsigned int>("logit_max"); pr.stats = b->stats;
-  bool pred_done = false;
-  // (sep / svsq: the head reads fin_scores of pred_cmp, which runs after the tail; p100: the wave-per-item head)
-  const bool pred_in_tail = c->fused_pred && b->pred_rec && !g.sep && d.nppf0 < 32;
   if (has_mul(d))
     tx_steps(c, c->mul, "mul", g, ws, b, x32, x16, g.S_mul, g.N_mul, g.npad_mul, g.nfrm, g.nppf,
              (float)g.nfrm, d.enc_dtype, steps, &x32, &x16, structured ? &va : nullptr, vis16,
              /*last_needs_f32=*/false, d.enc_dtype == VOG_F16 ? &sa : nullptr,
-             pred_in_tail ? &pr : nullptr, pred_in_tail ? ws.at<unsigned int>("pred_sync") : nullptr, &pred_done, nullptr,
              // (not structured: mul_tx would read the materialised token matrix, which has no remainder copy)
              structured ? vis16_lo : nullptr, structured ? vis16_lo : nullptr, false, nullptr, &tx_err);
   if (tx_err) return tx_err;
@@ -1020,7 +954,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     pa.NP = g.NP; pa.nfrm0 = d.nfrm0; pa.nppf0 = d.nppf0; pa.L = g.L; pa.dp0 = d.prop_enc; pa.dps = g.d_obj;
     steps.push_back({"pred_cmp", [=](hipStream_t st) { return vog_pred_cmp_head(&pa, st); }});
   }
-  if (b->pred_rec && !pred_done)
+  if (b->pred_rec)
     steps.push_back({"pred_head", [=](hipStream_t st) { return vog_pred_head(&pr, st); }});
   // ---- horizontal fusion (pair.hip): the language chain and the visual chain are independent until
   // mul_tx's attention, and neither fills the chip (the persistent BiLSTM layer holds 64 CUs for
@@ -1042,19 +976,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     // input projection they measured SLOWER than apart: 22.5 vs 9.5 + 7.4 us).
     struct Want { const char* lang; int occ; const char* vis; const char* then[3]; };
     const bool has_rep = find("seg_rep", 0) >= 0;
-    // p100 (an "obj_attnfb" step exists): layer 1 rides inside obj_tx's long attention instead of next to its tail - 192 + 64
-    // workgroups fill the chip exactly, the tail then runs alone on all of it (next to the layer it took 71 us instead of 39:
-    // 250 workgroups on the 192 CUs the layer left)
-    const bool long_attn = find("obj_attnfb", 0) >= 0 && c->pair_attn;
-    const Want want_gt5[] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
-                                     : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}},
-                             {"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}},
-                             {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
-    const Want want_long[] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", nullptr}}
-                                      : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", nullptr, nullptr}},
-                              {"lstm_layer", 1, "obj_attn", {"obj_attnfb", "obj_tail", nullptr}},
-                              {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
-    const Want (&want)[3] = long_attn ? want_long : want_gt5;
+    const Want want[3] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
+                                  : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}},
+                          {"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}},
+                          {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
     struct Plan2 { int ia, ib; int it[3]; };
     std::vector<Plan2> plans;
     bool ok = true;
@@ -1097,18 +1022,10 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         Step m = steps[i];
         auto fa = steps[q->ia].fn, fb = steps[q->ib].fn;
         m.name = steps[q->ia].name + "+" + steps[q->ib].name;
-        int chained = -1;
-        if (c->chain_obj_qkv && steps[q->ib].name == "vis_enc" && q->it[0] >= 0 && steps[q->it[0]].name == "obj_qkv") {
-          auto fc = steps[q->it[0]].fn;
-          m.name += "+obj_qkv";
-          m.fn = [fa, fb, fc](hipStream_t st) { return pair_launch3(fa, fb, fc, st, nullptr); };
-          chained = 0;
-        } else {
-          m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
-        }
+        m.fn = [fa, fb](hipStream_t st) { return pair_launch(fa, fb, st, nullptr); };
         out.push_back(m);
         for (int k = 0; k < 3; ++k)
-          if (q->it[k] >= 0 && k != chained) { Step t = steps[q->it[k]]; t.branch = m.branch; out.push_back(t); }
+          if (q->it[k] >= 0) { Step t = steps[q->it[k]]; t.branch = m.branch; out.push_back(t); }
       }
       steps.swap(out);
     }
@@ -1156,7 +1073,6 @@ extern "C" int vog_ctx_create(const vog_model_desc* d, vog_ctx** out) {
   if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { if (atoi(e) > 4) c->lstm_persistent = 0; }
   if (const char* e = getenv("VOG_LSTM_PERSISTENT")) c->lstm_persistent = atoi(e) ? 1 : 0;
   if (const char* e = perf_env("VOG_FUSED_IH")) c->fused_ih = atoi(e);
-  if (const char* e = perf_env("VOG_QKV_LEAN")) c->qkv_lean = atoi(e);
   const int R = d->rnn_size, E = d->emb_dim, L = d->lang_enc;
   add_w(c, "lstm_encoder.embed_tokens.weight", (int64_t)(d->vocab_size + 1) * E);
   for (int l = 0; l < d->rnn_layers; ++l)
@@ -1552,7 +1468,7 @@ static int graph_capture_impl(vog_ctx* c, const vog_batch* b, void* ws, size_t w
   if (rc == 0 && nseg > 0) rc = vog_copy_segments(segs, nseg, st);
   for (auto& s : steps) {
     if (rc != 0) break;
-    if (s.branch < 0) continue;          // join marker (AQL row bookkeeping)
+    if (s.branch < 0) continue;          // join marker
     rc = s.fn(st);
     if (rc != 0) break;
   }
@@ -1615,17 +1531,12 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   }
   if (strcmp(name, "lstm_persistent") == 0) { c->lstm_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "lstm_inject_stall") == 0) { c->lstm_inject_stall = value == 2 ? 2 : (value ? 1 : 0); return 0; }   // 2: direction 1 only
-  if (strcmp(name, "pair_attn") == 0) { c->pair_attn = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
-  if (strcmp(name, "fused_argvec") == 0) { c->fused_argvec = value ? 1 : 0; return 0; }
-  if (strcmp(name, "fused_pred") == 0) { c->fused_pred = value ? 1 : 0; return 0; }
-  if (strcmp(name, "chain_obj_qkv") == 0) { c->chain_obj_qkv = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_mask") == 0) { c->pair_mask = value & 7; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }
-  if (strcmp(name, "qkv_lean") == 0) { c->qkv_lean = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);
 }
 
@@ -1641,142 +1552,6 @@ extern "C" int vog_graph_destroy(vog_graph* g) {
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
   return 0;
-}
-
-// ---- AQL programs (aql.hip): the same launch sequence as vog_forward, recorded instead of launched
-struct vog_aql_program {
-  vog::AqlProgram* p = nullptr;
-};
-
-namespace vog {
-struct ChainRecorder : LaunchRecorder {
-  std::vector<LaunchRecord>* dst = nullptr;
-  void add(const LaunchRecord& r) override { dst->push_back(r); }
-};
-}  // namespace vog
-
-extern "C" int vog_aql_open(int n_queues) { return vog::aql_open(n_queues); }
-
-extern "C" int vog_aql_program_create(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,
-                                      int split_chains, vog_aql_program** out) {
-  VOG_CHECK_ARG(c && b && ws && out);
-  Plan plan;
-  std::vector<Step> steps;
-  VOG_TRY(build_steps(c, b, ws, ws_bytes, plan, steps));
-  // three chains: language (branch 1) and vision (branch 0) before the join marker are
-  // independent of each other; everything after the join is one chain
-  std::vector<LaunchRecord> pre, lang, vis, tail;
-  vog::ChainRecorder rec;
-  bool joined = false;
-  int rc = 0;
-  vog::g_recorder = &rec;
-  for (auto& s : steps) {
-    if (s.branch < 0) { joined = true; continue; }
-    rec.dst = joined ? &tail : (s.branch == 2 ? &pre : (s.branch == 1 ? &lang : &vis));
-    rc = s.fn(vog::recorder_stream());
-    if (rc != 0) break;
-  }
-  vog::g_recorder = nullptr;
-  if (rc != 0) return rc;
-  std::vector<std::vector<LaunchRecord>> rows;
-  for (auto& r : pre) rows.push_back({r});      // the fused prologue feeds both chains
-  if (split_chains) {
-    const size_t n = lang.size() > vis.size() ? lang.size() : vis.size();
-    for (size_t i = 0; i < n; ++i) {
-      // language kernel first: the persistent BiLSTM layer needs 64 completely EMPTY CUs (its waves
-      // hold ~440 registers per lane, nothing else fits beside them on a SIMD), which it only finds
-      // right behind the row's barrier; dispatched second it waits until the vision kernel of the row
-      // has drained and the row runs serially (measured: 290 us per forward either way)
-      std::vector<LaunchRecord> row;
-      if (i < lang.size()) row.push_back(lang[i]);
-      if (i < vis.size()) row.push_back(vis[i]);
-      rows.push_back(row);
-    }
-  } else {
-    for (auto& r : lang) rows.push_back({r});
-    for (auto& r : vis) rows.push_back({r});
-  }
-  if (tail.empty()) {
-    // the completion signal rides on the last packet: it must be alone in its row
-    if (!rows.empty() && rows.back().size() > 1) {
-      LaunchRecord last = rows.back().back();
-      rows.back().pop_back();
-      rows.push_back({last});
-    }
-  }
-  for (auto& r : tail) rows.push_back({r});
-  vog_aql_program* pr = new vog_aql_program();
-  rc = vog::aql_program_build(rows, &pr->p);
-  if (rc != 0) { delete pr; return rc; }
-  *out = pr;
-  return 0;
-}
-
-extern "C" int vog_group_aql_program_create(vog_ctx* c, const vog_batch* lb, void* lws, size_t lbytes,
-                                            const vog_batch* const* members, void* const* wss,
-                                            const size_t* wbytes, int n, vog_aql_program** out) {
-  VOG_CHECK_ARG(out);
-  std::vector<Step> steps;
-  std::vector<int> mo;
-  VOG_TRY(vog::build_group(c, lb, lws, lbytes, members, wss, wbytes, n, steps, mo));
-  // language rows one kernel each; then row r = r-th kernel of every member (independent of each other)
-  std::vector<LaunchRecord> lang;
-  std::vector<std::vector<LaunchRecord>> chains(n);
-  vog::ChainRecorder rec;
-  int rc = 0;
-  vog::g_recorder = &rec;
-  for (size_t i = 0; i < steps.size() && rc == 0; ++i) {
-    rec.dst = mo[i] < 0 ? &lang : &chains[mo[i]];
-    rc = steps[i].fn(vog::recorder_stream());
-  }
-  vog::g_recorder = nullptr;
-  if (rc != 0) return rc;
-  std::vector<std::vector<LaunchRecord>> rows;
-  for (auto& r : lang) rows.push_back({r});
-  size_t longest = 0;
-  for (auto& ch : chains) longest = ch.size() > longest ? ch.size() : longest;
-  for (size_t r = 0; r < longest; ++r) {
-    std::vector<LaunchRecord> row;
-    for (auto& ch : chains) if (r < ch.size()) row.push_back(ch[r]);
-    rows.push_back(row);
-  }
-  // one completion signal rides on the very last packet: close with a single-kernel row
-  if (rows.back().size() > 1) {
-    std::vector<LaunchRecord> last = rows.back();
-    rows.pop_back();
-    for (auto& r : last) rows.push_back({r});
-  }
-  vog_aql_program* pr = new vog_aql_program();
-  rc = vog::aql_program_build(rows, &pr->p);
-  if (rc != 0) { delete pr; return rc; }
-  *out = pr;
-  return 0;
-}
-
-extern "C" int vog_aql_program_info(const vog_aql_program* p, int* packets, int* rows) {
-  VOG_CHECK_ARG(p && p->p);
-  if (packets) *packets = vog::aql_program_packets(p->p);
-  if (rows) *rows = vog::aql_program_rows(p->p);
-  return 0;
-}
-
-extern "C" int vog_aql_submit(vog_aql_program* const* progs, int n, int queue) {
-  VOG_CHECK_ARG(progs && n >= 1 && n <= 64);
-  vog::AqlProgram* ps[64];
-  for (int i = 0; i < n; ++i) { VOG_CHECK_ARG(progs[i] && progs[i]->p); ps[i] = progs[i]->p; }
-  return vog::aql_submit(ps, n, queue);
-}
-
-extern "C" int vog_aql_wait(vog_aql_program* p, uint64_t timeout_us) {
-  VOG_CHECK_ARG(p && p->p);
-  return vog::aql_wait(p->p, timeout_us);
-}
-
-extern "C" int vog_aql_program_destroy(vog_aql_program* p) {
-  if (!p) return 0;
-  const int rc = vog::aql_program_destroy(p->p);
-  delete p;
-  return rc;
 }
 
 extern "C" int vog_time_kernel(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes,

@@ -7,8 +7,8 @@
 //  * gemm_pipe:   BMxBNx64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16, operands by LDS-DMA
 //    (global_load_lds) through a 2-4 stage ring, one raw s_barrier per K tile, epilogue through LDS
 //    (plain rows, or the Q / K / V^T MFMA-fragment images the attention kernels read). K % 64 == 0.
-//  * qkv_rowblock (vog_qkv_args.wqkv_p32): 64 rows x 512 columns per workgroup, rows in LDS once,
-//    weights streamed once in fragment order (the tail kernel's machinery); optional.
+//  * qkv_rowall (vog_qkv_args.wqkv_p32; p100): one workgroup per 64 rows walks all output columns, rows in LDS once,
+//    weights streamed in fragment order (the tail kernel's machinery).
 //  * gemm_skinny: M <= 64. Weight-streaming regime: one workgroup owns 16 output columns, its 4
 //    waves split K, weights and activations in fragment order go straight to registers (no LDS
 //    round trip for an operand that is read exactly once), v_mfma_f32_16x16x32, partial sums meet
@@ -136,14 +136,6 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
   p.w_frag = g->w_frag; p.a_frag = g->a_frag;
   if (g->w_lo && !(p.M <= 64 && (p.K % 32) == 0 && p.w_frag))
     VOG_FAIL(-1, "vog_gemm_args.w_lo: only the M <= 64 kernel with fragment-ordered weights takes hi + lo operands");
-  if (g->argvec_tail) {
-    const vog_argvec_tail* t = g->argvec_tail;
-    VOG_CHECK_ARG(t->counter && t->capture && t->inds_msk && t->w && t->bias && t->lang && t->Bn > 0 && t->nsrl > 0);
-    VOG_CHECK_ARG(p.M <= 64 && (p.K % 32) == 0 && p.c32 && p.N == t->L && p.ldc == t->L && t->L <= 512 && (t->L % 16) == 0 &&
-                  p.rep == 1 && !p.out_rows && ceil_div(p.N, 16) < 128);
-    p.av_counter = t->counter; p.av_capture = t->capture; p.av_msk = t->inds_msk; p.av_w = t->w; p.av_b = t->bias;
-    p.av_lang = t->lang; p.av_rows = t->Bn * t->nsrl; p.av_T = t->T; p.av_nsrl = t->nsrl; p.av_L = t->L;
-  }
   if (p.a_frag && !(p.M <= 64 && (p.K % 32) == 0 && !g->a_is_f32 && !g->a_rows))
     VOG_FAIL(-1, "a_frag activations are only valid for the M <= 64 kernel with a 16-bit A (M=%d K=%d)", p.M, p.K);
   if (p.w_frag && !(p.M <= 64 && (p.K % 32) == 0 && (p.N % 16) == 0))
@@ -181,16 +173,16 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
       // short K (a wave owns <= 2 k-steps: the language half of mul_tx's layer-0 QKV, K = 256): the 2-deep register chunk
       // - 84 instead of 192 registers (the 8-deep form loads six zero fragments per operand), i.e. 4 instead of 2
       // workgroups per CU for the 144 workgroups of that launch. Same k order per wave: bit-identical.
-      const bool shortk = p.K / 32 <= 8 && !p.av_counter;
+      const bool shortk = p.K / 32 <= 8;
       if (g->w_lo) {
         // hi + lo operands (round 6): fp32 rows split in the kernel, fragment-ordered W and W_lo
-        if (!(g->a_is_f32 && p.w_frag && !p.av_counter))
+        if (!(g->a_is_f32 && p.w_frag))
           VOG_FAIL(-1, "hi + lo M <= 64 GEMM: needs an fp32 A operand and fragment-ordered weights (w_frag) with their remainder (w_lo)");
         p.w_lo = (const unsigned short*)g->w_lo;
-        ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, false, true>), grid, dim3(256), lds1, st, p);
+        ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, true>), grid, dim3(256), lds1, st, p);
       } else if (shortk) {
-        if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
-        else ::vog::launch((gemm_skinny<T16, false, 2, 1, 4, false>), grid, dim3(256), lds1, st, p);
+        if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 2, 1, 4>), grid, dim3(256), lds1, st, p);
+        else ::vog::launch((gemm_skinny<T16, false, 2, 1, 4>), grid, dim3(256), lds1, st, p);
       } else if (g->a_is_f32) ::vog::launch((gemm_skinny<T16, true, 8, 1>), grid, dim3(256), lds1, st, p);
       else ::vog::launch((gemm_skinny<T16, false, 8, 1>), grid, dim3(256), lds1, st, p);
     }
@@ -209,10 +201,6 @@ const void* kid_gemm_pipe_qkv(int dtype) {
                            : reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 2, EPI_QKV>);
 }
 
-const void* kid_qkv_rowblock(int dtype) {
-  return dtype == VOG_BF16 ? reinterpret_cast<const void*>(qkv_rowblock_kernel<BF16, 2>)
-                           : reinterpret_cast<const void*>(qkv_rowblock_kernel<F16, 2>);
-}
 
 int gemm_run(const vog_gemm_args* g, hipStream_t st) {
   VOG_CHECK_ARG(g && g->a && g->w && (g->c32 || g->c16));
@@ -264,50 +252,21 @@ int qkv_run(const vog_qkv_args* a, hipStream_t st) {
       VOG_FAIL(-1, "hi + lo QKV projection needs the LDS-DMA GEMM (K %% 64 == 0, more than 64 rows, 16-byte aligned operands)");
     VOG_DISPATCH_DTYPE(a->dtype, return (launch_pipe_cfg<T16, 64, 64, 2, EPI_QKV, true>(p, st)));
   }
-  if (a->wqkv_p32) {
-    if (!qkv_rowblock_supported(p.N, p.K))
-      VOG_FAIL(-1, "row-block QKV: unsupported shape (K %% 128 == 0, 256 <= K <= 1024, (3*H*dp / 32) even)");
+  // one workgroup per row block walks ALL output columns (QkvRowAllBody, qkvrb_dev.h); shapes it does not take (K = 768: the staged
+  // rows + 8 epilogue tiles pass 160 KB of LDS) run the tiled GEMM on `wqkv`
+  if (a->wqkv_p32 && qkv_rowblock_supported(p.N, p.K) && (p.N % 32) == 0 && QkvRowAllBody<F16>::lds_bytes(p.K) <= 160 * 1024) {
     p.w_p32 = (const unsigned short*)a->wqkv_p32;
-    p.dep_flags = a->dep_flags; p.dep_nb0 = a->dep_nb0; p.dep_rep = a->dep_rep; p.dep_nh0 = a->dep_nh0; p.dep_nh1 = a->dep_nh1;
-    if (a->dep_flags) VOG_CHECK_ARG(a->dep_rep >= 1 && a->dep_nb0 >= 1 && a->dep_nh0 >= 1 && a->dep_nh1 >= 1);
-    // 256 instead of 512 columns per workgroup (84 instead of 146 registers: two or three workgroups share a CU and overlap their
-    // staging / streaming / epilogue phases) from 8192 rows: cfg 4 67.2 -> 58.8 and 82.2 -> 74.2 us, 5285 -> 5360 queries/s;
-    // at the few hundred rows of gt5 the wide form holds fewer CUs. VOG_QKV_NARROW = 0 / 1 forces (perf experiments).
-    static const int narrow_env = perf_env("VOG_QKV_NARROW") ? atoi(perf_env("VOG_QKV_NARROW")) : -1;
-    const int narrow = narrow_env >= 0 ? narrow_env : (p.M >= 8192 && !a->dep_flags ? 1 : 0);
     const int nrb = ceil_div(p.M, 64);
-    // many rows (p100): one workgroup per row block walks ALL output columns (QkvRowAllBody, qkvrb_dev.h)
-    static const int all_env = perf_env("VOG_QKV_ROWALL") ? atoi(perf_env("VOG_QKV_ROWALL")) : -1;
-    const bool rowall = (all_env >= 0 ? all_env != 0 : p.M >= 8192) && !a->dep_flags && (p.N % 32) == 0 &&
-                        QkvRowAllBody<F16>::lds_bytes(p.K) <= 160 * 1024;
-    if (rowall) {
-      const size_t lds_a = QkvRowAllBody<F16>::lds_bytes(p.K);
-      VOG_DISPATCH_DTYPE(a->dtype, {
-        auto kern = qkv_rowall_kernel<T16>;
-        static bool attr_set = false;
-        if (!attr_set) {
-          VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          attr_set = true;
-        }
-        ::vog::launch(kern, dim3(nrb), dim3(512), lds_a, st, p);
-      });
-      VOG_LAUNCH_CHECK();
-      return 0;
-    }
-    const size_t lds = QkvRowBlockBody<F16, 2>::lds_bytes(p.K);
-#define VOG_QKVRB(NBWV)                                                                                        \
-    VOG_DISPATCH_DTYPE(a->dtype, {                                                                              \
-      auto kern = qkv_rowblock_kernel<T16, NBWV>;                                                               \
-      static bool attr_set = false;                                                                             \
-      if (!attr_set) {                                                                                          \
-        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        attr_set = true;                                                                                        \
-      }                                                                                                         \
-      const int per = ceil_div(nrb * ceil_div(p.N, QkvRowBlockBody<T16, NBWV>::WG_COLS), 8);                    \
-      ::vog::launch(kern, dim3(per * 8), dim3(512), lds, st, p);                                                \
-    })
-    if (narrow) VOG_QKVRB(1); else VOG_QKVRB(2);
-#undef VOG_QKVRB
+    const size_t lds_a = QkvRowAllBody<F16>::lds_bytes(p.K);
+    VOG_DISPATCH_DTYPE(a->dtype, {
+      auto kern = qkv_rowall_kernel<T16>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      ::vog::launch(kern, dim3(nrb), dim3(512), lds_a, st, p);
+    });
     VOG_LAUNCH_CHECK();
     return 0;
   }

@@ -1,7 +1,6 @@
 // Device side of gemm.hip (kernel bodies; also included by pair.hip, which fuses two bodies into one launch).
 #pragma once
 #include "common.h"
-#include "argvec_dev.h"
 
 namespace vog {
 
@@ -38,13 +37,6 @@ struct GemmParams {
   // st_kv_vis: K and V fragments only for the VISUAL rows (ntok = nppf per sequence, npad_kv), no
   // language part added: the separable attention (attention.hip, attn_struct_kernel) adds it itself
   int st_kv_vis, npad_kv;
-  // tail of the M <= 64 kernel (av_counter != nullptr; vog_argvec_tail): the argument vectors in the same launch
-  unsigned int* av_counter; const int64_t* av_capture; const int64_t* av_msk; const float* av_w; const float* av_b;
-  float* av_lang; int av_rows, av_T, av_nsrl, av_L;
-  // row-block QKV as a consumer inside the encoders' launch (dep_flags != nullptr): its rows are written by the lean encoder
-  // workgroups (visenc_dev.h: done_flags[block * 2 + half]); dep_nb0 = proposal row blocks, dep_rep = proposals per segment
-  // row, dep_nh0 / dep_nh1 = column halves of the proposal / segment encoder
-  const unsigned int* dep_flags; int dep_nb0, dep_rep, dep_nh0, dep_nh1;
   // round 6, hi + lo operands: a_lo / w_lo = t16(x - t16(x)) of the fp32 activations / weights in the layout of a / w (w_lo in
   // fragment order for the M <= 64 kernel); product = a.w + a_lo.w + a.w_lo (three MFMAs, fp32 accumulate). QKV epilogue:
   // q_lo / k_lo = the remainders of the Q / K fragments (the attention kernels' hi + lo contraction reads them).
@@ -96,10 +88,6 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
       if (orow < 0) return;
       if (p.c32) p.c32[(int64_t)orow * p.ldc + col] = v;
       if (p.c16) p.c16[(int64_t)orow * p.ldc16 + col] = p.c16_bf16 ? to16<BF16>(v) : to16<F16>(v);
-      return;
-    }
-    if (p.av_counter) {   // argument-vector tail: other workgroups read this tile in the same launch -> write through
-      __hip_atomic_store(p.c32 + (int64_t)row * p.ldc + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
     for (int j = 0; j < p.rep; ++j) {
@@ -620,12 +608,9 @@ __global__ __launch_bounds__(256) void gemm_pipe(GemmParams p) {
 // SK_CH = k-steps (of 32) per register chunk. The W panel is the HBM-bound stream of this
 // kernel: with K = 2048 a wave owns 16 k-steps, and all 16 of its weight fragments are
 // requested before anything else (one round trip instead of two).
-// TAIL = false: the body without the argument-vector tail (vog_argvec_tail) - what shares a launch with the QKV GEMM
-// (pair.hip): the tail's row gather costs ~50 registers, and a pair kernel allocates the maximum of its halves for EVERY
-// workgroup (200 registers halved the occupancy of the 516 QKV workgroups riding with the 64 of the out-projection).
 // SPLIT (round 6; fp32 A, fragment-ordered W and W_lo): hi + lo operands, three MFMAs per k-step - the language half of
 // mul_tx's layer-0 QKV for checkpoints whose attention is too sharp for 16-bit logits.
-template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true, bool SPLIT = false>
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool SPLIT = false>
 struct GemmSkinnyBody {
   using Params = GemmParams;
   static constexpr int THREADS = KW * 64;
@@ -758,47 +743,13 @@ struct GemmSkinnyBody {
       }
     }
   }
-  // ---- tail (vog_argvec_tail): the argument vectors need rows of the WHOLE product (c32 = `full`): every
-  // workgroup writes its tile THROUGH to memory (sc1 stores, epilogue_store), counts itself in once the
-  // stores are acknowledged and waits for the other gx * gy workgroups of this launch (they are few - 16 x 4
-  // for the language out-projection - small, and dispatched first: all co-resident), then computes ITS
-  // share of the vectors - the 16 output columns bx, the rows by, by + gy, ... - reading `full` with
-  // L1-bypassing loads. No fences: a release / acquire pair per workgroup (buffer_wbl2 / buffer_inv)
-  // was measured first and cost more than the launch it removes - inside a pair launch the L2 write-back
-  // also flushes the Q / K / V fragments the partner GEMM is writing (212 vs 205 us per forward).
-  // The wait is bounded: on a timeout the share is written as NaN.
-  if constexpr (TAIL) if (p.av_counter) {
-    __syncthreads();
-    __shared__ unsigned int av_flag;
-    if (tid == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(p.av_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int want = cx.gx * cx.gy;
-      unsigned int spins = 0, bad = 0;
-      while (__hip_atomic_load(p.av_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 24)) { bad = 1; break; }
-      }
-      av_flag = bad;
-    }
-    __syncthreads();
-    const bool poison = av_flag != 0;
-    const int o0 = (int)cx.bx * 16 * NT + wid * 4;
-    if (wid < 4 * NT) {
-      for (int r0 = (int)cx.by; r0 < p.av_rows; r0 += 2 * (int)cx.gy) {
-        const int r1 = r0 + (int)cx.gy;
-        const int ba[2] = {r0, r1 < p.av_rows ? r1 : -1};
-        argvec_rows<2, true>(p.c32, p.av_capture, p.av_msk, p.av_w, p.av_b, p.av_lang, p.av_T, p.av_nsrl, p.av_L, o0, ba, lane, poison);
-      }
-    }
-  }
 }
 };
 
-template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool TAIL = true, bool SPLIT = false>
+template <typename T16, bool A_F32, int SK_CH, int NT, int KW = 4, bool SPLIT = false>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-  GemmSkinnyBody<T16, A_F32, SK_CH, NT, KW, TAIL, SPLIT>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, sk_smem);
+  GemmSkinnyBody<T16, A_F32, SK_CH, NT, KW, SPLIT>::run(p, BlockCtx{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, sk_smem);
 }
 
 }  // namespace vog

@@ -31,7 +31,6 @@
 #include "txtail_dev.h"
 #include "visenc_dev.h"
 #include "qkvrb_dev.h"
-#include "attn_tile2_dev.h"
 #include <tuple>
 #include "pair_ids.h"
 
@@ -61,70 +60,7 @@ void pair_kernel(typename A::Params a, typename B::Params b, unsigned nA, unsign
   }
 }
 
-// three bodies in one grid: A first (the persistent BiLSTM), then B, then C (C may depend on B through flags in memory:
-// its blocks are dispatched after B's, so a waiting C block can never keep a B block from becoming resident)
-template <typename A, typename B, typename Cc>
-__global__ __launch_bounds__((A::THREADS > B::THREADS ? (A::THREADS > Cc::THREADS ? A::THREADS : Cc::THREADS)
-                                                      : (B::THREADS > Cc::THREADS ? B::THREADS : Cc::THREADS)))
-void pair3_kernel(typename A::Params a, typename B::Params b, typename Cc::Params c, unsigned nA, unsigned nB, unsigned gax,
-                  unsigned gay, unsigned gbx, unsigned gby, unsigned gcx, unsigned gcy) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char pair3_smem[];
-  constexpr int MAXT = A::THREADS > B::THREADS ? (A::THREADS > Cc::THREADS ? A::THREADS : Cc::THREADS)
-                                               : (B::THREADS > Cc::THREADS ? B::THREADS : Cc::THREADS);
-  if (blockIdx.x < nA) {
-    if (A::THREADS < MAXT && (int)threadIdx.x >= A::THREADS) return;
-    A::run(a, BlockCtx{blockIdx.x % gax, blockIdx.x / gax, gax, gay}, pair3_smem);
-  } else if (blockIdx.x < nA + nB) {
-    const unsigned id = blockIdx.x - nA;
-    if (B::THREADS < MAXT && (int)threadIdx.x >= B::THREADS) return;
-    B::run(b, BlockCtx{id % gbx, id / gbx, gbx, gby}, pair3_smem);
-  } else {
-    const unsigned id = blockIdx.x - nA - nB;
-    if (Cc::THREADS < MAXT && (int)threadIdx.x >= Cc::THREADS) return;
-    Cc::run(c, BlockCtx{id % gcx, id / gcx, gcx, gcy}, pair3_smem);
-  }
-}
-
 typedef int (*PairFn)(const LaunchRecord&, const LaunchRecord&, hipStream_t);
-typedef int (*TripleFn)(const LaunchRecord&, const LaunchRecord&, const LaunchRecord&, hipStream_t);
-
-template <typename A, typename B, typename Cc>
-static int launch_triple(const LaunchRecord& ra, const LaunchRecord& rb, const LaunchRecord& rc, hipStream_t st) {
-  constexpr int MAXT = A::THREADS > B::THREADS ? (A::THREADS > Cc::THREADS ? A::THREADS : Cc::THREADS)
-                                               : (B::THREADS > Cc::THREADS ? B::THREADS : Cc::THREADS);
-  if ((int)ra.block[0] != A::THREADS || (int)rb.block[0] != B::THREADS || (int)rc.block[0] != Cc::THREADS || ra.grid[2] != 1 ||
-      rb.grid[2] != 1 || rc.grid[2] != 1 || ra.arg_bytes != sizeof(typename A::Params) ||
-      rb.arg_bytes != sizeof(typename B::Params) || rc.arg_bytes != sizeof(typename Cc::Params))
-    VOG_FAIL(-1, "triple launch: recorded launches do not match the registered bodies");
-  typename A::Params pa; typename B::Params pb; typename Cc::Params pc;
-  memcpy(&pa, ra.args, sizeof(pa)); memcpy(&pb, rb.args, sizeof(pb)); memcpy(&pc, rc.args, sizeof(pc));
-  const unsigned nA = ra.grid[0] * ra.grid[1], nB = rb.grid[0] * rb.grid[1], nC = rc.grid[0] * rc.grid[1];
-  size_t lds = ra.dyn_lds > rb.dyn_lds ? ra.dyn_lds : rb.dyn_lds;
-  lds = lds > rc.dyn_lds ? lds : rc.dyn_lds;
-  if (lds > 156 * 1024) VOG_FAIL(-1, "triple launch: %zu bytes of LDS", lds);
-  auto kern = pair3_kernel<A, B, Cc>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    attr_set = true;
-  }
-  ::vog::launch(kern, dim3(nA + nB + nC), dim3(MAXT), lds, st, pa, pb, pc, nA, nB, ra.grid[0], ra.grid[1], rb.grid[0], rb.grid[1],
-                rc.grid[0], rc.grid[1]);
-  VOG_LAUNCH_CHECK();
-  return 0;
-}
-
-static std::map<std::tuple<const void*, const void*, const void*>, TripleFn>& registry3() {
-  static std::map<std::tuple<const void*, const void*, const void*>, TripleFn> r;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    using Lstm = LstmLayerBody<F16, 32>;
-    r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16(), kid_qkv_rowblock(VOG_BF16)}] = &launch_triple<Lstm, VisEncLeanBody<F16>, QkvRowBlockBody<BF16, 2>>;
-    r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16(), kid_qkv_rowblock(VOG_F16)}] = &launch_triple<Lstm, VisEncLeanBody<F16>, QkvRowBlockBody<F16, 2>>;
-  });
-  return r;
-}
-
 template <typename A, typename B>
 static int launch_pair(const LaunchRecord& ra, const LaunchRecord& rb, hipStream_t st) {
   constexpr int MAXT = A::THREADS > B::THREADS ? A::THREADS : B::THREADS;
@@ -151,45 +87,27 @@ static int launch_pair(const LaunchRecord& ra, const LaunchRecord& rb, hipStream
   return 0;
 }
 
-// The paired out-projection body is compiled WITHOUT the argument-vector tail (128 registers, see below): a recorded launch
-// that carries one (fused_argvec = 1: GemmParams::av_counter) must not be paired, or `lang` would never be written.
-// Declined pairs run back to back (pair_launch).
 static constexpr int kPairDeclined = 1;
-template <typename A, typename B>
-static int launch_pair_no_argvec(const LaunchRecord& ra, const LaunchRecord& rb, hipStream_t st) {
-  GemmParams pa;
-  if (ra.arg_bytes != sizeof(pa)) VOG_FAIL(-1, "pair launch: recorded launches do not match the registered bodies");
-  memcpy(&pa, ra.args, sizeof(pa));
-  if (pa.av_counter != nullptr) return kPairDeclined;
-  return launch_pair<A, B>(ra, rb, st);
-}
-
 static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
   static std::map<std::pair<const void*, const void*>, PairFn> r;
   static std::once_flag once;
   std::call_once(once, [] {
-    // the out-projection next to the QKV GEMM: 4-deep register chunk, no argument-vector tail = 128 registers, so that the
-    // pair keeps the QKV workgroups' 4 per CU (the stand-alone kernel's 8-deep form has 200; same k order: bit-identical)
-    using SkinnyIh = GemmSkinnyBody<F16, false, 4, 1, 4, false>;
+    // the out-projection next to the QKV GEMM: 4-deep register chunk = 128 registers, so that the pair keeps the QKV workgroups'
+    // 4 per CU (the stand-alone kernel's 8-deep form has 200; same k order: bit-identical)
+    using SkinnyIh = GemmSkinnyBody<F16, false, 4, 1, 4>;
     using Lstm = LstmLayerBody<F16, 32>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_f16()}] = &launch_pair<Lstm, VisEncBody<F16>>;
-    r[{kid_lstm_layer_f16(), kid_vis_enc_lean_f16()}] = &launch_pair<Lstm, VisEncLeanBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_vis_enc_stream_f16()}] = &launch_pair<Lstm, VisEncStreamBody<F16, VOG_VS_PAIR_DEPTH>>;   // (one workgroup per CU inside the pair: depth instead of occupancy)
-    r[{kid_lstm_layer_f16(), kid_vis_enc_wide_f16()}] = &launch_pair<Lstm, VisEncWideBody<F16>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<Lstm, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<Lstm, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_BF16)}] = &launch_pair<Lstm, TxTailBody<BF16, F16, 2, false, 0>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_512(VOG_F16)}] = &launch_pair<Lstm, TxTailBody<F16, F16, 2, false, 0>>;
-    // p100 (round 5): obj_tx's long-sequence attention is 192 workgroups x 171 us - with the 64 of BiLSTM layer 1 the chip is
-    // exactly full and the layer's 40 us disappear inside the attention
-    r[{kid_lstm_layer_f16(), kid_attn_tile2_192(VOG_BF16)}] = &launch_pair<Lstm, AttnTile2Body<BF16, 6>>;
-    r[{kid_lstm_layer_f16(), kid_attn_tile2_192(VOG_F16)}] = &launch_pair<Lstm, AttnTile2Body<F16, 6>>;
     // hi + lo operand forms (round 6): the same three pairs for a checkpoint on the tx_split plan
     r[{kid_lstm_layer_f16(), kid_vis_enc_stream_split_f16()}] = &launch_pair<Lstm, VisEncStreamBody<F16, VOG_VS_DEPTH, true>>;
     r[{kid_lstm_layer_f16(), kid_tx_tail_split_512_f16()}] = &launch_pair<Lstm, TxTailBody<F16, F16, 2, false, 0, 1, true>>;
-    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv_split_f16()}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV, true>>;
-    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
-    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair_no_argvec<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
+    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv_split_f16()}] = &launch_pair<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV, true>>;
+    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
+    r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
   });
   return r;
 }
@@ -219,32 +137,6 @@ int pair_launch(const std::function<int(hipStream_t)>& fa, const std::function<i
   }
   VOG_TRY(fa(st));
   return fb(st);
-}
-
-// Three steps as one launch when a triple kernel is registered for them (fc may depend on fb: see pair3_kernel); otherwise
-// fa + fb as a pair, then fc.
-int pair_launch3(const std::function<int(hipStream_t)>& fa, const std::function<int(hipStream_t)>& fb,
-                 const std::function<int(hipStream_t)>& fc, hipStream_t st, bool* fused) {
-  if (fused) *fused = false;
-  if (g_pair_capture) { VOG_TRY(fa(st)); VOG_TRY(fb(st)); return fc(st); }
-  std::vector<LaunchRecord> recs;
-  g_pair_capture = &recs;
-  int rc = fa(st);
-  const size_t na = recs.size();
-  if (rc == 0) rc = fb(st);
-  const size_t nb = recs.size();
-  if (rc == 0) rc = fc(st);
-  g_pair_capture = nullptr;
-  if (rc != 0) return rc;
-  if (na == 1 && nb == 2 && recs.size() == 3) {
-    auto it = registry3().find({recs[0].host_fn, recs[1].host_fn, recs[2].host_fn});
-    if (it != registry3().end()) {
-      if (fused) *fused = true;
-      return it->second(recs[0], recs[1], recs[2], st);
-    }
-  }
-  VOG_TRY(pair_launch(fa, fb, st, nullptr));
-  return fc(st);
 }
 
 }  // namespace vog

@@ -141,12 +141,6 @@ int tx_tail_run(const vog_tx_tail_args* a, hipStream_t st) {
     VOG_CHECK_ARG((int64_t)a->score->n_vid * a->score->nfrm * a->score->nsrl * a->score->nppf == a->M);
     p.wl_p = (const unsigned short*)a->wl_p; p.bl = a->bl; p.wl2 = a->score->w2; p.bl2 = a->score->b2;
     p.sc = *a->score;
-    if (a->pred) {
-      VOG_CHECK_ARG(a->pred_counter && a->pred->outs_eval == a->score->outs_eval && a->pred->props && a->pred->rec &&
-                    a->pred->conc_type != VOG_CONC_SEP && a->pred->B > 0);
-      p.pred = *a->pred; p.pred_counter = a->pred_counter;
-      p.pred_rec_bytes = vog_pred_record_bytes(a->pred->ncmp, a->pred->nsrl, a->pred->nfrm0);
-    }
   }
   if (a->attn16_lo || a->wo_p_lo || a->w1_p_lo || a->w2_p_lo || a->y16_lo) {
     // hi + lo operands (round 6): every operand of the three GEMM stages with its 16-bit remainder

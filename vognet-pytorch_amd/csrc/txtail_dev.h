@@ -1,7 +1,6 @@
 // Device side of txtail.hip (kernel bodies; also included by pair.hip, which fuses two bodies into one launch).
 #pragma once
 #include "common.h"
-#include "pred_dev.h"
 
 #ifndef VOG_TAIL_PF1
 #define VOG_TAIL_PF1 4      // k-steps of weight prefetch in the FFN1 stage (one 32-column block per wave); 8 measured: 84 more bytes of scratch in the mul tail, 0.5-1 % slower at cfg 2 and cfg 4 (scratch/r4_pf.sh)
@@ -22,8 +21,6 @@ struct TailParams {
   float* y32; unsigned short* y16; int y16_bf16;
   const float *bl, *wl2, *bl2;
   vog_score_args sc;
-  // prediction head in the same launch (pred_counter != nullptr; SCORE kernels): the workgroup that arrives last runs it
-  vog_pred_args pred; int64_t pred_rec_bytes; unsigned int* pred_counter;
   int M;
   int nt_rows;   // non-temporal loads of the attention rows (large M)
   int xcds;      // > 0 (round 5): the row blocks run on the first `xcds` XCDs only (grid = ceil(blocks / xcds) * 8; block b sits on
@@ -586,25 +583,7 @@ struct TxTailBody {
       for (int ww = 0; ww < 8; ++ww) logit += red[ww * ROWS + tid];
       p.sc.outs[o_idx] = logit;
       const float ev = tail_sigmoid(logit) * am * cm;
-      if (p.pred_counter) __hip_atomic_store(&p.sc.outs_eval[o_idx], ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write through
-      else p.sc.outs_eval[o_idx] = ev;
-    }
-    // ---- prediction head (per-frame arg-max + box gather) without a launch of its own: every workgroup counts
-    // itself in once its scores are written through; the one that finds all others there runs the head for the
-    // whole batch, reading the scores past L1 / L2. Nobody waits for anybody.
-    if (p.pred_counter) {
-      unsigned int* flag = reinterpret_cast<unsigned int*>(red);          // (red is free: the logits were read above)
-      __syncthreads();
-      if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // wave 0 wrote this workgroup's 64 scores
-        const unsigned int old = __hip_atomic_fetch_add(p.pred_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = old == (unsigned)((p.M + ROWS - 1) / ROWS) - 1 ? 1u : 0u;
-      }
-      __syncthreads();
-      if (flag[0]) {
-        const int total = p.pred.B * p.pred.nsrl * p.pred.nfrm0 * p.pred.ncmp;
-        for (int i = tid; i < total; i += THREADS) pred_item<true>(p.pred, p.pred_rec_bytes, i);
-      }
+      p.sc.outs_eval[o_idx] = ev;
     }
   }
 }

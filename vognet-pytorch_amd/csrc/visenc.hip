@@ -42,9 +42,7 @@ __global__ __launch_bounds__(256) void seg_replicate_kernel(float* c32, unsigned
 }
 
 const void* kid_vis_enc_f16() { return reinterpret_cast<const void*>(vis_enc_kernel<F16>); }
-const void* kid_vis_enc_lean_f16() { return reinterpret_cast<const void*>(vis_enc_lean_kernel<F16>); }
 const void* kid_vis_enc_stream_f16() { return reinterpret_cast<const void*>(vis_enc_stream_kernel<F16>); }
-const void* kid_vis_enc_wide_f16() { return reinterpret_cast<const void*>(vis_enc_wide_kernel<F16>); }
 const void* kid_vis_enc_stream_split_f16() { return reinterpret_cast<const void*>(vis_enc_stream_kernel<F16, true>); }
 
 int vis_encode_supported(int prop_dim, int seg_dim, int prop_enc, int seg_enc) {
@@ -63,13 +61,12 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
   p.p[1] = VisEncProb{a->seg, (const unsigned short*)a->w_seg_f, a->b_seg, a->n_prop_rows / a->nppf0, a->seg_enc,
                       a->seg_dim, a->nppf0, a->prop_enc, (const unsigned short*)a->w_seg_f_lo};
   const bool split = a->w_prop_f_lo || a->w_seg_f_lo || a->c16_lo;     // hi + lo operands (round 6): the stream form only
-  if (split) VOG_CHECK_ARG(a->w_prop_f_lo && a->w_seg_f_lo && a->c16_lo && a->c16 && a->lean && !a->defer_replicas && !a->done_flags);
+  if (split) VOG_CHECK_ARG(a->w_prop_f_lo && a->w_seg_f_lo && a->c16_lo && a->c16 && a->lean && !a->defer_replicas);
   p.c16_lo = (unsigned short*)a->c16_lo;
   p.tiles0 = ceil_div(p.p[0].M, 16);
   p.tiles_all = p.tiles0 + ceil_div(p.p[1].M, 16);
   p.c32 = a->c32; p.c16 = (unsigned short*)a->c16; p.ldc = a->ldc;
   p.c16_bf16 = a->c16_dtype == VOG_BF16;
-  p.done_flags = a->lean ? a->done_flags : nullptr;
   if (a->lean) {
     const int nb = ceil_div(p.tiles0, 4) + ceil_div(p.tiles_all - p.tiles0, 4);
     // many replicas per segment row (p100: 100): the encoder kernel writes replica 0, a copy kernel the rest
@@ -77,11 +74,10 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
     if (a->defer_replicas && !can_copy) VOG_FAIL(-1, "vog_vis_encode: defer_replicas needs encode sizes and ldc %% 4 == 0");
     const bool split_rep = !a->defer_replicas && p.p[1].rep > 16 && can_copy;
     p.rep_first_only = (split_rep || a->defer_replicas) ? 1 : 0;
-    // the stream form (round 5; visenc_dev.h): same tiling, K chunks of 128, DEPTH chunks of fp32 rows in flight per workgroup.
-    // cfg 2 pair launch with BiLSTM layer 0: 36.0 -> 32.4 us; p100: 57.6 -> 45 us alone, 78 -> 69 us in the pair
-    // (VOG_VE_STREAM=0: round 4's lean form, perf experiments; the chained form - done_flags - stays on the lean body)
-    static const int stream_env = perf_env("VOG_VE_STREAM") ? atoi(perf_env("VOG_VE_STREAM")) : -1;
-    const bool stream = ((stream_env >= 0 ? stream_env != 0 : true) && p.done_flags == nullptr) || split;
+    // the stream form (round 5; visenc_dev.h): 64 rows x 128 columns per workgroup, K chunks of 128, two register sets of fp32 row
+    // pieces + weight fragments in flight. cfg 2 pair launch with BiLSTM layer 0: 36.0 -> 32.4 us; p100: 57.6 -> 45 us alone.
+    // (Round 4's lean form and the 128-row x 256-column wide form - measured 112 us against 41.5 at p100 - were removed in round 6:
+    // scratch/negatives/r6_pruned/.)
     if (split) {
       if (split_rep) VOG_FAIL(-1, "vog_vis_encode with hi + lo operands: more than 16 replicas per segment row are not supported");
       auto launch_split = [&](auto tag) {
@@ -99,21 +95,8 @@ int vis_encode_run(const vog_visenc_args* a, hipStream_t st) {
       VOG_LAUNCH_CHECK();
       return 0;
     }
-    // VOG_VE_WIDE=1 (perf experiments; measured, off): 128 rows x all 256 columns per workgroup - a row read once, a quarter of
-    // the weight bytes, but 127 workgroups of 224 registers with one chunk of look-ahead: 112 us alone at p100 against 41.5
-    // (the pair launch 113 against 68), cfg 4 5.52 vs 5.47 k queries/s (profiles/round5_vis_enc_stream.md)
-    static const int wide_env = perf_env("VOG_VE_WIDE") ? atoi(perf_env("VOG_VE_WIDE")) : -1;
-    const bool wide = stream && wide_env > 0 && p.p[0].N <= 256 && p.p[1].N <= 256;
-    if (wide) {
-      const int nbw = ceil_div(p.p[0].M, 128) + ceil_div(p.p[1].M, 128);
-      VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_wide_kernel<T16>), dim3(nbw), dim3(512), VisEncWideBody<T16>::LDS, st, p));
-    } else if (stream) {
-      VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_stream_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
-                                                 VisEncStreamBody<T16>::LDS, st, p));
-    } else {
-      VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_lean_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
-                                                 VisEncLeanBody<T16>::LDS, st, p));
-    }
+    VOG_DISPATCH_DTYPE(a->dtype, ::vog::launch((vis_enc_stream_kernel<T16>), dim3(ceil_div(nb, 8) * 16), dim3(512),
+                                               VisEncStreamBody<T16>::LDS, st, p));
     VOG_LAUNCH_CHECK();
     if (split_rep) {
       const int64_t total = (int64_t)p.p[1].M * (p.p[1].rep - 1) * (p.p[1].N / 4);

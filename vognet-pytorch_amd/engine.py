@@ -153,7 +153,7 @@ def attention_sharpness(sd, n_heads_obj: int, n_heads_mul: int) -> float:
 # serialised on the GPU whatever the caller does and at most N layer kernels are ever resident. N = 4; while
 # a cross-rank gather is pending the last lane yields to it (`_max_inflight`, `dist.pending_collective`).
 # Streams that keep to themselves (bench.py: one slot per stream; the evaluator: one stream)
-# never wait. (AQL programs run on the library's own queues: aql.hip has its own guard.)
+# never wait.
 _LANE_BOOK: Dict[int, Dict[int, "torch.cuda.Stream"]] = {}
 _STREAM_LANE: Dict[int, Dict[int, int]] = {}
 
@@ -461,7 +461,7 @@ class VogEngine:
             _lane_enter(self.device, None)
             ws = self.workspace(B, ncmp, T)
             if self.precise is not None:                    # checkpoints outside the f16 envelope: the fp32 path alone (precise.py)
-                self.precise.run(inp, out)
+                self.precise.run(inp, out, T=T)
             else:
                 L.check(self.lib.vog_forward(self.ctx, C.byref(b), ws.data_ptr(), ws.numel(),
                                              L.stream_ptr()), "vog_forward")
@@ -476,23 +476,6 @@ class VogEngine:
         stream one after the other (every forward re-initialises the state it needs in its prologue): N input sets
         cycling through a few workspaces, the layout of a serving loop whose requests arrive in fresh buffers."""
         return Slot(self, inp, T, with_pred, self.use_graph if graph is None else graph, pred_rec, share_ws_with)
-
-    def aql_open(self, n_queues: int = 1) -> None:
-        """Create the library's own hardware queues on this device (AQL submission path)."""
-        with torch.cuda.device(self.device):
-            L.check(self.lib.vog_aql_open(int(n_queues)), "vog_aql_open")
-
-    def aql_submit(self, slots, queue: int = 0) -> None:
-        """Enqueue the AQL programs of `slots` row-interleaved on one queue. NOT stream ordered:
-        the slots' inputs must already be complete; collect results with slot.wait()."""
-        if self.precise is not None:
-            raise L.VogError("the AQL path submits pre-built packets only; this checkpoint runs the fp32 path "
-                             "(attention sharpness outside the f16 envelope): use slot.launch()")
-        for sl in slots:
-            for m in getattr(sl, "slots", [sl]):
-                m._check_epoch()
-        arr = (C.c_void_p * len(slots))(*[s.aql for s in slots])
-        L.check(self.lib.vog_aql_submit(arr, len(slots), int(queue)), "vog_aql_submit")
 
     def record_words(self, ncmp: int) -> int:
         """fp32 words of one packed prediction record (boxes || scores || pred_cmp)."""
@@ -583,7 +566,6 @@ class Slot:
                 L.check(eng.lib.vog_workspace_init(eng.ctx, self.B, self.ncmp, self.T, self.ws.data_ptr(),
                                                    self.ws.numel(), L.stream_ptr()), "vog_workspace_init")
             self.graph = None
-            self.aql = None
             if graph:
                 torch.cuda.synchronize()
                 cap = torch.cuda.Stream(device=eng.device)
@@ -666,32 +648,9 @@ class Slot:
         ev.record(stream if stream is not None else torch.cuda.current_stream(self.eng.device))
         return ev
 
-    # ---- AQL path (include/vog_hip.h "AQL programs") ------------------------------------------
-    def build_aql(self, split_chains: bool = True) -> "Slot":
-        """Record this slot's forward as an AQL program (pre-built dispatch packets)."""
-        if getattr(self, "aql", None) is not None:
-            return self
-        with torch.cuda.device(self.eng.device):
-            torch.cuda.synchronize()
-            p = C.c_void_p()
-            L.check(self.eng.lib.vog_aql_program_create(self.eng.ctx, C.byref(self.batch), self.ws.data_ptr(),
-                                                        self.ws.numel(), int(split_chains), C.byref(p)),
-                    "vog_aql_program_create")
-            self.aql = p
-            npk, nrow = C.c_int32(), C.c_int32()
-            L.check(self.eng.lib.vog_aql_program_info(p, C.byref(npk), C.byref(nrow)), "vog_aql_program_info")
-            self.aql_packets, self.aql_rows = int(npk.value), int(nrow.value)
-        return self
-
-    def wait(self, timeout_us: int = 10_000_000):
-        """Block until the slot's AQL program has completed; returns the output dict."""
-        L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
-        self.check()                          # (ADVICE r5: a stalled hand-off is a VogError here too, never NaN outputs with rc 0)
-        return self.out
-
     def update_inputs(self, inp, check_lengths: bool = True):
         """Copy a new batch (same shapes, sentence lengths <= the T this slot was captured with) into
-        the slot's buffers. T is baked into the captured graph / AQL program and the workspace: a
+        the slot's buffers. T is baked into the captured graph and the workspace: a
         longer sentence would index the LSTM schedule out of its rows, so it is refused here (capture
         the slot with T = cfg.ds.max_seq_length when the lengths are not known in advance)."""
         lens = inp.get("srl_arg_word_mask_len") if check_lengths else None      # (the check reads the lengths: a host sync)
@@ -706,8 +665,8 @@ class Slot:
 
     def _check_epoch(self):
         if self.epoch != self.eng.weights_epoch:
-            raise L.VogError("the engine's weights were re-finalized after this slot was captured: its graph / "
-                             "AQL program points at freed weight buffers - create a new slot")
+            raise L.VogError("the engine's weights were re-finalized after this slot was captured: its graph "
+                             "points at freed weight buffers - create a new slot")
 
     def check(self) -> None:
         """Raise VogError if a launch of this slot stalled since the last check (host read of pinned memory, no device
@@ -743,15 +702,13 @@ class Slot:
             return
         with torch.cuda.device(self.eng.device):
             if stream is None:
-                pf.run(self.inp, self.out)
+                pf.run(self.inp, self.out, T=self.T)
             else:
                 with torch.cuda.stream(stream):
-                    pf.run(self.inp, self.out)
+                    pf.run(self.inp, self.out, T=self.T)
 
     def __del__(self):
         try:
-            if getattr(self, "aql", None) is not None:
-                self.eng.lib.vog_aql_program_destroy(self.aql)
             if self.graph is not None:
                 self.eng.lib.vog_graph_destroy(self.graph)
         except Exception:
@@ -963,7 +920,7 @@ class Batched:
 
 
 class Group:
-    """G batch slots + one shared language-encoder workspace + one graph / AQL program for all."""
+    """G batch slots + one shared language-encoder workspace + one graph for all."""
 
     def __init__(self, eng: VogEngine, inps, with_pred=True, graph=True, pred_rec=None):
         # pred_rec: optional [len(inps) * B, record_words] buffer; member m writes rows [m*B, (m+1)*B)
@@ -1015,7 +972,6 @@ class Group:
             self._wss = (C.c_void_p * G)(*[sl.ws.data_ptr() for sl in self.slots])
             self._wsb = (C.c_size_t * G)(*[sl.ws.numel() for sl in self.slots])
             self.graph = None
-            self.aql = None
             torch.cuda.synchronize()
             if graph:
                 cap = torch.cuda.Stream(device=dev)
@@ -1053,30 +1009,8 @@ class Group:
                                                    len(self.slots), sp), "vog_group_forward")
         return self.out
 
-    def build_aql(self) -> "Group":
-        if self.aql is None:
-            with torch.cuda.device(self.eng.device):
-                torch.cuda.synchronize()
-                p = C.c_void_p()
-                L.check(self.eng.lib.vog_group_aql_program_create(
-                    self.eng.ctx, C.byref(self.lb), self.lang_ws.data_ptr(), self.lang_ws.numel(), self._members,
-                    self._wss, self._wsb, len(self.slots), C.byref(p)), "vog_group_aql_program_create")
-                self.aql = p
-        return self
-
-    def wait(self, timeout_us: int = 10_000_000):
-        L.check(self.eng.lib.vog_aql_wait(self.aql, timeout_us), "vog_aql_wait")
-        for sl in self.slots:
-            sl.check()
-        if self._lb_fault_seen != int(self._lb_fault[0]):
-            k, self._lb_fault_seen = int(self._lb_fault[0]) - self._lb_fault_seen, int(self._lb_fault[0])
-            self.eng._stalled(k, "a group's shared language encoder")
-        return self.out
-
     def __del__(self):
         try:
-            if self.aql is not None:
-                self.eng.lib.vog_aql_program_destroy(self.aql)
             if self.graph is not None:
                 self.eng.lib.vog_graph_destroy(self.graph)
         except Exception:

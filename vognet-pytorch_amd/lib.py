@@ -26,17 +26,12 @@ class VogError(RuntimeError):
     pass
 
 
-class ArgvecTail(C.Structure):
-    _fields_ = [("counter", c_vp), ("capture", c_vp), ("inds_msk", c_vp), ("w", c_vp), ("bias", c_vp), ("lang", c_vp),
-                ("Bn", c_i32), ("T", c_i32), ("nsrl", c_i32), ("L", c_i32)]
-
-
 class GemmArgs(C.Structure):
     _fields_ = [("a", c_vp), ("a_is_f32", c_i32), ("lda", c_i64), ("a_rows", c_vp),
                 ("w", c_vp), ("ldw", c_i64), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
                 ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("ldc16", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32), ("rep", c_i32),
-                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32), ("a_frag", c_i32), ("argvec_tail", c_vp), ("w_lo", c_vp)]
+                ("dtype", c_i32), ("c16_dtype", c_i32), ("out_rows", c_vp), ("out_rows_ncol", c_i32), ("res_vislang", c_vp), ("splitk", c_i32), ("w_frag", c_i32), ("a_frag", c_i32), ("w_lo", c_vp)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -63,7 +58,6 @@ class QkvArgs(C.Structure):
                 ("K", c_i32), ("dtype", c_i32),
                 ("pl", c_vp), ("nsrl", c_i32), ("nppf", c_i32), ("nfrm", c_i32), ("lang_per_vid", c_i32),
                 ("nc_v", c_i32), ("kv_visual_only", c_i32), ("npad_kv", c_i32), ("wqkv_p32", c_vp),
-                ("dep_flags", c_vp), ("dep_nb0", c_i32), ("dep_rep", c_i32), ("dep_nh0", c_i32), ("dep_nh1", c_i32),
                 ("x16_lo", c_vp), ("wqkv_lo", c_vp), ("q_lo", c_vp), ("k_lo", c_vp)]
 
 
@@ -87,7 +81,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("vt", c_vp), ("out16", c_vp), ("u", c_vp), ("pe_b", c_vp),
                 ("S", c_i32), ("N", c_i32), ("H", c_i32), ("dp", c_i32), ("npad", c_i32),
                 ("use_rel", c_i32), ("n_box", c_i32), ("seq_per_vid", c_i32), ("NP", c_i32),
-                ("inv_scale", c_f32), ("dtype", c_i32), ("guard_flag", c_vp), ("guard_precleared", c_i32), ("phase", c_i32),
+                ("inv_scale", c_f32), ("dtype", c_i32), ("guard_flag", c_vp), ("guard_precleared", c_i32),
                 ("q_lo", c_vp), ("k_lo", c_vp), ("out16_lo", c_vp), ("logit_max", c_vp)]
 
 
@@ -124,7 +118,7 @@ class TxTailArgs(C.Structure):
                 ("ln1g", c_vp), ("ln1b", c_vp), ("b1", c_vp), ("b2", c_vp), ("ln2g", c_vp), ("ln2b", c_vp),
                 ("y32", c_vp), ("y16", c_vp), ("y16_dtype", c_i32), ("wl_p", c_vp), ("bl", c_vp),
                 ("score", c_vp), ("head_dtype", c_i32), ("x1_scratch", c_vp),
-                ("M", c_i32), ("d", c_i32), ("dh", c_i32), ("dtype", c_i32), ("pred", c_vp), ("pred_counter", c_vp),
+                ("M", c_i32), ("d", c_i32), ("dh", c_i32), ("dtype", c_i32),
                 ("attn16_lo", c_vp), ("wo_p_lo", c_vp), ("w1_p_lo", c_vp), ("w2_p_lo", c_vp), ("y16_lo", c_vp)]
 
     def __init__(self, *a, **k):
@@ -142,7 +136,7 @@ class VisencArgs(C.Structure):
                 ("b_seg", c_vp), ("c32", c_vp), ("c16", c_vp), ("ldc", c_i64), ("c16_dtype", c_i32),
                 ("n_prop_rows", c_i32), ("nppf0", c_i32), ("prop_dim", c_i32), ("seg_dim", c_i32),
                 ("prop_enc", c_i32), ("seg_enc", c_i32), ("dtype", c_i32), ("lean", c_i32), ("defer_replicas", c_i32),
-                ("done_flags", c_vp), ("w_prop_f_lo", c_vp), ("w_seg_f_lo", c_vp), ("c16_lo", c_vp)]
+                ("w_prop_f_lo", c_vp), ("w_seg_f_lo", c_vp), ("c16_lo", c_vp)]
 
 
 class LossArgs(C.Structure):
@@ -344,15 +338,6 @@ SYMBOLS = {
                                   C.POINTER(c_vp), C.POINTER(C.c_size_t), c_i32, c_vp]),
     "vog_group_graph_capture": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.POINTER(C.POINTER(Batch)),
                                         C.POINTER(c_vp), C.POINTER(C.c_size_t), c_i32, c_vp, C.POINTER(c_vp)]),
-    "vog_group_aql_program_create": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t,
-                                             C.POINTER(C.POINTER(Batch)), C.POINTER(c_vp),
-                                             C.POINTER(C.c_size_t), c_i32, C.POINTER(c_vp)]),
-    "vog_aql_open": (c_i32, [c_i32]),
-    "vog_aql_program_create": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, c_i32, C.POINTER(c_vp)]),
-    "vog_aql_program_info": (c_i32, [c_vp, C.POINTER(c_i32), C.POINTER(c_i32)]),
-    "vog_aql_submit": (c_i32, [C.POINTER(c_vp), c_i32, c_i32]),
-    "vog_aql_wait": (c_i32, [c_vp, C.c_uint64]),
-    "vog_aql_program_destroy": (c_i32, [c_vp]),
     "vog_time_kernel": (c_i32, [c_vp, C.POINTER(Batch), c_vp, C.c_size_t, C.c_char_p, c_i32, c_vp, C.POINTER(c_f32)]),
 }
 

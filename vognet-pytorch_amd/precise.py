@@ -36,11 +36,12 @@ class PreciseForward:
         self._one = torch.ones(1, dtype=torch.float32, device=dev)
         self._zero = torch.zeros(1, dtype=torch.float32, device=dev)
 
-    def run(self, inp: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]) -> None:
+    def run(self, inp: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor], T=None) -> None:
         """fp32 forward of `inp` on the CURRENT stream; overwrites mdl_outs / mdl_outs_eval (/ vidf_outs, fin_scores*,
-        pred_rec) of `out` in place."""
+        pred_rec) of `out` in place. `T`: the longest sentence when the caller knows it (a slot's launch stays
+        asynchronous - no host read of the lengths on the launch stream)."""
         eng, lib, d = self.eng, self.eng.lib, self.eng.desc
-        o, acts, g = self.tr.forward(inp)
+        o, acts, g = self.tr.forward(inp, T=T)
         st = L.stream_ptr()
         B, nc_v, nsrl = g["B"], g["nc_v"], g["nsrl"]
         NP = g["nfrm"] * g["nppf"]

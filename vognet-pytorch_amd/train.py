@@ -95,15 +95,15 @@ class FP32Trainer:
         y, xs, cats = BW.stack_forward(self.params, stack, n_layers, pe_name, x, S, N, n, heads, boxes, drop=drop)
         return y, (xs, cats)
 
-    def forward(self, batch):
+    def forward(self, batch, T=None):
         """fp32 forward on the device -> ({'mdl_outs' [B, nc_v, nsrl, NP] (, 'vidf_outs' [B, ncmp])}, activations at the seams of
-        the backward, geometry)."""
+        the backward, geometry). `T`: the longest sentence if the caller knows it (a slot does): no host read of the lengths."""
         g = self._geo(batch)
         p, lib, st = self.params, self.lib, L.stream_ptr()
         B, nc_v, nfrm, nppf, nsrl = g["B"], g["nc_v"], g["nfrm"], g["nppf"], g["nsrl"]
         NP = nfrm * nppf
         BV = B * nc_v                                                   # model "videos" (sequence sets)
-        T = int(batch["srl_arg_word_mask_len"].max())
+        T = int(batch["srl_arg_word_mask_len"].max()) if T is None else int(T)
         lf = BW.language_backward(p, batch, T, self.desc.rnn_layers, drop=g.get("drop_lang"))
         lang = lf["_lang_enc"]
         f32 = lambda k: batch[k].to(self.dev, torch.float32)
