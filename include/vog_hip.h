@@ -778,24 +778,26 @@ int vog_graph_launch(vog_graph* g, void* stream);
  * completed. */
 int vog_graph_capture_fed(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_bytes, const vog_copy_seg* dma,
                           const vog_assemble_args* asm_args, const vog_copy_seg* segs, int nseg, void* stream, vog_graph** out);
-/* Integer options of a context. ("graph_dag", the language chain as a parallel graph branch, was
- * removed: lower throughput with batches in flight and unstable in the runtime; setting it to 1 fails.)
+/* Integer options of a context: eight switches and the precision plan (round 6 removed chain_obj_qkv, pair_attn, fused_argvec,
+ * fused_pred, qkv_lean and graph_dag with the measured-negative paths behind them: scratch/negatives/r6_pruned/).
+ * "tx_split" (default 0; set by engine.py from the checkpoint): hi + lo 16-bit operands, see vog_ctx_split_supported below.
  * "lstm_persistent" (default 1; env VOG_LSTM_PERSISTENT presets it): use vog_bilstm_layer instead
  * of T step launches where vog_bilstm_layer_supported. Its co-residency limit (4 instances) is met
  * automatically on HIP streams (4 hardware queues execute at most 4 kernels at once); set it to 0
- * when submitting through more than 4 AQL queues or with GPU_MAX_HW_QUEUES > 4.
+ * with GPU_MAX_HW_QUEUES > 4. "lstm_inject_stall": test hook (vog_lstm_layer_args.inject_stall).
  * "fused_tail" (default 1): run everything after the attention of an encoder layer (and, for the
  * last mul_tx layer, lin2 + the score head) as ONE vog_tx_tail_fwd launch where
  * vog_tx_tail_supported; 0 = the separate GEMM / LayerNorm / score launches (always used for other shapes).
  * "fused_enc" (default 1): vog_vis_encode instead of cast + two split-K GEMMs + finish where supported.
- * "enc_lean" (default -1 = lean exactly when the encoders will share a BiLSTM layer's launch; 0 / 1 force).
+ * "enc_lean" (default -1 = the 64-row stream form exactly when the encoders will share a BiLSTM layer's launch; 0 / 1 force).
  * "pair_launches" (default 1): step i of the language chain (input projection / BiLSTM layer / out-projection)
  * and step i of the visual chain (encoders / obj_tx QKV, attention, tail / mul_tx QKV) - independent until
  * mul_tx's attention - share ONE launch (csrc/pair.hip: blocks [0, nA) run one kernel body, the rest the
  * other) wherever a pair kernel exists for the two shapes; 0 = every step its own launch. Same kernel
- * bodies either way: results are bit-identical (tests/test_gpu_forward.py).
+ * bodies either way: results are bit-identical (tests/test_gpu_forward.py). "pair_mask" (default 7): which of the three
+ * pairs are formed (1 BiLSTM layer 0 + encoders, 2 layer 1 + obj_tx tail, 4 out-projection + mul_tx QKV).
  * "fused_ih" (default 1): the BiLSTM input projections run inside the persistent layer kernel
- * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 64 and K % 256 == 0 (0: never,
+ * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 80 and K % 256 == 0 (0: never,
  * 2: layer 0 only, 3: layers >= 1 only). Measured on MI355X (cfg 2): two launches fewer, W_ih streamed
  * by the layer's 64 CUs (+7 / +17 us per layer against 6.4 / 9.7 us for the whole-chip GEMMs):
  * 43.1 k vs 40.9 k queries/s with 4 batches in flight, 10 us more single-batch latency. */

@@ -1520,10 +1520,6 @@ extern "C" int vog_group_graph_capture(vog_ctx* c, const vog_batch* lb, void* lw
 
 extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   VOG_CHECK_ARG(c && name);
-  if (strcmp(name, "graph_dag") == 0) {
-    if (value) VOG_FAIL(-4, "graph_dag was removed (parallel graph branches: slower with batches in flight, unstable in the runtime)");
-    return 0;
-  }
   if (strcmp(name, "tx_split") == 0) {        // takes effect at the next vog_ctx_finalize (the remainder weights are made there)
     if ((value != 0) != (c->tx_split != 0)) c->finalized = false;
     c->tx_split = value ? 1 : 0;
