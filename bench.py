@@ -377,7 +377,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend=os.environ.get("VOG_BENCH_BACKEND", "nccl"), init_method="env://")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if world > 1 and args.mode == "graph":
+    if world > 1:
         # one stream per lane of the engine's book (4; with a multi-rank group the last lane yields to a pending gather:
         # engine._lane_enter / dist.RecordRing - between collectives all 4 forwards are in flight)
         args.streams = min(args.streams, eng_mod._max_inflight())

@@ -178,8 +178,9 @@ typedef struct vog_attn_args {
    * projections, same fragment order as q / k (vog_qkv_args.q_lo / k_lo). With them Q.K^T = q.k + q_lo.k + q.k_lo (three MFMAs,
    * fp32 accumulate): the logits carry ~2^-21 relative operand error instead of 2^-11 (f16) - what a checkpoint with sharp
    * attention needs. Sequences of <= 256 tokens. out16_lo (optional): remainder of out16, same layout (read
-   * by a hi + lo vog_tx_tail_fwd). logit_max (optional): 4 device bytes, zero on entry; the launch leaves the largest |logit|
-   * (after bias and scale, in nats) it saw there as the bits of a non-negative float (atomic max). */
+   * by a hi + lo vog_tx_tail_fwd). logit_max (optional): 8 device words, zero on entry; the largest of them after the launch is the
+   * largest |logit| (after bias and scale, in nats) it saw, as the bits of a non-negative float (the workgroups spread their
+   * atomic maxima over the 8 words). */
   const void* q_lo; const void* k_lo; void* out16_lo; unsigned int* logit_max;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
@@ -478,10 +479,12 @@ int vog_pred_cmp_head(const vog_predcmp_args* a, void* stream);
 typedef struct vog_pred_args {
   const float* outs_eval; const float* props; const float* fin_scores; void* rec;
   int B, ncmp, nsrl, nfrm0, nppf0; int conc_type;
-  /* round 6, optional: logit_max = the forward's [2 stacks][32 layers] words of vog_attn_args.logit_max; the head (the last
+  /* round 6, optional: logit_max = the forward's [2 stacks][32] words (4 layers x the 8 words of vog_attn_args.logit_max); the head (the last
    * kernel of a forward) folds them into stats[0] (obj_tx) / stats[1] (mul_tx) with a system-scope atomic max - pinned host
    * memory, read by the host without a device synchronisation (vog_batch.stats). */
   const unsigned int* logit_max; unsigned int* stats;
+  unsigned int* published;     /* 2 device words, zero at first use: what this caller's forwards last folded into `stats` (the host
+                                * word is only touched when the value rises) */
 } vog_pred_args;
 int64_t vog_pred_record_bytes(int ncmp, int nsrl, int nfrm0);
 int vog_pred_head(const vog_pred_args* a, void* stream);

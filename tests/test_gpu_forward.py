@@ -835,7 +835,7 @@ def test_slots_sharing_a_workspace_on_one_stream():
 
 # ---- round 5: the fp32 path (checkpoints outside the f16 envelope) behind EVERY engine surface --------------------------------
 def test_fp32_path_behind_batched_group_and_fed_surfaces():
-    """`auto` on a checkpoint whose attention sharpness is outside the f16 envelope (full/cfg2_sharp16: 50.6 > 20): batched
+    """`auto` on a checkpoint whose attention sharpness is outside the f16 AND the hi + lo envelope (full/cfg2_sharp48: 455): batched
     requests, a shared-language group and host-fed slots all hand out the fp32 path's results (the reference golden / the eager
     precise forward to 1e-5), not the 16-bit kernels' (1.5e-3 there)."""
     import importlib
@@ -843,12 +843,12 @@ def test_fp32_path_behind_batched_group_and_fed_surfaces():
     synth = importlib.import_module("vognet-pytorch_amd.synth")
     from tests.gpu_util import comm_for
     from oracle import vog_oracle as vo
-    name = "full/cfg2_sharp16"
+    name = "full/cfg2_sharp48"           # (round 6: past the hi + lo plan's envelope too - x 16 runs that plan now)
     members = _group_members(name, 2)
     cfg, sd, batch0, c = members[0]
     eng = engine_mod.VogEngine(cfg, comm_for(c))
     eng.load_state_dict(sd)
-    assert eng.precise is not None and eng.sharpness > engine_mod.F16_SHARPNESS_MAX
+    assert eng.precise is not None and eng.plan == "f32" and eng.sharpness > engine_mod.SPLIT_SHARPNESS_MAX
     devs = [{k: torch.from_numpy(v).cuda() for k, v in m[2].items()} for m in members]
     refs = [{k: v.clone() for k, v in eng.forward(dv).items() if isinstance(v, torch.Tensor)} for dv in devs]
     torch.cuda.synchronize()

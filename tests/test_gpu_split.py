@@ -48,7 +48,7 @@ def test_rel_attention_hi_lo(S, N, H, dh, dp, nsrl, use_rel):
     for split in (0, 1):
         out = torch.full((S * N, H * dp), float("nan"), device="cuda").to(torch.float16)
         out_lo = torch.full_like(out, float("nan"))
-        lmax = torch.zeros(4, dtype=torch.int32, device="cuda")
+        lmax = torch.zeros(8, dtype=torch.int32, device="cuda")
         a = L.AttnArgs()
         frs = [to_frag(qh, "qk"), to_frag(kh, "qk"), to_frag(v16, "v")]       # (kept alive: the kernel reads them)
         a.q, a.k, a.vt, a.out16 = L.ptr(frs[0]), L.ptr(frs[1]), L.ptr(frs[2]), L.ptr(out)
@@ -77,7 +77,7 @@ def test_rel_attention_hi_lo(S, N, H, dh, dp, nsrl, use_rel):
             ub = u_tok.permute(0, 2, 1)
             lg = lg + torch.relu(ub.unsqueeze(-1) - ub.unsqueeze(-2) + peb.view(1, -1, 1, 1))
         want = (lg * inv_scale).abs().max().item()
-        seen = float(lmax[:1].cpu().numpy().view(np.float32)[0])
+        seen = float(lmax.cpu().numpy().view(np.float32).max())
         assert abs(seen - want) <= (2e-2 if not split else 1e-3) * want, (seen, want)
     print(f"max abs error vs fp32 logits: plain f16 {outs[0]:.2e}, hi + lo {outs[1]:.2e}")
     assert outs[1] <= 2.5e-3 * max(1.0, ref.abs().max().item())
@@ -126,7 +126,7 @@ def test_rel_attention_struct_hi_lo(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv
     errs = {}
     for split in (0, 1):
         out = torch.full((S * Nq, hd), float("nan"), device="cuda").to(torch.float16)
-        lmax = torch.zeros(4, dtype=torch.int32, device="cuda")
+        lmax = torch.zeros(8, dtype=torch.int32, device="cuda")
         a = L.AttnStructArgs()
         keep = [to_frag(qh, "qk"), to_frag(kh, "qk"), to_frag(vv16, "v"), to_frag(qlo, "qk"), to_frag(klo, "qk")]
         a.q_visual = 1
@@ -143,7 +143,7 @@ def test_rel_attention_struct_hi_lo(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv
         got = out.float().view(S, Nq, H, dp).permute(0, 2, 1, 3)
         assert torch.isfinite(got).all()
         errs[split] = (got - ref).abs().max().item()
-        seen = float(lmax[:1].cpu().numpy().view(np.float32)[0])
+        seen = float(lmax.cpu().numpy().view(np.float32).max())
         want = (logits * inv_scale).abs().max().item()
         assert want * 0.98 <= seen <= 2.05 * want, (seen, want)     # (a bound: max|x| + max|y| of the separable parts)
     print(f"struct attention, max abs error vs fp32: plain f16 {errs[0]:.2e}, hi + lo {errs[1]:.2e}")

@@ -18,7 +18,8 @@ struct AttnParams {
   // order; Q.K^T = q.k + q_lo.k + q.k_lo (three MFMAs, the lo x lo term is below fp32 resolution). out_lo (optional): the
   // 16-bit remainder of the output rows (the Wo GEMM of a split tail reads both).
   const unsigned short* q_lo; const unsigned short* k_lo; unsigned short* out_lo;
-  // optional: max |scaled logit| seen by this launch, as the bits of a non-negative float (atomicMax; zeroed by the caller)
+  // optional: 8 words (zeroed by the caller); their maximum = the largest |scaled logit| this launch saw, as the bits of a
+  // non-negative float (publish_logit_max)
   unsigned int* logit_max;
 };
 
@@ -38,12 +39,18 @@ __device__ __forceinline__ void split16(float v, unsigned short& hi, unsigned sh
   hi = to16<T16>(v);
   lo = to16<T16>(v - from16<T16>(hi));
 }
-// one wave's contribution to the launch's max |logit| (amax >= 0 in every lane)
+// one wave's contribution to the launch's max |logit| (amax >= 0 in every lane). `dst` is 8 words: the workgroups spread over
+// them and only a wave that would RAISE its word issues the atomic (a first form - every wave an atomicMax on one word - cost
+// mul_tx's attention 5 of its 12 us at cfg 2: 480 serialised read-modify-writes on one L2 line); readers take the max of the 8.
 __device__ __forceinline__ void publish_logit_max(unsigned int* dst, float amax, int lane) {
   if (!dst) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-  if (lane == 0 && amax > 0.f) atomicMax(dst, __float_as_uint(amax));
+  if (lane == 0 && amax > 0.f) {
+    unsigned int* w = dst + (blockIdx.x & 7);
+    const unsigned int bits = __float_as_uint(amax);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w, bits);
+  }
 }
 // output rows: 4 consecutive head columns as 16-bit (+ their 16-bit remainder when the consumer is a split tail)
 template <typename T16>

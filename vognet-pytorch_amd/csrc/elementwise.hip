@@ -173,13 +173,30 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
   const int r0 = (int)blockIdx.x * AV_ROWS;
   const int nr = min(AV_ROWS, nrows - r0);
   const int nq = (2 * L) >> 2, lq = L >> 2;
-  for (int idx = tid; idx < nr * nq; idx += 256) {
-    const int r = idx / nq, i = idx - r * nq;
-    const int row = r0 + r, b = row / nsrl;
-    int64_t c = capture[(int64_t)row * 2 + (i < lq ? 0 : 1)];
+  // (the capture positions first - one load per (row, end) - so that the row loads below depend on LDS values only and the
+  // unrolled loop keeps all of a thread's loads in flight: with the position load inside the loop every one of the 10 iterations
+  // was two dependent memory round trips, 28 us for the kernel)
+  __shared__ int av_src[AV_ROWS * 2];
+  if (tid < nr * 2) {
+    const int row = r0 + (tid >> 1), b = row / nsrl;
+    int64_t c = capture[(int64_t)row * 2 + (tid & 1)];
     c = c < 0 ? 0 : (c >= T ? T - 1 : c);
-    reinterpret_cast<float4*>(av_x)[idx] =
-        reinterpret_cast<const float4*>(full + ((int64_t)b * T + c) * L)[i < lq ? i : i - lq];
+    av_src[tid] = b * T + (int)c;
+  }
+  __syncthreads();
+  constexpr int AV_IT = AV_ROWS;                     // nq <= 256 float4 per row: <= AV_ROWS chunks per thread
+  float4 stg[AV_IT];
+#pragma unroll
+  for (int it = 0; it < AV_IT; ++it) {
+    int idx = tid + it * 256;
+    idx = idx < nr * nq ? idx : nr * nq - 1;         // (clamped, not skipped: every element of stg is assigned - registers, no scratch)
+    const int r = idx / nq, i = idx - r * nq;
+    stg[it] = reinterpret_cast<const float4*>(full + (int64_t)av_src[r * 2 + (i < lq ? 0 : 1)] * L)[i < lq ? i : i - lq];
+  }
+#pragma unroll
+  for (int it = 0; it < AV_IT; ++it) {
+    const int idx = tid + it * 256;
+    if (idx < nr * nq) reinterpret_cast<float4*>(av_x)[idx] = stg[it];
   }
   constexpr int MAXQ = 4;
   const int o0 = (int)blockIdx.y * 16 + wid * 4;
@@ -422,10 +439,20 @@ __device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
 
 // the forward's largest |attention logit| per stack -> the host's sticky maximum (vog_batch.stats): threads 0 / 1 of block 0
 __device__ __forceinline__ void publish_stats(const vog_pred_args& a) {
-  if (!a.stats || !a.logit_max || blockIdx.x != 0 || threadIdx.x >= 2) return;
-  unsigned int m = 0;
-  for (int l = 0; l < 32; ++l) { const unsigned int v = a.logit_max[threadIdx.x * 32 + l]; m = v > m ? v : m; }
-  if (m) __hip_atomic_fetch_max(a.stats + threadIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (!a.stats || !a.logit_max || !a.published || blockIdx.x != 0 || threadIdx.x >= 2) return;
+  unsigned int v[32], m = 0;
+#pragma unroll
+  for (int l = 0; l < 32; ++l) v[l] = a.logit_max[threadIdx.x * 32 + l];
+#pragma unroll
+  for (int l = 0; l < 32; ++l) m = v[l] > m ? v[l] : m;
+  // (the host word is touched only when this workspace's forwards have seen a larger value than they last published - a.published,
+  // zeroed with the workspace only: a system-scope atomic on pinned host memory is a PCIe round trip the kernel would otherwise wait
+  // out in every forward)
+  unsigned int* last = a.published + threadIdx.x;
+  if (m > *last) {
+    *last = m;
+    __hip_atomic_fetch_max(a.stats + threadIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t rec_bytes) {

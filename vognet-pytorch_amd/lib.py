@@ -177,7 +177,7 @@ class PredcmpArgs(C.Structure):
 class PredArgs(C.Structure):
     _fields_ = [("outs_eval", c_vp), ("props", c_vp), ("fin_scores", c_vp), ("rec", c_vp),
                 ("B", c_i32), ("ncmp", c_i32), ("nsrl", c_i32), ("nfrm0", c_i32), ("nppf0", c_i32),
-                ("conc_type", c_i32), ("logit_max", c_vp), ("stats", c_vp)]
+                ("conc_type", c_i32), ("logit_max", c_vp), ("stats", c_vp), ("published", c_vp)]
 
 
 class ModelDesc(C.Structure):
