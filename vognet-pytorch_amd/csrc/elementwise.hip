@@ -177,11 +177,15 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
   // unrolled loop keeps all of a thread's loads in flight: with the position load inside the loop every one of the 10 iterations
   // was two dependent memory round trips, 28 us for the kernel)
   __shared__ int av_src[AV_ROWS * 2];
+  __shared__ float av_msk[AV_ROWS];                  // (the argument masks too: a global load per row inside the dot-product loop was
+                                                     // 20 dependent round trips - the 28 us the kernel still took after the staging fix)
   if (tid < nr * 2) {
     const int row = r0 + (tid >> 1), b = row / nsrl;
     int64_t c = capture[(int64_t)row * 2 + (tid & 1)];
     c = c < 0 ? 0 : (c >= T ? T - 1 : c);
     av_src[tid] = b * T + (int)c;
+  } else if (tid >= 64 && tid < 64 + nr) {
+    av_msk[tid - 64] = (float)msk[r0 + tid - 64];
   }
   __syncthreads();
   constexpr int AV_IT = AV_ROWS;                     // nq <= 256 float4 per row: <= AV_ROWS chunks per thread
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
       for (int k = 0; k < 4; ++k)
         acc[k] += (wv[k][it].x * x.x + wv[k][it].y * x.y) + (wv[k][it].z * x.z + wv[k][it].w * x.w);
     }
-    const float mk = (float)msk[r0 + r];
+    const float mk = av_msk[r];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float v = wave_sum(acc[k]);
