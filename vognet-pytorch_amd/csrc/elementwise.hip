@@ -156,6 +156,7 @@ __global__ void srl_gather_kernel(const int64_t* __restrict__ words, const int64
 // one workgroup per (sentence, arg); wave-per-output dot products, fp32 exact
 // ---------------------------------------------------------------------------
 constexpr int AV_ROWS = 20;      // (sentence, argument) rows per workgroup
+constexpr int AV_MAXSL = 64;     // 2L / 16 <= 64 elements of a dot product per thread (L <= 512)
 __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ full,
                                                      const int64_t* __restrict__ capture,
                                                      const int64_t* __restrict__ msk,
@@ -164,21 +165,19 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
                                                      float* __restrict__ lang, int T, int nsrl, int L, int nrows) {
   // grid (ceil(rows / 20), L/16): a workgroup owns 16 output columns for up to 20 (sentence, argument) rows. Round 6: 16
   // workgroups at cfg 2 instead of 320 (one per row and column block: 1137 CU-us for 5 MFLOP, each re-fetching its 32 KB
-  // weight slice; profiles/round5_busy_cu_cfg2.md). The rows' [full[cap0] || full[cap1]] vectors are staged in LDS with ONE
-  // round of loads (every row of the block requested before anything is waited for; a first form that walked the rows in
-  // passes of dependent loads took 33 us), each wave keeps the weight rows of its 4 outputs in registers (requested in the
-  // same round) and forms 4 dot products per row: per-lane partial sums (16 bytes per lane and access), then a wave reduction.
+  // weight slice; profiles/round5_busy_cu_cfg2.md). Thread (o = tid & 15, s = tid >> 4) holds slice s (1/16 of the 2L-long
+  // dot product) of output column o's weight row in registers; the rows' [full[cap0] || full[cap1]] vectors are staged in
+  // LDS with ONE round of loads (capture positions and masks first, so nothing inside a loop waits for memory); partial
+  // sums meet in LDS. No wave reductions: the first 16-workgroup form kept the old kernel's wave-per-4-outputs mapping and
+  // spent 28 us in 80 dependent 64-lane shuffle reductions per wave (6 LDS-pipe round trips each).
   extern __shared__ __attribute__((aligned(16))) float av_x[];          // [AV_ROWS][2L]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ int av_src[AV_ROWS * 2];
+  __shared__ float av_msk[AV_ROWS];
+  __shared__ float av_part[AV_ROWS][16][17];
+  const int tid = threadIdx.x;
   const int r0 = (int)blockIdx.x * AV_ROWS;
   const int nr = min(AV_ROWS, nrows - r0);
-  const int nq = (2 * L) >> 2, lq = L >> 2;
-  // (the capture positions first - one load per (row, end) - so that the row loads below depend on LDS values only and the
-  // unrolled loop keeps all of a thread's loads in flight: with the position load inside the loop every one of the 10 iterations
-  // was two dependent memory round trips, 28 us for the kernel)
-  __shared__ int av_src[AV_ROWS * 2];
-  __shared__ float av_msk[AV_ROWS];                  // (the argument masks too: a global load per row inside the dot-product loop was
-                                                     // 20 dependent round trips - the 28 us the kernel still took after the staging fix)
+  const int K = 2 * L, nq = K >> 2, lq = L >> 2;
   if (tid < nr * 2) {
     const int row = r0 + (tid >> 1), b = row / nsrl;
     int64_t c = capture[(int64_t)row * 2 + (tid & 1)];
@@ -186,6 +185,23 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
     av_src[tid] = b * T + (int)c;
   } else if (tid >= 64 && tid < 64 + nr) {
     av_msk[tid - 64] = (float)msk[r0 + tid - 64];
+  }
+  // this thread's slice of its weight row (requested before the barrier: in flight while the rows are staged)
+  const int o = tid & 15, sl = tid >> 4;
+  const int col = (int)blockIdx.y * 16 + o;
+  const int SL = ((K + 15) >> 4), j0 = sl * SL;
+  const bool vec = (SL & 3) == 0;                                     // (L = 256: 32 elements per slice)
+  float wr[AV_MAXSL];
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < AV_MAXSL / 4; ++q) {
+      const bool ok = col < L && q * 4 < SL && j0 + q * 4 < K;
+      const float4 v = ok ? *reinterpret_cast<const float4*>(w + (int64_t)col * K + j0 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wr[q * 4] = v.x; wr[q * 4 + 1] = v.y; wr[q * 4 + 2] = v.z; wr[q * 4 + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < AV_MAXSL; ++q) wr[q] = (col < L && q < SL && j0 + q < K) ? w[(int64_t)col * K + j0 + q] : 0.f;
   }
   __syncthreads();
   constexpr int AV_IT = AV_ROWS;                     // nq <= 256 float4 per row: <= AV_ROWS chunks per thread
@@ -202,37 +218,32 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
     const int idx = tid + it * 256;
     if (idx < nr * nq) reinterpret_cast<float4*>(av_x)[idx] = stg[it];
   }
-  constexpr int MAXQ = 4;
-  const int o0 = (int)blockIdx.y * 16 + wid * 4;
-  float4 wv[4][MAXQ];
-#pragma unroll
-  for (int it = 0; it < MAXQ; ++it) {
-    const int i = lane + it * 64;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      wv[k][it] = (i < nq && o0 + k < L) ? reinterpret_cast<const float4*>(w + (int64_t)(o0 + k) * 2 * L)[i]
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float bs[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) bs[k] = o0 + k < L ? bias[o0 + k] : 0.f;
   __syncthreads();
   for (int r = 0; r < nr; ++r) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xr = av_x + r * K + j0;
+    float acc = 0.f;
+    if (vec) {
 #pragma unroll
-    for (int it = 0; it < MAXQ; ++it) {
-      const int i = lane + it * 64;
-      const float4 x = i < nq ? reinterpret_cast<const float4*>(av_x)[r * nq + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < AV_MAXSL / 4; ++q)
+        if (q * 4 < SL && j0 + q * 4 < K) {
+          const float4 x = *reinterpret_cast<const float4*>(xr + q * 4);
+          acc += (wr[q * 4] * x.x + wr[q * 4 + 1] * x.y) + (wr[q * 4 + 2] * x.z + wr[q * 4 + 3] * x.w);
+        }
+    } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        acc[k] += (wv[k][it].x * x.x + wv[k][it].y * x.y) + (wv[k][it].z * x.z + wv[k][it].w * x.w);
+      for (int q = 0; q < AV_MAXSL; ++q)
+        if (q < SL && j0 + q < K) acc += wr[q] * xr[q];
     }
-    const float mk = av_msk[r];
+    av_part[r][o][sl] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nr * 16; idx += 256) {
+    const int r = idx >> 4, oo = idx & 15, c2 = (int)blockIdx.y * 16 + oo;
+    if (c2 >= L) continue;
+    float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float v = wave_sum(acc[k]);
-      if (lane == 0 && o0 + k < L) lang[(int64_t)(r0 + r) * L + o0 + k] = relu_nan(v + bs[k]) * mk;
-    }
+    for (int q = 0; q < 16; ++q) v += av_part[r][oo][q];
+    lang[(int64_t)(r0 + r) * L + c2] = relu_nan(v + bias[c2]) * av_msk[r];
   }
 }
 
@@ -779,7 +790,12 @@ extern "C" int vog_srl_gather(const int64_t* words_ind, const int64_t* word_mask
 extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const int64_t* inds_msk,
                               const float* w, const float* bias, float* lang,
                               int Bn, int T, int nsrl, int L, void* stream) {
-  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512 && (L % 4) == 0);
+  VOG_CHECK_ARG(full && capture && inds_msk && w && bias && lang && Bn > 0 && L > 0 && L <= 512 && (L % 8) == 0);
+  static bool av_attr = false;
+  if (!av_attr && (size_t)AV_ROWS * 2 * L * sizeof(float) > 40 * 1024) {
+    VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(argvec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    av_attr = true;
+  }
   ::vog::launch(argvec_kernel, dim3(ceil_div(Bn * nsrl, AV_ROWS), ceil_div(L, 16)), dim3(256), (size_t)AV_ROWS * 2 * L * sizeof(float),
                      (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L, Bn * nsrl);
   VOG_LAUNCH_CHECK();
