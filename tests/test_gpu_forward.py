@@ -257,7 +257,8 @@ def test_observed_logit_scale_of_the_goldens():
     E = engine_mod
     rows = []
     for name in ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp10", "full/cfg2_sharp12", "full/cfg2_sharp16",
-                 "full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg3_sharp8", "full/cfg5_sharp8", "full/vog_spat_3layers_sharp8"]:
+                 "full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg3_sharp8", "full/cfg5_sharp8", "full/vog_spat_3layers_sharp8",
+                 "full/cfg4_p100_sharp8"]:      # (p100: the long-sequence kernels report row-reference magnitudes, a lower bound)
         eng, cfg, sd, batch, c, dev = build_engine(name)
         eng.forward(dev)
         torch.cuda.synchronize()

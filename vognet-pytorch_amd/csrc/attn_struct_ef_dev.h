@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
   {
     float m = -1e30f;
     for (int kb = 0; kb < nkb; ++kb) m = fmaxf(m, mblk[kb * 32 + ql]);
+    // (run-time logit-scale report, AttnStructParams::logit_max: |row maximum of the proposal part A| - with the argument part's
+    // |mB| published below, the larger of the two is a lower bound of the row's largest |A + B| within 2x; log2 units -> nats)
+    publish_logit_max(p.logit_max, p_ok ? fabsf(m) * 0.69314718056f : 0.f, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kb = wid + 4 * i;
@@ -264,7 +267,14 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
         const int ok = __shfl_xor(kB, o_);
         if (om > mB || (om == mB && ok < kB)) { mB = om; kB = ok; }
       }
-      if (sub == 0) kBl[a] = kB;
+      if (sub == 0) {
+        kBl[a] = kB;
+        if (p.logit_max) {                       // |mB| of this argument row (raise-only, as publish_logit_max)
+          const unsigned int bits = __float_as_uint(fabsf(mB) * 0.69314718056f);
+          unsigned int* w_ = p.logit_max + (blockIdx.x & 7);
+          if (__hip_atomic_load(w_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w_, bits);
+        }
+      }
       for (int key = sub; key < p.npad_kv; key += 32) brow[key] = __builtin_amdgcn_exp2f(brow[key] - mB);
     }
   }

@@ -161,6 +161,10 @@ struct AttnTile2Body {
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // (run-time logit-scale report, AttnParams::logit_max: this kernel's softmax never looks at single logits again, so what it
+    // reports is the magnitude of each row's reference - the maximum over its first 32 keys - a LOWER bound of the row's largest
+    // |logit| (typically within 2x: 2 sigma against ~4 sigma over 4000 keys); one value per wave, log2 units -> nats)
+    publish_logit_max(p.logit_max, (wave_ok && qi < p.N) ? fabsf(mx) * 0.69314718056f : 0.f, lane);
     // f16: the reference sits 4 binary orders ABOVE block 0's maximum - every P, row sum and accumulator carries 2^-4, which
     // cancels in O / l - so that the headroom to f16's 65504 is 19 binary orders (13 nats above block 0) instead of 15; block
     // 0's own maximum becomes 2^-4 and P stays a normal f16 number down to 2^-10 of it (below: absolute error 2^-25 per key)
