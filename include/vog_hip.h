@@ -160,6 +160,8 @@ int vog_qkv_combine(const vog_qkvcomb_args* a, void* stream);
  * to 32). u: [n_vid, NP, H] fp32; token j of sequence s uses row
  * (s / seq_per_vid)*NP + (s % seq_per_vid)*n_box + (j % n_box).
  * out16: [S*N, H*dp] t16 row-major (heads concatenated, padded). */
+#define VOG_LOGIT_WORDS 32     /* words of one logit_max report ... */
+#define VOG_LOGIT_STRIDE 32    /* ... this many 32-bit words apart (one 128-byte line each) */
 typedef struct vog_attn_args {
   const void* q; const void* k; const void* vt; void* out16;
   const float* u; const float* pe_b;
@@ -178,9 +180,10 @@ typedef struct vog_attn_args {
    * projections, same fragment order as q / k (vog_qkv_args.q_lo / k_lo). With them Q.K^T = q.k + q_lo.k + q.k_lo (three MFMAs,
    * fp32 accumulate): the logits carry ~2^-21 relative operand error instead of 2^-11 (f16) - what a checkpoint with sharp
    * attention needs. Sequences of <= 256 tokens. out16_lo (optional): remainder of out16, same layout (read
-   * by a hi + lo vog_tx_tail_fwd). logit_max (optional): 8 device words, zero on entry; the largest of them after the launch is the
-   * largest |logit| (after bias and scale, in nats) it saw, as the bits of a non-negative float (the workgroups spread their
-   * atomic maxima over the 8 words). */
+   * by a hi + lo vog_tx_tail_fwd). logit_max (optional): VOG_LOGIT_WORDS device words VOG_LOGIT_STRIDE words apart (4 KiB),
+   * which the launch only ever RAISES: zero them for a fresh measurement; the largest of them after the launch is the largest
+   * |logit| (after bias and scale, in nats) seen since, as the bits of a non-negative float (the workgroups spread over the
+   * words; a wave issues an atomic only when it would raise its word). */
   const void* q_lo; const void* k_lo; void* out16_lo; unsigned int* logit_max;
 } vog_attn_args;
 int vog_rel_attention_fwd(const vog_attn_args* a, void* stream);
@@ -479,7 +482,7 @@ int vog_pred_cmp_head(const vog_predcmp_args* a, void* stream);
 typedef struct vog_pred_args {
   const float* outs_eval; const float* props; const float* fin_scores; void* rec;
   int B, ncmp, nsrl, nfrm0, nppf0; int conc_type;
-  /* round 6, optional: logit_max = the forward's [2 stacks][32] words (4 layers x the 8 words of vog_attn_args.logit_max); the head (the last
+  /* round 6, optional: logit_max = the forward's [2 stacks][4 layers] reports of vog_attn_args.logit_max (4 KiB each); the head (the last
    * kernel of a forward) folds them into stats[0] (obj_tx) / stats[1] (mul_tx) with a system-scope atomic max - pinned host
    * memory, read by the host without a device synchronisation (vog_batch.stats). */
   const unsigned int* logit_max; unsigned int* stats;

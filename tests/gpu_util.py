@@ -26,13 +26,34 @@ def comm_for(c):
             "num_prop_per_frm": c["nppf0"]}
 
 
-def build_engine(name, tx_dtype=None):
-    """tx_dtype None: the package default (`auto`: f16 kernels inside their envelope, the fp32 path beyond; engine.py)."""
-    cfg, sd, batch, c = cases.build(name)
-    if tx_dtype is not None:
-        cfg.hip.tx_dtype = tx_dtype
-    eng = engine_mod.VogEngine(cfg, comm_for(c))
-    eng.load_state_dict(sd)
+_ENGINES = {}
+_DEFAULT_OPTIONS = {"lstm_persistent": 1, "lstm_inject_stall": 0, "fused_tail": 1, "fused_enc": 1, "pair_launches": 1, "pair_mask": 7,
+                    "fused_ih": 1, "enc_lean": -1}
+
+
+def build_engine(name, tx_dtype=None, cached=False):
+    """tx_dtype None: the package default (`auto`: f16 kernels inside their envelope, hi + lo operands / the fp32 path beyond;
+    engine.py). cached=True (round 6: the launch-structure variant tests, which only flip context options on the same
+    checkpoints): the engine of (case, tx_dtype) is built once per session - registering 44 M weights costs ~1 s, most of such a
+    test - and handed out with every option back at its default and fresh device inputs; an engine that has seen a stall or
+    whose plan was raised at run time is rebuilt."""
+    key = (name, tx_dtype)
+    hit = _ENGINES.get(key) if cached else None
+    if hit is not None and hit[0].stalls == 0 and hit[0].plan == hit[5]:
+        eng, cfg, sd, batch, c, _ = hit
+        for k, v in _DEFAULT_OPTIONS.items():
+            eng.set_option(k, v)
+        eng._fault_seen = int(eng._fault[0])
+    else:
+        cfg, sd, batch, c = cases.build(name)
+        if tx_dtype is not None:
+            cfg.hip.tx_dtype = tx_dtype
+        eng = engine_mod.VogEngine(cfg, comm_for(c))
+        eng.load_state_dict(sd)
+        if cached:
+            if len(_ENGINES) >= 48:
+                _ENGINES.pop(next(iter(_ENGINES)))
+            _ENGINES[key] = (eng, cfg, sd, batch, c, eng.plan)
     dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
     return eng, cfg, sd, batch, c, dev
 

@@ -95,8 +95,8 @@ def _check_against(name, out, pred, g, ora, tol_rel, tol_logit):
     return nflip
 
 
-def _run(name, tx_dtype=None, graph=False):
-    eng, cfg, sd, batch, c, dev = build_engine(name, tx_dtype)
+def _run(name, tx_dtype=None, graph=False, cached=True):
+    eng, cfg, sd, batch, c, dev = build_engine(name, tx_dtype, cached=cached)
     before = {k: v.clone() for k, v in dev.items()}
     if graph:
         slot = eng.make_slot(dev, graph=True)
@@ -296,7 +296,7 @@ def test_bf16_leaves_the_bound_where_f16_holds_it():
 def test_forward_persistent_lstm_layer(name):
     """The opt-in one-launch-per-layer LSTM (cross-workgroup hand-off through agent-scope
     atomics; 64 / 4 / 2 workgroups per direction here) must agree with the T-launch path."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
     eng.set_option("lstm_persistent", 0)
     a = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in eng.forward(dev).items()}
     eng.set_option("lstm_persistent", 1)
@@ -318,7 +318,7 @@ def test_forward_persistent_lstm_layer(name):
 def test_forward_step_launch_lstm_vs_reference_golden(name):
     """The step-launch BiLSTM (lstm_persistent = 0: lowest latency fallback, any number in flight)
     against the same reference goldens as the default persistent layer kernel."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
     eng.set_option("lstm_persistent", 0)
     out = eng.forward(dev)
     torch.cuda.synchronize()
@@ -333,7 +333,7 @@ def test_forward_step_launch_lstm_vs_reference_golden(name):
 def test_forward_unfused_tail_vs_reference_golden(name):
     """fused_tail = 0: the separate Wo / LayerNorm / FFN / lin2 / score launches (the path of every
     shape the fused kernel does not cover) against the same goldens."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
     eng.set_option("fused_tail", 0)
     out = eng.forward(dev)
     torch.cuda.synchronize()
@@ -346,7 +346,7 @@ def test_forward_unfused_tail_vs_reference_golden(name):
 def test_paired_launches_equal_separate_launches(name):
     """pair_launches: two independent steps in one grid (csrc/pair.hip) run the same kernel bodies as
     the stand-alone launches -> bit-identical outputs."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
     eng.set_option("enc_lean", 1)            # (the encoder form otherwise follows the pairing decision)
     eng.set_option("pair_launches", 0)
     a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
@@ -362,7 +362,7 @@ def test_paired_launches_equal_separate_launches(name):
 def test_fused_lstm_input_projection_matches_separate_gemm(name):
     """fused_ih: x W_ih^T + b computed in the persistent layer kernel's prologue vs the separate GEMM
     launch (same 16-bit operands, another fp32 summation order)."""
-    eng, cfg, sd, batch, c, dev = build_engine(name)
+    eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
     eng.set_option("fused_ih", 0)
     a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
     eng.set_option("fused_ih", 1)

@@ -48,7 +48,7 @@ def test_rel_attention_hi_lo(S, N, H, dh, dp, nsrl, use_rel):
     for split in (0, 1):
         out = torch.full((S * N, H * dp), float("nan"), device="cuda").to(torch.float16)
         out_lo = torch.full_like(out, float("nan"))
-        lmax = torch.zeros(8, dtype=torch.int32, device="cuda")
+        lmax = torch.zeros(L.LOGIT_WORDS * L.LOGIT_STRIDE, dtype=torch.int32, device="cuda")   # (vog_attn_args.logit_max: 4 KiB)
         a = L.AttnArgs()
         frs = [to_frag(qh, "qk"), to_frag(kh, "qk"), to_frag(v16, "v")]       # (kept alive: the kernel reads them)
         a.q, a.k, a.vt, a.out16 = L.ptr(frs[0]), L.ptr(frs[1]), L.ptr(frs[2]), L.ptr(out)
@@ -126,7 +126,7 @@ def test_rel_attention_struct_hi_lo(S, nfrm, nsrl, nppf, H, dh, dp, use_rel, lpv
     errs = {}
     for split in (0, 1):
         out = torch.full((S * Nq, hd), float("nan"), device="cuda").to(torch.float16)
-        lmax = torch.zeros(8, dtype=torch.int32, device="cuda")
+        lmax = torch.zeros(L.LOGIT_WORDS * L.LOGIT_STRIDE, dtype=torch.int32, device="cuda")   # (vog_attn_args.logit_max: 4 KiB)
         a = L.AttnStructArgs()
         keep = [to_frag(qh, "qk"), to_frag(kh, "qk"), to_frag(vv16, "v"), to_frag(qlo, "qk"), to_frag(klo, "qk")]
         a.q_visual = 1

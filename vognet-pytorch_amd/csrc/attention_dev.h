@@ -39,18 +39,26 @@ __device__ __forceinline__ void split16(float v, unsigned short& hi, unsigned sh
   hi = to16<T16>(v);
   lo = to16<T16>(v - from16<T16>(hi));
 }
-// one wave's contribution to the launch's max |logit| (amax >= 0 in every lane). `dst` is 8 words: the workgroups spread over
-// them and only a wave that would RAISE its word issues the atomic (a first form - every wave an atomicMax on one word - cost
-// mul_tx's attention 5 of its 12 us at cfg 2: 480 serialised read-modify-writes on one L2 line); readers take the max of the 8.
-__device__ __forceinline__ void publish_logit_max(unsigned int* dst, float amax, int lane) {
-  if (!dst) return;
+// one wave's contribution to the running max |logit| (amax >= 0 in every lane). `dst` is VOG_LOGIT_WORDS words, 128 bytes apart
+// (one L2 line each), that only ever RISE: a workgroup reads its word when it starts (logit_prev: the load is in flight behind
+// the whole kernel) and a wave issues a no-return atomic max only if it would raise it - in steady state no atomic at all.
+// Measured forms (cfg 2, 4 forwards in flight): every wave an atomicMax on one word cost mul_tx's attention 5 of its 12 us (480
+// serialised read-modify-writes on one L2 line); 8 adjacent words zeroed per forward with the read in front of the atomic, i.e.
+// in the middle of the kernel: 52.4 k queries/s against 57.2 k without any report (scratch/r6_i.sh); this form: see DESIGN.md.
+#ifndef VOG_LOGIT_SAMPLE
+#define VOG_LOGIT_SAMPLE 1        // 0: nobody reports (perf experiments)
+#endif
+static constexpr int kLogitWords = 32, kLogitStride = 32;     // = VOG_LOGIT_WORDS / VOG_LOGIT_STRIDE of vog_hip.h
+__device__ __forceinline__ unsigned int logit_prev(const unsigned int* dst) {
+  if (!dst || VOG_LOGIT_SAMPLE == 0) return 0xffffffffu;
+  return __hip_atomic_load(dst + (blockIdx.x & (kLogitWords - 1)) * kLogitStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_logit_max(unsigned int* dst, unsigned int prev, float amax, int lane) {
+  if (!dst || VOG_LOGIT_SAMPLE == 0) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-  if (lane == 0 && amax > 0.f) {
-    unsigned int* w = dst + (blockIdx.x & 7);
-    const unsigned int bits = __float_as_uint(amax);
-    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w, bits);
-  }
+  const unsigned int bits = __float_as_uint(amax);
+  if (lane == 0 && bits > prev) atomicMax(dst + (blockIdx.x & (kLogitWords - 1)) * kLogitStride, bits);
 }
 // output rows: 4 consecutive head columns as 16-bit (+ their 16-bit remainder when the consumer is a split tail)
 template <typename T16>
@@ -104,8 +112,9 @@ struct AttnFragBody {
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    stage_batched<4, 256, float>(p.npad, tid,
+        [&](int key) { return p.u[(u_base + ((key < p.N ? key : 0) % p.n_box)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.N ? v : 0.f; });
     if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
   }
   __syncthreads();
@@ -248,6 +257,7 @@ struct AttnFragBody {
 template <typename T16, int NDB, bool SPLIT = false>
 __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_frag_lean_kernel(AttnParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
   constexpr int MAXKB = 8;
   static_assert(KS % 2 == 0, "two k-steps per round");
   extern __shared__ __attribute__((aligned(16))) unsigned char afl_smem[];
@@ -283,8 +293,9 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_frag_lean_kernel(Attn
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    stage_batched<4, 256, float>(p.npad, tid,
+        [&](int key) { return p.u[(u_base + ((key < p.N ? key : 0) % p.n_box)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.N ? v : 0.f; });
     if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
   }
   __syncthreads();
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_frag_lean_kernel(Attn
       if (hi == 0) mloc[kb * 32 + ql] = mblk;
     }
   }
-  publish_logit_max(p.logit_max, q_ok ? amax * 0.69314718056f : 0.f, lane);      // (log2 units -> nats)
+  publish_logit_max(p.logit_max, lprev, q_ok ? amax * 0.69314718056f : 0.f, lane);      // (log2 units -> nats)
   __syncthreads();
   // ---- phase 2: probabilities against the row maximum over all key blocks; P^T fragments straight from the registers
   float m = -1e30f;
@@ -405,6 +416,7 @@ __global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
 template <typename T16, int NDB, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
   constexpr int HB = (NDB + 1) / 2;                  // d-blocks per half
   constexpr int SLOT = HB * 16 * 64;                 // floats of one wave's half partial
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -448,8 +460,9 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    stage_batched<4, 256, float>(p.npad, tid,
+        [&](int key) { return p.u[(u_base + ((key < p.N ? key : 0) % p.n_box)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.N ? v : 0.f; });
     if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
   }
   __syncthreads();
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void attn_sb_kernel(AttnParams p) {
       sacc[r] = x;
       m_w = fmaxf(m_w, x);
     }
-    publish_logit_max(p.logit_max, amax, lane);
+    publish_logit_max(p.logit_max, lprev, amax, lane);
     m_w = fmaxf(m_w, __shfl_xor(m_w, 32));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -610,8 +623,9 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(AttnParams p) {
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad; key += 256)
-      us[key] = key < p.N ? p.u[(u_base + (key % p.n_box)) * p.H + h] : 0.f;
+    stage_batched<4, 256, float>(p.npad, tid,
+        [&](int key) { return p.u[(u_base + ((key < p.N ? key : 0) % p.n_box)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.N ? v : 0.f; });
     if (q_ok) uq = p.u[(u_base + (qi % p.n_box)) * p.H + h];
   }
   // Q fragments of this wave's block: registers for the whole pass
@@ -845,6 +859,7 @@ __device__ __forceinline__ void struct_store(const AttnStructParams& p, const f3
 template <typename T16, int NDB, bool SPLIT = false>
 __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_struct1_lean_kernel(AttnStructParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
   static_assert(KS % 2 == 0, "two k-steps per round");
   extern __shared__ __attribute__((aligned(16))) float ssm[];
   float* us = ssm;                                   // [32] bias precursor of the visual keys
@@ -869,12 +884,17 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_struct1_lean_kernel(A
   float* pls = ssm + 32;                             // [nsrl][3][DP]
   {
     const int per_row = 3 * DP / 4;                  // float4 per argument
-    for (int i = tid; i < p.nsrl * per_row; i += 256) {
-      const int a = i / per_row, c = i - a * per_row;
-      const int part = c / (DP / 4), dd4 = c - part * (DP / 4);
-      *reinterpret_cast<float4*>(&pls[(a * 3 + part) * DP + dd4 * 4]) =
-          *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + part * hd + dd4 * 4);
-    }
+    stage_batched<4, 256, float4>(p.nsrl * per_row, tid,
+        [&](int i) {
+          const int a = i / per_row, c = i - a * per_row;
+          const int part = c / (DP / 4), dd4 = c - part * (DP / 4);
+          return *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + part * hd + dd4 * 4);
+        },
+        [&](int i, const float4& v) {
+          const int a = i / per_row, c = i - a * per_row;
+          const int part = c / (DP / 4), dd4 = c - part * (DP / 4);
+          *reinterpret_cast<float4*>(&pls[(a * 3 + part) * DP + dd4 * 4]) = v;
+        });
   }
   const int qbs = wave_ok ? qb : 0;
   int qa = 0, qp = 0;
@@ -993,7 +1013,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_struct1_lean_kernel(A
       av = fmaxf(av, key < p.nppf ? fabsf(x) : 0.f); al = fmaxf(al, key < p.nsrl ? fabsf(y) : 0.f);
     }
     // (the logit of key (a', p') is x[p'] + y[a']: the largest magnitude of the pair bounds it; log2 units -> nats)
-    publish_logit_max(p.logit_max, q_ok ? (av + al) * 0.69314718056f : 0.f, lane);
+    publish_logit_max(p.logit_max, lprev, q_ok ? (av + al) * 0.69314718056f : 0.f, lane);
     mv = fmaxf(mv, __shfl_xor(mv, 32));
     ml = fmaxf(ml, __shfl_xor(ml, 32));
     float lv_ = 0.f, ll = 0.f;
@@ -1075,8 +1095,9 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(At
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad_kv; key += 256)
-      us[key] = key < p.nppf ? p.u[(u_base + key) * p.H + h] : 0.f;
+    stage_batched<2, 256, float>(p.npad_kv, tid,
+        [&](int key) { return p.u[(u_base + (key < p.nppf ? key : 0)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.nppf ? v : 0.f; });
     if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
   }
   __syncthreads();

@@ -67,6 +67,7 @@ static inline size_t attn_struct_ef_lds(int npad_kv) {
 template <typename T16, int NDB, int WPE>
 __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructParams p) {
   constexpr int DP = NDB * 32, KS = DP / 16;
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
   constexpr int DPW = NDB / 4;                       // output d-blocks per wave
   constexpr int NA = EF_MAXA;                        // arguments (the launcher checks p.nsrl == NA)
   constexpr int PLS = 3 * DP + EF_PLS_PAD;           // floats per argument in the staged language rows
@@ -119,8 +120,9 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad_kv; key += 256)
-      us[key] = key < p.nppf ? p.u[(u_base + key) * p.H + h] : 0.f;
+    stage_batched<2, 256, float>(p.npad_kv, tid,
+        [&](int key) { return p.u[(u_base + (key < p.nppf ? key : 0)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.nppf ? v : 0.f; });
     if (p_ok) uq = p.u[(u_base + pi) * p.H + h];
   } else {
     for (int key = tid; key < p.npad_kv; key += 256) us[key] = 0.f;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
     for (int kb = 0; kb < nkb; ++kb) m = fmaxf(m, mblk[kb * 32 + ql]);
     // (run-time logit-scale report, AttnStructParams::logit_max: |row maximum of the proposal part A| - with the argument part's
     // |mB| published below, the larger of the two is a lower bound of the row's largest |A + B| within 2x; log2 units -> nats)
-    publish_logit_max(p.logit_max, p_ok ? fabsf(m) * 0.69314718056f : 0.f, lane);
+    publish_logit_max(p.logit_max, lprev, p_ok ? fabsf(m) * 0.69314718056f : 0.f, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kb = wid + 4 * i;
@@ -271,8 +273,7 @@ __global__ __launch_bounds__(256, WPE) void attn_struct_ef_kernel(AttnStructPara
         kBl[a] = kB;
         if (p.logit_max) {                       // |mB| of this argument row (raise-only, as publish_logit_max)
           const unsigned int bits = __float_as_uint(fabsf(mB) * 0.69314718056f);
-          unsigned int* w_ = p.logit_max + (blockIdx.x & 7);
-          if (__hip_atomic_load(w_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w_, bits);
+          if (bits > lprev) atomicMax(p.logit_max + (blockIdx.x & (kLogitWords - 1)) * kLogitStride, bits);
         }
       }
       for (int key = sub; key < p.npad_kv; key += 32) brow[key] = __builtin_amdgcn_exp2f(brow[key] - mB);

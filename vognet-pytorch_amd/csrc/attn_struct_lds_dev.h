@@ -58,17 +58,20 @@ __global__ __launch_bounds__(256, 1) void attn_struct_lds_kernel(AttnStructParam
   // the language rows of this (video, head) - Ql / Kl / Vl, nsrl x 3 x DP floats - are staged in LDS once
   // per workgroup: formed per wave from global memory, the query fragments and the language key block
   // cost ~100 small dependent loads per wave (95 + ~30 of the 360 us of this launch at cfg 4)
-  for (int i = tid; i < p.nsrl * 3 * (DP / 4); i += 256) {
-    const int a = i / (3 * (DP / 4)), r = i - a * 3 * (DP / 4);
-    const int which = r / (DP / 4), c = r - which * (DP / 4);
-    reinterpret_cast<float4*>(pls)[i] = *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + which * hd + c * 4);
-  }
+  stage_batched<4, 256, float4>(p.nsrl * 3 * (DP / 4), tid,
+      [&](int i) {
+        const int a = i / (3 * (DP / 4)), r = i - a * 3 * (DP / 4);
+        const int which = r / (DP / 4), c = r - which * (DP / 4);
+        return *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + which * hd + c * 4);
+      },
+      [&](int i, const float4& v) { reinterpret_cast<float4*>(pls)[i] = v; });
   float uq = 0.f, peb = 0.f;
   if (p.use_rel) {
     const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
     peb = p.pe_b[h];
-    for (int key = tid; key < p.npad_kv; key += 256)
-      us[key] = key < p.nppf ? p.u[(u_base + key) * p.H + h] : 0.f;
+    stage_batched<2, 256, float>(p.npad_kv, tid,
+        [&](int key) { return p.u[(u_base + (key < p.nppf ? key : 0)) * p.H + h]; },
+        [&](int key, float v) { us[key] = key < p.nppf ? v : 0.f; });
     if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
   } else {
     for (int key = tid; key < p.npad_kv; key += 256) us[key] = 0.f;

@@ -45,6 +45,7 @@ struct AttnTile2Body {
   static constexpr int THREADS = 512;
   static __device__ __forceinline__ void run(const AttnParams& p, const BlockCtx& cx, unsigned char* t2sm) {
   constexpr int DP = NDB * 32, KS = DP / 16;
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
   constexpr int NF = KS + 2 * NDB;                   // KiB fragments per key block (K then V^T)
   constexpr int NBUF = 4, DIST = 2;                  // ring depth; blocks requested ahead
   constexpr int FPW = (NF + 7) / 8;                  // DMA instructions per wave per block (tail waves repeat the last fragment)
@@ -82,8 +83,12 @@ struct AttnTile2Body {
       u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
       peb = p.pe_b[h];
     }
-    for (int key = tid; key < p.npad; key += 512)
-      us[key] = (p.use_rel && key < p.N) ? p.u[(u_base + (key % p.n_box)) * p.H + h] * c2 : 0.f;
+    if (p.use_rel)
+      stage_batched<8, 512, float>(p.npad, tid,
+          [&](int key) { return p.u[(u_base + ((key < p.N ? key : 0) % p.n_box)) * p.H + h]; },
+          [&](int key, float v) { us[key] = key < p.N ? v * c2 : 0.f; });
+    else
+      for (int key = tid; key < p.npad; key += 512) us[key] = 0.f;
     if (p.use_rel && qi < p.N) uq = (p.u[(u_base + (qi % p.n_box)) * p.H + h] + peb) * c2;
   }
   // Q fragments of this wave's block: registers for the whole pass
@@ -164,7 +169,7 @@ struct AttnTile2Body {
     // (run-time logit-scale report, AttnParams::logit_max: this kernel's softmax never looks at single logits again, so what it
     // reports is the magnitude of each row's reference - the maximum over its first 32 keys - a LOWER bound of the row's largest
     // |logit| (typically within 2x: 2 sigma against ~4 sigma over 4000 keys); one value per wave, log2 units -> nats)
-    publish_logit_max(p.logit_max, (wave_ok && qi < p.N) ? fabsf(mx) * 0.69314718056f : 0.f, lane);
+    publish_logit_max(p.logit_max, lprev, (wave_ok && qi < p.N) ? fabsf(mx) * 0.69314718056f : 0.f, lane);
     // f16: the reference sits 4 binary orders ABOVE block 0's maximum - every P, row sum and accumulator carries 2^-4, which
     // cancels in O / l - so that the headroom to f16's 65504 is 19 binary orders (13 nats above block 0) instead of 15; block
     // 0's own maximum becomes 2^-4 and P stays a normal f16 number down to 2^-10 of it (below: absolute error 2^-25 per key)

@@ -148,6 +148,20 @@ __host__ __device__ __forceinline__ int64_t frag_a(int m, int k, int K) {
 // with the hardware indices; pair_kernel (pair.hip) calls two different bodies from one grid.
 struct BlockCtx { unsigned bx, by, gx, gy; };
 
+// Cooperative staging with B loads in flight per thread. A "load, wait, store to LDS" loop with a run-time trip count pays one
+// memory round trip per iteration (the compiler does not move the next load over the LDS store); here a batch of B loads is issued
+// with clamped indices before the first store of the batch (round 6: the same change took argvec from 28 to 8.8 us).
+template <int B, int NT, typename T, typename Load, typename Store>
+__device__ __forceinline__ void stage_batched(int n, int tid, Load load, Store store) {
+  for (int i0 = tid; i0 < n; i0 += B * NT) {
+    T v[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) { const int i = i0 + q * NT; v[q] = load(i < n ? i : n - 1); }
+#pragma unroll
+    for (int q = 0; q < B; ++q) { const int i = i0 + q * NT; if (i < n) store(i, v[q]); }
+  }
+}
+
 // ---- kernel launch ---------------------------------------------------------------------------
 // Every kernel of the library is launched through vog::launch: hipLaunchKernelGGL on the caller's stream, or - while pair.hip
 // has its capture open - a record of the kernel's host stub, geometry and packed kernarg bytes, from which two independent steps

@@ -457,25 +457,38 @@ __device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
 }
 
 // the forward's largest |attention logit| per stack -> the host's sticky maximum (vog_batch.stats): threads 0 / 1 of block 0
-__device__ __forceinline__ void publish_stats(const vog_pred_args& a) {
-  if (!a.stats || !a.logit_max || !a.published || blockIdx.x != 0 || threadIdx.x >= 2) return;
-  unsigned int v[32], m = 0;
+// The head folds the two stacks' logit reports (vog_attn_args.logit_max: [2][4 layers][VOG_LOGIT_WORDS words, 128 B apart]) into the
+// pinned host words. Wave 0 of workgroup 0: lane (stack, word) loads its 4 layers' words when the kernel STARTS (stats_begin: in
+// flight behind the head's own loads) and folds them when it ends (stats_end). The host word is touched only when this workspace's
+// forwards have seen a larger value than they last published - a.published, zeroed with the workspace only: a system-scope atomic
+// on pinned host memory is a PCIe round trip the kernel would otherwise wait out in every forward.
+struct StatsProbe { unsigned int m, last; };
+__device__ __forceinline__ StatsProbe stats_begin(const vog_pred_args& a) {
+  StatsProbe s{0u, 0xffffffffu};
+  if (!a.stats || !a.logit_max || !a.published || blockIdx.x != 0 || threadIdx.x >= 64) return s;
+  static_assert(VOG_LOGIT_WORDS == 32, "one lane per (stack, word)");
+  const int stack = threadIdx.x >> 5, word = threadIdx.x & 31;
+  const unsigned int* w = a.logit_max + (stack * 4) * (VOG_LOGIT_WORDS * VOG_LOGIT_STRIDE) + word * VOG_LOGIT_STRIDE;
+  unsigned int v[4];
 #pragma unroll
-  for (int l = 0; l < 32; ++l) v[l] = a.logit_max[threadIdx.x * 32 + l];
+  for (int l = 0; l < 4; ++l) v[l] = __hip_atomic_load(w + l * (VOG_LOGIT_WORDS * VOG_LOGIT_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  s.last = a.published[stack];
 #pragma unroll
-  for (int l = 0; l < 32; ++l) m = v[l] > m ? v[l] : m;
-  // (the host word is touched only when this workspace's forwards have seen a larger value than they last published - a.published,
-  // zeroed with the workspace only: a system-scope atomic on pinned host memory is a PCIe round trip the kernel would otherwise wait
-  // out in every forward)
-  unsigned int* last = a.published + threadIdx.x;
-  if (m > *last) {
-    *last = m;
-    __hip_atomic_fetch_max(a.stats + threadIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int l = 0; l < 4; ++l) s.m = v[l] > s.m ? v[l] : s.m;
+  return s;
+}
+__device__ __forceinline__ void stats_end(const vog_pred_args& a, StatsProbe s) {
+  if (!a.stats || !a.logit_max || !a.published || blockIdx.x != 0 || threadIdx.x >= 64) return;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { const unsigned int t = __shfl_xor(s.m, o); s.m = t > s.m ? t : s.m; }
+  const int stack = threadIdx.x >> 5;
+  if ((threadIdx.x & 31) == 0 && s.m > s.last) {
+    a.published[stack] = s.m;
+    __hip_atomic_fetch_max(a.stats + stack, s.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
-__global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t rec_bytes) {
-  publish_stats(a);
+__device__ __forceinline__ void pred_wave_item(const vog_pred_args& a, int64_t rec_bytes) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int per_q = a.nsrl * a.nfrm0 * a.ncmp;
@@ -537,10 +550,16 @@ __global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t
   }
   if (lane == 0) idx[(int64_t)arg * a.nfrm0 + f] = out;
 }
+__global__ __launch_bounds__(256) void pred_wave_kernel(vog_pred_args a, int64_t rec_bytes) {
+  const StatsProbe sp = stats_begin(a);
+  pred_wave_item(a, rec_bytes);
+  stats_end(a, sp);
+}
 
 __global__ void pred_kernel(vog_pred_args a, int64_t rec_bytes) {
-  publish_stats(a);
+  const StatsProbe sp = stats_begin(a);
   pred_item<false>(a, rec_bytes, blockIdx.x * blockDim.x + threadIdx.x);
+  stats_end(a, sp);
 }
 
 // ---------------------------------------------------------------------------

@@ -357,6 +357,9 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   const int nl = d.rnn_layers;
   p.add("logit_pub", 256);                            // the logit maxima this workspace's forwards last published to the host
                                                       // (vog_pred_args.published; zeroed with the workspace, not per forward)
+  p.add("logit_max", 2 * 4 * VOG_LOGIT_WORDS * VOG_LOGIT_STRIDE * 4);   // [2 stacks][4 layers][words, 128 B apart]: the running largest
+                                                      // |attention logit| of this workspace's forwards (float bits; raise-only, zeroed
+                                                      // with the workspace)
   // ---- zero-initialised region (one memset per forward)
   p.zero_off = p.total;
   for (int l = 0; l < nl; ++l) {
@@ -372,7 +375,6 @@ static Plan make_plan(const vog_ctx* c, const Geo& g, bool lang_only = false) {
   p.add("obj_guard", 256);                            // vog_attn_args.guard_flag of the two stacks (long-sequence attention): zeroed
   p.add("mul_guard", 256);                            // with the rest of this region, so the attention needs no clearing launch
   p.add("mul_ef_guard", 256);                         // vog_attn_struct_args.guard_flag (E x F attention of mul_tx layer 0, p100)
-  p.add("logit_max", 256);                            // [2 stacks][4 layers][8 words] largest |attention logit| of this forward (float bits)
   p.zero_bytes = p.total - p.zero_off;
   // ---- 0xff-initialised region, directly behind the zeros (same fill loop of the prologue): the
   // hand-off slots of the persistent BiLSTM, [T][2][Bn][R] 16-bit per layer (lstm_dev.h)
@@ -467,7 +469,8 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
   const void* cur16 = x_in16;
   const bool split = c->tx_split != 0;
   const void* cur16_lo = x_in16_lo;
-  unsigned int* lmax = ws.at<unsigned int>("logit_max") + (n == "mul" ? 32 : 0);
+  constexpr int kLogitGroup = VOG_LOGIT_WORDS * VOG_LOGIT_STRIDE;                // words of one layer's report
+  unsigned int* lmax = ws.at<unsigned int>("logit_max") + (n == "mul" ? 4 * kLogitGroup : 0);
   for (int l = 0; l < tw.n_layers; ++l) {
     const TxLayer& L = tw.layers[l];
     const bool toA = (l % 2) == 0;
@@ -513,7 +516,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
       sa.nc_v = sv.nc_v; sa.use_rel = tw.use_rel; sa.seq_per_vid = spv; sa.NP = g.NP;
       sa.inv_scale = 1.0f / sqrtf((float)tw.d); sa.dtype = dt;
       sa.guard_flag = (n == "mul") ? ws.at<int>("mul_ef_guard") : nullptr;
-      sa.logit_max = lmax + (l < 3 ? l : 3) * 8;
+      sa.logit_max = lmax + (l < 3 ? l : 3) * kLogitGroup;
       if (split) { sa.q_lo = qa.q_lo; sa.kv_lo = qa.k_lo; sa.out16_lo = tail_split ? attn16_lo : nullptr; }
       steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_struct_fwd(&sa, st); }});
     } else {
@@ -528,7 +531,7 @@ static void tx_steps(const vog_ctx* c, const TxWeights& tw, const char* nm, cons
     // layer 0 stayed up - the prologue clears once per forward - and every later layer re-ran the running-maximum fallback)
     aa.guard_flag = ws.at<int>(n + "_guard") + (l < 63 ? l : 63);
     aa.guard_precleared = l < 63 ? 1 : 0;
-    aa.logit_max = lmax + (l < 3 ? l : 3) * 8;        // 8 words per layer (layers past the 4th share the last group)
+    aa.logit_max = lmax + (l < 3 ? l : 3) * kLogitGroup;   // (layers past the 4th share the last group)
     if (split) { aa.q_lo = qa.q_lo; aa.k_lo = qa.k_lo; aa.out16_lo = tail_split ? attn16_lo : nullptr; }
     if (!fact) steps.push_back({n + "_attn", [=](hipStream_t st) { return vog_rel_attention_fwd(&aa, st); }});
     const bool last = l == tw.n_layers - 1;

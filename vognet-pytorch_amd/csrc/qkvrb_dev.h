@@ -34,13 +34,18 @@ struct QkvRowAllBody {
     {
       const int cpr = p.K >> 3;
       const unsigned short* a = reinterpret_cast<const unsigned short*>(p.a);
-      for (int idx = tid; idx < 64 * cpr; idx += 512) {
-        const int r = idx / cpr, c = idx - r * cpr;
-        int m = m0 + r;
-        m = m < p.M ? m : p.M - 1;
-        const int64_t src = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
-        *reinterpret_cast<uint4*>(smem + r * pitch + c * 16) = *reinterpret_cast<const uint4*>(a + src * p.lda + c * 8);
-      }
+      stage_batched<8, 512, uint4>(64 * cpr, tid,
+          [&](int idx) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            const int64_t src = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
+            return *reinterpret_cast<const uint4*>(a + src * p.lda + c * 8);
+          },
+          [&](int idx, const uint4& v) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            *reinterpret_cast<uint4*>(smem + r * pitch + c * 16) = v;
+          });
     }
     const int KS = p.K >> 4, nblk = p.N >> 5;
     const int rot = (((cx.bx >> 3) & 7) * KS) >> 3;                // workgroups of one XCD start at different k

@@ -347,17 +347,37 @@ struct TxTailBody {
   // round trip: no epilogue below waits for a global load.
   {
     const int cpr = ((DBG & 4) && (p.dbgf & 2)) ? 0 : (p.KWO >> 3);
-    for (int idx = tid; idx < ROWS * cpr; idx += 512) {
-      const int r = idx / cpr, c = idx - r * cpr;
-      int m = m0 + r;
-      m = m < p.M ? m : p.M - 1;
-      // (read once: with p.nt_rows the load is non-temporal, so that at many row blocks per XCD - 156 at cfg 4 - the streamed
-      // activation rows do not displace the 2.75 MB of weights every workgroup of the XCD re-reads from its L2)
-      const u32x4* src = reinterpret_cast<const u32x4*>(p.attn16 + (int64_t)m * p.KWO + c * 8);
-      const u32x4 v = p.nt_rows ? __builtin_nontemporal_load(src) : *src;
-      *reinterpret_cast<u32x4*>(X + r * p1 + c * 16) = v;
-      if constexpr (SPLIT)
-        *reinterpret_cast<u32x4*>(XL + r * p1 + c * 16) = *reinterpret_cast<const u32x4*>(p.attn16_lo + (int64_t)m * p.KWO + c * 8);
+    // Round 6: ALL of a thread's row chunks (<= 12 x 16 bytes at 64 rows x 768 columns) are requested before the first one is
+    // stored. The loop this replaces (runtime trip count: load, wait, LDS store, next) paid one memory round trip per chunk -
+    // most of the ~17 us of "skeleton" the ablations of round 4 found around the GEMM stages (profiles/round4_tail_ablation_and_
+    // ingest.md). Indices past the end are clamped (no conditional load), their stores skipped.
+    constexpr int SIT = ROWS * (768 / 8) / 512;            // kwo <= 768
+    const int nchk = ROWS * cpr;
+    if (cpr > 0) {
+      u32x4 stg[SIT];
+      u32x4 stgl[SPLIT ? SIT : 1];
+      int ldsoff[SIT];
+#pragma unroll
+      for (int it = 0; it < SIT; ++it) {
+        int idx = tid + it * 512;
+        idx = idx < nchk ? idx : nchk - 1;
+        const int r = idx / cpr, c = idx - r * cpr;
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;
+        // (read once: with p.nt_rows the load is non-temporal, so that at many row blocks per XCD - 156 at cfg 4 - the streamed
+        // activation rows do not displace the 2.75 MB of weights every workgroup of the XCD re-reads from its L2)
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.attn16 + (int64_t)m * p.KWO + c * 8);
+        stg[it] = p.nt_rows ? __builtin_nontemporal_load(src) : *src;
+        if constexpr (SPLIT) stgl[it] = *reinterpret_cast<const u32x4*>(p.attn16_lo + (int64_t)m * p.KWO + c * 8);
+        ldsoff[it] = r * p1 + c * 16;
+      }
+#pragma unroll
+      for (int it = 0; it < SIT; ++it) {
+        if (tid + it * 512 < nchk) {
+          *reinterpret_cast<u32x4*>(X + ldsoff[it]) = stg[it];
+          if constexpr (SPLIT) *reinterpret_cast<u32x4*>(XL + ldsoff[it]) = stgl[it];
+        }
+      }
     }
     if constexpr (RB == 2) {
       for (int i = tid; i < D / 4; i += 512) {

@@ -163,6 +163,7 @@ class CopySeg(C.Structure):
 
 
 MAX_COPY_SEGS = 24
+LOGIT_WORDS, LOGIT_STRIDE = 32, 32      # VOG_LOGIT_WORDS / VOG_LOGIT_STRIDE (vog_attn_args.logit_max)
 
 
 class PredcmpArgs(C.Structure):
