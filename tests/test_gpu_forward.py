@@ -200,7 +200,7 @@ def test_forward_hi_lo_plan_vs_reference_golden(name):
     assert torch.equal(out["mdl_outs"], out2["mdl_outs"])
 
 
-@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_ragged", "full/cfg3_vog_temp_gt5_bs8",
+@pytest.mark.parametrize("name", ["full/cfg2_sharp8", "full/cfg3_vog_temp_gt5_bs8",
                                   "full/cfg5_vog_svsq_gt5_bs16", "full/vog_sep_gt5_bs4_ragged", "full/vgrnd_spat_sharp16",
                                   "full/vog_spat_gt5_bs4_3layers"])
 def test_forward_hi_lo_forced_vs_reference_golden(name):
@@ -259,7 +259,7 @@ def test_observed_logit_scale_of_the_goldens():
     for name in ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp10", "full/cfg2_sharp12", "full/cfg2_sharp16",
                  "full/cfg2_sharp24", "full/cfg2_sharp32", "full/cfg3_sharp8", "full/cfg5_sharp8", "full/vog_spat_3layers_sharp8",
                  "full/cfg4_p100_sharp8"]:      # (p100: the long-sequence kernels report row-reference magnitudes, a lower bound)
-        eng, cfg, sd, batch, c, dev = build_engine(name)
+        eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
         eng.forward(dev)
         torch.cuda.synchronize()
         lo, lm = eng.observed_logit_max()
@@ -313,8 +313,8 @@ def test_forward_persistent_lstm_layer(name):
     assert ds < 4e-4, ds
 
 
-@pytest.mark.parametrize("name", FULL_VARIANTS + ["small/vog_spat", "small/vgrnd_sep", "small/edge_temp_len1",
-                                         "small/edge_sep_maxlen"])
+@pytest.mark.parametrize("name", FULL_VARIANTS[::2] + ["small/vog_spat", "small/vgrnd_sep", "small/edge_temp_len1",
+                                              "small/edge_sep_maxlen"])
 def test_forward_step_launch_lstm_vs_reference_golden(name):
     """The step-launch BiLSTM (lstm_persistent = 0: lowest latency fallback, any number in flight)
     against the same reference goldens as the default persistent layer kernel."""
