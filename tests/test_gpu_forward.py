@@ -141,7 +141,7 @@ def test_precision_plan_follows_attention_sharpness():
     seen = {}
     for name in ("full/cfg2_vog_spat_gt5_bs4", "full/cfg2_sharp8", "full/cfg2_sharp10", "full/cfg2_sharp12", "full/cfg2_sharp16",
                  "full/cfg2_sharp32", "full/cfg2_sharp48"):
-        eng, *_ = build_engine(name)
+        eng, *_ = build_engine(name, cached=True)      # (the golden tests' engines: same key)
         seen[name] = (eng.sharpness, eng.plan)
         assert eng.desc.tx_dtype == L.VOG_F16 and (eng.precise is not None) == (eng.plan == "f32")
     print(seen)
@@ -178,11 +178,11 @@ def test_precision_plan_for_deep_stacks():
     """3-layer stacks: the f16 envelope ends at sharpness 5 (errors compound over sharp layers): x 4 stays on the f16 kernels,
     x 8 - inside the single-layer envelope - runs the fp32 path; both hold the reference golden (run by the FULL list too)."""
     E = engine_mod
-    eng, *_ = build_engine("full/vog_spat_3layers_sharp4")
+    eng, *_ = build_engine("full/vog_spat_3layers_sharp4", cached=True)
     assert eng.plan == "f16" and eng.sharpness < E.F16_SHARPNESS_MAX_DEEP
-    eng, *_ = build_engine("full/vog_spat_3layers_sharp8")      # round 6: hi + lo operands (fp32 path in round 5)
+    eng, *_ = build_engine("full/vog_spat_3layers_sharp8", cached=True)      # round 6: hi + lo operands (fp32 path in round 5)
     assert eng.plan == "split" and E.F16_SHARPNESS_MAX_DEEP < eng.sharpness < E.SPLIT_SHARPNESS_MAX_DEEP
-    eng, *_ = build_engine("full/cfg2_sharp8")
+    eng, *_ = build_engine("full/cfg2_sharp8", cached=True)
     assert eng.plan == "f16"
 
 
@@ -191,7 +191,7 @@ def test_forward_hi_lo_plan_vs_reference_golden(name):
     """Round 6: checkpoints past the f16 envelope (wq / wk x 12 ... x 32; 3-layer stacks x 8; temp / svsq / sep / VidGrnd x 16) on
     the hi + lo plan `auto` picks for them - the fast kernels with three MFMAs for everything that feeds attention logits - against
     the reference goldens, eager and from a graph slot. (Round 5 ran these on the fp32 path, 34 x slower.)"""
-    eng, *_ = build_engine(name)
+    eng, *_ = build_engine(name, cached=True)
     assert eng.plan == "split", (eng.plan, eng.sharpness)
     out, pred, g, _ = _run(name)
     nf = _check_against(name, out, pred, g, None, tol_rel=1e-3, tol_logit=6e-3)
