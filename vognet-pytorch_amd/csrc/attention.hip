@@ -118,6 +118,23 @@ static int launch_attn_struct(const AttnStructParams& p, hipStream_t st) {
     }
     VOG_FAIL(-1, "struct attention with hi + lo operands: needs q_visual, one visual key block (nppf <= 32) and a head dim of 64 / 128 / 192 / 256");
   }
+  // one visual key block, queries formed in the kernel: every operand through LDS after one round trip (round 6)
+  static int dma_form = -2;           // VOG_ATTN_STRUCT_DMA=0 (perf experiments): the lean form below
+  if (dma_form == -2) { const char* e = perf_env("VOG_ATTN_STRUCT_DMA"); dma_form = e ? atoi(e) : 1; }
+  if constexpr (((NDB * 32) / 16) % 2 == 0) {
+    const size_t lds_dma = (size_t)(7 * NDB) * 1024 + (size_t)2 * (p.nsrl + 1) * NDB * 32 * sizeof(unsigned short) + 32 * sizeof(float);
+    if (dma_form && p.npad_kv == 32 && p.q_visual && !p.out_lo && p.nsrl <= 16 && lds_dma <= 72 * 1024) {
+      auto kern = attn_struct1_dma_kernel<T16, NDB>;
+      static bool attr_dma = false;
+      if (!attr_dma) {
+        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        attr_dma = true;
+      }
+      ::vog::launch(kern, grid, dim3(256), lds_dma, st, p);
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   // one visual key block: the lean form (<= 128 registers, four workgroups per CU)
   if constexpr (((NDB * 32) / 16) % 2 == 0) {
     if (p.npad_kv == 32) {

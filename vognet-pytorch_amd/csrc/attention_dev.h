@@ -1055,6 +1055,233 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_struct1_lean_kernel(A
   }
 }
 
+// ---- ONE visual key block, queries formed in the kernel, every operand in LDS after ONE round trip (round 6). The lean form
+// above walks the head dimension in KS / 2 rounds of "fragments of the next round in flight"; at cfg 2 the launch is 120
+// workgroups - one per CU, nothing to hide those rounds behind - and per wave it spent (wall-clock stamps, scratch/ts_attn6.hip)
+// 2.2 us in Q.K^T (per k-step: fp32 adds and conversions to form q = Qv + Ql and the language keys, in every wave again),
+// 4.1 us in P.V (8 conditional LDS reads per d-block, each behind its own branch and wait) and 1.2 us in the softmax. Here:
+//  * the workgroup's K, Qv and V^T blocks (KS + KS + 2 NDB fragments of 1 KiB: 48 KiB at head dim 256 - the four waves share
+//    them) go global -> LDS by LDS-DMA, all requested before anything is waited for;
+//  * the language rows are converted ONCE per workgroup on their way into LDS: Ql and Kl as 16-bit rows (MFMA operands read
+//    with one 16-byte LDS load), Vl directly as the P.V product's A fragments;
+//  * q.k = (Qv + Ql).(k) is two MFMAs on 16-bit operands instead of one MFMA behind 24 VALU instructions (linearity; each part is
+//    rounded on its own, which is no worse than rounding the sum);
+//  * head dim 256: the output rows leave through LDS tiles (the K / Qv images are free by then), 4 rows x 256 B per store.
+// nsrl <= 16 (one language key step). The hi + lo plan and other shapes keep the lean kernel.
+#ifndef VOG_DMA_TSTORE
+#define VOG_DMA_TSTORE 1
+#endif
+template <typename T16, int NDB>
+__global__ __launch_bounds__(256, 2) void attn_struct1_dma_kernel(AttnStructParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16;
+  constexpr int NFRAG = 2 * KS + 2 * NDB;              // K, Qv, V^T
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+  unsigned char* Kl = dsm;                             // [KS][1024]
+  unsigned char* Ql = Kl + KS * 1024;                  // [KS][1024]  Qv of the frame's proposals (fragment order)
+  unsigned char* Vl = Ql + KS * 1024;                  // [2 NDB][1024]
+  unsigned char* Wl = Vl + 2 * NDB * 1024;             // [NDB][1024]  language V as A fragments of the P.V product
+  unsigned short* QL16 = reinterpret_cast<unsigned short*>(Wl + NDB * 1024);   // [nsrl + 1][DP] 16-bit Ql rows (+ a zero row)
+  unsigned short* KL16 = QL16 + (p.nsrl + 1) * DP;                             // [nsrl + 1][DP] 16-bit Kl rows (+ a zero row)
+  float* us = reinterpret_cast<float*>(KL16 + (p.nsrl + 1) * DP);              // [32] bias precursor of the visual keys
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int Nq = p.nsrl * p.nppf;
+  const int nqb = (Nq + 31) >> 5, nqg = (nqb + 3) >> 2;
+  const int pair = blockIdx.x / nqg, qg = blockIdx.x - pair * nqg;
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qb = qg * 4 + wid;
+  const bool wave_ok = qb < nqb;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = wave_ok && qi < Nq;
+  const int hd = p.H * DP, ldp = 3 * hd;
+  const int vid = s / p.nfrm;
+  const int lv = p.lpv ? vid : vid / p.ncv;
+  const float* plr = p.pl + (int64_t)lv * p.nsrl * ldp + h * DP;     // + hd: K block, + 2*hd: V block
+  VOG_ATS(0);
+  const int64_t kvbase = ((int64_t)s * p.H + h) * (int64_t)32 * DP;  // (npad_kv == 32)
+  {
+    const unsigned short* src[3] = {p.kv + kvbase, p.q + kvbase, p.vv + kvbase};
+#pragma unroll
+    for (int i = 0; i < (NFRAG + 3) / 4; ++i) {
+      int f = wid + 4 * i;                             // fragment of the [K | Qv | V^T] image
+      f = f < NFRAG ? f : NFRAG - 1;                   // (tail waves repeat the last one)
+      const int which = f < KS ? 0 : (f < 2 * KS ? 1 : 2);
+      const int fi = f - (which == 0 ? 0 : (which == 1 ? KS : 2 * KS));
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src[which] + (int64_t)fi * 512 + lane * 8),
+          (__attribute__((address_space(3))) void*)(dsm + (size_t)f * 1024), 16, 0, 0);
+    }
+  }
+  {
+    // Ql / Kl rows -> 16 bit (row nsrl of each = zeros: what the key lanes past nsrl read)
+    const int per_part = DP / 4, per_row = 2 * per_part;            // float4 per (argument, part)
+    stage_batched<3, 256, float4>(p.nsrl * per_row, tid,
+        [&](int i) {
+          const int a = i / per_row, c = i - a * per_row;
+          const int part = c / per_part, dd4 = c - part * per_part;
+          return *reinterpret_cast<const float4*>(plr + (int64_t)a * ldp + part * hd + dd4 * 4);
+        },
+        [&](int i, const float4& v) {
+          const int a = i / per_row, c = i - a * per_row;
+          const int part = c / per_part, dd4 = c - part * per_part;
+          *reinterpret_cast<u16x4*>((part ? KL16 : QL16) + a * DP + dd4 * 4) =
+              u16x4{to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
+        });
+    for (int i = tid; i < DP / 4; i += 256) {
+      *reinterpret_cast<u16x4*>(QL16 + p.nsrl * DP + i * 4) = u16x4{0, 0, 0, 0};
+      *reinterpret_cast<u16x4*>(KL16 + p.nsrl * DP + i * 4) = u16x4{0, 0, 0, 0};
+    }
+    // Vl -> the A fragments of the language P.V product: fragment db, lane (d = db * 32 + (lane & 31)), element j = key
+    // 8 (j >> 2) + 4 (lane >> 5) + (j & 3); one (d-block, lane) per thread and pass, its 8 row reads in flight together
+    const float* vrow = plr + 2 * hd;
+#pragma unroll
+    for (int it = 0; it < (NDB * 64 + 255) / 256; ++it) {
+      const int e = tid + it * 256;
+      const int db = (e >> 6) < NDB ? (e >> 6) : NDB - 1, ln = e & 63;
+      const int hh = ln >> 5, dcol = db * 32 + (ln & 31);
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int key = 8 * (j >> 2) + 4 * hh + (j & 3);
+        wv[j] = vrow[(int64_t)(key < p.nsrl ? key : 0) * ldp + dcol];
+      }
+      u16x8 w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int key = 8 * (j >> 2) + 4 * hh + (j & 3);
+        w[j] = key < p.nsrl ? to16<T16>(wv[j]) : (unsigned short)0;
+      }
+      if (e < NDB * 64) *reinterpret_cast<u16x8*>(Wl + (size_t)e * 16) = w;
+    }
+  }
+  const int t = (wave_ok ? qb : 0) * 32 + ql;
+  int qa = t / p.nppf;
+  const int qp = t - qa * p.nppf;
+  qa = qa < p.nsrl ? qa : p.nsrl - 1;                // tokens past the end are never stored
+  float uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.nppf;
+    peb = p.pe_b[h];
+    if (tid < 32) us[tid] = p.u[(u_base + (tid < p.nppf ? tid : 0)) * p.H + h];
+    if (q_ok) uq = p.u[(u_base + (qi % p.nppf)) * p.H + h];
+  }
+  VOG_ATS(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the DMA image
+  __syncthreads();                                   // ... everybody's, and the staged rows
+  VOG_ATS(2);
+  if (!wave_ok) return;
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+  f32x16 sv, sl;
+  {
+    f32x16 s1, l1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = 0.f; s1[r] = 0.f; sl[r] = 0.f; l1[r] = 0.f; }
+    const unsigned char* qsrc = Ql + frag_qk(qp, hi * 8, DP) * 2;        // + ks * 1024: Qv[p], this lane's 8 columns of k-step ks
+    const unsigned short* qlsrc = QL16 + qa * DP + hi * 8;               // + ks * 16:   Ql[a], the same columns
+    const unsigned char* ksrc = Kl + lane * 16;
+    const unsigned short* klsrc = KL16 + (ql < p.nsrl ? ql : p.nsrl) * DP + hi * 8;   // language key a = lane (zero row past nsrl)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u16x8 qv = *reinterpret_cast<const u16x8*>(qsrc + ks * 1024);
+      const u16x8 qlg = *reinterpret_cast<const u16x8*>(qlsrc + ks * 16);
+      const u16x8 k = *reinterpret_cast<const u16x8*>(ksrc + ks * 1024);
+      const u16x8 kl = *reinterpret_cast<const u16x8*>(klsrc + ks * 16);
+      sv = mfma32<T16>(k, qv, sv);                   // q.k = (Qv + Ql).k: two products on 16-bit operands
+      s1 = mfma32<T16>(k, qlg, s1);
+      sl = mfma32<T16>(kl, qv, sl);
+      l1 = mfma32<T16>(kl, qlg, l1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] += s1[r]; sl[r] += l1[r]; }
+  }
+  VOG_ATS(3);
+  // ---- two independent softmaxes, probabilities normalised before P.V
+  u16x8 pv_[2], pl_;
+  {
+    float mv = -1e30f, ml = -1e30f, av = 0.f, al = 0.f;
+    float ub[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ub[r] = us[c32_row(r, lane)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = c32_row(r, lane);
+      float x = sv[r];
+      if (p.use_rel) x += fmaxf(uqp - ub[r], 0.f);
+      x = key < p.nppf ? x * c2 : -1e30f;
+      const float y = key < p.nsrl ? sl[r] * c2 : -1e30f;
+      sv[r] = x; sl[r] = y;
+      mv = fmaxf(mv, x); ml = fmaxf(ml, y);
+      av = fmaxf(av, key < p.nppf ? fabsf(x) : 0.f); al = fmaxf(al, key < p.nsrl ? fabsf(y) : 0.f);
+    }
+    // (the logit of key (a', p') is x[p'] + y[a']: the largest magnitude of the pair bounds it; log2 units -> nats)
+    publish_logit_max(p.logit_max, lprev, q_ok ? (av + al) * 0.69314718056f : 0.f, lane);
+    mv = fmaxf(mv, __shfl_xor(mv, 32));
+    ml = fmaxf(ml, __shfl_xor(ml, 32));
+    float lv_ = 0.f, ll = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = __builtin_amdgcn_exp2f(sv[r] - mv); lv_ += sv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                    // (nsrl <= 16: the language keys are the first k-step's rows)
+      sl[r] = __builtin_amdgcn_exp2f(sl[r] - ml); ll += sl[r];
+    }
+    lv_ += __shfl_xor(lv_, 32);
+    ll += __shfl_xor(ll, 32);
+    const float iv = 1.0f / lv_, il = 1.0f / ll;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pv_[0][j] = to16<T16>(sv[j] * iv);
+      pv_[1][j] = to16<T16>(sv[8 + j] * iv);
+      pl_[j] = to16<T16>(sl[j] * il);
+    }
+  }
+  VOG_ATS(4);
+  // ---- output, one d-block at a time. Head dim 256 (VOG_DMA_TSTORE): the rows leave through LDS, four d-blocks (256 bytes of
+  // a row) at a time, so that a store instruction writes 4 rows x 256 contiguous bytes; straight from the accumulator layout a
+  // lane owns 4 columns of its row and an instruction scatters 16-byte pieces over 32 rows. The tile of wave w is the w-th
+  // quarter of the K / Qv images, which nobody reads after the Q.K^T phase (barrier below).
+  const unsigned char* vsrc = Vl + lane * 16;
+  const unsigned char* wsrc = Wl + lane * 16;
+  constexpr bool TSTORE = NDB == 8 && VOG_DMA_TSTORE;  // (4 tiles of 8 KiB = the K + Qv images at head dim 256)
+  unsigned char* tile = dsm + wid * 8192;             // [32 rows][256 B], 16-byte chunks XOR-swizzled by the row
+  if constexpr (TSTORE) __syncthreads();              // (waves without a query block have left; the barrier counts live waves)
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    const u16x8 v0 = *reinterpret_cast<const u16x8*>(vsrc + (db * 2) * 1024), v1 = *reinterpret_cast<const u16x8*>(vsrc + (db * 2 + 1) * 1024);
+    const u16x8 w0 = *reinterpret_cast<const u16x8*>(wsrc + db * 1024);
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    o = mfma32<T16>(v0, pv_[0], o);
+    o = mfma32<T16>(v1, pv_[1], o);
+    o = mfma32<T16>(w0, pl_, o);
+    if constexpr (!TSTORE) {
+      if (q_ok) struct_store<T16>(p, o, db, (int64_t)s * Nq + qi, h, DP, hi);
+    } else {
+      const int j4 = db & 3;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u16x4 v = {to16<T16>(o[g * 4]), to16<T16>(o[g * 4 + 1]), to16<T16>(o[g * 4 + 2]), to16<T16>(o[g * 4 + 3])};
+        *reinterpret_cast<u16x4*>(tile + ql * 256 + (((j4 * 4 + g) ^ (ql & 15)) << 4) + hi * 8) = v;
+      }
+      if (j4 == 3) {                                 // four d-blocks parked: 32 rows x 256 bytes, 8 instructions of 4 rows each
+        const int64_t o0 = ((int64_t)s * Nq + qb * 32) * ((int64_t)p.H * DP) + (int64_t)h * DP + (db - 3) * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = i * 4 + (lane >> 4), ch = lane & 15;
+          const u16x8 v = *reinterpret_cast<const u16x8*>(tile + row * 256 + ((ch ^ (row & 15)) << 4));
+          if (qb * 32 + row < Nq) *reinterpret_cast<u16x8*>(p.out + o0 + (int64_t)row * ((int64_t)p.H * DP) + ch * 8) = v;
+        }
+      }
+    }
+  }
+  VOG_ATS(5);
+}
+
 // ---- general form: flash loop over the visual key blocks (p100), then the language block
 template <typename T16, int NDB>
 __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void attn_struct_kernel(AttnStructParams p) {
