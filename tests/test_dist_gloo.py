@@ -169,7 +169,7 @@ def _grad_worker(rank, world, port, q):
     fb = D.all_reduce_grads_begin(gb, bucket_bytes=400)
     n = fa() + fb()
     if rank == 0:
-        q.put((n, {k: v.clone() for k, v in grads.items()}))
+        q.put((n, {k: v.numpy().copy() for k, v in grads.items()}))      # numpy: a tensor would travel as an fd the exiting worker may close first
     D.synchronize()
     dist.destroy_process_group()
 
@@ -195,8 +195,8 @@ def test_gradient_allreduce_world2():
                          ("mult_txf.encoder.layers.0.selfattn.layer.wo.weight", (12, 12))):
             ref[k] = ref.get(k, 0) + torch.randn(*shape, generator=g) / world
     for k in ref:
-        assert torch.allclose(got[k], ref[k], atol=1e-6), k
-    assert torch.equal(got["_d_x"], torch.zeros(3))                      # rank 0's own, not reduced
+        assert torch.allclose(torch.from_numpy(got[k]), ref[k], atol=1e-6), k
+    assert torch.equal(torch.from_numpy(got["_d_x"]), torch.zeros(3))                      # rank 0's own, not reduced
 
 
 # ---- world = 8 (round 5): exactly the exchange code `bench.py --gpus 8` and `Evaluator.forward` run, sized as they size it ----
