@@ -273,6 +273,25 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
   // <= 8 key blocks: the lean form (<= 128 registers, four workgroups per CU; VOG_ATTN_FRAG_LEAN=0 (perf experiments): the old one)
   static int lean_f = -2;
   if (lean_f == -2) { const char* e = perf_env("VOG_ATTN_FRAG_LEAN"); lean_f = e ? atoi(e) : 1; }
+  // ... with every operand requested in one round trip (8 waves; VOG_ATTN_FRAG8=0 (perf experiments): the lean form)
+  static int frag8_f = -2;
+  if (frag8_f == -2) { const char* e = perf_env("VOG_ATTN_FRAG8"); frag8_f = e ? atoi(e) : 1; }
+  if constexpr (((NDB * 32) / 16) % 2 == 0) {
+    if (frag8_f && lean_f && p.npad <= 256 && !p.out_lo) {
+      constexpr int KS = (NDB * 32) / 16;
+      const size_t lds8 = (size_t)(KS + 16) * 1024 + (size_t)2 * 8 * 32 * sizeof(float) + (size_t)p.npad * sizeof(float);
+      dim3 grid(ceil_div(p.N, 32) * p.H * p.S);
+      auto kern8 = attn_frag8_kernel<T16, NDB>;
+      static bool attr_f8 = false;
+      if (!attr_f8 && lds8 > 48 * 1024) {
+        VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern8), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_f8 = true;
+      }
+      ::vog::launch(kern8, grid, dim3(512), lds8, st, p);
+      VOG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if constexpr (((NDB * 32) / 16) % 2 == 0) {
     if (lean_f && p.npad <= 256) {
       const size_t ldsl = (size_t)8 * 2 * 64 * 16 + (size_t)2 * 8 * 32 * sizeof(float) + (size_t)p.npad * sizeof(float);

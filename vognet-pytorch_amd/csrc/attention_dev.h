@@ -395,6 +395,172 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 4) void attn_frag_lean_kernel(Attn
   }
 }
 
+// ---- attn_frag with every operand requested in ONE round trip (round 6; <= 8 key blocks: obj_tx at gt5). The lean form above walks
+// Q.K^T in KS / 2 rounds and P.V in one round per key block, each round one L2 latency behind the previous one (fragments of the
+// next round only): 84 workgroups at cfg 2, one per CU, nothing to hide ~13 dependent round trips behind - 10.5 us for 0.25 us of
+// MFMA work. Here 8 waves: wave w owns KEY block w in phases 1-2 and OUTPUT d-block w in phase 3, so a wave's whole K block (KS
+// fragments) and its whole V^T column (2 fragments per key block) are register-resident and requested at kernel start together
+// with the query block (shared: staged in LDS once per workgroup) and the bias precursors; the V^T fragments land while Q.K^T and
+// the softmax run. The output rows leave through an LDS tile (the query image, free after phase 1): a store instruction writes
+// whole 16-byte pieces of contiguous head rows instead of scattering 8-byte pieces over 32 rows.
+// Same arithmetic as the lean form except the P.V sum, which runs as two chains (even / odd fragments) added at the end.
+template <typename T16, int NDB>
+__global__ __launch_bounds__(512, 2) void attn_frag8_kernel(AttnParams p) {
+  constexpr int DP = NDB * 32, KS = DP / 16, MAXKB = 8, QF = (KS + 7) / 8;
+  static_assert(KS % 2 == 0, "two accumulation chains");
+  const unsigned int lprev = logit_prev(p.logit_max);   // (in flight behind the kernel: publish_logit_max)
+  extern __shared__ __attribute__((aligned(16))) unsigned char af8_smem[];
+  u16x8* Qimg = reinterpret_cast<u16x8*>(af8_smem);                             // [KS][64] fragments; later the output tile
+  u16x8* Pl = Qimg + KS * 64;                                                   // [MAXKB * 2][64] fragments
+  float* mloc = reinterpret_cast<float*>(Pl + MAXKB * 2 * 64);                  // [MAXKB][32] block maxima
+  float* lloc = mloc + MAXKB * 32;                                              // [MAXKB][32] block sums
+  float* us = lloc + MAXKB * 32;                                                // [npad] bias precursor of every key
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int nqb = (p.N + 31) >> 5;
+  const int npair = p.S * p.H;
+  int pair, qb;
+  {   // as the lean form: all query blocks of a (sequence, head) on ONE XCD (block b runs on XCD b % 8; speed only)
+    const int b = blockIdx.x;
+    const int full = (npair / 8) * 8;
+    const int grp = b / (8 * nqb);
+    if (grp * 8 < full) { pair = grp * 8 + (b & 7); qb = (b >> 3) % nqb; }
+    else { const int r = b - full * nqb; pair = full + r / nqb; qb = r % nqb; }
+  }
+  const int s = pair / p.H, h = pair - s * p.H;
+  const int qi = qb * 32 + ql;
+  const bool q_ok = qi < p.N;
+  const int nkb = nqb;
+  const bool kb_ok = wid < nkb, db_ok = wid < NDB;
+  const int kb = kb_ok ? wid : 0, db = db_ok ? wid : 0;
+  const int64_t base = ((int64_t)s * p.H + h) * (int64_t)p.npad * DP;
+  const u16x8* Qf = reinterpret_cast<const u16x8*>(p.q + base) + (int64_t)qb * KS * 64 + lane;
+  const u16x8* Kf = reinterpret_cast<const u16x8*>(p.k + base) + (int64_t)kb * KS * 64 + lane;
+  const u16x8* Vf = reinterpret_cast<const u16x8*>(p.vt + base) + (int64_t)(db * 2) * 64 + lane;
+  // ---- every request of the kernel (no load below this block)
+  u16x8 qf[QF];
+#pragma unroll
+  for (int i = 0; i < QF; ++i) {
+    const int f = wid + 8 * i;
+    qf[i] = Qf[(f < KS ? f : KS - 1) * 64];
+  }
+  float uk = 0.f, uq = 0.f, peb = 0.f;
+  if (p.use_rel) {
+    const int64_t u_base = (int64_t)(s / p.seq_per_vid) * p.NP + (int64_t)(s % p.seq_per_vid) * p.n_box;
+    peb = p.pe_b[h];
+    uk = p.u[(u_base + ((tid < p.N ? tid : 0) % p.n_box)) * p.H + h];
+    uq = p.u[(u_base + ((q_ok ? qi : 0) % p.n_box)) * p.H + h];
+  }
+  u16x8 kf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kf[ks] = Kf[ks * 64];
+  u16x8 vf[MAXKB * 2];
+#pragma unroll
+  for (int j = 0; j < MAXKB; ++j) {
+    const int kbc = j < nkb ? j : nkb - 1;           // (blocks past the end repeat the last one: no conditional load)
+    vf[2 * j] = Vf[(int64_t)kbc * NDB * 2 * 64];
+    vf[2 * j + 1] = Vf[((int64_t)kbc * NDB * 2 + 1) * 64];
+  }
+#pragma unroll
+  for (int i = 0; i < QF; ++i) {
+    const int f = wid + 8 * i;
+    if (f < KS) Qimg[f * 64 + lane] = qf[i];
+  }
+  if (tid < p.npad) us[tid] = (p.use_rel && tid < p.N) ? uk : 0.f;
+  __syncthreads();
+  const float c2 = p.inv_scale * 1.44269504088896340736f;   // exp(x * inv_scale) = 2^(x * c2)
+  const float uqp = uq + peb;
+
+  // ---- phase 1: the S^T tile of this wave's key block, scaled logits kept in registers
+  f32x16 sacc;
+  float amax = 0.f;
+  if (kb_ok) {
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    float4 ub[4];                                      // bias precursors of this lane's 16 keys (rows 8g + 4hi + 0..3): read ahead of
+#pragma unroll                                         // the MFMAs, not one by one behind a branch after them
+    for (int g = 0; g < 4; ++g) ub[g] = *reinterpret_cast<const float4*>(us + kb * 32 + g * 8 + hi * 4);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      const u16x8 q0 = Qimg[ks * 64 + lane], q1 = Qimg[(ks + 1) * 64 + lane];
+      s0 = mfma32<T16>(kf[ks], q0, s0);
+      s1 = mfma32<T16>(kf[ks + 1], q1, s1);
+    }
+    float mblk = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + c32_row(r, lane);
+      float x = s0[r] + s1[r];
+      const float ukey = (r & 3) == 0 ? ub[r >> 2].x : ((r & 3) == 1 ? ub[r >> 2].y : ((r & 3) == 2 ? ub[r >> 2].z : ub[r >> 2].w));
+      if (p.use_rel) x += fmaxf(uqp - ukey, 0.f);
+      x = key < p.N ? x * c2 : -1e30f;
+      sacc[r] = x;
+      mblk = fmaxf(mblk, x);
+      amax = fmaxf(amax, key < p.N ? fabsf(x) : 0.f);
+    }
+    mblk = fmaxf(mblk, __shfl_xor(mblk, 32));
+    if (hi == 0) mloc[kb * 32 + ql] = mblk;
+  }
+  publish_logit_max(p.logit_max, lprev, (kb_ok && q_ok) ? amax * 0.69314718056f : 0.f, lane);      // (log2 units -> nats)
+  __syncthreads();
+  // ---- phase 2: probabilities against the row maximum over all key blocks; P^T fragments straight from the registers
+  if (kb_ok) {
+    float m = -1e30f;
+    for (int j = 0; j < nkb; ++j) m = fmaxf(m, mloc[j * 32 + ql]);
+    float lsum = 0.f;
+    u16x8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sacc[r] - m);
+      lsum += e;
+      pf[r >> 3][r & 7] = to16<T16>(e);
+    }
+    lsum += __shfl_xor(lsum, 32);
+    if (hi == 0) lloc[kb * 32 + ql] = lsum;
+    Pl[(kb * 2 + 0) * 64 + lane] = pf[0];
+    Pl[(kb * 2 + 1) * 64 + lane] = pf[1];
+  }
+  __syncthreads();
+  // ---- phase 3: the O^T d-block of this wave, V^T fragments from registers, P^T from LDS; rows parked in the output tile
+  unsigned char* tile = af8_smem;                    // [32 rows][NDB * 64 B], 16-byte chunks XOR-swizzled by the row (low 3 bits)
+  constexpr int SWZ = NDB * 4 >= 8 ? 7 : NDB * 4 - 1;
+  if (db_ok) {
+    float l = 0.f;
+    for (int j = 0; j < nkb; ++j) l += lloc[j * 32 + ql];
+    const float inv_l = 1.0f / l;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < MAXKB; ++j)
+      if (j < nkb) {
+        o0 = mfma32<T16>(vf[2 * j], Pl[(j * 2 + 0) * 64 + lane], o0);
+        o1 = mfma32<T16>(vf[2 * j + 1], Pl[(j * 2 + 1) * 64 + lane], o1);
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u16x4 v = {to16<T16>((o0[g * 4] + o1[g * 4]) * inv_l), to16<T16>((o0[g * 4 + 1] + o1[g * 4 + 1]) * inv_l),
+                       to16<T16>((o0[g * 4 + 2] + o1[g * 4 + 2]) * inv_l), to16<T16>((o0[g * 4 + 3] + o1[g * 4 + 3]) * inv_l)};
+      *reinterpret_cast<u16x4*>(tile + ql * (NDB * 64) + (((db * 4 + g) ^ (ql & SWZ)) << 4) + hi * 8) = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int64_t ldo = (int64_t)p.H * DP;
+    unsigned short* o0p = p.out + ((int64_t)s * p.N + qb * 32) * ldo + (int64_t)h * DP;
+#pragma unroll
+    for (int it = 0; it < (32 * NDB * 4 + 511) / 512; ++it) {
+      const int c = tid + it * 512;
+      const int row = c / (NDB * 4), ch = c - row * (NDB * 4);
+      if (c < 32 * NDB * 4 && qb * 32 + row < p.N)
+        *reinterpret_cast<u16x8*>(o0p + (int64_t)row * ldo + ch * 8) =
+            *reinterpret_cast<const u16x8*>(tile + row * (NDB * 64) + ((ch ^ (row & SWZ)) << 4));
+    }
+  }
+}
+
 template <typename T16, int NDB>
 __global__ __launch_bounds__(256) void attn_frag_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char af_smem[];
