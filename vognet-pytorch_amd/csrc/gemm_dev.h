@@ -329,22 +329,41 @@ __device__ __forceinline__ void qkv_epilogue_tile(const GemmParams& p, const flo
     } else if (which < 2) {
       unsigned short* base = which == 0 ? p.q : p.k;
       unsigned short* base_lo = which == 0 ? p.q_lo : p.k_lo;   // (hi + lo operands: the remainder fragments, or null)
-      const int c = lane & 7, rsub = lane >> 3;     // 8 chunks of 4 columns per row, 8 rows per pass
-#pragma unroll 4
-      for (int ps = 0; ps < WTM / 8; ++ps) {
-        const int rl = ps * 8 + rsub;
+      const int c = lane & 3, rsub = lane >> 2;     // 4 chunks of 8 columns (one 16-byte fragment piece) per row, 16 rows per pass
+#pragma unroll
+      for (int ps = 0; ps < WTM / 16; ++ps) {
+        const int rl = ps * 16 + rsub;
         const int m = mw + rl;
         if (m >= p.M) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 4 * c]);
+        const float4 v = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c]);
+        const float4 w = *reinterpret_cast<const float4*>(&ep[rl * EP_LD + cg * 32 + 8 * c + 4]);
         const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
-        const u16x4 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w)};
-        const int64_t off = ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_qk(tok, dd0 + 4 * c, p.dp);
-        *reinterpret_cast<u16x4*>(base + off) = o;
+        const u16x8 o = {to16<T16>(v.x), to16<T16>(v.y), to16<T16>(v.z), to16<T16>(v.w),
+                         to16<T16>(w.x), to16<T16>(w.y), to16<T16>(w.z), to16<T16>(w.w)};
+        const int64_t off = ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_qk(tok, dd0 + 8 * c, p.dp);
+        *reinterpret_cast<u16x8*>(base + off) = o;
         if (base_lo) {
-          const u16x4 l = {to16<T16>(v.x - from16<T16>(o[0])), to16<T16>(v.y - from16<T16>(o[1])),
-                           to16<T16>(v.z - from16<T16>(o[2])), to16<T16>(v.w - from16<T16>(o[3]))};
-          *reinterpret_cast<u16x4*>(base_lo + off) = l;
+          const u16x8 l = {to16<T16>(v.x - from16<T16>(o[0])), to16<T16>(v.y - from16<T16>(o[1])),
+                           to16<T16>(v.z - from16<T16>(o[2])), to16<T16>(v.w - from16<T16>(o[3])),
+                           to16<T16>(w.x - from16<T16>(o[4])), to16<T16>(w.y - from16<T16>(o[5])),
+                           to16<T16>(w.z - from16<T16>(o[6])), to16<T16>(w.w - from16<T16>(o[7]))};
+          *reinterpret_cast<u16x8*>(base_lo + off) = l;
         }
+      }
+    } else if ((ntok_w & 3) == 0 && (mw & 3) == 0) {
+      // V fragments, vector form (round 6; as the structured writer above): an aligned group of 4 token rows = 4 consecutive j of
+      // one fragment lane -> one 8-byte store; lanes run along dd (conflict-free LDS column reads). The token-per-lane form below
+      // issues 32 two-byte stores per lane: most of the 1.8 us this epilogue took of a 7.4 us QKV launch at cfg 2.
+      const int dd = lane & 31, gsub = lane >> 5;
+#pragma unroll
+      for (int rg = gsub; rg < WTM / 4; rg += 2) {
+        const int rl = rg * 4;
+        const int m = mw + rl;
+        if (m >= p.M) continue;                      // (M % 4 == 0: ntok % 4 == 0)
+        const int sq = fast_div(m, p.fdT_mul, p.fdT_shr), tok = m - sq * ntok_w;
+        const u16x4 o = {to16<T16>(ep[rl * EP_LD + cg * 32 + dd]), to16<T16>(ep[(rl + 1) * EP_LD + cg * 32 + dd]),
+                         to16<T16>(ep[(rl + 2) * EP_LD + cg * 32 + dd]), to16<T16>(ep[(rl + 3) * EP_LD + cg * 32 + dd])};
+        *reinterpret_cast<u16x4*>(p.vt + ((int64_t)sq * p.H + h) * npad_w * p.dp + frag_v(tok, dd0 + dd, p.dp)) = o;
       }
     } else {
       // V fragments: lane = token; 2-byte stores inside this token's fragment block
