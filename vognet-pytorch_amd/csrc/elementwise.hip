@@ -217,14 +217,26 @@ __global__ __launch_bounds__(256) void argvec_kernel(const float* __restrict__ f
     const int r = idx / nq, i = idx - r * nq;
     stg[it] = reinterpret_cast<const float4*>(full + (int64_t)av_src[r * 2 + (i < lq ? 0 : 1)] * L)[i < lq ? i : i - lq];
   }
+  // CSL > 0: a thread's slice of a row starts SLP = CSL + 4 floats after the previous one's (not CSL): the 16 slices of a row are
+  // read at the same moment by the 16 threads of an output column, and at a stride of 32 floats all of them sit on the same
+  // four LDS banks (16-way conflict on every one of the 160 float4 reads of the product loop)
+  constexpr int SLP = CSL > 0 ? CSL + 4 : 0;
+  const int KP = CSL > 0 ? 16 * SLP : K;               // row pitch in LDS
 #pragma unroll
   for (int it = 0; it < AV_IT; ++it) {
     const int idx = tid + it * 256;
-    if (idx < nr * nq) reinterpret_cast<float4*>(av_x)[idx] = stg[it];
+    if (idx < nr * nq) {
+      if constexpr (CSL > 0) {
+        const int r = idx / nq, i = idx - r * nq;      // float4 i of row r: slice i / (CSL / 4), piece i % (CSL / 4)
+        reinterpret_cast<float4*>(av_x)[r * (KP / 4) + (i / (CSL / 4)) * (SLP / 4) + (i % (CSL / 4))] = stg[it];
+      } else {
+        reinterpret_cast<float4*>(av_x)[idx] = stg[it];
+      }
+    }
   }
   __syncthreads();
   for (int r = 0; r < nr; ++r) {
-    const float* xr = av_x + r * K + j0;
+    const float* xr = av_x + r * KP + (CSL > 0 ? sl * SLP : j0);
     float acc = 0.f;
     if (vec) {
 #pragma unroll
@@ -817,7 +829,13 @@ extern "C" int vog_srl_argvec(const float* full, const int64_t* capture, const i
   const dim3 grid(ceil_div(Bn * nsrl, AV_ROWS), ceil_div(L, 16));
   const size_t lds = (size_t)AV_ROWS * 2 * L * sizeof(float);
   if (L == 256) {      // lang_encode_size of the reference configuration
-    ::vog::launch(argvec_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L, Bn * nsrl);
+    const size_t lds32 = (size_t)AV_ROWS * 16 * (32 + 4) * sizeof(float);      // (slices 36 floats apart: bank spread)
+    static bool av32_attr = false;
+    if (!av32_attr) {
+      VOG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(argvec_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      av32_attr = true;
+    }
+    ::vog::launch(argvec_kernel<32>, grid, dim3(256), lds32, (hipStream_t)stream, full, capture, inds_msk, w, bias, lang, T, nsrl, L, Bn * nsrl);
   } else {
     static bool av_attr = false;
     if (!av_attr && lds > 40 * 1024) {

@@ -62,7 +62,8 @@ static int launch_pipe(const GemmParams& p, hipStream_t st) {
     case 7: return launch_pipe_cfg<T16, 64, 64, 3, EPI>(p, st);
     default: break;
   }
-  // Measured on MI355X (scratch/mb_gemm.py, M = 800..8192): occupancy beats pipeline
+  // Measured on MI355X (scratch/mb_gemm.py, M = 800..8192; again in round 6 with exactly counted waits for 5 / 6 / 8 stages on
+  // the cfg 3 / cfg 5 input projections: 17.2 / 18.3-34 / 18.1-34 us against 16.0-19.0, scratch/r6_x.sh): occupancy beats pipeline
   // depth — 2-stage rings (2-5 workgroups per CU hide each other's barrier and
   // LDS-latency stalls) are faster than 3-4-stage rings at one workgroup per CU
   // for every shape of this model. 128x128 only when there are >= 8 tiles per CU.

@@ -5,6 +5,9 @@
 namespace vog {
 
 enum { EPI_PLAIN = 0, EPI_QKV = 1 };
+#ifndef VOG_GEMM_COLMAJOR
+#define VOG_GEMM_COLMAJOR 1      // 0 (perf experiments): row-major tile order for every shape
+#endif
 struct GemmParams;
 static bool pipe_ok(const GemmParams& p, bool a_f32);
 
@@ -422,7 +425,12 @@ struct GemmPipeBody {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int bm = bid / nbn, bn = bid % nbn;
+  // Few row blocks over many column blocks (the BiLSTM input projections of cfg 3 / cfg 5: M = 96 / 192, N = 8192, K = 2048): the
+  // row blocks of ONE column panel are neighbours (round 6), i.e. they run on the same XCD at the same time and the 256 KB weight
+  // panel is fetched from the fabric by one of them and found in that L2 by the others. In row-major tile order the 2-3 readers
+  // of a panel sit on different XCDs and the 33.5 MB of W_ih cross the fabric 2-3 times.
+  const bool col_major = nbm <= 4 && nbn >= 32 && VOG_GEMM_COLMAJOR;
+  const int bm = col_major ? bid % nbm : bid / nbn, bn = col_major ? bid / nbm : bid % nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // per-lane source pointers of this wave's DMA instructions (advance by 64 halfwords per tile)
@@ -488,10 +496,19 @@ struct GemmPipeBody {
     if (s < nk) issue(s, s);
   for (int kt = 0; kt < nk; ++kt) {
     // tiles in flight now: kt .. min(kt+STAGES-2, nk-1). Retire tile kt only.
+    // (counted exactly for every ring depth, round 6: the 2-tile cap of the first form made rings deeper than 4 stages pointless)
     const int ahead = (nk - 1 - kt) < (STAGES - 2) ? (nk - 1 - kt) : (STAGES - 2);
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert((STAGES - 2) * LPT <= 63 && STAGES <= 9, "vmcnt is a 6-bit counter");
+    switch (ahead) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT <= 63 ? 3 * LPT : 63) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT <= 63 ? 4 * LPT : 63) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPT <= 63 ? 5 * LPT : 63) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPT <= 63 ? 6 * LPT : 63) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * LPT <= 63 ? 7 * LPT : 63) : "memory"); break;
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
