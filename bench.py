@@ -408,6 +408,10 @@ def main():
     # i + 4 of a run share a queue): the streams are created here, back to back, before any slot exists, and reused. (Picking
     # them by a pairwise timing test was tried: what overlaps during the test does not reliably overlap afterwards.)
     stream_pool = [torch.cuda.Stream(device=dev) for _ in range(16)]
+    if os.environ.get("VOG_PERF_EXPERIMENTS") and os.environ.get("VOG_BENCH_STREAM_IDS"):
+        # experiment only: which members of the pool carry the forwards (e.g. "0,2,5,7")
+        ids = [int(x) for x in os.environ["VOG_BENCH_STREAM_IDS"].split(",")]
+        stream_pool = [stream_pool[i] for i in ids] + [st for i, st in enumerate(stream_pool) if i not in ids]
     if os.environ.get("VOG_PERF_EXPERIMENTS") and os.environ.get("VOG_BENCH_CU_MASK"):
         # experiment only (no `value` is printed under VOG_PERF_EXPERIMENTS): streams restricted to a subset of the CUs
         # (hipExtStreamCreateWithCUMask) - "is the 4-stream loop bound by CU time?" VOG_BENCH_CU_MASK = a 32-bit hex pattern
@@ -422,6 +426,8 @@ def main():
             rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
             assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
             stream_pool.append(torch.cuda.ExternalStream(h.value, device=dev))
+
+    host_issue = [0.0]
 
     def measure(G, steps, warmup, batched=False, rotate=0, eng=eng):
         """K timed steps (one step = one batch of the workload) after W warm-up steps with G
@@ -510,6 +516,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         run(steps)
+        host_issue[0] = time.perf_counter() - t0      # the host's share: issuing `steps` launches (the device runs behind it)
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
@@ -521,6 +528,7 @@ def main():
     G = max(1, args.cobatch)
     rot_sets = (args.rotate_inputs + max(1, args.streams) - 1) // max(1, args.streams) if args.rotate_inputs > 0 else 0
     dt, slots, batches, nstreams = measure(G, args.steps, args.warmup, rotate=rot_sets if args.rotate_main else 0)
+    host_issue_main = host_issue[0]
     T = slots[0].T
     # a short timed region (the driver's K = 20) carries a fixed ~160 us of pipeline fill and drain (4 forwards in flight,
     # a forward takes ~280 us under load): the same strict path timed over 400 steps is reported BESIDE `value`
@@ -625,7 +633,7 @@ def main():
         del slots4
     if args.throughput_only:
         if rank == 0:
-            print(f"{world * args.steps * w['B'] / dt:.1f} {dt / args.steps * 1e6:.2f}", file=out, flush=True)
+            print(f"{world * args.steps * w['B'] / dt:.1f} {dt / args.steps * 1e6:.2f} host_issue_us_per_step {host_issue_main / args.steps * 1e6:.2f}", file=out, flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -656,7 +664,8 @@ def main():
         "parity": parity,
         "n_gpus": world, "host_numa_node": numa_node, "device_warmup_ms": float(os.environ.get("VOG_BENCH_BURNIN_MS", "25")), "rccl_ranks": dist.get_world_size() if use_dist else 1, "per_rank_value": value / world,
         "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "host_issue_ms_per_step": host_issue_main / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": w["tx"], "data": "synthetic",
         "config": {"workload": w["desc"], "global_batch": world * w["B"], "batch_per_gpu": w["B"],
                    "sentence_len": T, "batches_in_flight": nstreams, "lang_cobatch": G,

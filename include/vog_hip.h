@@ -420,6 +420,13 @@ typedef struct vog_lstm_layer_args {
    * if its hand-off had timed out at once, 2 = only the workgroups of direction 1 do. Whichever workgroup ends dead first
    * reports (sync[3], re-armed by the prologue): exactly +1 per stalled launch. */
   uint32_t* fault; int inject_stall;
+  /* round 6, gate table (gx_table != NULL; gxs and wih are then ignored): the layer's input is an embedding row, so its
+   * projection depends on the TOKEN alone. gx_table = [vocab + 1][2][R][4] fp32, row v = emb[v] W_ih^T + b_ih + b_hh for
+   * (direction, unit, gate i f g o) - built once per checkpoint for the whole vocabulary (vog_ctx_finalize; 164 MB at vocab 5000,
+   * R = 1024); tok = [Bn * T] token ids (vog_lang_prep). The kernel reads its gate inputs of step s + 1 from the rows of
+   * that step's tokens while step s runs: no input projection for this layer, neither as a GEMM launch nor in the kernel's
+   * prologue, for any Bn * T (LSTMEncoder.forward, utils/mdl_srl_utils.py:134-148). */
+  const float* gx_table; const int32_t* tok;
 } vog_lstm_layer_args;
 int vog_bilstm_layer_supported(int Bn, int R);
 int vog_bilstm_fused_cols(void);                      /* largest Bn*T the in-kernel input projection (wih) takes: 80 */
@@ -803,8 +810,11 @@ int vog_graph_capture_fed(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_by
  * bodies either way: results are bit-identical (tests/test_gpu_forward.py). "pair_mask" (default 7): which of the three
  * pairs are formed (1 BiLSTM layer 0 + encoders, 2 layer 1 + obj_tx tail, 4 out-projection + mul_tx QKV).
  * "fused_ih" (default 1): the BiLSTM input projections run inside the persistent layer kernel
- * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 80 and K % 256 == 0 (0: never,
- * 2: layer 0 only, 3: layers >= 1 only). Measured on MI355X (cfg 2): two launches fewer, W_ih streamed
+ * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 80 and K % 256 == 0; round 6: where that prologue
+ * does not reach (more than 80 columns: cfg 3, cfg 5, grouped requests) layer 0 reads its gate inputs from the checkpoint's
+ * gate table (vog_lstm_layer_args.gx_table, built by vog_ctx_finalize; VOG_GX_TABLE_MAX_MB, default 2048, bounds its size)
+ * instead of running a GEMM launch (0: GEMM launches only, 2: layer 0 only, 3: layers >= 1 only, 4: as 1 without the table,
+ * 5: the table wherever the checkpoint has one). Measured on MI355X (cfg 2): two launches fewer, W_ih streamed
  * by the layer's 64 CUs (+7 / +17 us per layer against 6.4 / 9.7 us for the whole-chip GEMMs):
  * 43.1 k vs 40.9 k queries/s with 4 batches in flight, 10 us more single-batch latency. */
 int vog_ctx_set_int(vog_ctx* c, const char* name, int value);

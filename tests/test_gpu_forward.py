@@ -357,6 +357,30 @@ def test_paired_launches_equal_separate_launches(name):
         assert torch.equal(a[k], b[k]), (name, k)
 
 
+@pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg5_vog_svsq_gt5_bs16",
+                                  "small/vog_temp"])
+def test_gate_table_matches_input_projection(name):
+    """round 6: layer 0's gate inputs read from the checkpoint's gate table (emb . W_ih^T + b for every token, built once at
+    vog_ctx_finalize; `fused_ih` = 5: wherever it exists, the default uses it beyond 80 columns) against the projection computed per
+    batch (4: in the layer kernel's prologue / a GEMM launch) - same 16-bit operands, another fp32 summation order - and against
+    the reference's golden."""
+    eng, cfg, sd, batch, c, dev = build_engine(name, cached=True)
+    eng.set_option("fused_ih", 4)
+    a = {k: v.clone() for k, v in eng.forward(dev).items() if isinstance(v, torch.Tensor)}
+    eng.set_option("fused_ih", 5)
+    try:
+        out = eng.forward(dev)
+        torch.cuda.synchronize()
+        b = {k: v.clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        pred = eng.unpack_pred(out["pred_rec"], batch["new_srl_idxs"].shape[1])
+        _check_against(name, out, pred, np.load(cases.golden_path(name)), None, tol_rel=1e-3, tol_logit=6e-3)
+    finally:
+        eng.set_option("fused_ih", 1)
+    assert torch.isfinite(b["mdl_outs"]).all()
+    dl = (a["mdl_outs"] - b["mdl_outs"]).abs().max().item()
+    assert dl < 1.5e-3, dl                 # (often exactly 0: the gate inputs differ in the last fp32 bits, h is rounded to 16 bits)
+
+
 @pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/vog_sep_gt5_bs4_ragged",
                                   "full/cfg1_igrnd_spat_gt5_bs2"])
 def test_fused_lstm_input_projection_matches_separate_gemm(name):

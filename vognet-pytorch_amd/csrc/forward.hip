@@ -99,6 +99,8 @@ struct vog_ctx {
                                         // layer against 6.4 / 9.7 us whole-chip launches -> 5 % more throughput with 4 batches
                                         // in flight, 10 us more single-batch latency)
   std::vector<float*> bsum;                             // [layer] [8R]
+  float* gx0_tab = nullptr;             // round 6: [vocab + 1][2][R][4 gates] fp32 = emb . W_ih_l0^T + b_ih + b_hh for every token and both directions
+                                        // (vog_lstm_layer_args.gx_table): layer 0's gate inputs are a look-up, built once per checkpoint
   unsigned short *w_outproj = nullptr, *w_prop = nullptr, *w_seg = nullptr, *w_lin2 = nullptr;
   unsigned short* w_lin2_p = nullptr;                   // lin2.0 in 32x16 fragment order (fused score head)
   unsigned short *w_prop_f = nullptr, *w_seg_f = nullptr;   // encoder weights in 16x32 fragment order (visenc.hip)
@@ -668,9 +670,18 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     const int nsrl = d.nsrl, sl = d.seq_len, V = d.vocab_size;
     float* gx = ws.at<float>("gx");
     int32_t* lrows = ws.at<int32_t>("lstm_rows");
+    // layer-0 gate inputs read from the checkpoint's gate table by the layer kernel itself (no input projection for layer 0 at all)
+    // Used where the in-kernel projection does not reach (Bn x T > 80 columns: cfg 3, cfg 5, grouped / batched requests): there it
+    // replaces a GEMM launch and the gate round trip (cfg 3 +2.3 %, cfg 5 +4.7 ... 7 %). Where the layer kernel can project in its
+    // prologue (cfg 2) the two forms measured EQUAL (63.3 vs 63.5 k queries/s: the table reads are not quite hidden, 29.8 vs 30.7 us
+    // for the layer) and the prologue, whose operands are always cache-resident, stays. fused_ih = 5: the table wherever it exists.
+    const bool fuse0_ok = c->lstm_persistent && vog_bilstm_layer_supported(Bn, R) && !c->wih_p.empty() && c->wih_p[0] &&
+                          (g.E % 256) == 0 && Bn * T <= vog_bilstm_fused_cols() && c->emb16 && (g.E % 32) == 0;
+    const bool use_tab = c->gx0_tab && ((c->fused_ih == 1 && !fuse0_ok) || c->fused_ih == 5) && c->lstm_persistent &&
+                         vog_bilstm_layer_supported(Bn, R) && Bn * T <= 16 * 24;
     {
       const int64_t* lens = b->srl_arg_word_mask_len;
-      const bool a0f = Bn * T <= vog_bilstm_fused_cols() && c->emb16 && (g.E % 32) == 0;
+      const bool a0f = !use_tab && Bn * T <= vog_bilstm_fused_cols() && c->emb16 && (g.E % 32) == 0;
       const void* e16 = c->emb16;
       void* a0 = a0f ? ws.at<void>("emb_a0") : nullptr;
       const int E = g.E;
@@ -686,10 +697,13 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     // input projection inside the persistent layer kernel (no GEMM launch, no gx round trip): needs the layer input in fragment
     // order (embedding rows from lang_prep / the previous layer's out16). Round 6: up to 80 (sentence, position) columns (64
     // before: a bs = 4 batch whose longest sentence has 17-20 words fell back to the GEMM launches).
-    // fused_ih: 1 = every layer, 2 = layer 0 only, 3 = layers >= 1 only (experiments)
+    // fused_ih: 1 = every layer in the kernel where its prologue reaches, layer 0 by table look-up where it does not; 4 = the same
+    // without the table (GEMM launches beyond 80 columns: the default before round 6); 5 = the table wherever the checkpoint has
+    // one; 2 = layer 0 only, 3 = layers >= 1 only (experiments), 0 = GEMM launches
     auto can_fuse_ih = [&](int l) {
       const int Kin = l == 0 ? g.E : 2 * R;
-      return l < d.rnn_layers && (c->fused_ih == 1 || (c->fused_ih == 2 && l == 0) || (c->fused_ih == 3 && l > 0)) && c->lstm_persistent &&
+      if (l == 0 && use_tab) return false;
+      return l < d.rnn_layers && (c->fused_ih == 1 || c->fused_ih == 4 || c->fused_ih == 5 || (c->fused_ih == 2 && l == 0) || (c->fused_ih == 3 && l > 0)) && c->lstm_persistent &&
              vog_bilstm_layer_supported(Bn, R) && c->wih_p[l] && (Kin % 256) == 0 && Bn * T <= vog_bilstm_fused_cols() &&
              (l > 0 || (c->emb16 && (g.E % 32) == 0));
     };
@@ -722,7 +736,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
       ga.M = Bn * T; ga.N = 8 * R; ga.rep = 1; ga.dtype = et;
       ga.out_rows = lrows; ga.out_rows_ncol = 4 * R;
       if (ga.M <= 64 && c->wih_f[l]) { ga.w = c->wih_f[l]; ga.w_frag = 1; }
-      if (!ih_fused)
+      if (!ih_fused && !(l == 0 && use_tab))
         steps.push_back({"lstm_ih" + std::to_string(l), [=](hipStream_t st) { return vog_gemm_bias_act(&ga, st); }});
       // final state must land in hA (adjacent to out16): after T steps it is in buf[T % 2]
       void* hA = ofrag ? ws.at<void>("lstm_hA2_" + std::to_string(l))
@@ -736,6 +750,7 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
         pa.out16 = ws.at<void>("lstm_out16_" + std::to_string(l));
         pa.lens = b->srl_arg_word_mask_len; pa.Bn = Bn; pa.T = T; pa.R = R; pa.dtype = et; pa.out_frag = ofrag ? 1 : 0;
         pa.fault = b->fault; pa.inject_stall = c->lstm_inject_stall;
+        if (l == 0 && use_tab) { pa.gx_table = c->gx0_tab; pa.tok = tok; }
         if (ih_fused) {
           pa.wih = c->wih_p[l]; pa.bias = c->bsum[l]; pa.K = Kin;
           pa.xa = l == 0 ? ws.at<void>("emb_a0") : ws.at<void>("lstm_out16_" + std::to_string(l - 1));
@@ -1228,6 +1243,54 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
     VOG_TRY(upload<unsigned short>(c, whh, &ph));
     VOG_TRY(upload<float>(c, bs, &pb));
     c->wih.push_back(pw); c->whh.push_back(ph); c->bsum.push_back(pb);
+  }
+  // Gate table of layer 0 (round 6): G[v] = emb[v] . W_ih_l0^T + b_ih + b_hh for every token v and both directions - the input
+  // projection of layer 0 depends on the token alone, so it is computed ONCE per checkpoint for the whole vocabulary (the same
+  // 16-bit operands and fp32 accumulation the per-batch projection used) and a forward reads Bn x T rows of it (vog_lstm_layer_args.gx_table).
+  // 164 MB at vocab 5000, R = 1024: sized for 288 GB of HBM. VOG_GX_TABLE_MAX_MB bounds it (default 2048; 0 = never).
+  c->gx0_tab = nullptr;
+  {
+    const int64_t rows = (int64_t)d.vocab_size + 1, cols = (int64_t)8 * R;
+    static const int64_t max_mb = getenv("VOG_GX_TABLE_MAX_MB") ? atoll(getenv("VOG_GX_TABLE_MAX_MB")) : 2048;
+    if (c->emb16 && rows > 64 && (d.emb_dim % 64) == 0 && rows * cols * 4 <= max_mb * (1ll << 20) && vog_bilstm_layer_supported(1, R)) {
+      float* tab = nullptr;
+      VOG_HIP(hipMalloc(&tab, (size_t)(rows * cols * 4)));
+      c->allocs.push_back(tab);
+      // table column (dir, unit, gate): the four gates of a unit adjacent (one 16-byte read per lane of the layer kernel) -
+      // W_ih rows and biases permuted accordingly for the one GEMM that builds it
+      const int E0 = d.emb_dim;
+      std::vector<unsigned short> wperm((size_t)8 * R * E0);
+      std::vector<float> bperm((size_t)8 * R);
+      {
+        int dd = 0;
+        for (const char* sfx : {"", "_reverse"}) {
+          const auto& a = W(c, std::string("lstm_encoder.lstm.weight_ih_l0") + sfx);
+          const auto& bi = W(c, std::string("lstm_encoder.lstm.bias_ih_l0") + sfx);
+          const auto& bh = W(c, std::string("lstm_encoder.lstm.bias_hh_l0") + sfx);
+          for (int r = 0; r < 4; ++r)
+            for (int u = 0; u < R; ++u) {
+              const size_t dst = (size_t)dd * 4 * R + (size_t)u * 4 + r, src = (size_t)r * R + u;
+              bperm[dst] = bi[src] + bh[src];
+              for (int k = 0; k < E0; ++k) wperm[dst * E0 + k] = h_to16(a[src * E0 + k], et);
+            }
+          ++dd;
+        }
+      }
+      unsigned short* wp_d = nullptr; float* bp_d = nullptr;
+      VOG_HIP(hipMalloc(&wp_d, wperm.size() * 2));
+      VOG_HIP(hipMalloc(&bp_d, bperm.size() * 4));
+      VOG_HIP(hipMemcpy(wp_d, wperm.data(), wperm.size() * 2, hipMemcpyHostToDevice));
+      VOG_HIP(hipMemcpy(bp_d, bperm.data(), bperm.size() * 4, hipMemcpyHostToDevice));
+      vog_gemm_args ga{}; ga.c16_dtype = -1;
+      ga.a = c->emb16; ga.a_is_f32 = 0; ga.lda = E0; ga.K = E0;
+      ga.w = wp_d; ga.ldw = E0; ga.bias = bp_d; ga.c32 = tab; ga.ldc = cols;
+      ga.M = (int)rows; ga.N = (int)cols; ga.rep = 1; ga.dtype = (vog_dtype)et;
+      const int grc = vog_gemm_bias_act(&ga, nullptr);
+      VOG_HIP(hipStreamSynchronize(nullptr));
+      (void)hipFree(wp_d); (void)hipFree(bp_d);
+      if (grc != 0) return grc;
+      c->gx0_tab = tab;
+    }
   }
   VOG_TRY(up16(c, "lstm_out_feat_proj.0.weight", et, &c->w_outproj));
   c->w_outproj_f = nullptr;

@@ -79,15 +79,17 @@ extern "C" int64_t vog_bilstm_hx_bytes(int Bn, int T, int R) {
 }
 
 extern "C" int vog_bilstm_layer(const vog_lstm_layer_args* a, void* stream) {
-  VOG_CHECK_ARG(a && (a->gxs || a->wih) && a->whh && a->hx && a->sync && a->out16 && a->lens && a->T > 0);
+  VOG_CHECK_ARG(a && (a->gxs || a->wih || a->gx_table) && a->whh && a->hx && a->sync && a->out16 && a->lens && a->T > 0);
+  VOG_CHECK_ARG(!a->gx_table || (a->tok && a->Bn * a->T <= vog::LstmLayerBody<vog::F16, 32>::TOK_MAX));
   if (!vog_bilstm_layer_supported(a->Bn, a->R))
     VOG_FAIL(-1, "persistent BiLSTM layer: unsupported Bn=%d R=%d (use vog_bilstm_step)", a->Bn, a->R);
   vog::LstmLayerParams p{a->gxs, (const unsigned short*)a->whh, (unsigned short*)a->hx, a->sync,
                          (unsigned short*)a->out16, a->lens, a->Bn, a->T, a->R, a->out_frag,
                          (const unsigned short*)a->wih, (const unsigned short*)a->xa, a->bias, a->K,
-                         a->fault, a->inject_stall, 0};
+                         a->fault, a->inject_stall, 0, a->gx_table, a->tok};
   if (const char* e = vog::perf_env("VOG_LSTM_HALF_PROJ")) p.half_proj = atoi(e);
-  const bool fused = a->wih != nullptr;
+  const bool fused = a->wih != nullptr && !a->gx_table;
+  if (a->gx_table) p.wih = nullptr;
   if (fused) VOG_CHECK_ARG(a->xa && a->bias && a->K > 0 && (a->K % 256) == 0 && a->Bn * a->T <= vog_bilstm_fused_cols());
   dim3 grid(a->R / 32, 2);
   hipStream_t st = (hipStream_t)stream;

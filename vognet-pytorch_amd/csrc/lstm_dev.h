@@ -144,6 +144,11 @@ struct LstmLayerParams {
   unsigned int* fault; int inject_stall;
   int half_proj;   // perf experiments only (WRONG results): layers with K >= 2048 run half of their input projection - bounds what
                    // moving half of it to helper workgroups could give (profiles/round5_lstm_proj_bound.md)
+  // round 6, gate table (gxtab != nullptr; gxs / wih unused): the layer input is an embedding row, so x W_ih^T + bias is a
+  // function of the TOKEN: gxtab = [vocab + 1][2][R][4 gates] fp32 holds it for every token (built once per checkpoint), tok = [Bn * T]
+  // token ids. The gate inputs of step s + 1 are requested right behind step s's hand-off barrier - a whole step before they are
+  // used - so the layer has no input projection and no prologue.
+  const float* gxtab; const int32_t* tok;
 };
 
 #define VOG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -205,7 +210,8 @@ struct LstmLayerBody {
   static constexpr size_t GX_BYTES = gx_bytes(16 * NCT_MAX);
   static constexpr size_t hs_bytes(int Bn) { return ((size_t)2 * Bn * HS_LD * 2 + 15) / 16 * 16; }
   static constexpr size_t xbuf_bytes(int ncols) { return (size_t)2 * ((ncols + 15) / 16) * 8 * 1024; }
-  static constexpr size_t TAIL = 16 + 16 * 32 * 2;          // flags + the publish buffer [<= 16 sentences][32 units]
+  static constexpr int TOK_MAX = 16 * 24;                   // token ids staged for the gate table (Bn * T)
+  static constexpr size_t TAIL = 16 + 16 * 32 * 2 + TOK_MAX * 4;   // flags + the publish buffer [<= 16 sentences][32 units] + token ids
   static constexpr size_t lds_plain(int Bn) { return hs_bytes(Bn) + TAIL; }
   static constexpr size_t lds_fused(int Bn, int ncols) {
     return gx_bytes(ncols) + (hs_bytes(Bn) > xbuf_bytes(ncols) ? hs_bytes(Bn) : xbuf_bytes(ncols)) + TAIL;
@@ -229,6 +235,28 @@ struct LstmLayerBody {
     const size_t uni_bytes = fused ? (hs_bytes(p.Bn) > xbuf_bytes(ncols) ? hs_bytes(p.Bn) : xbuf_bytes(ncols)) : hs_bytes(p.Bn);
     unsigned int* flags = reinterpret_cast<unsigned int*>(uni + uni_bytes);   // [0] timeout seen, [1] direction shares an XCD
     unsigned short* pub = reinterpret_cast<unsigned short*>(uni + uni_bytes + 16);
+    int* tokl = reinterpret_cast<int*>(uni + uni_bytes + 16 + 16 * 32 * 2);
+    const bool tab = p.gxtab != nullptr;
+    const int unit0 = tile0 * 4 + ul;
+    // gate inputs of step s2 from the table row of that step's token (zeros past the sentence's end: never used)
+    auto load_tab = [&](int s2, float (&g)[4], const int* tk) __attribute__((always_inline)) {
+      int row = 0;
+      const bool on = valid_b && s2 < len && s2 < p.T;
+      if (on) row = tk[b * p.T + (dir == 0 ? s2 : len - 1 - s2)];
+      // (the four gates of a unit are adjacent in the table: one 16-byte load per lane, 64 contiguous bytes per sentence and
+      // wave; unconditional: lanes that are off read row 0 and never use it)
+      const float4 v = *reinterpret_cast<const float4*>(p.gxtab + (((int64_t)row * 2 + dir) * R + unit0) * 4);
+      g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+    };
+    float gtA[4] = {0.f, 0.f, 0.f, 0.f}, gtB[4] = {0.f, 0.f, 0.f, 0.f}, gtC[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tab) {
+      // steps 0 - 2 straight from the global token ids (two dependent loads from kernel start, beside the W_hh loads); the
+      // ids of the later steps come from LDS
+      load_tab(0, gtA, p.tok);
+      load_tab(1, gtB, p.tok);
+      load_tab(2, gtC, p.tok);
+      for (int i = tid; i < p.Bn * p.T; i += THREADS) tokl[i] = p.tok[i];
+    }
 
     // where am I: one report per workgroup, read back before the first publish (after the prologue)
     if (tid == 0) {
@@ -368,6 +396,11 @@ struct LstmLayerBody {
       VOG_TSL(s, 0);
       // input projections of this step (address-independent of everything else)
       float gin[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tab) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gin[r] = gtA[r]; gtA[r] = gtB[r]; gtB[r] = gtC[r]; }
+        if (s == 0) load_tab(3, gtC, tokl);                  // (no hand-off in step 0: requested here)
+      } else
       if (fused) {
         if (valid_b && s < len) {
           const int pos_in = dir == 0 ? s : len - 1 - s;
@@ -429,6 +462,11 @@ struct LstmLayerBody {
         VOG_TSL(s, 1);
         __syncthreads();
         VOG_TSL(s, 2);
+        // the table rows of step s + 3 (gtA / gtB hold steps s + 1 / s + 2 by now), two steps ahead of their use - one step
+        // was measured short: +0.5 us per step at Bn = 4, +0.7 at Bn = 16 (random 64-byte reads of a 164 MB table). Issued
+        // behind this step's hand-off, so that the wait for the NEXT hand-off - loads return in order - is the first one that
+        // can see them.
+        if (tab) load_tab(s + 3, gtC, tokl);
         const unsigned int dead_wg = flags[0];
         // lanes of the unused MFMA columns read sentence 0 (their results are never looked at)
         const unsigned short* hrow = hsb + (valid_b ? b : 0) * HS_LD + kg;

@@ -94,7 +94,8 @@ class LstmStepArgs(C.Structure):
 class LstmLayerArgs(C.Structure):
     _fields_ = [("gxs", c_vp), ("whh", c_vp), ("hx", c_vp), ("sync", c_vp), ("out16", c_vp),
                 ("lens", c_vp), ("Bn", c_i32), ("T", c_i32), ("R", c_i32), ("dtype", c_i32), ("out_frag", c_i32),
-                ("wih", c_vp), ("xa", c_vp), ("bias", c_vp), ("K", c_i32), ("fault", c_vp), ("inject_stall", c_i32)]
+                ("wih", c_vp), ("xa", c_vp), ("bias", c_vp), ("K", c_i32), ("fault", c_vp), ("inject_stall", c_i32),
+                ("gx_table", c_vp), ("tok", c_vp)]
 
 
 class VislangArgs(C.Structure):
