@@ -41,6 +41,8 @@ f, w, sq = load(fcsv), load(wcsv), load(sqcsv)
 rows, total, kern = [], 0.0, {}
 for key in sorted(f, key=lambda k: -sum(f[k]["FETCH_SIZE"])):
     fv = f[key]["FETCH_SIZE"]
+    if len(fv) * 2 < forwards:      # once-per-checkpoint kernels (vog_ctx_finalize: the gate-table GEMM), not part of a forward
+        continue
     lpf = max(1, round(len(fv) / forwards))
     fb = 2.0 * 1024 * sum(fv) / len(fv)
     wv = w.get(key, {}).get("WRITE_SIZE", [0.0])

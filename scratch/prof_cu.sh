@@ -12,6 +12,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     acc[(n[:70], r["Grid_Size"])].append(float(r["Counter_Value"]))
 tot = 0
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    if len(v) < 10: continue            # once-per-checkpoint kernels (the gate-table GEMM of vog_ctx_finalize)
     per_fwd = sum(v) / 20 / 2100.0
     tot += per_fwd
     print(f"{per_fwd:8.0f} CU*us/forward  x{len(v)//20}  {k[0]} [{k[1]}]")
