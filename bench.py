@@ -740,23 +740,32 @@ def main():
         # persistent layer kernel: W_hh is read ONCE per launch and kept in registers for all T steps
         nbytes = lstm_step_bytes(w, T) + (T - 1) * (lstm_step_bytes(w, T) - 2 * 4 * 1024 * 1024 * 2)
         us_launch = lstm_us[1]
-        fused_ih = not ktimes.get("lstm_ih0") and ktimes.get("lstm_layer#0") and ktimes.get("lstm_layer#1")
-        if fused_ih:
-            # the layer kernel also computes x W_ih^T + b in its prologue (no separate GEMM launch): W_ih is
-            # read once per launch too - 2 dirs x 4R x K 16-bit, K = 512 (embedding) for layer 0, 2R for
-            # layer 1 - plus the 16-bit layer input; figures are the average of the two launches
-            R, E = 1024, 512
-            Bn = w["B"] * ((1 if w["conc"] == "svsq" else 4) if w["conc"] in ("sep", "svsq") else 1)
-            wih = [2 * 4 * R * E * 2, 2 * 4 * R * 2 * R * 2]
-            xin = [Bn * T * E * 2, Bn * T * 2 * R * 2]
-            nbytes = nbytes + (sum(wih) + sum(xin)) // 2
+        # what each layer launch reads besides W_hh and the states: its input projection where the kernel computes it in its
+        # prologue (W_ih once per launch - 2 dirs x 4R x K 16-bit, K = 512 for layer 0, 2R for layer 1 - plus the 16-bit layer
+        # input), or (round 6, layer 0 beyond 80 columns) the gate-table rows of the batch's tokens; a projection that runs as
+        # a GEMM launch (lstm_ih*) is that launch's traffic, not the layer's. Figures are the average of the two launches.
+        R, E = 1024, 512
+        Bn = w["B"] * ((1 if w["conc"] == "svsq" else 4) if w["conc"] in ("sep", "svsq") else 1)
+        both = bool(ktimes.get("lstm_layer#0") and ktimes.get("lstm_layer#1"))
+        proj = ["gemm launch", "gemm launch"]
+        extra = 0
+        if both and not ktimes.get("lstm_ih0"):
+            if Bn * T <= 80:
+                proj[0] = "kernel prologue"; extra += 2 * 4 * R * E * 2 + Bn * T * E * 2
+            else:
+                proj[0] = "gate table"; extra += Bn * T * 2 * 4 * R * 4
+        if both and not ktimes.get("lstm_ih1"):
+            proj[1] = "kernel prologue"; extra += 2 * 4 * R * 2 * R * 2 + Bn * T * 2 * R * 2
+        fused_ih = proj[0] != "gemm launch" or proj[1] != "gemm launch"
+        if both:
+            nbytes = nbytes + extra // 2
             us_launch = 0.5 * (ktimes["lstm_layer#0"] + ktimes["lstm_layer#1"])
         ach_b = nbytes / (us_launch * 1e-6) / 1e9
         res["roofline"] = {"bound": "latency (cache stream)", "governing_peak": "hbm", "kernel": "lstm_layer", "achieved": ach_b, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBS,
                            "traffic": (pmc.get("kernels", {}).get("lstm_layer") or {}).get("bytes_per_launch"),
                            "usec_per_launch": us_launch, "bytes_per_launch": nbytes, "launches_per_forward": 2,
-                           "input_projection_in_kernel": bool(fused_ih),
+                           "input_projection_in_kernel": bool(fused_ih), "input_projection": {"layer0": proj[0], "layer1": proj[1]},
                            "bytes_source": "Infinity Cache (MALL), not HBM: the 88 MB of 16-bit weights stay resident in the 256 MB "
                                            "cache between launches (the PMC `traffic` is the L2's memory-side request counter, which "
                                            "counts cache hits too); `peak` is the HBM figure the bench contract names - read `frac` as "
