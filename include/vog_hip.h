@@ -807,8 +807,9 @@ int vog_graph_capture_fed(vog_ctx* c, const vog_batch* b, void* ws, size_t ws_by
  * and step i of the visual chain (encoders / obj_tx QKV, attention, tail / mul_tx QKV) - independent until
  * mul_tx's attention - share ONE launch (csrc/pair.hip: blocks [0, nA) run one kernel body, the rest the
  * other) wherever a pair kernel exists for the two shapes; 0 = every step its own launch. Same kernel
- * bodies either way: results are bit-identical (tests/test_gpu_forward.py). "pair_mask" (default 7): which of the three
- * pairs are formed (1 BiLSTM layer 0 + encoders, 2 layer 1 + obj_tx tail, 4 out-projection + mul_tx QKV).
+ * bodies either way: results are bit-identical (tests/test_gpu_forward.py). "pair_mask" (default 15): which of the
+ * pairs are formed (1 BiLSTM layer 0 + encoders, 2 layer 1 + obj_tx tail, 4 out-projection + mul_tx QKV, 8 (round 6) layer-1 input
+ * projection + obj_tx QKV where that projection is a GEMM launch: more than 80 (sentence, position) columns).
  * "fused_ih" (default 1): the BiLSTM input projections run inside the persistent layer kernel
  * (vog_lstm_layer_args.wih) instead of as GEMM launches, where Bn*T <= 80 and K % 256 == 0; round 6: where that prologue
  * does not reach (more than 80 columns: cfg 3, cfg 5, grouped requests) layer 0 reads its gate inputs from the checkpoint's

@@ -27,7 +27,7 @@ def comm_for(c):
 
 
 _ENGINES = {}
-_DEFAULT_OPTIONS = {"lstm_persistent": 1, "lstm_inject_stall": 0, "fused_tail": 1, "fused_enc": 1, "pair_launches": 1, "pair_mask": 7,
+_DEFAULT_OPTIONS = {"lstm_persistent": 1, "lstm_inject_stall": 0, "fused_tail": 1, "fused_enc": 1, "pair_launches": 1, "pair_mask": 15,
                     "fused_ih": 1, "enc_lean": -1}
 
 

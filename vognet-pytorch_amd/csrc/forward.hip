@@ -107,7 +107,8 @@ struct vog_ctx {
   int fused_enc = 1;                    // both feature encoders + concat as one launch where supported
   int enc_lean = -1;                    // -1: lean form exactly when the encoders share a BiLSTM layer's launch
   int pair_launches = 1;                // step i of the language chain shares a launch with step i of the visual chain (pair.hip)
-  int pair_mask = 7;                    // which of the three pairs are formed: 1 BiLSTM layer 0 + encoders, 2 layer 1 + obj tail, 4 out-projection + mul QKV
+  int pair_mask = 15;                   // which pairs are formed: 1 BiLSTM layer 0 + encoders, 2 layer 1 + obj tail, 4 out-projection + mul QKV,
+                                        // 8 layer-1 input projection (where it is a GEMM launch) + obj QKV
   float *b_outproj = nullptr, *b_prop = nullptr, *b_seg = nullptr, *b_lin2 = nullptr;
   float *w_arg = nullptr, *b_arg = nullptr, *w_lin2b = nullptr, *b_lin2b = nullptr;
   float *w_sv0 = nullptr, *b_sv0 = nullptr, *w_sv2 = nullptr, *b_sv2 = nullptr;
@@ -996,10 +997,22 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     // input projection they measured SLOWER than apart: 22.5 vs 9.5 + 7.4 us).
     struct Want { const char* lang; int occ; const char* vis; const char* then[3]; };
     const bool has_rep = find("seg_rep", 0) >= 0;
-    const Want want[3] = {has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
-                                  : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}},
-                          {"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}},
-                          {"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}}};
+    // (round 6) where layer 1's input projection is a GEMM launch (more than 80 columns) obj_tx's QKV projection shares THAT launch
+    // (pair_mask bit 8) and the attention follows it, instead of both following the first pair on their own
+    // Measured (scratch/r6_ae.sh, three interleaved runs each): cfg 3 (Bn x T = 96: the projection is 256 tiles, one per CU) 68.2 vs
+    // 66.9 k queries/s; cfg 5 (192 columns: 384 tiles) 111.5 vs 113.1 k - the pair only where the projection leaves room on the chip.
+    const bool ih1_pair = find("lstm_ih1", 0) >= 0 && find("obj_qkv", 0) >= 0 && ((c->pair_mask >> 3) & 1) && Bn * T <= 128;
+    std::vector<Want> want;
+    if (!ih1_pair) {
+      want.push_back(has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", "obj_qkv", "obj_attn"}}
+                             : Want{"lstm_layer", 0, "vis_enc", {"obj_qkv", "obj_attn", nullptr}});
+    } else {
+      want.push_back(has_rep ? Want{"lstm_layer", 0, "vis_enc", {"seg_rep", nullptr, nullptr}}
+                             : Want{"lstm_layer", 0, "vis_enc", {nullptr, nullptr, nullptr}});
+    }
+    want.push_back({"lstm_layer", 1, "obj_tail", {nullptr, nullptr, nullptr}});
+    want.push_back({"lstm_outproj", 0, "mul_pv", {nullptr, nullptr, nullptr}});
+    if (ih1_pair) want.insert(want.begin() + 1, Want{"lstm_ih1", 0, "obj_qkv", {"obj_attn", nullptr, nullptr}});
     struct Plan2 { int ia, ib; int it[3]; };
     std::vector<Plan2> plans;
     bool ok = true;
@@ -1007,7 +1020,8 @@ static int build_steps(const vog_ctx* c, const vog_batch* b, void* wsp, size_t w
     int wi = -1;
     for (auto& w : want) {
       ++wi;
-      if (!((c->pair_mask >> wi) & 1)) continue;       // this pair stays two launches (its visual step keeps its place)
+      const int bit = std::string(w.lang) == "lstm_ih1" ? 3 : (std::string(w.lang) == "lstm_outproj" ? 2 : w.occ);
+      if (!((c->pair_mask >> bit) & 1)) continue;      // this pair stays two launches (its visual step keeps its place)
       Plan2 q{find(w.lang, w.occ), find(w.vis, 0), {-1, -1, -1}};
       // every visual step only moves EARLIER (its producers sit in earlier pairs) and the visual chain
       // keeps its own order; any missing piece (other model variants / shapes) leaves the rest unpaired
@@ -1598,7 +1612,7 @@ extern "C" int vog_ctx_set_int(vog_ctx* c, const char* name, int value) {
   if (strcmp(name, "fused_tail") == 0) { c->fused_tail = value ? 1 : 0; return 0; }
   if (strcmp(name, "fused_enc") == 0) { c->fused_enc = value ? 1 : 0; return 0; }
   if (strcmp(name, "pair_launches") == 0) { c->pair_launches = value ? 1 : 0; return 0; }
-  if (strcmp(name, "pair_mask") == 0) { c->pair_mask = value & 7; return 0; }
+  if (strcmp(name, "pair_mask") == 0) { c->pair_mask = value & 15; return 0; }
   if (strcmp(name, "fused_ih") == 0) { c->fused_ih = value; return 0; }
   if (strcmp(name, "enc_lean") == 0) { c->enc_lean = value; return 0; }
   VOG_FAIL(-4, "unknown option '%s'", name);

@@ -197,6 +197,7 @@ static int gemm_dispatch(const vog_gemm_args* g, hipStream_t st) {
 const void* kid_gemm_skinny_f16() { return reinterpret_cast<const void*>(gemm_skinny<F16, false, 8, 1, 4>); }
 const void* kid_gemm_skinny_wide_f16() { return reinterpret_cast<const void*>(gemm_skinny<F16, false, 8, 2, 8>); }
 const void* kid_gemm_pipe_qkv_split_f16() { return reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 2, EPI_QKV, true>); }
+const void* kid_gemm_pipe_plain3_f16() { return reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 3, EPI_PLAIN>); }
 const void* kid_gemm_pipe_qkv(int dtype) {
   return dtype == VOG_BF16 ? reinterpret_cast<const void*>(gemm_pipe<BF16, 64, 64, 2, EPI_QKV>)
                            : reinterpret_cast<const void*>(gemm_pipe<F16, 64, 64, 2, EPI_QKV>);

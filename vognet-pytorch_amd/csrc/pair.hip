@@ -108,6 +108,10 @@ static std::map<std::pair<const void*, const void*>, PairFn>& registry() {
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv_split_f16()}] = &launch_pair<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV, true>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<SkinnyIh, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
     r[{kid_gemm_skinny_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<SkinnyIh, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
+    // the layer-1 input projection where it is a GEMM launch (more than 80 columns: cfg 3, cfg 5) next to obj_tx's QKV projection:
+    // two LDS-DMA GEMM bodies of the same shape (round 6; round 2's attempt paired the 512-thread skinny form: 22.5 vs 9.5 + 7.4 us)
+    r[{kid_gemm_pipe_plain3_f16(), kid_gemm_pipe_qkv(VOG_BF16)}] = &launch_pair<GemmPipeBody<F16, 64, 64, 3, EPI_PLAIN>, GemmPipeBody<BF16, 64, 64, 2, EPI_QKV>>;
+    r[{kid_gemm_pipe_plain3_f16(), kid_gemm_pipe_qkv(VOG_F16)}] = &launch_pair<GemmPipeBody<F16, 64, 64, 3, EPI_PLAIN>, GemmPipeBody<F16, 64, 64, 2, EPI_QKV>>;
   });
   return r;
 }

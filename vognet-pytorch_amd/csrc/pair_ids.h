@@ -6,6 +6,7 @@ namespace vog {
 const void* kid_gemm_skinny_f16();          // gemm_skinny<F16, false, 8, 1, 4>   (M <= 64 projections)
 const void* kid_gemm_skinny_wide_f16();     // gemm_skinny<F16, false, 8, 2, 8>   (N >= 8192)
 const void* kid_gemm_pipe_qkv(int dtype);   // gemm_pipe<T16, 64, 64, 2, EPI_QKV>
+const void* kid_gemm_pipe_plain3_f16();     // gemm_pipe<F16, 64, 64, 3, EPI_PLAIN>  (BiLSTM input projections beyond 80 columns)
 const void* kid_lstm_layer_f16();           // lstm_layer_kernel<F16, 32>
 const void* kid_tx_tail_512(int dtype);     // tx_tail_kernel<T16, F16, 2, false, 0>
 const void* kid_vis_enc_f16();              // vis_enc_kernel<F16>
