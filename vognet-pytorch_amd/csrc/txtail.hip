@@ -91,7 +91,8 @@ const void* kid_tx_tail_512(int dtype) {
 }
 
 int tx_tail_supported(int d, int dh, int kwo) {
-  return (d == 512 || d == 768) && dh == d / 2 && kwo > 0 && (kwo % 64) == 0 && kwo <= 768;
+  // (d = 768: the Wo stage walks kwo / 16 k-steps three at a time, VOG_TAIL_PFA3 - every head layout of a 768-wide model gives 768)
+  return (d == 512 || d == 768) && dh == d / 2 && kwo > 0 && (kwo % 64) == 0 && kwo <= 768 && (d != 768 || (kwo % 192) == 0);
 }
 
 int64_t tx_tail_scratch_bytes(int M, int d) {

@@ -335,7 +335,13 @@ struct TxTailBody {
   // speed only): staggers the k order of the weight streams
   const int xpos = (cx.bx >> 3) & 7;
   constexpr bool PRIME = VOG_TAIL_PRIME != 0;
-  constexpr int PF_WO = NB == 3 ? 4 : 6, PF_W2 = NB == 3 ? 4 : 8;
+#ifndef VOG_TAIL_PFA3
+#define VOG_TAIL_PFA3 3      // k-steps of weight prefetch in the Wo / FFN2 stages at d = 768. Measured (scratch/r6_ah.sh, r6_ai.sh): 2: 49.6 /
+                             // 266 us (cfg 2 / cfg 4 mul tail), 3: 49.2 / 268, 4 (rounds 2-6): 50.3 / 273, 6: 52.0 / 285 - the deeper sets
+                             // cost spills (48 B of scratch at 4); cfg 4 5535 -> 5585 queries/s with 3, cfg 2 equal. Same k order:
+                             // bit-identical. Needs (kwo / 16) % 3 == 0 (tx_tail_supported: kwo % 192 == 0 at d = 768)
+#endif
+  constexpr int PF_WO = NB == 3 ? VOG_TAIL_PFA3 : 6, PF_W2 = NB == 3 ? VOG_TAIL_PFA3 : 8;
   u16x8 wq_a[PF_WO][NB];                              // primed weights of the NB-block stages (Wo, then W2)
   u16x8 wq_b[PF_W2][NB];
   u16x8 wq_1[VOG_TAIL_PF1][1];                        // ... of FFN1's pass(es)
