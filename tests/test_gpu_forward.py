@@ -357,6 +357,21 @@ def test_paired_launches_equal_separate_launches(name):
         assert torch.equal(a[k], b[k]), (name, k)
 
 
+def test_cfg2_forward_is_eleven_launches():
+    """The headline forward's launch structure: 11 launches, every fusion in place. A support probe that
+    silently turns one of them off (round 6: the score head fell out of the mul_tx tail after `vog_tx_tail_supported` was
+    tightened - two more launches, all goldens still green) must fail here, not in a bench line."""
+    eng, cfg, sd, batch, c, dev = build_engine("full/cfg2_vog_spat_gt5_bs4", "bf16", cached=True)
+    slot = eng.make_slot(dev, graph=False)
+    for k in ("prep", "lstm_layer+vis_enc", "obj_qkv", "obj_attn", "lstm_layer+obj_tail", "lstm_outproj+mul_pv", "argvec", "mul_pl",
+              "mul_attn", "mul_tail", "pred_head"):
+        assert eng.time_kernel(slot, k, 1) > 0, k
+    for k in ("lin2", "score", "lstm_ih0", "lstm_ih1", "mul_wo", "obj_wo", "mul_ffn1", "obj_ffn1", "prop_enc", "seg_enc", "vislang",
+              "mul_qkv", "lstm_step"):
+        with pytest.raises(L.VogError):
+            eng.time_kernel(slot, k, 1)
+
+
 @pytest.mark.parametrize("name", ["full/cfg2_vog_spat_gt5_bs4", "full/cfg2_ragged", "full/cfg5_vog_svsq_gt5_bs16",
                                   "small/vog_temp"])
 def test_gate_table_matches_input_projection(name):

@@ -1340,7 +1340,7 @@ extern "C" int vog_ctx_finalize(vog_ctx* c) {
   c->w_lin2_p = nullptr;
   {
     const int dm = d.prop_enc + d.seg_enc + d.lang_enc;
-    if (has_mul(d) && tx_tail_supported(dm, dm / 2, 64))
+    if (has_mul(d) && tx_tail_supported(dm, dm / 2, 192))    // (any kwo both widths take: only d / dh are in question here)
       VOG_TRY(up_frag32(c, W(c, "lin2.0.weight").data(), dm, 256, dm, et, &c->w_lin2_p));
   }
   VOG_TRY(up32(c, "lin2.2.weight", &c->w_lin2b));
